@@ -1,0 +1,88 @@
+"""Helpers shared by the CPU and GPU parity tests: load a tests/golden/*.npz fixture (produced
+by oracle/gen_golden.py from the LIVE reference) and rebuild the oracle Problem for it."""
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import dynamics as dyn
+from oracle import mppi_oracle as orc
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TDT = {"f32": torch.float32, "f64": torch.float64}
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load(name):
+    d = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    cfg = json.loads(str(d["config"]))
+    return cfg, d
+
+
+def t(d, key, dtype):
+    return torch.from_numpy(np.array(d[key])).to(dtype)
+
+
+def ctor_tensors(cfg, dtype):
+    kw = {}
+    for k, v in cfg["ctor"].items():
+        if k in ("u_min", "u_max", "noise_mu", "u_init") or isinstance(v, list):
+            kw[k] = torch.tensor(v, dtype=dtype)
+        else:
+            kw[k] = v
+    return kw
+
+
+def torch_callables(cfg, d, dtype):
+    """(dynamics, running_cost, terminal) torch callables of the fixture's model."""
+    m = cfg["model"]
+    if m == "pendulum":
+        return dyn.pendulum_dynamics, dyn.pendulum_cost, None
+    if m == "quadtoy":
+        f, q = dyn.make_quadtoy(cfg["nx"], cfg["nu"])
+        return f, q, None
+    if m == "linear_goal":
+        return dyn.make_linear_goal(t(d, "B", dtype), t(d, "goal", dtype))
+    if m == "mlp":
+        f, q = dyn.make_mlp(t(d, "W1", dtype), t(d, "b1", dtype), t(d, "W2", dtype), t(d, "b2", dtype),
+                            cfg["model_args"].get("res_scale", 0.1))
+        return f, q, None
+    raise ValueError(m)
+
+
+def oracle_problem(cfg, d, dtype=None):
+    dtype = dtype or TDT[cfg["dtype"]]
+    f, q, term = torch_callables(cfg, d, dtype)
+    kw = ctor_tensors(cfg, dtype)
+    return orc.Problem(dynamics=f, running_cost=q, nx=cfg["nx"],
+                       noise_sigma=torch.tensor(cfg["sigma"], dtype=dtype), K=cfg["K"], T=cfg["T"],
+                       terminal_state_cost=term if cfg["terminal"] else None, **kw)
+
+
+def oracle_run(cfg, d, dtype=None):
+    """Replays the fixture through the oracle; returns the list of per-step result dicts."""
+    dtype = dtype or TDT[cfg["dtype"]]
+    p = oracle_problem(cfg, d, dtype)
+    U = t(d, "U_init", dtype)
+    state = t(d, "state", dtype)
+    sampler = t(d, "sampler_actions", dtype) if cfg["sampler_rows"] else None
+    outs = []
+    if cfg["kmppi"]:
+        W, W_shift, _, _ = orc.kmppi_matrices(cfg["T"], cfg["S"], dtype)
+        theta = torch.zeros(cfg["S"], cfg["nu"], dtype=dtype)
+    for s in range(cfg["steps"]):
+        z = t(d, f"z{s}", dtype)
+        shift = bool(d[f"shift{s}"])
+        if cfg["kmppi"]:
+            r = orc.kmppi_command(p, theta, U, state, z, W, W_shift, shift, sampler)
+            theta = r["theta"]
+        else:
+            r = orc.command(p, U, state, z, shift, sampler)
+        U = r["U"]
+        outs.append(r)
+    return outs
