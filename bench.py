@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""bench.py -- rollouts/sec per `.command()` call (BASELINE.json metric) on N MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2|c4] [--rng torch-native|torch|philox]
+
+A "step" is one full `MPPI.command(state)`: on-device noise draw, fused rollout+cost (K1),
+exp-weighting + weighted update (K3/K4) and, for N>1, the single record all-gather + combine.
+Default workload = BASELINE.json configs[2] ("c3": 12-DoF quadratic toy dynamics, K=65536, T=64,
+nx=16, nu=12, fp32) -- the configuration the north_star's roofline target is quoted on; K is
+per GPU (weak scaling: the sample axis is sharded, K_global = N*65536).
+Prints ONE JSON line (rank 0).  `roofline` is for K1 = rollout_cost_kernel (HBM-bound: it streams
+the K*T*nu standard normals once): algorithmic bytes 4*K*T*nu + 4*K per launch
+divided by its average duration, measured with HIP events around every K1 launch inside the
+timed region (the engine launches on torch's current stream, so torch.cuda.Event brackets it).
+`cpu_baseline` times the oracle (CPU restatement of the reference path, kind "port") on a bounded
+sample of the same workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (description, model factory, nx, nu, K per GPU, T, sigma, bounds)
+    "c2": ("C2 pendulum K=8192 T=32 nx=2 nu=1 fp32", "pendulum", 2, 1, 8192, 32),
+    "c3": ("C3 12-DoF quadratic toy (integrator) K=65536 T=64 nx=16 nu=12 fp32", "integrator", 16, 12, 65536, 64),
+    "c4": ("C4 2-layer MLP dynamics nx=16 H=256 nu=4 K=65536 T=64 fp32", "mlp", 16, 4, 65536, 64),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_COPY_CEILING_GBS = 6290.0
+
+
+def make_controller(pm, wl, device, rng, shard, K):
+    _, kind, nx, nu, _, T = WORKLOADS[wl]
+    dtype = torch.float32
+    torch.manual_seed(0)
+    if kind == "pendulum":
+        model = pm.models.Pendulum()
+        sigma = torch.tensor(10.0, dtype=dtype)
+        kw = dict(u_min=torch.tensor(-2.0, dtype=dtype), u_max=torch.tensor(2.0, dtype=dtype), lambda_=1.0)
+        x0 = torch.tensor([3.141592653589793, 1.0], dtype=dtype)
+    elif kind == "integrator":
+        model = pm.models.Integrator(nx, nu)
+        sigma = torch.eye(nu, dtype=dtype)
+        kw = dict(lambda_=1.0)
+        x0 = torch.randn(nx, dtype=dtype)
+    else:
+        model = pm.models.MLPResidual.random(nx, nu, 256, seed=2, dtype=dtype)
+        sigma = torch.eye(nu, dtype=dtype)
+        kw = dict(lambda_=1.0)
+        x0 = torch.randn(nx, dtype=dtype)
+    U0 = torch.randn(T, nu, dtype=dtype) * 0.3
+    ctrl = pm.MPPI(model.dynamics, model.running_cost, nx, sigma, num_samples=K, horizon=T, device=device,
+                   U_init=U0, rng=rng, seed=1234, shard=shard, **kw)
+    return ctrl, x0.to(device), model
+
+
+def cpu_baseline(wl, budget_s=15.0):
+    """The oracle (oracle/mppi_oracle.py, a CPU restatement of the reference's command()) timed on a
+    bounded sample of the same workload: same T/nx/nu/model, fewer samples, incl. torch.randn."""
+    from oracle import dynamics as dyn
+    from oracle import mppi_oracle as orc
+    _, kind, nx, nu, Kfull, T = WORKLOADS[wl]
+    K = min(Kfull, 8192)
+    dtype = torch.float32
+    if kind == "pendulum":
+        f, q = dyn.pendulum_dynamics, dyn.pendulum_cost
+        p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=torch.tensor(10.0), K=K, T=T,
+                        u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0))
+    elif kind == "integrator":
+        f, q = dyn.make_quadtoy(nx, nu)
+        p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=torch.eye(nu), K=K, T=T)
+    else:
+        W = dyn.make_mlp_weights(nx, nu, 256, seed=2, dtype=dtype)
+        f, q = dyn.make_mlp(*W)
+        p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=torch.eye(nu), K=K, T=T)
+    U = torch.randn(T, nu) * 0.3
+    x0 = torch.randn(nx)
+    times = []
+    t_start = time.perf_counter()
+    it = 0
+    while True:
+        t0 = time.perf_counter()
+        z = torch.randn(K, T, nu, dtype=dtype)            # the reference's draw, mppi.py:203
+        r = orc.command(p, U, x0, z, True)
+        U = r["U"]
+        dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)                              # first call = warm-up
+        it += 1
+        if time.perf_counter() - t_start > budget_s or len(times) >= 50:
+            break
+    t = sorted(times)[len(times) // 2]
+    return {"value": K / t, "unit": "rollouts/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"oracle command() incl. randn, K={K} of {Kfull}, T={T}, nx={nx}, nu={nu}, fp32, "
+                      f"median of {len(times)} calls ({t * 1e3:.1f} ms each)",
+            "state_evals_per_s": K * T / t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--rng", default="torch-native", choices=["torch", "torch-native", "philox"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import pytorch_mppi_amd as pm
+
+    desc, kind, nx, nu, Kper, T = WORKLOADS[args.workload]
+    Kglobal = Kper * world                      # weak scaling over the sample axis
+    shard = (rank, world) if world > 1 else None
+    ctrl, x0, _ = make_controller(pm, args.workload, device, args.rng, shard, Kglobal)
+
+    # healthy softmax: lambda ~ std of the cost, from one untimed command
+    ctrl.command(x0)
+    if kind != "pendulum":
+        lam = ctrl.cost_total.float().std()
+        if world > 1:
+            dist.all_reduce(lam, op=dist.ReduceOp.AVG)
+        ctrl.lambda_ = float(lam)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctrl.command(x0)
+    ctrl._profile = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctrl.command(x0)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctrl._profile
+    ctrl._profile = None
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    ms_per_step = dt / args.steps * 1e3
+    value = Kglobal * args.steps / dt
+    n_eff = 1.0 / float((ctrl.omega.double() ** 2).sum()) if ctrl.omega is not None else None
+
+    # ---- roofline of K1 from the HIP events recorded inside the timed region ----
+    k1 = [a.elapsed_time(b) for a, b in prof.get("rollout_cost", [])]
+    k1_ms = sum(k1) / max(1, len(k1))
+    Klocal = ctrl.K_local
+    alg_bytes = 4 * Klocal * T * nu + 4 * Klocal
+    roofline = None
+    if k1:
+        if args.rng == "philox":
+            # no-HBM mode: the normals never exist in memory; report the time against the
+            # external-z byte count for orientation only
+            ach = alg_bytes / (k1_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "note": "rng=philox generates z in registers: K1 is VALU-bound, 'achieved' is "
+                                "external-z-equivalent bytes / time, not HBM traffic"}
+        else:
+            ach = alg_bytes / (k1_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "rollout_cost_kernel", "avg_launch_us": k1_ms * 1e3,
+                        "algorithmic_bytes": alg_bytes,
+                        "frac_of_measured_copy_ceiling": ach / HBM_COPY_CEILING_GBS}
+
+    out = {
+        "metric": "rollouts/sec (K x T state evals) per .command() call",
+        "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "K_per_gpu": Kper, "K_global": Kglobal, "T": T, "nx": nx, "nu": nu,
+                   "rng": args.rng, "lambda": float(ctrl.lambda_), "n_eff": n_eff,
+                   "sharding": f"samples/{world}" if world > 1 else "none"},
+        "state_evals_per_s": value * T,
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        # other noise modes of the same workload (short runs), for the record
+        extras = {}
+        for mode in ("philox", "torch-native", "torch"):
+            if mode == args.rng:
+                continue
+            c2, x2, _ = make_controller(pm, args.workload, device, mode, None, Kglobal)
+            c2.lambda_ = ctrl.lambda_
+            for _ in range(3):
+                c2.command(x2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n = max(5, args.steps // 5)
+            for _ in range(n):
+                c2.command(x2)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t1
+            extras[mode] = {"rollouts_per_s": Kglobal * n / d2, "ms_per_step": d2 / n * 1e3}
+            del c2
+        out["other_rng_modes"] = extras
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+/* mppi_amd.h -- C-ABI of the MI355X-native MPPI rollout-and-update engine.
+ *
+ * The reference (UM-ARM-Lab/pytorch_mppi v0.9.1) has no FFI of its own: its hot path is the
+ * private-method chain of `pytorch_mppi.MPPI` in src/pytorch_mppi/mppi.py.  Each entry point
+ * below names the reference lines it replaces.  Every function
+ *   - is `extern "C"`, takes plain pointers/sizes (device pointers are raw HIP addresses),
+ *   - launches on the HIP stream it is handed and never synchronises the device,
+ *   - allocates nothing (all workspace is caller-provided, see mppi_workspace_floats),
+ *   - returns 0 on success, a negative MPPI_E_* code for an engine-side refusal, or a
+ *     positive hipError_t value; mppi_last_error() returns a thread-local message.
+ *
+ * All arrays hold `dtype` elements (MPPI_F32 / MPPI_F64 = the dtype of `noise_sigma`,
+ * mppi.py:88).  Names follow the reference: K samples, T horizon, nx/nu state/control dims,
+ * U nominal control sequence, S KMPPI support points.
+ *
+ * Noise layouts
+ *   MPPI_NOISE_TNK4   engine-native, sample-minor: z4[jb][k][c] with j = 4*jb + c the flat
+ *                     (t*nu + n) index, jb < J4 = mppi_noise_rows4(T, nu).  One wave reads
+ *                     1 KiB contiguous per instruction (16 B per lane).
+ *   MPPI_NOISE_PHILOX no array: the float4 at [jb][k] is generated in-kernel from
+ *                     Philox4x32-10(counter = (k_global, jb, call_lo, call_hi), key = seed)
+ *                     + Box-Muller, so results do not depend on launch geometry or on the
+ *                     number of shards.
+ * The reference's own layout (K,T,nu) (mppi.py:203) is converted with mppi_noise_from_ktn.
+ *
+ * KMPPI (mppi.py:593-688): mppi_kmppi_interp turns support-point noise (K,S,nu) into raw
+ * trajectories W*clamp(theta+eps) in TNK4 layout, which K1 consumes as MPPI_NOISE_ACTIONS;
+ * the theta update is K3/K4 run on a problem whose "sequence" is theta (T:=S, U:=theta).
+ */
+#ifndef MPPI_AMD_H
+#define MPPI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPPI_ABI_VERSION 3
+
+enum { MPPI_F32 = 0, MPPI_F64 = 1 };
+enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
+       MPPI_NOISE_ACTIONS = 2 /* p->z holds pre-made raw actions (TNK4), KMPPI; K1/prepare only */ };
+
+/* native dynamics/cost models (device functors in pytorch_mppi_amd/csrc/models.hpp) */
+enum {
+  MPPI_MODEL_NONE = 0,        /* no fused model: generic path, callbacks stay in Python   */
+  MPPI_MODEL_PENDULUM = 1,    /* reference tests/pendulum.py:30-60                        */
+  MPPI_MODEL_INTEGRATOR = 2,  /* "quad-toy": reference tests/benchmark_mppi.py:65-78      */
+  MPPI_MODEL_LINEAR_GOAL = 3, /* reference tests/test_mppi.py:25-51                       */
+  MPPI_MODEL_MLP = 4          /* x + s*(W2 tanh(W1[x;u]+b1)+b2), tests/pendulum_approximate.py:47-67 */
+};
+
+enum {
+  MPPI_E_BADARG = -1,      /* null pointer / inconsistent sizes                            */
+  MPPI_E_UNSUPPORTED = -2, /* no kernel instantiated for this (model, nx, nu, dtype, ...)  */
+  MPPI_E_WORKSPACE = -3    /* workspace too small                                          */
+};
+
+/* One command()'s worth of inputs/outputs.  Pointers marked [opt] may be NULL. */
+typedef struct MppiProblem {
+  /* ---- dimensions ---- */
+  int32_t K;              /* samples held by THIS shard                                    */
+  int32_t T, nx, nu;
+  int32_t S;              /* KMPPI support points; 0 for plain MPPI                        */
+  int32_t dtype;          /* MPPI_F32 | MPPI_F64                                           */
+  int64_t k_offset;       /* global index of this shard's sample 0 (row bookkeeping, RNG)  */
+  /* ---- configuration ---- */
+  int32_t model_id;
+  int32_t sigma_diagonal;     /* mppi.py:131                                               */
+  int32_t noise_abs_cost;     /* mppi.py:190,196                                           */
+  int32_t sample_null_action; /* mppi.py:390-392: global row 0 := 0                        */
+  int32_t n_sampler_rows;     /* mppi.py:393-399: rows [null, null+n) := sampler_actions   */
+  int32_t state_per_sample;   /* state is (K,nx) instead of (nx,)  (mppi.py:302-305)       */
+  int32_t shift;              /* apply shift_nominal_trajectory (mppi.py:232-238) on read  */
+  int32_t use_terminal;       /* add the model's terminal cost (mppi.py:324-328)           */
+  int32_t noise_src;          /* MPPI_NOISE_*                                              */
+  int32_t u_per_command;      /* mppi.py:271                                               */
+  int32_t step_offset;        /* reserved (0)                                              */
+  int32_t hidden;             /* MLP hidden width                                          */
+  double lambda_;             /* mppi.py:96, read live                                     */
+  double u_scale;             /* mppi.py:313                                               */
+  uint64_t seed, call;        /* Philox key / per-command counter word                     */
+  /* ---- inputs (device) ---- */
+  const void* state;          /* (nx) or (K,nx)                                            */
+  const void* U;              /* (T,nu) nominal sequence BEFORE this command's shift       */
+  const void* u_init;         /* (nu)                                                      */
+  const void* noise_mu;       /* (nu)                                                      */
+  const void* noise_L;        /* (nu,nu) row-major: chol(Sigma), or diag(sqrt(diag))       */
+  const void* sigma_inv;      /* (nu,nu) row-major                                         */
+  const void* u_min;          /* (nu) (+-inf when unbounded, mppi.py:124-126)              */
+  const void* u_max;          /* (nu)                                                      */
+  const void* model_params;   /* model blob, see models.hpp                          [opt] */
+  const void* z;              /* TNK4 noise, J4*K*4 elements                         [opt] */
+  const void* sampler_actions;/* (n_sampler_rows,T,nu)                               [opt] */
+  const void* W;              /* KMPPI (T,S) interpolation operator                  [opt] */
+  const void* theta;          /* KMPPI (S,nu) control points (after shift)           [opt] */
+  /* ---- outputs (device) ---- */
+  void* cost_total;           /* (K)                                                       */
+  void* omega;                /* (K) normalised weights (mppi.py:258)                [opt] */
+  void* cost_total_non_zero;  /* (K) exp(-(c-beta)/lambda) (mppi.py:256)             [opt] */
+  void* U_out;                /* (T,nu) updated sequence (MPPI) / (S,nu) theta (KMPPI)     */
+  void* action_out;           /* (u_per_command,nu)                                  [opt] */
+  void* perturbed_action;     /* (K,T,nu) row-major, only written by mppi_prepare    [opt] */
+  void* noise;                /* (K,T,nu) row-major, only written by mppi_prepare    [opt] */
+  void* pert_cost;            /* (K) action perturbation cost (mppi.py:415)          [opt] */
+  void* states;               /* (K,T,nx) visited states (mppi.py:321)               [opt] */
+  void* record;               /* (2 + J) shard record {beta, eta, P[J]} for the exchange   */
+  /* ---- scratch ---- */
+  void* workspace;            /* >= mppi_workspace_elems() elements of dtype               */
+  int64_t workspace_elems;
+} MppiProblem;
+
+int mppi_abi_version(void);
+/* sizeof(MppiProblem) as the library was compiled: bindings check their mirror against it */
+int64_t mppi_problem_size(void);
+const char* mppi_last_error(void);
+
+/* rows of 4 in the TNK4 layout for a (T,nu) sequence: ceil(T*nu/4), padded so that whole
+ * super-steps of lcm(4,nu) elements can be read without a tail test. */
+int64_t mppi_noise_rows4(int32_t T, int32_t nu);
+
+/* elements of dtype the workspace must hold for this problem */
+int64_t mppi_workspace_elems(const MppiProblem* p);
+
+/* 1 if a fused rollout kernel exists for (model_id, nx, nu, dtype, hidden), else 0 */
+int mppi_model_supported(int32_t model_id, int32_t nx, int32_t nu, int32_t dtype, int32_t hidden);
+
+/* replaces torch.randn(K,T,nu) at mppi.py:203 (called from :378 / KMPPI :660): fills
+ * p->z (written, despite the const) in TNK4 layout with the Philox stream the fused mode uses */
+int mppi_noise_fill_philox(const MppiProblem* p, void* z_tnk4, void* stream);
+
+/* (K,T,nu) row-major standard normals (the reference's layout, mppi.py:203) -> TNK4 */
+int mppi_noise_from_ktn(const MppiProblem* p, const void* z_ktn, void* z_tnk4, void* stream);
+
+/* KMPPI._compute_perturbed_action_and_noise (mppi.py:657-666): eps_S = colour(z_S) over the S
+ * support points (p->z / Philox, J = S*nu), ctrl = clamp(theta + eps_S), raw action
+ * v[t] = sum_s W[t,s] ctrl[s]  (the constant-operator form of the vmap'd solve at :630-655),
+ * written in TNK4 layout (J = T*nu) to v_tnk4. */
+int mppi_kmppi_interp(const MppiProblem* p, void* v_tnk4, void* stream);
+
+/* K1 -- replaces _compute_total_cost_batch (mppi.py:407-417) = _sample_noise colouring
+ * (:201-206), _compute_perturbed_action_and_noise (:375-385), _sample_specific_actions
+ * (:387-400), _bound_action (:419-420), _compute_action_cost (:186-199) and
+ * _compute_rollout_costs_single (:297-332) for a native model: writes cost_total (K) and the
+ * per-block minima into the workspace. */
+int mppi_rollout_cost(const MppiProblem* p, void* stream);
+
+/* generic path (user callbacks stay Python callables, mppi.py:63-64): everything of
+ * _compute_total_cost_batch except the rollout loop: writes perturbed_action, noise (K,T,nu)
+ * and pert_cost (K).  Also serves the lazily materialised public attributes
+ * `perturbed_action` / `noise` (mppi.py:383-385) of the fused path. */
+int mppi_prepare(const MppiProblem* p, void* stream);
+
+/* generic path: block minima of a cost_total (K) that Python assembled (mppi.py:416) */
+int mppi_cost_block_min(const MppiProblem* p, void* stream);
+
+/* K3 -- replaces _compute_weighting (mppi.py:254-259, :12-13) and the weighted sum of
+ * einsum('k,ktn->tn', omega, noise) (:268; KMPPI :679 on noise_theta): per-block partial
+ * eta and P[j] relative to this shard's own beta, into the workspace. */
+int mppi_weights_partial(const MppiProblem* p, void* stream);
+
+/* K4 -- fixed-order reduction of the block partials into p->record = {beta, eta, P[J]};
+ * with `apply` != 0 also finishes the single-shard command: U_out = shift(U) + P/eta
+ * (mppi.py:270; KMPPI: theta_out, then U = W theta is applied by the host), action_out
+ * (:271-275), omega / cost_total_non_zero (:256-258). */
+int mppi_finalize(const MppiProblem* p, int apply, void* stream);
+
+/* K5 -- multi-GPU: combine `n_shards` records (all-gathered, rank order) exactly the same way
+ * on every rank: beta = min beta_g; s_g = exp(-(beta_g-beta)/lambda); eta = sum s_g eta_g;
+ * U_out = shift(U) + sum s_g P_g / eta; rescales this shard's omega. */
+int mppi_combine(const MppiProblem* p, const void* records, int32_t n_shards, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPPI_AMD_H */

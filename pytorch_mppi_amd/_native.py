@@ -1,0 +1,111 @@
+"""ctypes binding of the C-ABI in include/mppi_amd.h (libmppi_amd.so, built by _build.py).
+
+There is no fallback: if the HIP library cannot be built or loaded, importing the engine's
+compute entry points raises.  All functions take raw device addresses (torch ``data_ptr()``)
+and the caller's HIP stream handle; tensors stay owned by PyTorch.
+"""
+import ctypes as C
+import os
+
+from . import _build
+
+ABI_VERSION = 3
+
+F32, F64 = 0, 1
+NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS = 0, 1, 2
+MODEL_NONE, MODEL_PENDULUM, MODEL_INTEGRATOR, MODEL_LINEAR_GOAL, MODEL_MLP = 0, 1, 2, 3, 4
+
+_vp = C.c_void_p
+
+
+class MppiProblem(C.Structure):
+    """Mirror of ``struct MppiProblem`` (include/mppi_amd.h) -- field order is the ABI."""
+    _fields_ = [
+        ("K", C.c_int32), ("T", C.c_int32), ("nx", C.c_int32), ("nu", C.c_int32),
+        ("S", C.c_int32), ("dtype", C.c_int32),
+        ("k_offset", C.c_int64),
+        ("model_id", C.c_int32), ("sigma_diagonal", C.c_int32), ("noise_abs_cost", C.c_int32),
+        ("sample_null_action", C.c_int32), ("n_sampler_rows", C.c_int32),
+        ("state_per_sample", C.c_int32), ("shift", C.c_int32), ("use_terminal", C.c_int32),
+        ("noise_src", C.c_int32), ("u_per_command", C.c_int32), ("step_offset", C.c_int32),
+        ("hidden", C.c_int32),
+        ("lambda_", C.c_double), ("u_scale", C.c_double),
+        ("seed", C.c_uint64), ("call", C.c_uint64),
+        ("state", _vp), ("U", _vp), ("u_init", _vp), ("noise_mu", _vp), ("noise_L", _vp),
+        ("sigma_inv", _vp), ("u_min", _vp), ("u_max", _vp), ("model_params", _vp), ("z", _vp),
+        ("sampler_actions", _vp), ("W", _vp), ("theta", _vp),
+        ("cost_total", _vp), ("omega", _vp), ("cost_total_non_zero", _vp), ("U_out", _vp),
+        ("action_out", _vp), ("perturbed_action", _vp), ("noise", _vp), ("pert_cost", _vp),
+        ("states", _vp), ("record", _vp),
+        ("workspace", _vp), ("workspace_elems", C.c_int64),
+    ]
+
+
+_PP = C.POINTER(MppiProblem)
+
+# name -> (restype, argtypes); every symbol include/mppi_amd.h declares
+SYMBOLS = {
+    "mppi_abi_version": (C.c_int, []),
+    "mppi_problem_size": (C.c_int64, []),
+    "mppi_last_error": (C.c_char_p, []),
+    "mppi_noise_rows4": (C.c_int64, [C.c_int32, C.c_int32]),
+    "mppi_workspace_elems": (C.c_int64, [_PP]),
+    "mppi_model_supported": (C.c_int, [C.c_int32] * 5),
+    "mppi_noise_fill_philox": (C.c_int, [_PP, _vp, _vp]),
+    "mppi_noise_from_ktn": (C.c_int, [_PP, _vp, _vp, _vp]),
+    "mppi_kmppi_interp": (C.c_int, [_PP, _vp, _vp]),
+    "mppi_rollout_cost": (C.c_int, [_PP, _vp]),
+    "mppi_prepare": (C.c_int, [_PP, _vp]),
+    "mppi_cost_block_min": (C.c_int, [_PP, _vp]),
+    "mppi_weights_partial": (C.c_int, [_PP, _vp]),
+    "mppi_finalize": (C.c_int, [_PP, C.c_int, _vp]),
+    "mppi_combine": (C.c_int, [_PP, _vp, C.c_int32, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (building first if the in-tree library is missing or stale) libmppi_amd.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not _build.is_current():
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # stale-but-present library on a box without hipcc is still usable
+            if not os.path.exists(path):
+                raise RuntimeError(
+                    "pytorch_mppi_amd: the HIP engine library is missing and could not be built "
+                    f"({e}); there is no CPU fallback") from e
+    try:
+        l = C.CDLL(path)
+    except OSError as e:
+        raise RuntimeError(f"pytorch_mppi_amd: cannot load {path}: {e}; there is no CPU fallback") from e
+    for name, (res, args) in SYMBOLS.items():
+        f = getattr(l, name)
+        f.restype = res
+        f.argtypes = args
+    v = l.mppi_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"pytorch_mppi_amd: ABI mismatch (library {v}, binding {ABI_VERSION}); rebuild")
+    if l.mppi_problem_size() != C.sizeof(MppiProblem):
+        raise RuntimeError(f"pytorch_mppi_amd: struct MppiProblem mismatch (library {l.mppi_problem_size()} B, "
+                           f"binding {C.sizeof(MppiProblem)} B)")
+    _lib = l
+    return l
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().mppi_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {code}): {msg}")
+
+
+def noise_rows4(T, nu):
+    return int(lib().mppi_noise_rows4(int(T), int(nu)))
+
+
+def model_supported(model_id, nx, nu, dtype_code, hidden=0):
+    return bool(lib().mppi_model_supported(int(model_id), int(nx), int(nu), int(dtype_code), int(hidden)))

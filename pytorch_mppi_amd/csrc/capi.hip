@@ -1,0 +1,241 @@
+// capi.hip -- the extern "C" boundary declared in include/mppi_amd.h.
+// Validates the problem block, carves the caller's workspace, builds the typed kernel argument
+// block and dispatches.  No allocation, no device synchronisation, no global state besides a
+// thread-local error string.
+#include <cstdio>
+#include <cstring>
+#include "dispatch.hpp"
+#include "update.hpp"
+
+using namespace mppi;
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+static int hipfail(int code, const char* where) {
+  if (code > 0)
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString((hipError_t)code));
+  else if (code == MPPI_E_UNSUPPORTED)
+    snprintf(g_err, sizeof(g_err), "%s: no kernel instantiated for this model/nx/nu/dtype", where);
+  else if (code < 0)
+    snprintf(g_err, sizeof(g_err), "%s: bad argument", where);
+  return code;
+}
+
+static int gcd4(int nu) { return nu % 4 == 0 ? 4 : (nu % 2 == 0 ? 2 : 1); }
+
+extern "C" int64_t mppi_noise_rows4(int32_t T, int32_t nu) {
+  if (T <= 0 || nu <= 0) return 0;
+  const int g = gcd4(nu), p4 = nu / g, tt = 4 / g;
+  return (int64_t)((T + tt - 1) / tt) * p4;
+}
+
+namespace {
+struct Carve { int nb1, nkc, Jpad, R; int64_t total; };
+
+Carve carve(const MppiProblem* p) {
+  Carve c;
+  const int64_t J4 = mppi_noise_rows4(p->T, p->nu);
+  c.Jpad = (int)(J4 * 4);
+  if (c.Jpad % UPD_TJ) c.Jpad += UPD_TJ - c.Jpad % UPD_TJ;
+  c.nb1 = (p->K + BLOCK - 1) / BLOCK;
+  // samples per lane in K3: enough k-chunks to fill the chip, at most 8 loads in flight per lane
+  int R = 8;
+  const int njt = c.Jpad / UPD_TJ;
+  while (R > 1 && (int64_t)((p->K + BLOCK * R - 1) / (BLOCK * R)) * njt < 1024) R >>= 1;
+  c.R = R;
+  c.nkc = (p->K + BLOCK * R - 1) / (BLOCK * R);
+  c.total = (int64_t)c.nb1 + c.nkc + (int64_t)c.nkc * c.Jpad;
+  return c;
+}
+
+template <typename T>
+int make_args(const MppiProblem* p, KArgs<T>& a) {
+  if (p == nullptr) return fail(MPPI_E_BADARG, "null problem");
+  if (p->K <= 0 || p->T <= 0 || p->nx <= 0 || p->nu <= 0) return fail(MPPI_E_BADARG, "bad dims");
+  if (!(p->lambda_ > 0)) return fail(MPPI_E_BADARG, "lambda_ must be > 0");
+  if (!p->U || !p->u_init || !p->noise_mu || !p->noise_L || !p->sigma_inv || !p->u_min || !p->u_max)
+    return fail(MPPI_E_BADARG, "missing parameter array");
+  if (p->n_sampler_rows > 0 && !p->sampler_actions) return fail(MPPI_E_BADARG, "sampler rows without actions");
+  const Carve c = carve(p);
+  if (!p->workspace || p->workspace_elems < c.total) return fail(MPPI_E_WORKSPACE, "workspace too small");
+  a.K = p->K; a.Tn = p->T; a.nx = p->nx; a.nu = p->nu; a.J = p->T * p->nu;
+  a.J4 = (int)mppi_noise_rows4(p->T, p->nu); a.S = p->S;
+  a.k_offset = p->k_offset;
+  a.model_id = p->model_id; a.diag = p->sigma_diagonal; a.abs_cost = p->noise_abs_cost;
+  a.null_action = p->sample_null_action; a.n_sampler = p->n_sampler_rows;
+  a.state_per_sample = p->state_per_sample; a.shift = p->shift; a.use_terminal = p->use_terminal;
+  a.noise_src = p->noise_src; a.u_per_command = p->u_per_command; a.hidden = p->hidden;
+  a.lambda_ = (T)p->lambda_; a.u_scale = (T)p->u_scale;
+  a.seed = p->seed; a.call = p->call;
+  a.state = (const T*)p->state; a.U = (const T*)p->U; a.u_init = (const T*)p->u_init;
+  a.mu = (const T*)p->noise_mu; a.L = (const T*)p->noise_L; a.sinv = (const T*)p->sigma_inv;
+  a.umin = (const T*)p->u_min; a.umax = (const T*)p->u_max; a.mp = (const T*)p->model_params;
+  a.z = (const T*)p->z; a.sampler = (const T*)p->sampler_actions; a.W = (const T*)p->W;
+  a.theta = (const T*)p->theta;
+  a.cost = (T*)p->cost_total; a.omega = (T*)p->omega; a.wnz = (T*)p->cost_total_non_zero;
+  a.U_out = (T*)p->U_out; a.action_out = (T*)p->action_out; a.pa = (T*)p->perturbed_action;
+  a.noise = (T*)p->noise; a.pert = (T*)p->pert_cost; a.states = (T*)p->states;
+  a.record = (T*)p->record;
+  T* ws = (T*)p->workspace;
+  a.block_min = ws; a.eta_part = ws + c.nb1; a.P_part = ws + c.nb1 + c.nkc;
+  a.nb1 = c.nb1; a.nkc = c.nkc; a.Jpad = c.Jpad; a.R = c.R;
+  return 0;
+}
+
+template <typename T>
+int need_noise(const KArgs<T>& a) {
+  if (a.noise_src != MPPI_NOISE_PHILOX && a.z == nullptr) return fail(MPPI_E_BADARG, "noise_src needs p->z");
+  if (a.noise_src < 0 || a.noise_src > MPPI_NOISE_ACTIONS) return fail(MPPI_E_BADARG, "bad noise_src");
+  return 0;
+}
+
+template <typename T>
+int do_rollout(const MppiProblem* p, hipStream_t st) {
+  KArgs<T> a;
+  if (int e = make_args<T>(p, a)) return e;
+  if (int e = need_noise(a)) return e;
+  if (!a.state || !a.cost) return fail(MPPI_E_BADARG, "rollout needs state and cost_total");
+  int r;
+  switch (p->model_id) {
+    case MPPI_MODEL_PENDULUM: r = rollout_pendulum(a, st); break;
+    case MPPI_MODEL_INTEGRATOR: r = rollout_integrator(a, st); break;
+    case MPPI_MODEL_LINEAR_GOAL: r = rollout_linear_goal(a, st); break;
+    case MPPI_MODEL_MLP: r = rollout_mlp(a, st); break;
+    default: return fail(MPPI_E_UNSUPPORTED, "mppi_rollout_cost: model has no fused kernel");
+  }
+  return hipfail(r, "mppi_rollout_cost");
+}
+}  // namespace
+
+#define BY_DTYPE(p, expr_f32, expr_f64)                                 \
+  ((p) == nullptr ? fail(MPPI_E_BADARG, "null problem")                 \
+   : (p)->dtype == MPPI_F32 ? (expr_f32)                                \
+   : (p)->dtype == MPPI_F64 ? (expr_f64)                                \
+                            : fail(MPPI_E_BADARG, "bad dtype"))
+
+extern "C" int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
+extern "C" int64_t mppi_problem_size(void) { return (int64_t)sizeof(MppiProblem); }
+extern "C" const char* mppi_last_error(void) { return g_err; }
+
+extern "C" int64_t mppi_workspace_elems(const MppiProblem* p) {
+  if (p == nullptr || p->K <= 0 || p->T <= 0 || p->nu <= 0) return 0;
+  return carve(p).total;
+}
+
+extern "C" int mppi_model_supported(int32_t model_id, int32_t nx, int32_t nu, int32_t dtype, int32_t hidden) {
+  if (dtype != MPPI_F32 && dtype != MPPI_F64) return 0;
+  switch (model_id) {
+    case MPPI_MODEL_PENDULUM: return supported_pendulum(nx, nu, hidden);
+    case MPPI_MODEL_INTEGRATOR: return supported_integrator(nx, nu, hidden);
+    case MPPI_MODEL_LINEAR_GOAL: return supported_linear_goal(nx, nu, hidden);
+    case MPPI_MODEL_MLP: return supported_mlp(nx, nu, hidden);
+    default: return 0;
+  }
+}
+
+template <typename T>
+static int do_fill(const MppiProblem* p, void* z, hipStream_t st) {
+  KArgs<T> a;
+  if (int e = make_args<T>(p, a)) return e;
+  if (!z) return fail(MPPI_E_BADARG, "null z");
+  return hipfail(launch_noise_fill_philox<T>(a, (T*)z, st), "mppi_noise_fill_philox");
+}
+extern "C" int mppi_noise_fill_philox(const MppiProblem* p, void* z, void* stream) {
+  return BY_DTYPE(p, do_fill<float>(p, z, (hipStream_t)stream), do_fill<double>(p, z, (hipStream_t)stream));
+}
+
+template <typename T>
+static int do_from_ktn(const MppiProblem* p, const void* in, void* out, hipStream_t st) {
+  KArgs<T> a;
+  if (int e = make_args<T>(p, a)) return e;
+  if (!in || !out) return fail(MPPI_E_BADARG, "null z");
+  return hipfail(launch_noise_from_ktn<T>(a, (const T*)in, (T*)out, st), "mppi_noise_from_ktn");
+}
+extern "C" int mppi_noise_from_ktn(const MppiProblem* p, const void* in, void* out, void* stream) {
+  return BY_DTYPE(p, do_from_ktn<float>(p, in, out, (hipStream_t)stream),
+                  do_from_ktn<double>(p, in, out, (hipStream_t)stream));
+}
+
+template <typename T>
+static int do_interp(const MppiProblem* p, void* out, hipStream_t st) {
+  // p describes the trajectory problem (T, U); theta/W/S describe the support points
+  if (p == nullptr || p->S <= 0 || !p->theta || !p->W || !out) return fail(MPPI_E_BADARG, "kmppi_interp needs S, theta, W");
+  MppiProblem q = *p;
+  q.T = p->S; q.U = p->theta; q.shift = 0; q.sample_null_action = 0; q.n_sampler_rows = 0;
+  KArgs<T> a;
+  if (int e = make_args<T>(&q, a)) return e;
+  if (int e = need_noise(a)) return e;
+  if (a.noise_src == MPPI_NOISE_ACTIONS) return fail(MPPI_E_BADARG, "kmppi_interp needs a noise stream");
+  const int J4out = (int)mppi_noise_rows4(p->T, p->nu);
+  return hipfail(launch_kmppi_interp<T>(a, (const T*)p->W, p->T, J4out, (T*)out, st), "mppi_kmppi_interp");
+}
+extern "C" int mppi_kmppi_interp(const MppiProblem* p, void* out, void* stream) {
+  return BY_DTYPE(p, do_interp<float>(p, out, (hipStream_t)stream), do_interp<double>(p, out, (hipStream_t)stream));
+}
+
+extern "C" int mppi_rollout_cost(const MppiProblem* p, void* stream) {
+  return BY_DTYPE(p, do_rollout<float>(p, (hipStream_t)stream), do_rollout<double>(p, (hipStream_t)stream));
+}
+
+template <typename T>
+static int do_prepare(const MppiProblem* p, hipStream_t st) {
+  KArgs<T> a;
+  if (int e = make_args<T>(p, a)) return e;
+  if (int e = need_noise(a)) return e;
+  return hipfail(launch_prepare<T>(a, st), "mppi_prepare");
+}
+extern "C" int mppi_prepare(const MppiProblem* p, void* stream) {
+  return BY_DTYPE(p, do_prepare<float>(p, (hipStream_t)stream), do_prepare<double>(p, (hipStream_t)stream));
+}
+
+template <typename T>
+static int do_bmin(const MppiProblem* p, hipStream_t st) {
+  KArgs<T> a;
+  if (int e = make_args<T>(p, a)) return e;
+  if (!a.cost) return fail(MPPI_E_BADARG, "null cost_total");
+  return hipfail(launch_cost_block_min<T>(a, st), "mppi_cost_block_min");
+}
+extern "C" int mppi_cost_block_min(const MppiProblem* p, void* stream) {
+  return BY_DTYPE(p, do_bmin<float>(p, (hipStream_t)stream), do_bmin<double>(p, (hipStream_t)stream));
+}
+
+template <typename T>
+static int do_weights(const MppiProblem* p, hipStream_t st) {
+  KArgs<T> a;
+  if (int e = make_args<T>(p, a)) return e;
+  if (int e = need_noise(a)) return e;
+  if (!a.cost) return fail(MPPI_E_BADARG, "null cost_total");
+  return hipfail(launch_weights_partial<T>(a, st), "mppi_weights_partial");
+}
+extern "C" int mppi_weights_partial(const MppiProblem* p, void* stream) {
+  return BY_DTYPE(p, do_weights<float>(p, (hipStream_t)stream), do_weights<double>(p, (hipStream_t)stream));
+}
+
+template <typename T>
+static int do_finalize(const MppiProblem* p, int apply, hipStream_t st) {
+  KArgs<T> a;
+  if (int e = make_args<T>(p, a)) return e;
+  if (!a.record || !a.cost) return fail(MPPI_E_BADARG, "finalize needs record and cost_total");
+  if (apply && !a.U_out) return fail(MPPI_E_BADARG, "finalize(apply) needs U_out");
+  return hipfail(launch_finalize<T>(a, apply, st), "mppi_finalize");
+}
+extern "C" int mppi_finalize(const MppiProblem* p, int apply, void* stream) {
+  return BY_DTYPE(p, do_finalize<float>(p, apply, (hipStream_t)stream),
+                  do_finalize<double>(p, apply, (hipStream_t)stream));
+}
+
+template <typename T>
+static int do_combine(const MppiProblem* p, const void* rec, int G, hipStream_t st) {
+  KArgs<T> a;
+  if (int e = make_args<T>(p, a)) return e;
+  if (!rec || G <= 0 || !a.U_out || !a.cost) return fail(MPPI_E_BADARG, "combine needs records, U_out, cost_total");
+  return hipfail(launch_combine<T>(a, (const T*)rec, G, st), "mppi_combine");
+}
+extern "C" int mppi_combine(const MppiProblem* p, const void* rec, int32_t G, void* stream) {
+  return BY_DTYPE(p, do_combine<float>(p, rec, G, (hipStream_t)stream),
+                  do_combine<double>(p, rec, G, (hipStream_t)stream));
+}

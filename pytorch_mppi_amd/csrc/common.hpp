@@ -1,0 +1,194 @@
+// common.hpp -- kernel argument block, Philox4x32-10 + Box-Muller, wave64 reductions.
+// gfx950 only: wavefront = 64 lanes is hard-coded throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mppi_amd.h"
+
+namespace mppi {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;            // threads per workgroup of the per-sample kernels
+constexpr int UPD_TJ = 64;            // j-columns per K3 tile (= one value per lane after the
+                                      // transposing wave reduction)
+
+// typed, by-value kernel argument block (lives in kernarg memory -> SGPRs)
+template <typename T>
+struct KArgs {
+  int K, Tn, nx, nu, J, J4, S;
+  long long k_offset;
+  int model_id, diag, abs_cost, null_action, n_sampler, state_per_sample, shift, use_terminal,
+      noise_src, u_per_command, hidden;
+  T lambda_, u_scale;
+  unsigned long long seed, call;
+  const T *state, *U, *u_init, *mu, *L, *sinv, *umin, *umax, *mp, *z, *sampler, *W, *theta;
+  T *cost, *omega, *wnz, *U_out, *action_out, *pa, *noise, *pert, *states, *record;
+  // workspace carve-up
+  T* block_min;   // [nb1]
+  T* eta_part;    // [nkc]
+  T* P_part;      // [nkc][Jpad]
+  int nb1, nkc, Jpad, R;
+};
+
+// ---------------------------------------------------------------------------------------------
+// scalar math overloads (accurate ocml forms: parity against the CPU oracle is the first gate)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float m_sin(float x) { return sinf(x); }
+__device__ __forceinline__ double m_sin(double x) { return sin(x); }
+__device__ __forceinline__ float m_exp(float x) { return expf(x); }
+__device__ __forceinline__ double m_exp(double x) { return exp(x); }
+__device__ __forceinline__ float m_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
+__device__ __forceinline__ float m_fmod(float a, float b) { return fmodf(a, b); }
+__device__ __forceinline__ double m_fmod(double a, double b) { return fmod(a, b); }
+__device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double m_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float m_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double m_fma(double a, double b, double c) { return fma(a, b, c); }
+
+// torch.clamp(x, lo, hi) = min(max(x, lo), hi); NaN propagates in torch, here it cannot occur
+template <typename T>
+__device__ __forceinline__ T clampT(T x, T lo, T hi) {
+  return x < lo ? lo : (x > hi ? hi : x);
+}
+
+template <typename T> __device__ __forceinline__ T inf_v();
+template <> __device__ __forceinline__ float inf_v<float>() { return __builtin_huge_valf(); }
+template <> __device__ __forceinline__ double inf_v<double>() { return __builtin_huge_val(); }
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011; constants as in rocrand_philox4x32_10.h:62-65).
+// counter = (k_global, jb, call_lo, call_hi), key = (seed_lo, seed_hi)  -- engine-defined.
+// ---------------------------------------------------------------------------------------------
+struct U4 { unsigned x, y, z, w; };
+
+__host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
+  constexpr unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    unsigned long long p0 = (unsigned long long)M0 * c.x;
+    unsigned long long p1 = (unsigned long long)M1 * c.z;
+    U4 n;
+    n.x = (unsigned)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (unsigned)p1;
+    n.z = (unsigned)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (unsigned)p0;
+    c = n;
+    k0 += W0;
+    k1 += W1;
+  }
+  return c;
+}
+
+// Box-Muller on two 32-bit words -> two N(0,1) floats.  u1 in (0,1], u2 in [0,1).
+// v_sin/v_cos take their argument in revolutions, so 2*pi*u2 is never formed.
+__device__ __forceinline__ void box_muller(unsigned a, unsigned b, float& z0, float& z1) {
+  float u1 = fmaf((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);  // 2^-32, 2^-33
+  float u2 = (float)b * 2.3283064365386963e-10f;
+  float r = sqrtf(-2.0f * __logf(u1));
+  z0 = r * __builtin_amdgcn_cosf(u2);
+  z1 = r * __builtin_amdgcn_sinf(u2);
+}
+
+template <typename T>
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned long long call,
+                                               long long kg, long long jb, T (&out)[4]) {
+  U4 c{(unsigned)kg, (unsigned)jb, (unsigned)call, (unsigned)(call >> 32) ^ (unsigned)(kg >> 32)};
+  U4 r = philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+  float a, b, d, e;
+  box_muller(r.x, r.y, a, b);
+  box_muller(r.z, r.w, d, e);
+  out[0] = (T)a; out[1] = (T)b; out[2] = (T)d; out[3] = (T)e;
+}
+
+// one row-of-4 of the noise stream for (jb, local sample k)
+template <typename T>
+__device__ __forceinline__ void load4(const T* __restrict__ z, long long K, long long jb, int k,
+                                      T (&out)[4]);
+template <>
+__device__ __forceinline__ void load4<float>(const float* __restrict__ z, long long K,
+                                             long long jb, int k, float (&out)[4]) {
+  const float4 v = *reinterpret_cast<const float4*>(z + (jb * K + k) * 4);
+  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void load4<double>(const double* __restrict__ z, long long K,
+                                              long long jb, int k, double (&out)[4]) {
+  const double2* p = reinterpret_cast<const double2*>(z + (jb * K + k) * 4);
+  const double2 a = p[0], b = p[1];
+  out[0] = a.x; out[1] = a.y; out[2] = b.x; out[3] = b.y;
+}
+
+template <typename T, int NOISE>
+__device__ __forceinline__ void noise4(const KArgs<T>& a, long long jb, int k, T (&out)[4]) {
+  if constexpr (NOISE == MPPI_NOISE_PHILOX) {
+    philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, out);
+  } else {
+    load4<T>(a.z, a.K, jb, k, out);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 / block reductions (fixed order -> deterministic)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    T o = __shfl_xor(v, m, WAVE);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+  return v;
+}
+
+// block-wide min / sum over BLOCK threads; result valid in every thread.  `sm` >= BLOCK/WAVE
+template <typename T>
+__device__ __forceinline__ T block_min(T v, T* sm) {
+  v = wave_min(v);
+  const int w = threadIdx.x / WAVE;
+  __syncthreads();
+  if ((threadIdx.x & (WAVE - 1)) == 0) sm[w] = v;
+  __syncthreads();
+  T r = sm[0];
+#pragma unroll
+  for (int i = 1; i < BLOCK / WAVE; ++i) r = sm[i] < r ? sm[i] : r;
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* sm) {
+  v = wave_sum(v);
+  const int w = threadIdx.x / WAVE;
+  __syncthreads();
+  if ((threadIdx.x & (WAVE - 1)) == 0) sm[w] = v;
+  __syncthreads();
+  T r = sm[0];
+#pragma unroll
+  for (int i = 1; i < BLOCK / WAVE; ++i) r += sm[i];
+  return r;
+}
+
+// Transposing wave reduction: every lane holds v[0..64); afterwards lane l holds
+// sum over lanes of v[l].  63 shuffles per lane instead of 64*6.
+template <typename T>
+__device__ __forceinline__ T wave_reduce_transpose64(T (&v)[64]) {
+  const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const bool upper = (lane & s) != 0;
+#pragma unroll
+    for (int i = 0; i < s; ++i) {
+      const T send = upper ? v[i] : v[i + s];
+      const T keep = upper ? v[i + s] : v[i];
+      v[i] = keep + __shfl_xor(send, s, WAVE);
+    }
+  }
+  return v[0];
+}
+
+}  // namespace mppi

@@ -1,0 +1,16 @@
+// dispatch.hpp -- per-model launchers (one translation unit per model so hipcc runs in parallel).
+// Each returns 0 / hipError_t, or MPPI_E_UNSUPPORTED when no (nx,nu) instantiation exists.
+#pragma once
+#include "common.hpp"
+
+namespace mppi {
+#define MPPI_DECL_MODEL(name)                                          \
+  int rollout_##name(const KArgs<float>& a, hipStream_t st);            \
+  int rollout_##name(const KArgs<double>& a, hipStream_t st);           \
+  bool supported_##name(int nx, int nu, int hidden);
+MPPI_DECL_MODEL(pendulum)
+MPPI_DECL_MODEL(integrator)
+MPPI_DECL_MODEL(linear_goal)
+MPPI_DECL_MODEL(mlp)
+#undef MPPI_DECL_MODEL
+}  // namespace mppi

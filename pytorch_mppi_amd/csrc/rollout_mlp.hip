@@ -1,0 +1,23 @@
+// K1 instantiations: 2-layer MLP residual dynamics, per-lane VALU form (any hidden width, f32/f64).
+// BASELINE.json configs[3..4] are (nx,nu,H)=(16,4,256).
+#include "dispatch.hpp"
+#include "rollout.hpp"
+namespace mppi {
+#define MPPI_MLP_DIMS(X) X(16, 4) X(2, 1) X(4, 2)
+bool supported_mlp(int nx, int nu, int hidden) {
+  if (hidden <= 0) return false;
+#define X(NX, NU) if (nx == NX && nu == NU) return true;
+  MPPI_MLP_DIMS(X)
+#undef X
+  return false;
+}
+template <typename T> static int go(const KArgs<T>& a, hipStream_t st) {
+  if (a.mp == nullptr || a.hidden <= 0) return MPPI_E_BADARG;
+#define X(NX, NU) if (a.nx == NX && a.nu == NU) return launch_rollout<MlpModel<T, NX, NU>, T>(a, st);
+  MPPI_MLP_DIMS(X)
+#undef X
+  return MPPI_E_UNSUPPORTED;
+}
+int rollout_mlp(const KArgs<float>& a, hipStream_t st) { return go(a, st); }
+int rollout_mlp(const KArgs<double>& a, hipStream_t st) { return go(a, st); }
+}  // namespace mppi

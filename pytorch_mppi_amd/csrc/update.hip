@@ -1,0 +1,559 @@
+// update.hip -- everything of one command() that is not the fused rollout:
+//   noise_fill_philox / noise_from_ktn   noise stream producers (TNK4 layout)
+//   kmppi_interp                         KMPPI support points -> raw trajectories
+//   prepare                              generic path + lazily materialised public attributes
+//   cost_block_min                       generic path: minima of a host-assembled cost_total
+//   weights_partial (K3)                 beta, w = exp(-(c-beta)/lambda), per-block eta and P
+//   finalize (K4) / combine (K5)         fixed-order reductions, U update, action, omega
+// All reductions are fixed-order (no float atomics): the same inputs give the same bits on every
+// launch and on every rank.
+#include "actions.hpp"
+#include "update.hpp"
+
+namespace mppi {
+
+// =============================================================================================
+// noise producers
+// =============================================================================================
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) noise_fill_philox_kernel(const KArgs<T> a, T* __restrict__ out) {
+  const int k = blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= a.K) return;
+  for (int jb = blockIdx.y; jb < a.J4; jb += gridDim.y) {
+    T r[4];
+    philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, r);
+    T* o = out + ((long long)jb * a.K + k) * 4;
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
+  }
+}
+
+// (K, J) row-major -> [J4][K][4].  Tile: 64 samples x 64 columns through LDS so that both the
+// read (along j) and the write (along k) are coalesced.
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) noise_from_ktn_kernel(const KArgs<T> a, const T* __restrict__ in,
+                                                               T* __restrict__ out) {
+  __shared__ T tile[64][65];
+  const int k0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+  for (int r = ty; r < 64; r += 4) {
+    const int k = k0 + r, j = j0 + tx;
+    tile[r][tx] = (k < a.K && j < a.J) ? in[(long long)k * a.J + j] : T(0);
+  }
+  __syncthreads();
+  // each thread writes rows-of-4: 16 rows-of-4 per tile column block x 64 samples
+  for (int q = threadIdx.x; q < 16 * 64; q += BLOCK) {
+    const int jbl = q >> 6, kl = q & 63;
+    const int k = k0 + kl, jb = (j0 >> 2) + jbl;
+    if (k < a.K && jb < a.J4) {
+      T* o = out + ((long long)jb * a.K + k) * 4;
+      o[0] = tile[kl][4 * jbl + 0]; o[1] = tile[kl][4 * jbl + 1];
+      o[2] = tile[kl][4 * jbl + 2]; o[3] = tile[kl][4 * jbl + 3];
+    }
+  }
+}
+
+// =============================================================================================
+// KMPPI interpolation: v_raw[t] = sum_s W[t,s] * clamp(theta[s] + colour(z_S)[s])
+// ctrl points of the block's samples live in LDS as [S*NU][BLOCKK] (conflict-free columns).
+// `a` describes the support-point stream: a.Tn = S, a.J = S*nu, a.U = theta, a.shift = 0.
+// =============================================================================================
+template <typename T, int NU, int NOISE>
+__global__ void __launch_bounds__(64) kmppi_interp_kernel(const KArgs<T> a, const T* __restrict__ W,
+                                                          int Thor, int J4out, T* __restrict__ out) {
+  constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* ctrl = reinterpret_cast<T*>(smem_raw);             // [S*NU][64]
+  const int lane = threadIdx.x;
+  const int kraw = blockIdx.x * 64 + lane;
+  const bool active = kraw < a.K;
+  const int k = active ? kraw : a.K - 1;
+  const int S = a.Tn;
+  const int nss = (S + TT - 1) / TT;
+  for (int ss = 0; ss < nss; ++ss) {
+    T zc[P4 * 4];
+#pragma unroll
+    for (int i = 0; i < P4; ++i) {
+      T r[4];
+      noise4<T, NOISE>(a, (long long)ss * P4 + i, k, r);
+      zc[4 * i] = r[0]; zc[4 * i + 1] = r[1]; zc[4 * i + 2] = r[2]; zc[4 * i + 3] = r[3];
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int s = ss * TT + tt;
+      if (s < S) {
+        T z[NU], v[NU], e[NU];
+#pragma unroll
+        for (int n = 0; n < NU; ++n) z[n] = zc[tt * NU + n];
+        make_action<T, NU>(a, a.U, s, z, -2, v, e);      // theta + eps, clamp (mppi.py:660-663)
+#pragma unroll
+        for (int n = 0; n < NU; ++n) ctrl[(s * NU + n) * 64 + lane] = v[n];
+      }
+    }
+  }
+  // no barrier needed: every lane reads back only its own column
+  T ob[4];
+  int c = 0;
+  long long jb = 0;
+  for (int t = 0; t < Thor; ++t) {
+    T acc[NU];
+#pragma unroll
+    for (int n = 0; n < NU; ++n) acc[n] = T(0);
+    for (int s = 0; s < S; ++s) {
+      const T w = W[t * S + s];
+#pragma unroll
+      for (int n = 0; n < NU; ++n) acc[n] += w * ctrl[(s * NU + n) * 64 + lane];   // :665
+    }
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+      ob[c++] = acc[n];
+      if (c == 4) {
+        if (active) {
+          T* o = out + (jb * a.K + k) * 4;
+          o[0] = ob[0]; o[1] = ob[1]; o[2] = ob[2]; o[3] = ob[3];
+        }
+        ++jb; c = 0;
+      }
+    }
+  }
+  // flush the padded tail rows (zeros) so that K1's whole-super-step reads see defined data
+  while (jb < J4out) {
+    for (; c < 4; ++c) ob[c] = T(0);
+    if (active) {
+      T* o = out + (jb * a.K + k) * 4;
+      o[0] = ob[0]; o[1] = ob[1]; o[2] = ob[2]; o[3] = ob[3];
+    }
+    ++jb; c = 0;
+    ob[0] = ob[1] = ob[2] = ob[3] = T(0);
+  }
+}
+
+// =============================================================================================
+// prepare: perturbed_action / noise (K,T,nu) + pert_cost (K)
+// =============================================================================================
+template <typename T, int NU, int NOISE>
+__global__ void __launch_bounds__(BLOCK) prepare_kernel(const KArgs<T> a) {
+  constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Ue = reinterpret_cast<T*>(smem_raw);
+  for (int j = threadIdx.x; j < a.J; j += BLOCK) Ue[j] = u_eff(a, j);
+  __syncthreads();
+  const int k = blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= a.K) return;
+  const int orow = overwrite_row(a, a.k_offset + k);
+  const int nss = (a.Tn + TT - 1) / TT;
+  T pert = T(0);
+  for (int ss = 0; ss < nss; ++ss) {
+    T zc[P4 * 4];
+#pragma unroll
+    for (int i = 0; i < P4; ++i) {
+      T r[4];
+      noise4<T, NOISE>(a, (long long)ss * P4 + i, k, r);
+      zc[4 * i] = r[0]; zc[4 * i + 1] = r[1]; zc[4 * i + 2] = r[2]; zc[4 * i + 3] = r[3];
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int t = ss * TT + tt;
+      if (t < a.Tn) {
+        T z[NU], v[NU], e[NU];
+#pragma unroll
+        for (int n = 0; n < NU; ++n) z[n] = zc[tt * NU + n];
+        make_action<T, NU>(a, Ue, t, z, orow, v, e);
+        pert += action_cost_dot<T, NU>(a, Ue, t, e);
+        const long long o = ((long long)k * a.Tn + t) * NU;
+#pragma unroll
+        for (int n = 0; n < NU; ++n) {
+          if (a.pa != nullptr) a.pa[o + n] = v[n];
+          if (a.noise != nullptr) a.noise[o + n] = e[n];
+        }
+      }
+    }
+  }
+  if (a.pert != nullptr) a.pert[k] = pert;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) cost_block_min_kernel(const KArgs<T> a) {
+  __shared__ T red[BLOCK / WAVE];
+  const int k = blockIdx.x * BLOCK + threadIdx.x;
+  const T bm = block_min<T>(k < a.K ? a.cost[k] : inf_v<T>(), red);
+  if (threadIdx.x == 0) a.block_min[blockIdx.x] = bm;
+}
+
+// =============================================================================================
+// K3: weights + per-block partial weighted sums
+// grid = (nkc, njt).  Block (kc, jt): samples [kc*BLOCK*R, +BLOCK*R), columns [jt*64, +64).
+// Each lane keeps 64 accumulators (one per column), loops its R samples inside each row-of-4 so
+// that R independent 1 KiB wave loads are in flight, then one transposing wave reduction.
+//   NU == 0 : diagonal Sigma, any nu (element-wise in j; per-column constants in LDS)
+//   NU  > 0 : full Sigma (colouring needs whole timesteps; tile = whole super-steps)
+// =============================================================================================
+template <typename T>
+__device__ __forceinline__ T shard_beta(const KArgs<T>& a, T* red) {
+  T m = inf_v<T>();
+  for (int i = threadIdx.x; i < a.nb1; i += BLOCK) {
+    const T v = a.block_min[i];
+    m = v < m ? v : m;
+  }
+  return block_min<T>(m, red);
+}
+
+// mppi.py:12-13 / :256: exp(-(1/lambda) * (cost - beta))
+template <typename T>
+__device__ __forceinline__ T weight_of(T cost, T beta, T inv_lambda) {
+  return m_exp(-inv_lambda * (cost - beta));
+}
+
+constexpr int K3_RMAX = 8;
+
+template <typename T, int NOISE>
+__global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs<T> a) {
+  __shared__ __attribute__((aligned(16))) T cU[UPD_TJ], cS[UPD_TJ], cM[UPD_TJ], cLo[UPD_TJ], cHi[UPD_TJ];
+  __shared__ T red[BLOCK / WAVE];
+  __shared__ T wsum[BLOCK / WAVE][UPD_TJ];
+  const int kc = blockIdx.x, jt = blockIdx.y;
+  const int j0 = jt * UPD_TJ;
+  if (threadIdx.x < UPD_TJ) {
+    const int j = j0 + threadIdx.x;
+    const bool ok = j < a.J;
+    const int n = ok ? j % a.nu : 0;
+    cU[threadIdx.x] = ok ? u_eff(a, j) : T(0);
+    cS[threadIdx.x] = ok ? a.L[n * a.nu + n] : T(0);
+    cM[threadIdx.x] = ok ? a.mu[n] : T(0);
+    cLo[threadIdx.x] = ok ? a.umin[n] : T(0);
+    cHi[threadIdx.x] = ok ? a.umax[n] : T(0);
+  }
+  const T beta = shard_beta(a, red);   // contains the barriers that publish the constants
+  const T inv_lambda = T(1) / a.lambda_;
+
+  T w[K3_RMAX];
+  int kk[K3_RMAX];
+  int orow[K3_RMAX];
+  T eta = T(0);
+  bool any_over = false;
+#pragma unroll
+  for (int r = 0; r < K3_RMAX; ++r) {
+    const int k = (kc * a.R + r) * BLOCK + threadIdx.x;
+    const bool ok = r < a.R && k < a.K;
+    kk[r] = ok ? k : a.K - 1;
+    w[r] = ok ? weight_of<T>(a.cost[kk[r]], beta, inv_lambda) : T(0);
+    orow[r] = ok ? overwrite_row(a, a.k_offset + k) : -2;
+    any_over |= orow[r] != -2;
+    eta += w[r];
+    if (ok && jt == 0 && a.wnz != nullptr) a.wnz[k] = w[r];
+  }
+
+  T acc[UPD_TJ];
+#pragma unroll
+  for (int i = 0; i < UPD_TJ; ++i) acc[i] = T(0);
+
+#pragma unroll
+  for (int jbl = 0; jbl < UPD_TJ / 4; ++jbl) {
+    const long long jb = (long long)jt * (UPD_TJ / 4) + jbl;
+    if (jb < a.J4) {   // block-uniform
+      T zz[K3_RMAX][4];
+#pragma unroll
+      for (int r = 0; r < K3_RMAX; ++r)
+        if (r < a.R) noise4<T, NOISE>(a, jb, kk[r], zz[r]);
+#pragma unroll
+      for (int r = 0; r < K3_RMAX; ++r) {
+        if (r < a.R) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int i = 4 * jbl + c;
+            T v = cU[i] + (zz[r][c] * cS[i] + cM[i]);
+            if (any_over) {
+              if (orow[r] == -1) v = T(0);
+              else if (orow[r] >= 0) {
+                const int j = j0 + i;
+                v = j < a.J ? a.sampler[(long long)orow[r] * a.J + j] : T(0);
+              }
+            }
+            v = clampT<T>(v, cLo[i], cHi[i]);
+            acc[i] += w[r] * (v - cU[i]);
+          }
+        }
+      }
+    }
+  }
+
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const T colsum = wave_reduce_transpose64<T>(acc);   // lane l: this wave's sum of column j0+l
+  wsum[wv][lane] = colsum;
+  const T eta_b = block_sum<T>(eta, red);             // barriers also publish wsum
+  if (threadIdx.x < UPD_TJ) {
+    T s = wsum[0][threadIdx.x];
+#pragma unroll
+    for (int i = 1; i < BLOCK / WAVE; ++i) s += wsum[i][threadIdx.x];
+    const int j = j0 + threadIdx.x;
+    if (j < a.Jpad) a.P_part[(long long)kc * a.Jpad + j] = s;
+  }
+  if (jt == 0 && threadIdx.x == 0) a.eta_part[kc] = eta_b;
+}
+
+// full-Sigma variant: one tile = SSB super-steps of NU-aligned timesteps, at most 64 columns
+template <typename T, int NU, int NOISE>
+__global__ void __launch_bounds__(BLOCK) weights_partial_full_kernel(const KArgs<T> a) {
+  constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
+  constexpr int SSB = (16 / P4) > 0 ? (16 / P4) : 1;     // super-steps per tile
+  constexpr int TJ = SSB * P4 * 4;                      // columns per tile (<= 64)
+  static_assert(TJ <= 64, "tile too wide");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Ue = reinterpret_cast<T*>(smem_raw);               // [J + slack]
+  __shared__ T red[BLOCK / WAVE];
+  __shared__ T wsum[BLOCK / WAVE][64];
+  const int kc = blockIdx.x, jt = blockIdx.y;
+  for (int j = threadIdx.x; j < a.J; j += BLOCK) Ue[j] = u_eff(a, j);
+  const T beta = shard_beta(a, red);
+  const T inv_lambda = T(1) / a.lambda_;
+
+  T acc[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc[i] = T(0);
+  T eta = T(0);
+  for (int r = 0; r < a.R; ++r) {
+    const int k = (kc * a.R + r) * BLOCK + threadIdx.x;
+    const bool ok = k < a.K;
+    const int kq = ok ? k : a.K - 1;
+    const T w = ok ? weight_of<T>(a.cost[kq], beta, inv_lambda) : T(0);
+    const int orow = ok ? overwrite_row(a, a.k_offset + k) : -2;
+    eta += w;
+    if (ok && jt == 0 && a.wnz != nullptr) a.wnz[k] = w;
+#pragma unroll
+    for (int sb = 0; sb < SSB; ++sb) {
+      const int ss = jt * SSB + sb;
+      if (ss * TT < a.Tn) {
+        T zc[P4 * 4];
+#pragma unroll
+        for (int i = 0; i < P4; ++i) {
+          T q[4];
+          noise4<T, NOISE>(a, (long long)ss * P4 + i, kq, q);
+          zc[4 * i] = q[0]; zc[4 * i + 1] = q[1]; zc[4 * i + 2] = q[2]; zc[4 * i + 3] = q[3];
+        }
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          const int t = ss * TT + tt;
+          if (t < a.Tn) {
+            T z[NU], v[NU], e[NU];
+#pragma unroll
+            for (int n = 0; n < NU; ++n) z[n] = zc[tt * NU + n];
+            make_action<T, NU>(a, Ue, t, z, orow, v, e);
+#pragma unroll
+            for (int n = 0; n < NU; ++n) acc[(sb * TT + tt) * NU + n] += w * e[n];
+          }
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const T colsum = wave_reduce_transpose64<T>(acc);
+  wsum[wv][lane] = colsum;
+  const T eta_b = block_sum<T>(eta, red);
+  if (threadIdx.x < TJ) {
+    T s = wsum[0][threadIdx.x];
+#pragma unroll
+    for (int i = 1; i < BLOCK / WAVE; ++i) s += wsum[i][threadIdx.x];
+    const int j = jt * TJ + threadIdx.x;
+    if (j < a.Jpad) a.P_part[(long long)kc * a.Jpad + j] = s;
+  }
+  if (jt == 0 && threadIdx.x == 0) a.eta_part[kc] = eta_b;
+}
+
+// =============================================================================================
+// K4 finalize / K5 combine
+// =============================================================================================
+template <typename T>
+__device__ __forceinline__ T fixed_sum(const T* __restrict__ p, int n, T* red) {
+  // fixed-order: every thread sums a strided slice sequentially, then the block tree
+  T s = T(0);
+  for (int i = threadIdx.x; i < n; i += BLOCK) s += p[i];
+  return block_sum<T>(s, red);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) finalize_kernel(const KArgs<T> a, int apply) {
+  __shared__ T red[BLOCK / WAVE];
+  const T beta = shard_beta(a, red);
+  const T eta = fixed_sum<T>(a.eta_part, a.nkc, red);
+  const T inv_eta = T(1) / eta;                                        // mppi.py:258
+  const int gid = blockIdx.x * BLOCK + threadIdx.x;
+  if (gid == 0) { a.record[0] = beta; a.record[1] = eta; }
+  if (gid < a.J) {
+    T P = T(0);
+    for (int c = 0; c < a.nkc; ++c) P += a.P_part[(long long)c * a.Jpad + gid];
+    a.record[2 + gid] = P;
+    if (apply) {
+      const T un = u_eff(a, gid) + P * inv_eta;                        // :268-270
+      a.U_out[gid] = un;
+      if (a.action_out != nullptr && gid < a.u_per_command * a.nu) a.action_out[gid] = un;   // :271
+    }
+  }
+  if (apply && a.omega != nullptr) {
+    const T inv_lambda = T(1) / a.lambda_;
+    for (int k = gid; k < a.K; k += gridDim.x * BLOCK)
+      a.omega[k] = inv_eta * weight_of<T>(a.cost[k], beta, inv_lambda);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) combine_kernel(const KArgs<T> a, const T* __restrict__ rec,
+                                                        int G) {
+  const int stride = 2 + a.J;
+  T beta = rec[0];
+  for (int g = 1; g < G; ++g) { const T b = rec[(long long)g * stride]; beta = b < beta ? b : beta; }
+  const T inv_lambda = T(1) / a.lambda_;
+  T eta = T(0);
+  for (int g = 0; g < G; ++g)
+    eta += m_exp(-inv_lambda * (rec[(long long)g * stride] - beta)) * rec[(long long)g * stride + 1];
+  const T inv_eta = T(1) / eta;
+  const int gid = blockIdx.x * BLOCK + threadIdx.x;
+  if (gid < a.J) {
+    T P = T(0);
+    for (int g = 0; g < G; ++g)
+      P += m_exp(-inv_lambda * (rec[(long long)g * stride] - beta)) * rec[(long long)g * stride + 2 + gid];
+    const T un = u_eff(a, gid) + P * inv_eta;
+    a.U_out[gid] = un;
+    if (a.action_out != nullptr && gid < a.u_per_command * a.nu) a.action_out[gid] = un;
+  }
+  if (a.omega != nullptr) {
+    for (int k = gid; k < a.K; k += gridDim.x * BLOCK)
+      a.omega[k] = inv_eta * weight_of<T>(a.cost[k], beta, inv_lambda);
+  }
+}
+
+// =============================================================================================
+// host-side launchers
+// =============================================================================================
+#define MPPI_NU_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(10) X(12) X(16)
+
+template <typename T>
+int launch_noise_fill_philox(const KArgs<T>& a, T* out, hipStream_t st) {
+  const dim3 grid((a.K + BLOCK - 1) / BLOCK, a.J4 < 64 ? a.J4 : 64);
+  hipLaunchKernelGGL(noise_fill_philox_kernel<T>, grid, dim3(BLOCK), 0, st, a, out);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+int launch_noise_from_ktn(const KArgs<T>& a, const T* in, T* out, hipStream_t st) {
+  const dim3 grid((a.K + 63) / 64, (a.J4 * 4 + 63) / 64);
+  hipLaunchKernelGGL(noise_from_ktn_kernel<T>, grid, dim3(BLOCK), 0, st, a, in, out);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+int launch_kmppi_interp(const KArgs<T>& a, const T* W, int Thor, int J4out, T* out, hipStream_t st) {
+  const size_t smem = (size_t)a.J * 64 * sizeof(T);
+  if (smem > 160 * 1024) return MPPI_E_UNSUPPORTED;
+  const dim3 grid((a.K + 63) / 64), block(64);
+#define X(N)                                                                                      \
+  if (a.nu == N) {                                                                                \
+    if (a.noise_src == MPPI_NOISE_PHILOX) {                                                       \
+      if (smem > 64 * 1024)                                                                       \
+        (void)hipFuncSetAttribute((const void*)kmppi_interp_kernel<T, N, MPPI_NOISE_PHILOX>,      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);        \
+      hipLaunchKernelGGL((kmppi_interp_kernel<T, N, MPPI_NOISE_PHILOX>), grid, block, smem, st,   \
+                         a, W, Thor, J4out, out);                                                 \
+    } else {                                                                                      \
+      if (smem > 64 * 1024)                                                                       \
+        (void)hipFuncSetAttribute((const void*)kmppi_interp_kernel<T, N, MPPI_NOISE_TNK4>,        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);        \
+      hipLaunchKernelGGL((kmppi_interp_kernel<T, N, MPPI_NOISE_TNK4>), grid, block, smem, st, a,  \
+                         W, Thor, J4out, out);                                                    \
+    }                                                                                             \
+    return (int)hipGetLastError();                                                                \
+  }
+  MPPI_NU_LIST(X)
+#undef X
+  return MPPI_E_UNSUPPORTED;
+}
+
+template <typename T>
+int launch_prepare(const KArgs<T>& a, hipStream_t st) {
+  const size_t smem = (size_t)a.J * sizeof(T);
+  const dim3 grid((a.K + BLOCK - 1) / BLOCK), block(BLOCK);
+#define X(N)                                                                                      \
+  if (a.nu == N) {                                                                                \
+    if (a.noise_src == MPPI_NOISE_PHILOX)                                                         \
+      hipLaunchKernelGGL((prepare_kernel<T, N, MPPI_NOISE_PHILOX>), grid, block, smem, st, a);    \
+    else                                                                                          \
+      hipLaunchKernelGGL((prepare_kernel<T, N, MPPI_NOISE_TNK4>), grid, block, smem, st, a);      \
+    return (int)hipGetLastError();                                                                \
+  }
+  MPPI_NU_LIST(X)
+#undef X
+  return MPPI_E_UNSUPPORTED;
+}
+
+template <typename T>
+int launch_cost_block_min(const KArgs<T>& a, hipStream_t st) {
+  hipLaunchKernelGGL(cost_block_min_kernel<T>, dim3(a.nb1), dim3(BLOCK), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+int launch_weights_partial(const KArgs<T>& a, hipStream_t st) {
+  if (a.noise_src == MPPI_NOISE_ACTIONS) return MPPI_E_BADARG;
+  if (a.diag) {
+    const dim3 grid(a.nkc, (a.J4 * 4 + UPD_TJ - 1) / UPD_TJ), block(BLOCK);
+    if (a.noise_src == MPPI_NOISE_PHILOX)
+      hipLaunchKernelGGL((weights_partial_diag_kernel<T, MPPI_NOISE_PHILOX>), grid, block, 0, st, a);
+    else
+      hipLaunchKernelGGL((weights_partial_diag_kernel<T, MPPI_NOISE_TNK4>), grid, block, 0, st, a);
+    return (int)hipGetLastError();
+  }
+  const size_t smem = (size_t)a.J * sizeof(T);
+#define X(N)                                                                                      \
+  if (a.nu == N) {                                                                                \
+    constexpr int P4 = Stream<N>::P4, TT = Stream<N>::TT;                                         \
+    constexpr int SSB = (16 / P4) > 0 ? (16 / P4) : 1;                                            \
+    const int nss = (a.Tn + TT - 1) / TT;                                                         \
+    const dim3 grid(a.nkc, (nss + SSB - 1) / SSB), block(BLOCK);                                  \
+    if (a.noise_src == MPPI_NOISE_PHILOX)                                                         \
+      hipLaunchKernelGGL((weights_partial_full_kernel<T, N, MPPI_NOISE_PHILOX>), grid, block,     \
+                         smem, st, a);                                                            \
+    else                                                                                          \
+      hipLaunchKernelGGL((weights_partial_full_kernel<T, N, MPPI_NOISE_TNK4>), grid, block, smem, \
+                         st, a);                                                                  \
+    return (int)hipGetLastError();                                                                \
+  }
+  MPPI_NU_LIST(X)
+#undef X
+  return MPPI_E_UNSUPPORTED;
+}
+
+template <typename T>
+int launch_finalize(const KArgs<T>& a, int apply, hipStream_t st) {
+  int nb = (a.J + BLOCK - 1) / BLOCK;
+  if (apply && a.omega != nullptr) {
+    const int nbk = (a.K + BLOCK - 1) / BLOCK;
+    nb = nbk > nb ? nbk : nb;
+    if (nb > 1024) nb = 1024;
+  }
+  hipLaunchKernelGGL(finalize_kernel<T>, dim3(nb), dim3(BLOCK), 0, st, a, apply);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+int launch_combine(const KArgs<T>& a, const T* rec, int G, hipStream_t st) {
+  int nb = (a.J + BLOCK - 1) / BLOCK;
+  if (a.omega != nullptr) {
+    const int nbk = (a.K + BLOCK - 1) / BLOCK;
+    nb = nbk > nb ? nbk : nb;
+    if (nb > 1024) nb = 1024;
+  }
+  hipLaunchKernelGGL(combine_kernel<T>, dim3(nb), dim3(BLOCK), 0, st, a, rec, G);
+  return (int)hipGetLastError();
+}
+
+#define MPPI_INST(T)                                                                     \
+  template int launch_noise_fill_philox<T>(const KArgs<T>&, T*, hipStream_t);             \
+  template int launch_noise_from_ktn<T>(const KArgs<T>&, const T*, T*, hipStream_t);      \
+  template int launch_kmppi_interp<T>(const KArgs<T>&, const T*, int, int, T*, hipStream_t); \
+  template int launch_prepare<T>(const KArgs<T>&, hipStream_t);                           \
+  template int launch_cost_block_min<T>(const KArgs<T>&, hipStream_t);                    \
+  template int launch_weights_partial<T>(const KArgs<T>&, hipStream_t);                   \
+  template int launch_finalize<T>(const KArgs<T>&, int, hipStream_t);                     \
+  template int launch_combine<T>(const KArgs<T>&, const T*, int, hipStream_t);
+MPPI_INST(float)
+MPPI_INST(double)
+
+}  // namespace mppi

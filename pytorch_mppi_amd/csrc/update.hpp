@@ -1,0 +1,13 @@
+// update.hpp -- launchers implemented in update.hip
+#pragma once
+#include "common.hpp"
+namespace mppi {
+template <typename T> int launch_noise_fill_philox(const KArgs<T>& a, T* out, hipStream_t st);
+template <typename T> int launch_noise_from_ktn(const KArgs<T>& a, const T* in, T* out, hipStream_t st);
+template <typename T> int launch_kmppi_interp(const KArgs<T>& a, const T* W, int Thor, int J4out, T* out, hipStream_t st);
+template <typename T> int launch_prepare(const KArgs<T>& a, hipStream_t st);
+template <typename T> int launch_cost_block_min(const KArgs<T>& a, hipStream_t st);
+template <typename T> int launch_weights_partial(const KArgs<T>& a, hipStream_t st);
+template <typename T> int launch_finalize(const KArgs<T>& a, int apply, hipStream_t st);
+template <typename T> int launch_combine(const KArgs<T>& a, const T* rec, int G, hipStream_t st);
+}  // namespace mppi

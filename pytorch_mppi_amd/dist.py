@@ -1,0 +1,54 @@
+"""Multi-GPU sharding of the sample axis K (one process per GPU, torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm).
+
+The reference has no multi-GPU path.  K is split contiguously by global sample
+index -- rank g owns [k_offset, k_offset + K_local) -- so the row bookkeeping of
+`sample_null_action` / sampler rows (mppi.py:387-400) and the Philox counters are independent of
+the number of ranks.  U, the state and all parameters are replicated.  Each rank reduces its
+shard against its OWN minimum beta_g (K3/K4) into a record {beta_g, eta_g, P_g[T*nu]}; ONE
+all-gather of that (T*nu+2)-element record is the only collective of a command; every rank
+then combines the records in rank order (mppi_combine, K5), which yields bit-identical U on
+all ranks:   beta = min beta_g,  s_g = exp(-(beta_g-beta)/lambda),
+             eta = sum_g s_g eta_g,  U += sum_g s_g P_g / eta.
+"""
+import torch
+import torch.distributed as dist
+
+
+class ShardPlan:
+    def __init__(self, K, rank, world_size, group=None):
+        if not (0 <= rank < world_size):
+            raise ValueError("bad rank/world_size")
+        if K < world_size:
+            raise ValueError("need at least one sample per rank")
+        self.K, self.rank, self.world_size, self.group = int(K), int(rank), int(world_size), group
+        base, rem = divmod(self.K, self.world_size)
+        self.K_local = base + (1 if rank < rem else 0)
+        self.k_offset = rank * base + min(rank, rem)
+
+    def bounds(self, rank):
+        base, rem = divmod(self.K, self.world_size)
+        lo = rank * base + min(rank, rem)
+        return lo, lo + base + (1 if rank < rem else 0)
+
+    def all_gather(self, record):
+        """(2+J,) shard record -> (world_size, 2+J), rank order.  The single collective."""
+        out = torch.empty(self.world_size, record.numel(), device=record.device, dtype=record.dtype)
+        dist.all_gather_into_tensor(out, record.contiguous(), group=self.group)
+        return out
+
+
+def combine_records_host(records, U_eff, lambda_):
+    """Host restatement of mppi_combine (K5) in torch ops -- used by the CPU (gloo) tests to check
+    the exchange + rank-order combine logic, and by the GPU tests as the checker of the kernel.
+    records: (G, 2+J); U_eff: (T,nu) nominal sequence after the shift.  Returns (U_new, beta, eta)."""
+    beta_g = records[:, 0]
+    beta = beta_g.min()
+    s = torch.exp(-(1.0 / lambda_) * (beta_g - beta))
+    eta = torch.zeros((), dtype=records.dtype, device=records.device)
+    P = torch.zeros(records.shape[1] - 2, dtype=records.dtype, device=records.device)
+    for g in range(records.shape[0]):          # fixed rank order, like the kernel
+        eta = eta + s[g] * records[g, 1]
+        P = P + s[g] * records[g, 2:]
+    U_new = U_eff + (P * (1.0 / eta)).reshape(U_eff.shape)
+    return U_new, beta, eta

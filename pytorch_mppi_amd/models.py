@@ -1,0 +1,187 @@
+"""Native model specs: the objects that let `MPPI` fuse the rollout.
+
+The reference's plugin API is "any callable": ``dynamics(state, u[, t])``,
+``running_cost(state, u[, t])``, ``terminal_state_cost(states, actions)``
+(/root/reference/src/pytorch_mppi/mppi.py:63-64, :314, :318, :325).  A Python callable cannot be
+compiled into a HIP kernel, so each native model is ONE object that is both
+
+* ordinary torch callables in exactly that convention -- ``model.dynamics``,
+  ``model.running_cost``, ``model.terminal_state_cost`` -- usable with the reference `MPPI`
+  or with this engine's generic (callback) path, and
+* a ``model_id`` + parameter blob for the device functor of the same formula in
+  ``csrc/models.hpp``.
+
+``MPPI(model.dynamics, model.running_cost, ...)`` detects the bound methods and launches the
+fused kernel; any other callable takes the generic path (kernels around a Python T-loop).
+"""
+import math
+
+import torch
+
+from . import _native as N
+
+
+class NativeModel:
+    model_id = N.MODEL_NONE
+    nx = 0
+    nu = 0
+    hidden = 0
+    has_terminal = False
+
+    def __init__(self):
+        self._blob_cache = {}
+
+    # -- torch callables in the reference's plugin convention ----------------------------------
+    def dynamics(self, state, action):
+        raise NotImplementedError
+
+    def running_cost(self, state, action):
+        raise NotImplementedError
+
+    def terminal_state_cost(self, states, actions):
+        raise NotImplementedError(f"{type(self).__name__} has no terminal cost")
+
+    def __call__(self, state, action):
+        return self.dynamics(state, action)
+
+    # -- device-side parameters ----------------------------------------------------------------
+    def _param_list(self):
+        return []
+
+    def param_blob(self, device, dtype):
+        """Flat parameter vector in the layout csrc/models.hpp documents (cached per device/dtype)."""
+        key = (str(device), dtype)
+        if key not in self._blob_cache:
+            parts = [torch.as_tensor(p, dtype=dtype).reshape(-1) for p in self._param_list()]
+            blob = torch.cat(parts) if parts else torch.zeros(1, dtype=dtype)
+            self._blob_cache[key] = blob.to(device).contiguous()
+        return self._blob_cache[key]
+
+    def invalidate(self):
+        """Call after mutating parameters in place (e.g. re-trained MLP weights)."""
+        self._blob_cache.clear()
+
+
+class Pendulum(NativeModel):
+    """gym Pendulum-v1 true dynamics + cost, /root/reference/tests/pendulum.py:30-60."""
+    model_id = N.MODEL_PENDULUM
+    nx, nu = 2, 1
+
+    def dynamics(self, state, action):
+        th = state[:, 0:1]
+        thdot = state[:, 1:2]
+        u = torch.clamp(action, -2, 2)                                   # pendulum.py:41-42
+        newthdot = thdot + (15.0 * torch.sin(th) + 3.0 * u) * 0.05       # :44
+        newthdot = torch.clamp(newthdot, -8, 8)                          # :45
+        newth = th + newthdot * 0.05                                     # :46
+        return torch.cat((newth, newthdot), dim=1)
+
+    def running_cost(self, state, action):
+        an = ((state[:, 0] + math.pi) % (2 * math.pi)) - math.pi         # :52-53
+        return an ** 2 + 0.1 * state[:, 1] ** 2                          # :56-61
+
+
+class Integrator(NativeModel):
+    """n-D integrator ("quad-toy"): x[:nu] += u, cost = sum x^2
+    (/root/reference/tests/benchmark_mppi.py:65-78)."""
+    model_id = N.MODEL_INTEGRATOR
+
+    def __init__(self, nx, nu):
+        super().__init__()
+        self.nx, self.nu = int(nx), int(nu)
+
+    def dynamics(self, state, action):
+        nxt = state.clone()
+        nxt[..., :self.nu] = nxt[..., :self.nu] + action
+        return nxt
+
+    def running_cost(self, state, action):
+        return (state ** 2).sum(dim=-1)
+
+
+class LinearGoal(NativeModel):
+    """x' = x + u @ B.T, cost = sum((goal-x)^2), terminal = the same on the last state
+    (/root/reference/tests/test_mppi.py:25-51)."""
+    model_id = N.MODEL_LINEAR_GOAL
+    has_terminal = True
+
+    def __init__(self, B, goal):
+        super().__init__()
+        self.B = torch.as_tensor(B)
+        self.goal = torch.as_tensor(goal)
+        self.nx, self.nu = self.B.shape
+
+    def _param_list(self):
+        return [self.B, self.goal]
+
+    def _on(self, ref):
+        return self.B.to(ref.device, ref.dtype), self.goal.to(ref.device, ref.dtype)
+
+    def dynamics(self, state, action):
+        B, _ = self._on(state)
+        return state + action @ B.T
+
+    def running_cost(self, state, action):
+        _, goal = self._on(state)
+        return ((goal - state) ** 2).sum(dim=-1)
+
+    def terminal_state_cost(self, states, actions):
+        _, goal = self._on(states)
+        return ((goal - states[..., -1, :]) ** 2).sum(dim=-1)
+
+
+class MLPResidual(NativeModel):
+    """x' = x + res_scale * (W2 tanh(W1 [x;u] + b1) + b2), cost = sum x^2 -- the 2-layer
+    approximate-dynamics shape of /root/reference/tests/pendulum_approximate.py:47-67."""
+    model_id = N.MODEL_MLP
+
+    def __init__(self, W1, b1, W2, b2, nx, nu, res_scale=0.1):
+        super().__init__()
+        self.W1, self.b1, self.W2, self.b2 = (torch.as_tensor(t) for t in (W1, b1, W2, b2))
+        self.nx, self.nu = int(nx), int(nu)
+        self.hidden = int(self.W1.shape[0])
+        self.res_scale = float(res_scale)
+        assert self.W1.shape == (self.hidden, self.nx + self.nu) and self.W2.shape == (self.nx, self.hidden)
+
+    @classmethod
+    def random(cls, nx, nu, hidden, seed=2, dtype=torch.float32, res_scale=0.1):
+        """torch.nn.Linear default initialisation under a private generator state."""
+        g = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        l1 = torch.nn.Linear(nx + nu, hidden)
+        l2 = torch.nn.Linear(hidden, nx)
+        torch.random.set_rng_state(g)
+        with torch.no_grad():
+            return cls(l1.weight.detach().to(dtype).clone(), l1.bias.detach().to(dtype).clone(),
+                       l2.weight.detach().to(dtype).clone(), l2.bias.detach().to(dtype).clone(),
+                       nx, nu, res_scale)
+
+    def _param_list(self):
+        return [self.W1, self.b1, self.W2, self.b2, torch.tensor([self.res_scale])]
+
+    def dynamics(self, state, action):
+        W1, b1, W2, b2 = (t.to(state.device, state.dtype) for t in (self.W1, self.b1, self.W2, self.b2))
+        h = torch.tanh(torch.cat((state, action), dim=1) @ W1.T + b1)
+        return state + self.res_scale * (h @ W2.T + b2)
+
+    def running_cost(self, state, action):
+        return (state ** 2).sum(dim=-1)
+
+
+def native_model_of(dynamics, running_cost, terminal_state_cost=None):
+    """The NativeModel whose bound methods were passed as the reference-style callables, or None."""
+    m = dynamics if isinstance(dynamics, NativeModel) else getattr(dynamics, "__self__", None)
+    if not isinstance(m, NativeModel):
+        return None
+    if getattr(dynamics, "__func__", None) not in (None, type(m).dynamics) and not isinstance(dynamics, NativeModel):
+        return None
+    rc_self = getattr(running_cost, "__self__", None)
+    if rc_self is not m or getattr(running_cost, "__func__", None) is not type(m).running_cost:
+        return None
+    if terminal_state_cost is not None:
+        ts = getattr(terminal_state_cost, "__self__", None)
+        if ts is not m or getattr(terminal_state_cost, "__func__", None) is not type(m).terminal_state_cost:
+            return None
+        if not m.has_terminal:
+            return None
+    return m

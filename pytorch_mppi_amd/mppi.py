@@ -1,0 +1,761 @@
+"""`MPPI` / `KMPPI` with the reference's constructor and `.command(state)` surface
+(/root/reference/src/pytorch_mppi/mppi.py:35-448, :593-688), backed by the HIP engine.
+
+Host code here is parameter resolution and launch plumbing only; the arithmetic of
+`_compute_total_cost_batch` -> `_compute_weighting` -> weighted update runs in
+csrc/*.hip through the C-ABI (include/mppi_amd.h).  Two ways into the engine:
+
+* fused path  -- `dynamics`/`running_cost` are the bound methods of a `models.NativeModel`:
+  one K1 launch does noise colouring, bounding, action cost, the T-step rollout and the
+  running cost; K3/K4 do the exp-weighted update.  Nothing of shape (K,T,nu) is materialised
+  unless a caller reads `noise` / `perturbed_action` / `states` (lazy).
+* generic path -- any other callable (the reference's plugin API): `mppi_prepare` materialises
+  the bounded actions, the T-loop calls the user's torch callables on device tensors exactly
+  like mppi.py:312-322, then the same K3/K4.
+
+Additive, keyword-only extras (not in the reference): ``rng`` ("torch": draw
+``torch.randn(K,T,nu)`` like mppi.py:203 -- identical generator consumption and, on the same
+device and seed, identical draws; "torch-native": the same generator drawn directly in the
+engine's sample-minor layout; "philox": generate in-kernel, no (K,T,nu) array at all),
+``seed``, ``shard`` (multi-GPU, see dist.py).
+"""
+import ctypes as C
+import logging
+import typing
+
+import torch
+
+from . import _native as N
+from .models import NativeModel, native_model_of
+
+logger = logging.getLogger(__name__)
+
+_DT = {torch.float32: N.F32, torch.float64: N.F64}
+
+
+class SpecificActionSampler:
+    """Same hook as mppi.py:16-32."""
+
+    def __init__(self):
+        self.start_idx = 0
+        self.end_idx = 0
+        self.slice = slice(0, 0)
+
+    def sample_trajectories(self, state, info):
+        raise NotImplementedError
+
+    def specific_dynamics(self, next_state, state, action, t):
+        return next_state
+
+    def register_sample_start_end(self, start_idx, end_idx):
+        self.start_idx = start_idx
+        self.end_idx = end_idx
+        self.slice = slice(start_idx, end_idx)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class MPPI:
+    """Model Predictive Path Integral control (Williams et al. 2017, alg. 2), drop-in for
+    `pytorch_mppi.MPPI` on MI355X."""
+
+    def __init__(self, dynamics, running_cost, nx, noise_sigma, num_samples=100, horizon=15, device="cpu",
+                 terminal_state_cost=None,
+                 lambda_=1.,
+                 noise_mu=None,
+                 u_min=None,
+                 u_max=None,
+                 u_init=None,
+                 U_init=None,
+                 u_scale=1,
+                 u_per_command=1,
+                 step_dependent_dynamics=False,
+                 rollout_samples=1,
+                 rollout_var_cost=0,
+                 rollout_var_discount=0.95,
+                 sample_null_action=False,
+                 specific_action_sampler: typing.Optional[SpecificActionSampler] = None,
+                 noise_abs_cost=False,
+                 *, rng="torch", seed=None, shard=None):
+        self.d = torch.device(device) if not isinstance(device, torch.device) else device
+        self.dtype = noise_sigma.dtype                                   # mppi.py:88
+        if self.dtype not in _DT:
+            raise TypeError(f"noise_sigma dtype {self.dtype} unsupported (float32/float64)")
+        self.K = num_samples
+        self.T = horizon
+        self.nx = nx
+        self.nu = 1 if len(noise_sigma.shape) == 0 else noise_sigma.shape[0]   # :94
+        self.lambda_ = lambda_
+
+        if noise_mu is None:
+            noise_mu = torch.zeros(self.nu, dtype=self.dtype)
+        if u_init is None:
+            u_init = torch.zeros_like(noise_mu)
+        if self.nu == 1:                                                  # :104-106
+            noise_mu = noise_mu.view(-1)
+            noise_sigma = noise_sigma.view(-1, 1)
+
+        self.u_scale = u_scale
+        self.u_per_command = u_per_command
+        if u_max is not None and u_min is None:                           # :112-119
+            if not torch.is_tensor(u_max):
+                u_max = torch.tensor(u_max)
+            u_min = -u_max
+        if u_min is not None and u_max is None:
+            if not torch.is_tensor(u_min):
+                u_min = torch.tensor(u_min)
+            u_max = -u_min
+        if u_min is not None:                                             # :121-126
+            self.u_min = u_min.to(device=self.d)
+            self.u_max = u_max.to(device=self.d)
+        else:
+            self.u_min = torch.tensor(float('-inf'), device=self.d)
+            self.u_max = torch.tensor(float('inf'), device=self.d)
+
+        self.noise_mu = noise_mu.to(self.d)
+        self.noise_sigma = noise_sigma.to(self.d)
+        self._refresh_noise_factors()                                     # :130-139
+        self.U = U_init
+        self.u_init = u_init.to(self.d)
+        if self.U is None:
+            self.U = self._sample_noise((self.T,))                        # :144-145
+        else:
+            self.U = self.U.to(device=self.d, dtype=self.dtype)
+
+        self.step_dependency = step_dependent_dynamics
+        if step_dependent_dynamics:                                       # :147-154
+            self._dynamics_fn = dynamics
+            self._running_cost_fn = running_cost
+        else:
+            self._dynamics_fn = lambda state, u, t: dynamics(state, u)
+            self._running_cost_fn = lambda state, u, t: running_cost(state, u)
+        self.F = dynamics
+        self.running_cost = running_cost
+        self.terminal_state_cost = terminal_state_cost
+        self.sample_null_action = sample_null_action
+        self.specific_action_sampler = specific_action_sampler
+        self._terminal_state_cost_fn = terminal_state_cost if terminal_state_cost is not None \
+            else (lambda states, actions: 0)
+        self.noise_abs_cost = noise_abs_cost
+        self.state = None
+        self.info = None
+
+        self.M = rollout_samples
+        self.rollout_var_cost = rollout_var_cost
+        self.rollout_var_discount = rollout_var_discount
+        if self.M > 1:
+            self._var_discount_factors = rollout_var_discount ** torch.arange(
+                self.T, device=self.d, dtype=self.dtype)
+        else:
+            self._var_discount_factors = None
+
+        # results of the last command (mppi.py:180-184)
+        self.cost_total = None
+        self.cost_total_non_zero = None
+        self.omega = None
+        self._states = None
+        self._actions = None
+        self._noise = None
+        self._perturbed_action = None
+        self._last = None          # what the lazy attributes need to re-derive (K,T,nu) arrays
+
+        # ---- engine state ----
+        if rng not in ("torch", "torch-native", "philox"):
+            raise ValueError("rng must be 'torch', 'torch-native' or 'philox'")
+        self.rng = rng
+        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        self._call = 0
+        self._injected = []
+        self._model = None
+        if not step_dependent_dynamics and self.M == 1:
+            self._model = native_model_of(dynamics, running_cost, terminal_state_cost)
+        if self._model is not None and (self._model.nx != self.nx or self._model.nu != self.nu):
+            raise ValueError(f"native model dims ({self._model.nx},{self._model.nu}) != (nx,nu)=({self.nx},{self.nu})")
+        # shard = (rank, world_size[, process_group]): this controller holds samples
+        # [k_offset, k_offset + K_local) of the K global ones (dist.py)
+        self._shard = None
+        self.k_offset = 0
+        self.K_local = self.K
+        if shard is not None:
+            from .dist import ShardPlan
+            self._shard = ShardPlan(self.K, *shard)
+            self.k_offset = self._shard.k_offset
+            self.K_local = self._shard.K_local
+        self._ws = None
+        self._z_native = None
+        self._profile = None       # bench.py: {"rollout_cost": [(ev0, ev1), ...]} HIP events around K1
+
+    # ------------------------------------------------------------------------------------------
+    # parameter resolution (host, once per change)
+    # ------------------------------------------------------------------------------------------
+    def _refresh_noise_factors(self):
+        """mppi.py:130-139.  Also packs the (nu,nu) factor the kernels read: chol(Sigma), or
+        diag(sqrt(diag Sigma)) when Sigma is diagonal."""
+        self._diagonal_sigma = torch.equal(self.noise_sigma, torch.diag(torch.diag(self.noise_sigma)))
+        if self._diagonal_sigma:
+            diag = torch.diag(self.noise_sigma)
+            self._noise_sigma_inv_diag = 1.0 / diag
+            self._noise_sigma_sqrt_diag = torch.sqrt(diag)
+            self.noise_sigma_inv = torch.diag(self._noise_sigma_inv_diag)
+            self._noise_L = torch.diag(self._noise_sigma_sqrt_diag).contiguous()
+        else:
+            self.noise_sigma_inv = torch.linalg.inv(self.noise_sigma)
+            self._noise_sigma_chol = torch.linalg.cholesky(self.noise_sigma)
+            self._noise_L = self._noise_sigma_chol.contiguous()
+
+    def set_noise(self, noise_sigma=None, noise_mu=None):
+        """Replace Sigma / mu and refresh every derived factor (in the reference
+        autotune rewrites `noise_sigma` but the sampler keeps the init-time factors)."""
+        if noise_sigma is not None:
+            s = torch.as_tensor(noise_sigma, dtype=self.dtype).to(self.d)
+            self.noise_sigma = s.view(-1, 1) if self.nu == 1 else s
+            self._refresh_noise_factors()
+        if noise_mu is not None:
+            self.noise_mu = torch.as_tensor(noise_mu, dtype=self.dtype).to(self.d).view(-1)
+
+    def _sample_noise(self, shape):
+        """mppi.py:201-206 -- only used for the (T,nu) initial / reset sequence."""
+        z = torch.randn(*shape, self.nu, device=self.d, dtype=self.dtype)
+        if self._diagonal_sigma:
+            return z * self._noise_sigma_sqrt_diag + self.noise_mu
+        return z @ self._noise_sigma_chol.T + self.noise_mu
+
+    def compile(self, **kwargs):
+        """mppi.py:208-215.  The fused path is already compiled HIP; on the generic path the
+        user's callbacks are handed to torch.compile exactly like the reference."""
+        if self._model is None:
+            self._dynamics_fn = torch.compile(self._dynamics_fn, **kwargs)
+            self._running_cost_fn = torch.compile(self._running_cost_fn, **kwargs)
+
+    def get_params(self):
+        return f"K={self.K} T={self.T} M={self.M} lambda={self.lambda_} noise_mu={self.noise_mu.cpu().numpy()} noise_sigma={self.noise_sigma.cpu().numpy()}".replace(
+            "\n", ",")
+
+    def get_action_sequence(self):
+        return self.U
+
+    def shift_nominal_trajectory(self):
+        """mppi.py:232-238 (explicit call; `command` folds the shift into the kernels' reads)."""
+        self.U = torch.roll(self.U, -1, dims=0)
+        self.U[-1] = self.u_init
+
+    def change_horizon(self, horizon):
+        if horizon < self.U.shape[0]:
+            self.U = self.U[:horizon]
+        elif horizon > self.U.shape[0]:
+            self.U = torch.cat((self.U, self.u_init.repeat(horizon - self.U.shape[0], 1)))
+        self.T = horizon
+        self._ws = None
+        self._z_native = None
+
+    def reset(self):
+        self.U = self._sample_noise((self.T,))
+
+    # ------------------------------------------------------------------------------------------
+    # noise plumbing
+    # ------------------------------------------------------------------------------------------
+    def inject_noise(self, z):
+        """Queue standard-normal draws in the reference's layout (K,T,nu) (KMPPI: (K,S,nu)) for
+        the next `command()` instead of drawing them -- "identical inputs" for parity checks."""
+        self._injected.append(z)
+
+    def _noise_shape(self):
+        return (self.K_local, self.T, self.nu)
+
+    def _vec(self, t):
+        """(nu,) parameter on device in dtype (0-dim bounds broadcast, mppi.py:124-126)."""
+        t = torch.as_tensor(t).to(device=self.d, dtype=self.dtype)
+        return t.reshape(-1).expand(self.nu).contiguous() if t.numel() == 1 else t.reshape(-1).contiguous()
+
+    def _problem(self, Tn=None, U=None):
+        """Fill the static part of an MppiProblem for this controller."""
+        if self.d.type != "cuda":
+            raise RuntimeError("pytorch_mppi_amd runs on the MI355X only: construct the controller with "
+                               "device='cuda' (there is no CPU compute path)")
+        p = N.MppiProblem()
+        p.K, p.T, p.nx, p.nu = self.K_local, (Tn or self.T), self.nx, self.nu
+        p.S = 0
+        p.dtype = _DT[self.dtype]
+        p.k_offset = self.k_offset
+        p.model_id = self._model.model_id if self._model is not None else N.MODEL_NONE
+        p.hidden = self._model.hidden if self._model is not None else 0
+        p.sigma_diagonal = int(self._diagonal_sigma)
+        p.noise_abs_cost = int(bool(self.noise_abs_cost))
+        p.sample_null_action = int(bool(self.sample_null_action))
+        p.u_per_command = int(self.u_per_command)
+        p.lambda_ = float(self.lambda_)
+        p.u_scale = float(self.u_scale)
+        p.seed = self.seed
+        keep = dict(
+            U=(self.U if U is None else U).to(device=self.d, dtype=self.dtype).contiguous(),
+            u_init=self._vec(self.u_init), mu=self._vec(self.noise_mu),
+            L=self._noise_L.to(device=self.d, dtype=self.dtype).contiguous(),
+            sinv=self.noise_sigma_inv.to(device=self.d, dtype=self.dtype).contiguous(),
+            umin=self._vec(self.u_min), umax=self._vec(self.u_max))
+        p.U, p.u_init, p.noise_mu = _ptr(keep["U"]), _ptr(keep["u_init"]), _ptr(keep["mu"])
+        p.noise_L, p.sigma_inv = _ptr(keep["L"]), _ptr(keep["sinv"])
+        p.u_min, p.u_max = _ptr(keep["umin"]), _ptr(keep["umax"])
+        if self._model is not None:
+            keep["mp"] = self._model.param_blob(self.d, self.dtype)
+            p.model_params = _ptr(keep["mp"])
+        p._keep = keep      # keep the tensors alive as long as the struct
+        return p
+
+    def _attach_workspace(self, p):
+        lib = N.lib()
+        need = int(lib.mppi_workspace_elems(C.byref(p)))
+        if self._ws is None or self._ws.numel() < need or self._ws.dtype != self.dtype:
+            self._ws = torch.empty(max(need, 1), device=self.d, dtype=self.dtype)
+        p.workspace = _ptr(self._ws)
+        p.workspace_elems = self._ws.numel()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.d).cuda_stream)
+
+    def _draw_noise(self, p, shape):
+        """Bind this command's standard normals to the problem: injected / torch.randn (reference
+        layout, converted to the engine's sample-minor rows-of-4) or in-kernel Philox."""
+        lib = N.lib()
+        K, Tn, nu = shape
+        if self._injected:
+            z = self._injected.pop(0)
+            z = torch.as_tensor(z).to(device=self.d, dtype=self.dtype)
+            if tuple(z.shape) == (self.K, Tn, nu) and self.K != K:
+                z = z[self.k_offset:self.k_offset + K]          # global draw, this shard's rows
+            if tuple(z.shape) != (K, Tn, nu):
+                raise ValueError(f"injected noise has shape {tuple(z.shape)}, expected {(K, Tn, nu)}")
+            z = z.contiguous()
+        elif self.rng == "torch":
+            z = torch.randn(K, Tn, nu, device=self.d, dtype=self.dtype)   # mppi.py:203
+        elif self.rng == "torch-native":
+            # same generator, drawn straight into the engine's sample-minor layout: no conversion
+            # pass; which (k,t,n) gets which draw differs from the reference-layout draw
+            rows4 = N.noise_rows4(Tn, nu)
+            zn = torch.randn(rows4 * K * 4, device=self.d, dtype=self.dtype)
+            p.noise_src = N.NOISE_TNK4
+            p.z = _ptr(zn)
+            p._keep["z"] = zn
+            return
+        else:
+            self._call += 1
+            p.noise_src = N.NOISE_PHILOX
+            p.call = self._call
+            p.z = None
+            return
+        rows4 = N.noise_rows4(Tn, nu)
+        zn = torch.empty(rows4 * K * 4, device=self.d, dtype=self.dtype)
+        N.check(lib.mppi_noise_from_ktn(C.byref(p), _ptr(z), _ptr(zn), self._stream()), "mppi_noise_from_ktn")
+        p.noise_src = N.NOISE_TNK4
+        p.z = _ptr(zn)
+        p._keep["z"] = zn
+
+    # ------------------------------------------------------------------------------------------
+    # command
+    # ------------------------------------------------------------------------------------------
+    def command(self, state, shift_nominal_trajectory=True, info=None):
+        """mppi.py:240-252: returns the (nu,) / (u_per_command,nu) action as a device tensor,
+        without synchronising."""
+        self.info = info
+        return self._command(state, bool(shift_nominal_trajectory))
+
+    def _to_state(self, state):
+        if not torch.is_tensor(state):
+            state = torch.tensor(state)
+        return state.to(dtype=self.dtype, device=self.d)                  # mppi.py:262-264
+
+    def _sampler_rows(self, p):
+        """mppi.py:393-399: rows [null, null+n) come from the sampler; global indices."""
+        s = self.specific_action_sampler
+        if s is None:
+            return
+        actions = s.sample_trajectories(self.state, self.info)
+        actions = torch.as_tensor(actions).to(device=self.d, dtype=self.dtype).reshape(-1, self.T, self.nu).contiguous()
+        i = 1 if self.sample_null_action else 0
+        s.register_sample_start_end(i, i + actions.shape[0])
+        p.n_sampler_rows = actions.shape[0]
+        p.sampler_actions = _ptr(actions)
+        p._keep["sampler"] = actions
+
+    def _needs_generic(self):
+        if self._model is None:
+            return True
+        s = self.specific_action_sampler
+        if s is not None and type(s).specific_dynamics is not SpecificActionSampler.specific_dynamics:
+            return True      # arbitrary Python post-processing of the dynamics (mppi.py:315-317)
+        p_ok = N.model_supported(self._model.model_id, self.nx, self.nu, _DT[self.dtype], self._model.hidden)
+        return not p_ok
+
+    def _command(self, state, shift):
+        lib = N.lib()
+        self.state = self._to_state(state)
+        if self.M != 1:
+            raise NotImplementedError("rollout_samples > 1 is not built yet (SURVEY.md 8f-3)")
+        p = self._problem()
+        p.shift = int(shift)
+        st = self._stream()
+        self._attach_workspace(p)
+        self._draw_noise(p, self._noise_shape())
+        self._sampler_rows(p)
+        K = self.K_local
+        cost_total = torch.empty(K, device=self.d, dtype=self.dtype)
+        p.cost_total = _ptr(cost_total)
+        per_sample = tuple(self.state.shape) == (K, self.nx)              # mppi.py:302
+        self._states = self._actions = self._noise = self._perturbed_action = None
+
+        if not self._needs_generic():
+            s0 = self.state.contiguous() if per_sample else self.state.reshape(-1).contiguous()
+            p.state = _ptr(s0)
+            p._keep["state"] = s0
+            p.state_per_sample = int(per_sample)
+            p.use_terminal = int(self.terminal_state_cost is not None)
+            prof = self._profile
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
+            if prof is not None:
+                e1.record()
+                prof.setdefault("rollout_cost", []).append((e0, e1))
+        else:
+            self._generic_total_cost(p, cost_total, st)
+
+        self.cost_total = cost_total
+        omega = torch.empty(K, device=self.d, dtype=self.dtype)
+        wnz = torch.empty(K, device=self.d, dtype=self.dtype)
+        U_new = torch.empty(self.T, self.nu, device=self.d, dtype=self.dtype)
+        record = torch.empty(2 + self.T * self.nu, device=self.d, dtype=self.dtype)
+        p.omega, p.cost_total_non_zero, p.U_out, p.record = _ptr(omega), _ptr(wnz), _ptr(U_new), _ptr(record)
+        N.check(lib.mppi_weights_partial(C.byref(p), st), "mppi_weights_partial")
+        if self._shard is None or self._shard.world_size == 1:
+            N.check(lib.mppi_finalize(C.byref(p), 1, st), "mppi_finalize")
+        else:
+            N.check(lib.mppi_finalize(C.byref(p), 0, st), "mppi_finalize")
+            records = self._shard.all_gather(record)
+            p._keep["records"] = records
+            N.check(lib.mppi_combine(C.byref(p), _ptr(records), self._shard.world_size, st), "mppi_combine")
+        self.omega = omega
+        self.cost_total_non_zero = wnz
+        self._record = record
+        self._last = p                # keeps z / U / sampler tensors alive for the lazy attributes
+        self.U = U_new                                                    # mppi.py:270 (new tensor)
+        action = self.U[:self.u_per_command]
+        if self.u_per_command == 1:
+            action = action[0]                                            # :271-275
+        return action
+
+    # ------------------------------------------------------------------------------------------
+    # generic (callback) path: mppi.py:297-332 around the engine's prepare kernel
+    # ------------------------------------------------------------------------------------------
+    def _generic_total_cost(self, p, cost_total, st):
+        lib = N.lib()
+        K, T, nu = self.K_local, self.T, self.nu
+        pa = torch.empty(K, T, nu, device=self.d, dtype=self.dtype)
+        noise = torch.empty(K, T, nu, device=self.d, dtype=self.dtype)
+        pert = torch.empty(K, device=self.d, dtype=self.dtype)
+        p.perturbed_action, p.noise, p.pert_cost = _ptr(pa), _ptr(noise), _ptr(pert)
+        N.check(lib.mppi_prepare(C.byref(p), st), "mppi_prepare")
+        p.perturbed_action = p.noise = p.pert_cost = None
+        self._perturbed_action, self._noise = pa, noise
+        rollout_cost, self._states, actions = self._compute_rollout_costs(pa)
+        self._actions = actions / self.u_scale if actions is not None else None
+        torch.add(rollout_cost, pert, out=cost_total)                     # mppi.py:416
+        N.check(lib.mppi_cost_block_min(C.byref(p), st), "mppi_cost_block_min")
+
+    def _compute_rollout_costs(self, perturbed_actions):
+        """The user-callback T-loop, as mppi.py:297-332 (M == 1)."""
+        K, T, nu = perturbed_actions.shape
+        cost_total = torch.zeros(K, device=self.d, dtype=self.dtype)
+        if tuple(self.state.shape) == (K, self.nx):
+            state = self.state.clone()
+        else:
+            state = self.state.view(1, -1).expand(K, -1)
+        need_storage = self.terminal_state_cost is not None
+        if need_storage:
+            states = torch.empty(1, K, T, self.nx, device=self.d, dtype=self.dtype)
+            actions = torch.empty(1, K, T, nu, device=self.d, dtype=self.dtype)
+        sampler = self.specific_action_sampler
+        for t in range(T):
+            u = self.u_scale * perturbed_actions[:, t]
+            state = self._dynamics_fn(state, u, t)
+            if sampler is not None:
+                state = sampler.specific_dynamics(state.unsqueeze(0), state.unsqueeze(0), u.unsqueeze(0), t).squeeze(0)
+            c = self._running_cost_fn(state, u, t)
+            cost_total = cost_total + c.reshape(K)
+            if need_storage:
+                states[0, :, t] = state[:, :self.nx]
+                actions[0, :, t] = u
+        if need_storage:
+            c = self._terminal_state_cost_fn(states, actions)
+            if torch.is_tensor(c) and c.dim() > 1:
+                c = c.squeeze(0)
+            cost_total = cost_total + c
+        else:
+            states = actions = None
+        return cost_total, states, actions
+
+    # ------------------------------------------------------------------------------------------
+    # lazily materialised public attributes of the fused path (mppi.py:383-385, :411-412)
+    # ------------------------------------------------------------------------------------------
+    def _materialize(self):
+        if self._last is None:
+            return
+        lib = N.lib()
+        p = self._last
+        K, T, nu = self.K_local, self.T, self.nu
+        pa = torch.empty(K, T, nu, device=self.d, dtype=self.dtype)
+        noise = torch.empty(K, T, nu, device=self.d, dtype=self.dtype)
+        p.perturbed_action, p.noise = _ptr(pa), _ptr(noise)
+        N.check(lib.mppi_prepare(C.byref(p), self._stream()), "mppi_prepare")
+        p.perturbed_action = p.noise = None
+        self._perturbed_action, self._noise = pa, noise
+
+    @property
+    def noise(self):
+        if self._noise is None:
+            self._materialize()
+        return self._noise
+
+    @noise.setter
+    def noise(self, v):
+        self._noise = v
+
+    @property
+    def perturbed_action(self):
+        if self._perturbed_action is None:
+            self._materialize()
+        return self._perturbed_action
+
+    @perturbed_action.setter
+    def perturbed_action(self, v):
+        self._perturbed_action = v
+
+    @property
+    def states(self):
+        """(1,K,T,nx) visited states; like the reference only kept when a terminal cost is set
+        (mppi.py:307-310, :329-331)."""
+        if self._states is None and self._last is not None and self.terminal_state_cost is not None \
+                and not self._needs_generic():
+            lib = N.lib()
+            p = self._last
+            K = self.K_local
+            states = torch.empty(1, K, self.T, self.nx, device=self.d, dtype=self.dtype)
+            scratch = torch.empty(K, device=self.d, dtype=self.dtype)
+            old = p.cost_total
+            p.states, p.cost_total = _ptr(states), _ptr(scratch)
+            N.check(lib.mppi_rollout_cost(C.byref(p), self._stream()), "mppi_rollout_cost")
+            p.states, p.cost_total = None, old
+            # the rerun rewrote the block minima with identical values; nothing else changed
+            self._states = states
+        return self._states
+
+    @states.setter
+    def states(self, v):
+        self._states = v
+
+    @property
+    def actions(self):
+        if self._actions is None and self._last is not None and self.terminal_state_cost is not None \
+                and not self._needs_generic():
+            self._actions = self.perturbed_action.unsqueeze(0)   # = (u_scale*v)/u_scale, mppi.py:412
+        return self._actions
+
+    @actions.setter
+    def actions(self, v):
+        self._actions = v
+
+    def _bound_action(self, action):
+        return torch.clamp(action, self.u_min, self.u_max)
+
+    def get_rollouts(self, state, num_rollouts=1, U=None):
+        """mppi.py:425-448 (off the hot path): (num_rollouts, T, nx) states under the nominal U."""
+        state = state.view(-1, self.nx)
+        if state.size(0) == 1:
+            state = state.expand(num_rollouts, -1)
+        if U is None:
+            U = self.get_action_sequence()
+        T = U.shape[0]
+        states = torch.zeros((num_rollouts, T + 1, self.nx), dtype=U.dtype, device=U.device)
+        states[:, 0] = state
+        for t in range(T):
+            next_state = self._dynamics_fn(states[:, t].view(num_rollouts, -1),
+                                           self.u_scale * U[t].expand(num_rollouts, -1), t)
+            states[:, t + 1] = next_state[:, :self.nx]
+        return states[:, 1:]
+
+
+class TimeKernel:
+    """mppi.py:573-577"""
+
+    def __call__(self, t, tk):
+        raise NotImplementedError
+
+
+class RBFKernel(TimeKernel):
+    """mppi.py:580-590"""
+
+    def __init__(self, sigma=1):
+        self.sigma = sigma
+
+    def __repr__(self):
+        return f"RBFKernel(sigma={self.sigma})"
+
+    def __call__(self, t, tk):
+        d = torch.sum((t[:, None] - tk) ** 2, dim=-1)
+        return torch.exp(-d / (1e-8 + 2 * self.sigma ** 2))
+
+
+class KMPPI(MPPI):
+    """MPPI with kernel interpolation of control points (mppi.py:593-688).
+
+    The reference solves K identical (S,S) systems under vmap each command; every sample sees
+    the same `Tk`/`Hs`, so the interpolation is one constant operator W = K(Hs,Tk) Ktktk^-1
+    (T,S) -- built once on the host here, applied in `mppi_kmppi_interp`."""
+
+    def __init__(self, *args, num_support_pts=None, kernel: TimeKernel = RBFKernel(), **kwargs):
+        super().__init__(*args, **kwargs)
+        self.num_support_pts = num_support_pts or self.T // 2
+        self.theta = torch.zeros((self.num_support_pts, self.nu), dtype=self.dtype, device=self.d)
+        self.interpolation_kernel = kernel
+        self._noise_theta = None
+        self._last_theta = None
+        self.prepare_vmap_interpolation()
+
+    def get_params(self):
+        return f"{super().get_params()} num_support_pts={self.num_support_pts} kernel={self.interpolation_kernel}"
+
+    def reset(self):
+        super().reset()
+        self.theta.zero_()
+
+    def change_horizon(self, horizon):
+        """The reference inherits MPPI.change_horizon and leaves Tk/Hs stale (next command raises
+        a shape error); here the operators are rebuilt."""
+        super().change_horizon(horizon)
+        self.prepare_vmap_interpolation()
+
+    def prepare_vmap_interpolation(self):
+        """Name kept from mppi.py:636-651; builds Tk, Hs and the constant operators."""
+        S = int(self.num_support_pts)
+        tk = torch.linspace(0, self.T - 1, S, device=self.d, dtype=self.dtype)
+        hs = torch.linspace(0, self.T - 1, int(self.T), device=self.d, dtype=self.dtype)
+        self.Tk = tk.unsqueeze(0).repeat(self.K, 1)
+        self.Hs = hs.unsqueeze(0).repeat(self.K, 1)
+        k = self.interpolation_kernel
+        Ktktk = k(tk.unsqueeze(-1), tk.unsqueeze(-1))
+        self._W = torch.linalg.solve(Ktktk, k(hs.unsqueeze(-1), tk.unsqueeze(-1)), left=False).contiguous()
+        self._W_shift = torch.linalg.solve(Ktktk, k((tk + 1).unsqueeze(-1), tk.unsqueeze(-1)), left=False).contiguous()
+
+    def do_kernel_interpolation(self, t, tk, c):
+        K = self.interpolation_kernel(t.unsqueeze(-1), tk.unsqueeze(-1))
+        Ktktk = self.interpolation_kernel(tk.unsqueeze(-1), tk.unsqueeze(-1))
+        KK = torch.linalg.solve(Ktktk, K, left=False)
+        return torch.matmul(KK, c), K
+
+    def deparameterize_to_trajectory_single(self, theta):
+        return self.do_kernel_interpolation(self.Hs[0], self.Tk[0], theta)
+
+    def deparameterize_to_trajectory_batch(self, theta):
+        assert theta.shape == (self.K, self.num_support_pts, self.nu)
+        K = self.interpolation_kernel(self.Hs[0].unsqueeze(-1), self.Tk[0].unsqueeze(-1))
+        return torch.einsum("ts,ksn->ktn", self._W, theta), K.unsqueeze(0).expand(self.K, -1, -1)
+
+    def shift_nominal_trajectory(self):
+        super().shift_nominal_trajectory()
+        self.theta = self._W_shift @ self.theta                           # mppi.py:617-619
+
+    def _noise_shape(self):
+        return (self.K_local, int(self.num_support_pts), self.nu)
+
+    def _command(self, state, shift):
+        lib = N.lib()
+        self.state = self._to_state(state)
+        if self.M != 1:
+            raise NotImplementedError("rollout_samples > 1 is not built yet (SURVEY.md 8f-3)")
+        if shift:
+            # explicit shift (tiny (T,nu)/(S,S) host-launched ops) so that theta and U move together
+            self.shift_nominal_trajectory()
+        S = int(self.num_support_pts)
+        K = self.K_local
+        st = self._stream()
+        # --- support-point stream problem: "sequence" = theta (S,nu) ---
+        pt = self._problem(Tn=S, U=self.theta)
+        pt.shift = 0
+        pt.sample_null_action = 0
+        self._attach_workspace(pt)
+        self._draw_noise(pt, self._noise_shape())
+        # --- trajectory problem ---
+        p = self._problem()
+        p.shift = 0
+        p.S = S
+        p.theta = pt.U
+        p._keep["theta_keep"] = pt._keep
+        p.W = _ptr(self._W)
+        p.noise_src, p.z, p.call = pt.noise_src, pt.z, pt.call
+        self._attach_workspace(p)
+        pt.workspace, pt.workspace_elems = p.workspace, p.workspace_elems
+        rows4 = N.noise_rows4(self.T, self.nu)
+        v_raw = torch.empty(rows4 * K * 4, device=self.d, dtype=self.dtype)
+        N.check(lib.mppi_kmppi_interp(C.byref(p), _ptr(v_raw), st), "mppi_kmppi_interp")
+        p.noise_src, p.z = N.NOISE_ACTIONS, _ptr(v_raw)
+        p._keep["v_raw"] = v_raw
+        self._sampler_rows(p)
+        cost_total = torch.empty(K, device=self.d, dtype=self.dtype)
+        p.cost_total = _ptr(cost_total)
+        per_sample = tuple(self.state.shape) == (K, self.nx)
+        self._states = self._actions = self._noise = self._perturbed_action = None
+        self._noise_theta = None
+        if not self._needs_generic():
+            s0 = self.state.contiguous() if per_sample else self.state.reshape(-1).contiguous()
+            p.state = _ptr(s0)
+            p._keep["state"] = s0
+            p.state_per_sample = int(per_sample)
+            p.use_terminal = int(self.terminal_state_cost is not None)
+            N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
+        else:
+            self._generic_total_cost(p, cost_total, st)
+        self.cost_total = cost_total
+        # --- theta update: K3/K4 on the support-point stream (mppi.py:679-681) ---
+        omega = torch.empty(K, device=self.d, dtype=self.dtype)
+        wnz = torch.empty(K, device=self.d, dtype=self.dtype)
+        theta_new = torch.empty(S, self.nu, device=self.d, dtype=self.dtype)
+        record = torch.empty(2 + S * self.nu, device=self.d, dtype=self.dtype)
+        pt.cost_total = p.cost_total
+        pt.omega, pt.cost_total_non_zero, pt.U_out, pt.record = _ptr(omega), _ptr(wnz), _ptr(theta_new), _ptr(record)
+        pt.u_per_command = 0
+        N.check(lib.mppi_weights_partial(C.byref(pt), st), "mppi_weights_partial")
+        if self._shard is None or self._shard.world_size == 1:
+            N.check(lib.mppi_finalize(C.byref(pt), 1, st), "mppi_finalize")
+        else:
+            N.check(lib.mppi_finalize(C.byref(pt), 0, st), "mppi_finalize")
+            records = self._shard.all_gather(record)
+            pt._keep["records"] = records
+            N.check(lib.mppi_combine(C.byref(pt), _ptr(records), self._shard.world_size, st), "mppi_combine")
+        self.omega, self.cost_total_non_zero = omega, wnz
+        self._record = record
+        self._last, self._last_theta = p, pt
+        self.theta = theta_new
+        self.U = self._W @ self.theta                                     # mppi.py:682
+        action = self.U[:self.u_per_command]
+        if self.u_per_command == 1:
+            action = action[0]
+        return action
+
+    @property
+    def noise_theta(self):
+        """(K,S,nu) bounded control-point noise (mppi.py:664), materialised on first read."""
+        if self._noise_theta is None and self._last_theta is not None:
+            lib = N.lib()
+            pt = self._last_theta
+            K, S, nu = self.K_local, int(self.num_support_pts), self.nu
+            nt = torch.empty(K, S, nu, device=self.d, dtype=self.dtype)
+            pt.noise = _ptr(nt)
+            N.check(lib.mppi_prepare(C.byref(pt), self._stream()), "mppi_prepare")
+            pt.noise = None
+            self._noise_theta = nt
+        return self._noise_theta
+
+    @noise_theta.setter
+    def noise_theta(self, v):
+        self._noise_theta = v

@@ -38,9 +38,16 @@ def ctor_tensors(cfg, dtype):
     return kw
 
 
-def torch_callables(cfg, d, dtype):
+def torch_callables(cfg, d, dtype, device="cpu"):
     """(dynamics, running_cost, terminal) torch callables of the fixture's model."""
     m = cfg["model"]
+    if device != "cpu":
+        tt = lambda key: t(d, key, dtype).to(device)
+        if m == "linear_goal":
+            return dyn.make_linear_goal(tt("B"), tt("goal"))
+        if m == "mlp":
+            f, q = dyn.make_mlp(tt("W1"), tt("b1"), tt("W2"), tt("b2"), cfg["model_args"].get("res_scale", 0.1))
+            return f, q, None
     if m == "pendulum":
         return dyn.pendulum_dynamics, dyn.pendulum_cost, None
     if m == "quadtoy":
@@ -86,3 +93,50 @@ def oracle_run(cfg, d, dtype=None):
         U = r["U"]
         outs.append(r)
     return outs
+
+
+def native_model(cfg, d, dtype):
+    """The engine's NativeModel for a fixture (pytorch_mppi_amd.models)."""
+    from pytorch_mppi_amd import models
+    m = cfg["model"]
+    if m == "pendulum":
+        return models.Pendulum()
+    if m == "quadtoy":
+        return models.Integrator(cfg["nx"], cfg["nu"])
+    if m == "linear_goal":
+        return models.LinearGoal(t(d, "B", dtype), t(d, "goal", dtype))
+    if m == "mlp":
+        return models.MLPResidual(t(d, "W1", dtype), t(d, "b1", dtype), t(d, "W2", dtype), t(d, "b2", dtype),
+                                  cfg["nx"], cfg["nu"], cfg["model_args"].get("res_scale", 0.1))
+    raise ValueError(m)
+
+
+def engine_controller(cfg, d, *, native=True, device="cuda", dtype=None, **extra):
+    """Build pytorch_mppi_amd.MPPI / KMPPI for a fixture, on the fused (native model) or the
+    generic (plain torch callables) path."""
+    import pytorch_mppi_amd as pm
+    dtype = dtype or TDT[cfg["dtype"]]
+    kw = ctor_tensors(cfg, dtype)
+    if native:
+        model = native_model(cfg, d, dtype)
+        f, q = model.dynamics, model.running_cost
+        term = model.terminal_state_cost if cfg["terminal"] else None
+    else:
+        f, q, term = torch_callables(cfg, d, dtype, device)
+        term = term if cfg["terminal"] else None
+    if term is not None:
+        kw["terminal_state_cost"] = term
+    if cfg["sampler_rows"]:
+        sa = t(d, "sampler_actions", dtype)
+
+        class _S(pm.SpecificActionSampler):
+            def sample_trajectories(self, state, info):
+                return sa.clone()
+
+        kw["specific_action_sampler"] = _S()
+    kw.update(extra)
+    cls = pm.KMPPI if cfg["kmppi"] else pm.MPPI
+    if cfg["kmppi"]:
+        kw["num_support_pts"] = cfg["S"]
+    return cls(f, q, cfg["nx"], torch.tensor(cfg["sigma"], dtype=dtype), num_samples=cfg["K"],
+               horizon=cfg["T"], device=device, U_init=t(d, "U_init", dtype).clone(), **kw)
