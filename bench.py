@@ -57,7 +57,9 @@ def make_controller(pm, wl, device, rng, shard, K):
         sigma = torch.eye(nu, dtype=dtype)
         kw = dict(lambda_=1.0)
         x0 = torch.randn(nx, dtype=dtype)
-    U0 = torch.randn(T, nu, dtype=dtype) * 0.3
+    # small nominal sequence: the lambda-independent term sum(U*eps)/sigma^2 of the cost has std |U|_2,
+    # which must stay O(1) for a healthy softmax (N_eff >> 1)
+    U0 = torch.randn(T, nu, dtype=dtype) * 0.02
     ctrl = pm.MPPI(model.dynamics, model.running_cost, nx, sigma, num_samples=K, horizon=T, device=device,
                    U_init=U0, rng=rng, seed=1234, shard=shard, **kw)
     return ctrl, x0.to(device), model

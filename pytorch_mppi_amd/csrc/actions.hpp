@@ -1,5 +1,5 @@
 // actions.hpp -- per-sample, per-timestep action pipeline shared by K1 (fused rollout),
-// mppi_prepare (generic path / lazy attributes) and K3 (weighted update):
+// mppi_prepare (generic path / lazy attributes), kmppi_interp and the full-Sigma K3:
 //   eps  = z*sqrt(diag)+mu | L z + mu                         mppi.py:201-206
 //   v    = U[t] + eps                                          :380
 //   v    = 0 (global row 0, sample_null_action) | sampler row  :387-400
@@ -7,6 +7,8 @@
 //   e    = v - U[t]              (post-clamp noise)            :385
 //   a    = lambda*e*diag^-1 | (lambda*e) Sigma^-1 (|e| if abs) :186-199
 //   pert += sum_n U[t,n]*a[n]                                  :415
+// The per-control constants are read ONCE at kernel entry (before any store, so the backend can
+// use scalar loads and keep them in SGPRs); full-Sigma factors are staged in LDS.
 #pragma once
 #include "common.hpp"
 
@@ -20,7 +22,7 @@ __device__ __forceinline__ T u_eff(const KArgs<T>& a, int j) {
   return jn < a.J ? a.U[jn] : a.u_init[jn - a.J];
 }
 
-// which overwrite row (if any) global sample kg is: returns -2 none, -1 null action, >=0 sampler row
+// which overwrite row (if any) global sample kg is: -2 none, -1 null action, >=0 sampler row
 template <typename T>
 __device__ __forceinline__ int overwrite_row(const KArgs<T>& a, long long kg) {
   if (a.null_action && kg == 0) return -1;
@@ -30,65 +32,116 @@ __device__ __forceinline__ int overwrite_row(const KArgs<T>& a, long long kg) {
 }
 
 template <typename T, int NU>
-__device__ __forceinline__ void make_action(const KArgs<T>& a, const T* __restrict__ Ue /* [J] */,
-                                            int t, const T (&z)[NU], int orow, T (&v)[NU],
-                                            T (&e)[NU]) {
-  const T* __restrict__ Ut = Ue + t * NU;
-  if (a.noise_src == MPPI_NOISE_ACTIONS) {
+struct ActionConsts {
+  T sd[NU], mu[NU], lo[NU], hi[NU], ci[NU];   // sqrt(diag), mu, bounds, 1/diag
+  const T* Lm;                                // (NU,NU) chol(Sigma), row-major   (full Sigma only)
+  const T* Sm;                                // (NU,NU) Sigma^-1
+  T lambda_;
+  int abs_cost;
+  // elements of LDS the full-Sigma factors need
+  static constexpr int LDS_ELEMS = 2 * NU * NU;
+
+  // `lds` may be nullptr when Sigma is diagonal.  Caller must __syncthreads() afterwards.
+  __device__ __forceinline__ void load(const KArgs<T>& a, T* lds) {
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+      sd[n] = a.L[n * NU + n];
+      mu[n] = a.mu[n];
+      lo[n] = a.umin[n];
+      hi[n] = a.umax[n];
+      ci[n] = a.sinv[n * NU + n];
+    }
+    lambda_ = a.lambda_;
+    abs_cost = a.abs_cost;
+    Lm = lds;
+    Sm = lds + NU * NU;
+    if (!a.diag && lds != nullptr) {
+      for (int i = threadIdx.x; i < NU * NU; i += blockDim.x) {
+        lds[i] = a.L[i];
+        lds[NU * NU + i] = a.sinv[i];
+      }
+    }
+  }
+};
+
+// SRC_ACTIONS: z already holds raw actions (KMPPI), no colouring and no "+U"
+template <typename T, int NU, bool DIAG, bool SRC_ACTIONS>
+__device__ __forceinline__ void make_action(const ActionConsts<T, NU>& c, const T* __restrict__ Ut,
+                                            const T* __restrict__ sampler_row /* this t, or null */,
+                                            const T (&z)[NU], int orow, T (&v)[NU], T (&e)[NU]) {
+  if constexpr (SRC_ACTIONS) {
 #pragma unroll
     for (int n = 0; n < NU; ++n) v[n] = z[n];
-  } else if (a.diag) {
+  } else if constexpr (DIAG) {
 #pragma unroll
-    for (int n = 0; n < NU; ++n) v[n] = Ut[n] + (z[n] * a.L[n * NU + n] + a.mu[n]);
+    for (int n = 0; n < NU; ++n) v[n] = Ut[n] + (z[n] * c.sd[n] + c.mu[n]);
   } else {
 #pragma unroll
     for (int n = 0; n < NU; ++n) {
-      T s = z[0] * a.L[n * NU];
+      T s = z[0] * c.Lm[n * NU];
 #pragma unroll
-      for (int m = 1; m < NU; ++m) s += z[m] * a.L[n * NU + m];
-      v[n] = Ut[n] + (s + a.mu[n]);
+      for (int m = 1; m < NU; ++m) s += z[m] * c.Lm[n * NU + m];
+      v[n] = Ut[n] + (s + c.mu[n]);
     }
   }
-  if (orow == -1) {
+  if (orow != -2) {
+    if (orow == -1) {
 #pragma unroll
-    for (int n = 0; n < NU; ++n) v[n] = T(0);
-  } else if (orow >= 0) {
-    const T* __restrict__ sa = a.sampler + ((long long)orow * a.Tn + t) * NU;
+      for (int n = 0; n < NU; ++n) v[n] = T(0);
+    } else {
 #pragma unroll
-    for (int n = 0; n < NU; ++n) v[n] = sa[n];
+      for (int n = 0; n < NU; ++n) v[n] = sampler_row[n];
+    }
   }
 #pragma unroll
   for (int n = 0; n < NU; ++n) {
-    v[n] = clampT<T>(v[n], a.umin[n], a.umax[n]);
+    v[n] = clampT(v[n], c.lo[n], c.hi[n]);
     e[n] = v[n] - Ut[n];
   }
 }
 
-template <typename T, int NU>
-__device__ __forceinline__ T action_cost_dot(const KArgs<T>& a, const T* __restrict__ Ue, int t,
+template <typename T, int NU, bool DIAG>
+__device__ __forceinline__ T action_cost_dot(const ActionConsts<T, NU>& c, const T* __restrict__ Ut,
                                              const T (&e)[NU]) {
-  const T* __restrict__ Ut = Ue + t * NU;
   T nn[NU];
 #pragma unroll
-  for (int n = 0; n < NU; ++n) nn[n] = a.lambda_ * (a.abs_cost ? m_abs(e[n]) : e[n]);
+  for (int n = 0; n < NU; ++n) nn[n] = c.lambda_ * (c.abs_cost ? m_abs(e[n]) : e[n]);
   T acc = T(0);
-  if (a.diag) {
+  if constexpr (DIAG) {
 #pragma unroll
     for (int n = 0; n < NU; ++n) {
-      const T p = Ut[n] * (nn[n] * a.sinv[n * NU + n]);
+      const T p = Ut[n] * (nn[n] * c.ci[n]);
       acc = (n == 0) ? p : acc + p;
     }
   } else {
 #pragma unroll
     for (int n = 0; n < NU; ++n) {
-      T s = nn[0] * a.sinv[n];
+      T s = nn[0] * c.Sm[n];
 #pragma unroll
-      for (int m = 1; m < NU; ++m) s += nn[m] * a.sinv[m * NU + n];
+      for (int m = 1; m < NU; ++m) s += nn[m] * c.Sm[m * NU + n];
       const T p = Ut[n] * s;
       acc = (n == 0) ? p : acc + p;
     }
   }
   return acc;
+}
+
+// runtime-flag front ends for the kernels that are not specialised on DIAG / source
+template <typename T, int NU>
+__device__ __forceinline__ void make_action_rt(const KArgs<T>& a, const ActionConsts<T, NU>& c,
+                                               const T* __restrict__ Ue, int t, const T (&z)[NU],
+                                               int orow, T (&v)[NU], T (&e)[NU]) {
+  const T* Ut = Ue + t * NU;
+  const T* srow = orow >= 0 ? a.sampler + ((long long)orow * a.Tn + t) * NU : nullptr;
+  if (a.noise_src == MPPI_NOISE_ACTIONS) make_action<T, NU, true, true>(c, Ut, srow, z, orow, v, e);
+  else if (a.diag) make_action<T, NU, true, false>(c, Ut, srow, z, orow, v, e);
+  else make_action<T, NU, false, false>(c, Ut, srow, z, orow, v, e);
+}
+template <typename T, int NU>
+__device__ __forceinline__ T action_cost_dot_rt(const KArgs<T>& a, const ActionConsts<T, NU>& c,
+                                                const T* __restrict__ Ue, int t, const T (&e)[NU]) {
+  return a.diag ? action_cost_dot<T, NU, true>(c, Ue + t * NU, e)
+                : action_cost_dot<T, NU, false>(c, Ue + t * NU, e);
 }
 
 // compile-time layout of the TNK4 stream for a given NU: a super-step of TT timesteps consumes

@@ -3,6 +3,7 @@
 // block and dispatches.  No allocation, no device synchronisation, no global state besides a
 // thread-local error string.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "dispatch.hpp"
 #include "update.hpp"
@@ -43,9 +44,10 @@ Carve carve(const MppiProblem* p) {
   if (c.Jpad % UPD_TJ) c.Jpad += UPD_TJ - c.Jpad % UPD_TJ;
   c.nb1 = (p->K + BLOCK - 1) / BLOCK;
   // samples per lane in K3: enough k-chunks to fill the chip, at most 8 loads in flight per lane
-  int R = 8;
+  int R = 4;
   const int njt = c.Jpad / UPD_TJ;
-  while (R > 1 && (int64_t)((p->K + BLOCK * R - 1) / (BLOCK * R)) * njt < 1024) R >>= 1;
+  while (R > 1 && (int64_t)((p->K + BLOCK * R - 1) / (BLOCK * R)) * njt < 512) R >>= 1;
+  if (const char* e = getenv("MPPI_K3_R")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) R = v; }
   c.R = R;
   c.nkc = (p->K + BLOCK * R - 1) / (BLOCK * R);
   c.total = (int64_t)c.nb1 + c.nkc + (int64_t)c.nkc * c.Jpad;

@@ -46,11 +46,9 @@ __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
 __device__ __forceinline__ float m_fma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double m_fma(double a, double b, double c) { return fma(a, b, c); }
 
-// torch.clamp(x, lo, hi) = min(max(x, lo), hi); NaN propagates in torch, here it cannot occur
-template <typename T>
-__device__ __forceinline__ T clampT(T x, T lo, T hi) {
-  return x < lo ? lo : (x > hi ? hi : x);
-}
+// torch.clamp(x, lo, hi) = min(max(x, lo), hi)  (v_max_f32 / v_min_f32)
+__device__ __forceinline__ float clampT(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ double clampT(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
 template <typename T> __device__ __forceinline__ T inf_v();
 template <> __device__ __forceinline__ float inf_v<float>() { return __builtin_huge_valf(); }
@@ -183,8 +181,12 @@ __device__ __forceinline__ T wave_reduce_transpose64(T (&v)[64]) {
     const bool upper = (lane & s) != 0;
 #pragma unroll
     for (int i = 0; i < s; ++i) {
-      const T send = upper ? v[i] : v[i + s];
-      const T keep = upper ? v[i + s] : v[i];
+      T lo = v[i], hi = v[i + s];
+      // keep both operands in VGPRs: without this the compiler folds the lane-dependent select
+      // into a dynamically indexed load of v[], which forces the whole array into scratch
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      const T send = upper ? lo : hi;
+      const T keep = upper ? hi : lo;
       v[i] = keep + __shfl_xor(send, s, WAVE);
     }
   }

@@ -20,9 +20,9 @@ struct PendulumModel {
   static constexpr int NX = 2, NU = 1;
   __device__ explicit PendulumModel(const KArgs<T>&) {}
   __device__ __forceinline__ void step(T (&x)[NX], const T (&u)[NU], int) const {
-    const T uc = clampT<T>(u[0], T(-2), T(2));                         // pendulum.py:41-42
+    const T uc = clampT(u[0], T(-2), T(2));                         // pendulum.py:41-42
     T nthd = x[1] + (T(15) * m_sin(x[0]) + T(3) * uc) * T(0.05);       // :44  3g/(2l)=15, 3/(ml^2)=3
-    nthd = clampT<T>(nthd, T(-8), T(8));                               // :45
+    nthd = clampT(nthd, T(-8), T(8));                               // :45
     x[0] = x[0] + nthd * T(0.05);                                      // :46
     x[1] = nthd;
   }

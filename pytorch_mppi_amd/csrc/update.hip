@@ -63,6 +63,10 @@ __global__ void __launch_bounds__(64) kmppi_interp_kernel(const KArgs<T> a, cons
   constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* ctrl = reinterpret_cast<T*>(smem_raw);             // [S*NU][64]
+  T* fac = ctrl + (size_t)a.J * 64;                     // [2*NU*NU]
+  ActionConsts<T, NU> ac;
+  ac.load(a, fac);
+  __syncthreads();
   const int lane = threadIdx.x;
   const int kraw = blockIdx.x * 64 + lane;
   const bool active = kraw < a.K;
@@ -84,7 +88,7 @@ __global__ void __launch_bounds__(64) kmppi_interp_kernel(const KArgs<T> a, cons
         T z[NU], v[NU], e[NU];
 #pragma unroll
         for (int n = 0; n < NU; ++n) z[n] = zc[tt * NU + n];
-        make_action<T, NU>(a, a.U, s, z, -2, v, e);      // theta + eps, clamp (mppi.py:660-663)
+        make_action_rt<T, NU>(a, ac, a.U, s, z, -2, v, e);   // theta + eps, clamp (mppi.py:660-663)
 #pragma unroll
         for (int n = 0; n < NU; ++n) ctrl[(s * NU + n) * 64 + lane] = v[n];
       }
@@ -135,6 +139,9 @@ __global__ void __launch_bounds__(BLOCK) prepare_kernel(const KArgs<T> a) {
   constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ue = reinterpret_cast<T*>(smem_raw);
+  T* fac = Ue + a.J;
+  ActionConsts<T, NU> ac;
+  ac.load(a, fac);
   for (int j = threadIdx.x; j < a.J; j += BLOCK) Ue[j] = u_eff(a, j);
   __syncthreads();
   const int k = blockIdx.x * BLOCK + threadIdx.x;
@@ -157,8 +164,8 @@ __global__ void __launch_bounds__(BLOCK) prepare_kernel(const KArgs<T> a) {
         T z[NU], v[NU], e[NU];
 #pragma unroll
         for (int n = 0; n < NU; ++n) z[n] = zc[tt * NU + n];
-        make_action<T, NU>(a, Ue, t, z, orow, v, e);
-        pert += action_cost_dot<T, NU>(a, Ue, t, e);
+        make_action_rt<T, NU>(a, ac, Ue, t, z, orow, v, e);
+        pert += action_cost_dot_rt<T, NU>(a, ac, Ue, t, e);
         const long long o = ((long long)k * a.Tn + t) * NU;
 #pragma unroll
         for (int n = 0; n < NU; ++n) {
@@ -203,9 +210,28 @@ __device__ __forceinline__ T weight_of(T cost, T beta, T inv_lambda) {
   return m_exp(-inv_lambda * (cost - beta));
 }
 
-constexpr int K3_RMAX = 8;
+// Overwritten rows (sample_null_action / sampler rows, mppi.py:387-400) are masked out of the
+// streaming loop (weight 0) and added back afterwards, one lane per column: their "noise" is
+// clamp(0 | sampler action) - U, independent of z.  Returns the correction for column j.
+template <typename T>
+__device__ __forceinline__ T overwrite_correction(const KArgs<T>& a, int kbeg, int kend, int j,
+                                                  T uj, T lo, T hi, T beta, T inv_lambda) {
+  // rows are global indices [0, n_over); this block covers local samples [kbeg, kend)
+  const long long n_over = (a.null_action ? 1 : 0) + (long long)a.n_sampler;
+  T corr = T(0);
+  for (int k = kbeg; k < kend; ++k) {
+    const long long kg = a.k_offset + k;
+    if (kg >= n_over) break;
+    const int orow = overwrite_row(a, kg);
+    T v = T(0);
+    if (orow >= 0) v = a.sampler[(long long)orow * a.J + j];
+    v = clampT(v, lo, hi);
+    corr += weight_of<T>(a.cost[k], beta, inv_lambda) * (v - uj);
+  }
+  return corr;
+}
 
-template <typename T, int NOISE>
+template <typename T, int NOISE, int R>
 __global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs<T> a) {
   __shared__ __attribute__((aligned(16))) T cU[UPD_TJ], cS[UPD_TJ], cM[UPD_TJ], cLo[UPD_TJ], cHi[UPD_TJ];
   __shared__ T red[BLOCK / WAVE];
@@ -224,53 +250,47 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs
   }
   const T beta = shard_beta(a, red);   // contains the barriers that publish the constants
   const T inv_lambda = T(1) / a.lambda_;
+  const long long n_over = (a.null_action ? 1 : 0) + (long long)a.n_sampler;
 
-  T w[K3_RMAX];
-  int kk[K3_RMAX];
-  int orow[K3_RMAX];
+  T w[R];
+  int kk[R];
   T eta = T(0);
-  bool any_over = false;
 #pragma unroll
-  for (int r = 0; r < K3_RMAX; ++r) {
-    const int k = (kc * a.R + r) * BLOCK + threadIdx.x;
-    const bool ok = r < a.R && k < a.K;
+  for (int r = 0; r < R; ++r) {
+    const int k = (kc * R + r) * BLOCK + threadIdx.x;
+    const bool ok = k < a.K;
     kk[r] = ok ? k : a.K - 1;
-    w[r] = ok ? weight_of<T>(a.cost[kk[r]], beta, inv_lambda) : T(0);
-    orow[r] = ok ? overwrite_row(a, a.k_offset + k) : -2;
-    any_over |= orow[r] != -2;
-    eta += w[r];
-    if (ok && jt == 0 && a.wnz != nullptr) a.wnz[k] = w[r];
+    const T wr = ok ? weight_of<T>(a.cost[kk[r]], beta, inv_lambda) : T(0);
+    eta += wr;
+    if (ok && jt == 0 && a.wnz != nullptr) a.wnz[k] = wr;
+    w[r] = (a.k_offset + k < n_over) ? T(0) : wr;   // overwritten rows: see overwrite_correction
   }
 
   T acc[UPD_TJ];
 #pragma unroll
   for (int i = 0; i < UPD_TJ; ++i) acc[i] = T(0);
 
+  const int nrows = a.J4 - jt * (UPD_TJ / 4);   // rows-of-4 of this tile that exist (block-uniform)
 #pragma unroll
   for (int jbl = 0; jbl < UPD_TJ / 4; ++jbl) {
-    const long long jb = (long long)jt * (UPD_TJ / 4) + jbl;
-    if (jb < a.J4) {   // block-uniform
-      T zz[K3_RMAX][4];
+    if (jbl < nrows) {
+      const long long jb = (long long)jt * (UPD_TJ / 4) + jbl;
+      T zz[R][4];
 #pragma unroll
-      for (int r = 0; r < K3_RMAX; ++r)
-        if (r < a.R) noise4<T, NOISE>(a, jb, kk[r], zz[r]);
+      for (int r = 0; r < R; ++r) noise4<T, NOISE>(a, jb, kk[r], zz[r]);
+      T u4[4], s4[4], m4[4], lo4[4], hi4[4];
 #pragma unroll
-      for (int r = 0; r < K3_RMAX; ++r) {
-        if (r < a.R) {
+      for (int c = 0; c < 4; ++c) {
+        u4[c] = cU[4 * jbl + c]; s4[c] = cS[4 * jbl + c]; m4[c] = cM[4 * jbl + c];
+        lo4[c] = cLo[4 * jbl + c]; hi4[c] = cHi[4 * jbl + c];
+      }
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int i = 4 * jbl + c;
-            T v = cU[i] + (zz[r][c] * cS[i] + cM[i]);
-            if (any_over) {
-              if (orow[r] == -1) v = T(0);
-              else if (orow[r] >= 0) {
-                const int j = j0 + i;
-                v = j < a.J ? a.sampler[(long long)orow[r] * a.J + j] : T(0);
-              }
-            }
-            v = clampT<T>(v, cLo[i], cHi[i]);
-            acc[i] += w[r] * (v - cU[i]);
-          }
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          T v = u4[c] + (zz[r][c] * s4[c] + m4[c]);
+          v = clampT(v, lo4[c], hi4[c]);
+          acc[4 * jbl + c] += w[r] * (v - u4[c]);
         }
       }
     }
@@ -285,6 +305,12 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs
 #pragma unroll
     for (int i = 1; i < BLOCK / WAVE; ++i) s += wsum[i][threadIdx.x];
     const int j = j0 + threadIdx.x;
+    const int kbeg = kc * R * BLOCK;
+    if (a.k_offset + kbeg < n_over && j < a.J) {
+      const int kend = (kbeg + R * BLOCK) < a.K ? (kbeg + R * BLOCK) : a.K;
+      s += overwrite_correction<T>(a, kbeg, kend, j, cU[threadIdx.x], cLo[threadIdx.x], cHi[threadIdx.x],
+                                   beta, inv_lambda);
+    }
     if (j < a.Jpad) a.P_part[(long long)kc * a.Jpad + j] = s;
   }
   if (jt == 0 && threadIdx.x == 0) a.eta_part[kc] = eta_b;
@@ -298,10 +324,13 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_full_kernel(const KArgs
   constexpr int TJ = SSB * P4 * 4;                      // columns per tile (<= 64)
   static_assert(TJ <= 64, "tile too wide");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* Ue = reinterpret_cast<T*>(smem_raw);               // [J + slack]
+  T* Ue = reinterpret_cast<T*>(smem_raw);               // [J]
+  T* fac = Ue + a.J;                                    // [2*NU*NU]
   __shared__ T red[BLOCK / WAVE];
   __shared__ T wsum[BLOCK / WAVE][64];
   const int kc = blockIdx.x, jt = blockIdx.y;
+  ActionConsts<T, NU> ac;
+  ac.load(a, fac);
   for (int j = threadIdx.x; j < a.J; j += BLOCK) Ue[j] = u_eff(a, j);
   const T beta = shard_beta(a, red);
   const T inv_lambda = T(1) / a.lambda_;
@@ -336,7 +365,7 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_full_kernel(const KArgs
             T z[NU], v[NU], e[NU];
 #pragma unroll
             for (int n = 0; n < NU; ++n) z[n] = zc[tt * NU + n];
-            make_action<T, NU>(a, Ue, t, z, orow, v, e);
+            make_action_rt<T, NU>(a, ac, Ue, t, z, orow, v, e);
 #pragma unroll
             for (int n = 0; n < NU; ++n) acc[(sb * TT + tt) * NU + n] += w * e[n];
           }
@@ -369,27 +398,56 @@ __device__ __forceinline__ T fixed_sum(const T* __restrict__ p, int n, T* red) {
   return block_sum<T>(s, red);
 }
 
+// sum over the nkc block partials of column j: 4 waves take every 4th chunk (independent loads,
+// 8 in flight), then a fixed-order combine through LDS.  Valid for threadIdx.x < 64 on return.
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) finalize_kernel(const KArgs<T> a, int apply) {
+__device__ __forceinline__ T column_sum(const KArgs<T>& a, int j, T (*part)[WAVE]) {
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  T s = T(0);
+  if (j < a.Jpad) {
+    int c = wv;
+    for (; c + 7 * (BLOCK / WAVE) < a.nkc; c += 8 * (BLOCK / WAVE)) {
+      T v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = a.P_part[(long long)(c + q * (BLOCK / WAVE)) * a.Jpad + j];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; c < a.nkc; c += BLOCK / WAVE) s += a.P_part[(long long)c * a.Jpad + j];
+  }
+  __syncthreads();
+  part[wv][lane] = s;
+  __syncthreads();
+  T r = part[0][lane];
+#pragma unroll
+  for (int i = 1; i < BLOCK / WAVE; ++i) r += part[i][lane];
+  return r;
+}
+
+// grid.x = ceil(J/64) column blocks (+ extra blocks that only write omega)
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) finalize_kernel(const KArgs<T> a, int apply, int ncolblocks) {
   __shared__ T red[BLOCK / WAVE];
+  __shared__ T part[BLOCK / WAVE][WAVE];
   const T beta = shard_beta(a, red);
   const T eta = fixed_sum<T>(a.eta_part, a.nkc, red);
   const T inv_eta = T(1) / eta;                                        // mppi.py:258
-  const int gid = blockIdx.x * BLOCK + threadIdx.x;
-  if (gid == 0) { a.record[0] = beta; a.record[1] = eta; }
-  if (gid < a.J) {
-    T P = T(0);
-    for (int c = 0; c < a.nkc; ++c) P += a.P_part[(long long)c * a.Jpad + gid];
-    a.record[2 + gid] = P;
-    if (apply) {
-      const T un = u_eff(a, gid) + P * inv_eta;                        // :268-270
-      a.U_out[gid] = un;
-      if (a.action_out != nullptr && gid < a.u_per_command * a.nu) a.action_out[gid] = un;   // :271
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.record[0] = beta; a.record[1] = eta; }
+  if ((int)blockIdx.x < ncolblocks) {
+    const int j = blockIdx.x * WAVE + (threadIdx.x & (WAVE - 1));
+    const T P = column_sum<T>(a, j, part);
+    if (threadIdx.x < WAVE && j < a.J) {
+      a.record[2 + j] = P;
+      if (apply) {
+        const T un = u_eff(a, j) + P * inv_eta;                        // :268-270
+        a.U_out[j] = un;
+        if (a.action_out != nullptr && j < a.u_per_command * a.nu) a.action_out[j] = un;   // :271
+      }
     }
   }
   if (apply && a.omega != nullptr) {
     const T inv_lambda = T(1) / a.lambda_;
-    for (int k = gid; k < a.K; k += gridDim.x * BLOCK)
+    for (int k = blockIdx.x * BLOCK + threadIdx.x; k < a.K; k += gridDim.x * BLOCK)
       a.omega[k] = inv_eta * weight_of<T>(a.cost[k], beta, inv_lambda);
   }
 }
@@ -441,7 +499,7 @@ int launch_noise_from_ktn(const KArgs<T>& a, const T* in, T* out, hipStream_t st
 
 template <typename T>
 int launch_kmppi_interp(const KArgs<T>& a, const T* W, int Thor, int J4out, T* out, hipStream_t st) {
-  const size_t smem = (size_t)a.J * 64 * sizeof(T);
+  const size_t smem = ((size_t)a.J * 64 + 2 * a.nu * a.nu) * sizeof(T);
   if (smem > 160 * 1024) return MPPI_E_UNSUPPORTED;
   const dim3 grid((a.K + 63) / 64), block(64);
 #define X(N)                                                                                      \
@@ -468,7 +526,7 @@ int launch_kmppi_interp(const KArgs<T>& a, const T* W, int Thor, int J4out, T* o
 
 template <typename T>
 int launch_prepare(const KArgs<T>& a, hipStream_t st) {
-  const size_t smem = (size_t)a.J * sizeof(T);
+  const size_t smem = ((size_t)a.J + 2 * a.nu * a.nu) * sizeof(T);
   const dim3 grid((a.K + BLOCK - 1) / BLOCK), block(BLOCK);
 #define X(N)                                                                                      \
   if (a.nu == N) {                                                                                \
@@ -494,13 +552,21 @@ int launch_weights_partial(const KArgs<T>& a, hipStream_t st) {
   if (a.noise_src == MPPI_NOISE_ACTIONS) return MPPI_E_BADARG;
   if (a.diag) {
     const dim3 grid(a.nkc, (a.J4 * 4 + UPD_TJ - 1) / UPD_TJ), block(BLOCK);
-    if (a.noise_src == MPPI_NOISE_PHILOX)
-      hipLaunchKernelGGL((weights_partial_diag_kernel<T, MPPI_NOISE_PHILOX>), grid, block, 0, st, a);
-    else
-      hipLaunchKernelGGL((weights_partial_diag_kernel<T, MPPI_NOISE_TNK4>), grid, block, 0, st, a);
-    return (int)hipGetLastError();
+#define LAUNCH_R(RR)                                                                              \
+  if (a.R == RR) {                                                                                \
+    if (a.noise_src == MPPI_NOISE_PHILOX)                                                         \
+      hipLaunchKernelGGL((weights_partial_diag_kernel<T, MPPI_NOISE_PHILOX, RR>), grid, block, 0, \
+                         st, a);                                                                  \
+    else                                                                                          \
+      hipLaunchKernelGGL((weights_partial_diag_kernel<T, MPPI_NOISE_TNK4, RR>), grid, block, 0,   \
+                         st, a);                                                                  \
+    return (int)hipGetLastError();                                                                \
   }
-  const size_t smem = (size_t)a.J * sizeof(T);
+    LAUNCH_R(1) LAUNCH_R(2) LAUNCH_R(4) LAUNCH_R(8)
+#undef LAUNCH_R
+    return MPPI_E_BADARG;
+  }
+  const size_t smem = ((size_t)a.J + 2 * a.nu * a.nu) * sizeof(T);
 #define X(N)                                                                                      \
   if (a.nu == N) {                                                                                \
     constexpr int P4 = Stream<N>::P4, TT = Stream<N>::TT;                                         \
@@ -522,13 +588,14 @@ int launch_weights_partial(const KArgs<T>& a, hipStream_t st) {
 
 template <typename T>
 int launch_finalize(const KArgs<T>& a, int apply, hipStream_t st) {
-  int nb = (a.J + BLOCK - 1) / BLOCK;
+  const int ncol = (a.J + WAVE - 1) / WAVE;
+  int nb = ncol;
   if (apply && a.omega != nullptr) {
-    const int nbk = (a.K + BLOCK - 1) / BLOCK;
+    int nbk = (a.K + 4 * BLOCK - 1) / (4 * BLOCK);
+    if (nbk > 256) nbk = 256;
     nb = nbk > nb ? nbk : nb;
-    if (nb > 1024) nb = 1024;
   }
-  hipLaunchKernelGGL(finalize_kernel<T>, dim3(nb), dim3(BLOCK), 0, st, a, apply);
+  hipLaunchKernelGGL(finalize_kernel<T>, dim3(nb), dim3(BLOCK), 0, st, a, apply, ncol);
   return (int)hipGetLastError();
 }
 

@@ -33,9 +33,10 @@ class ShardPlan:
 
     def all_gather(self, record):
         """(2+J,) shard record -> (world_size, 2+J), rank order.  The single collective."""
-        out = torch.empty(self.world_size, record.numel(), device=record.device, dtype=record.dtype)
-        dist.all_gather_into_tensor(out, record.contiguous(), group=self.group)
-        return out
+        n = record.numel()
+        out = torch.empty(self.world_size * n, device=record.device, dtype=record.dtype)
+        dist.all_gather_into_tensor(out, record.contiguous().view(-1), group=self.group)
+        return out.view(self.world_size, n)
 
 
 def combine_records_host(records, U_eff, lambda_):

@@ -157,7 +157,7 @@ class MLPResidual(NativeModel):
                        nx, nu, res_scale)
 
     def _param_list(self):
-        return [self.W1, self.b1, self.W2, self.b2, torch.tensor([self.res_scale])]
+        return [self.W1, self.b1, self.W2, self.b2, torch.tensor([self.res_scale], dtype=torch.float64)]
 
     def dynamics(self, state, action):
         W1, b1, W2, b2 = (t.to(state.device, state.dtype) for t in (self.W1, self.b1, self.W2, self.b2))

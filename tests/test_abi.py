@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library builds for gfx950, loads without a GPU and exports every symbol that
+include/mppi_amd.h declares; host-side argument validation refuses bad calls before touching HIP."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from pytorch_mppi_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mppi_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mppi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    lib = N.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mppi_amd.h but not exported"
+        assert name in N.SYMBOLS, f"{name} has no ctypes prototype in _native.SYMBOLS"
+    assert sorted(N.SYMBOLS) == declared
+
+
+def test_abi_version_and_struct_mirror():
+    lib = N.lib()
+    assert lib.mppi_abi_version() == N.ABI_VERSION
+    assert lib.mppi_problem_size() == C.sizeof(N.MppiProblem)
+    hdr = open(os.path.join(ROOT, "include", "mppi_amd.h")).read()
+    assert f"#define MPPI_ABI_VERSION {N.ABI_VERSION}" in hdr
+    # field order of the mirror == field order of the header
+    body = hdr[hdr.index("typedef struct MppiProblem {") + len("typedef struct MppiProblem {"):hdr.index("} MppiProblem;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl or decl.startswith("typedef"):
+            continue
+        parts = decl.replace("*", " ").split(",")
+        first = parts[0].split()
+        names.append(first[-1])
+        names += [x.strip() for x in parts[1:]]
+    assert names == [f[0] for f in N.MppiProblem._fields_]
+
+
+@pytest.mark.parametrize("T,nu,rows", [(64, 12, 192), (15, 1, 4), (10, 2, 5), (10, 3, 9), (32, 1, 8), (8, 4, 8), (7, 6, 12)])
+def test_noise_rows4(T, nu, rows):
+    assert N.noise_rows4(T, nu) == rows
+    assert rows * 4 >= T * nu
+
+
+def test_model_support_table():
+    assert N.model_supported(N.MODEL_PENDULUM, 2, 1, N.F32)
+    assert N.model_supported(N.MODEL_PENDULUM, 2, 1, N.F64)
+    assert N.model_supported(N.MODEL_INTEGRATOR, 16, 12, N.F32)
+    assert N.model_supported(N.MODEL_LINEAR_GOAL, 2, 2, N.F64)
+    assert N.model_supported(N.MODEL_MLP, 16, 4, N.F32, 256)
+    assert not N.model_supported(N.MODEL_MLP, 16, 4, N.F32, 0)
+    assert not N.model_supported(N.MODEL_INTEGRATOR, 7, 5, N.F32)
+    assert not N.model_supported(N.MODEL_NONE, 2, 2, N.F32)
+    assert not N.model_supported(N.MODEL_PENDULUM, 2, 1, 7)
+
+
+def test_bad_calls_refused_on_host():
+    lib = N.lib()
+    assert lib.mppi_rollout_cost(None, None) == -1
+    p = N.MppiProblem()
+    assert lib.mppi_workspace_elems(C.byref(p)) == 0
+    p.K, p.T, p.nx, p.nu, p.dtype = 256, 8, 2, 2, N.F32
+    need = lib.mppi_workspace_elems(C.byref(p))
+    assert need > 0
+    p.lambda_ = 1.0
+    assert lib.mppi_rollout_cost(C.byref(p), None) == -1          # missing parameter arrays
+    assert b"missing" in lib.mppi_last_error()
+    p.dtype = 9
+    assert lib.mppi_prepare(C.byref(p), None) == -1
+    assert b"dtype" in lib.mppi_last_error()
+    with pytest.raises(RuntimeError, match="code -1"):
+        N.check(-1, "x")

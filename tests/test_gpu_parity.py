@@ -175,13 +175,13 @@ def test_size_independent_properties_at_full_size():
     K, T, nx, nu = 65536, 64, 16, 12
     m = pm.models.Integrator(nx, nu)
     torch.manual_seed(0)
-    U0 = torch.randn(T, nu) * 0.3
+    U0 = torch.randn(T, nu) * 0.02     # |U|_2 ~ 0.5: the lambda-independent U.eps term keeps N_eff healthy
     x0 = torch.randn(nx).cuda()
     z = torch.randn(K, T, nu, device="cuda")
 
     def run(zz):
         c = pm.MPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), num_samples=K, horizon=T, device="cuda",
-                    lambda_=500.0, U_init=U0.clone(), sample_null_action=True,
+                    lambda_=1.0e4, U_init=U0.clone(), sample_null_action=True,
                     u_min=torch.tensor([-1.5] * nu), u_max=torch.tensor([1.5] * nu))
         c.inject_noise(zz)
         c.command(x0)

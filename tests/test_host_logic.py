@@ -1,0 +1,213 @@
+"""CPU: host-side mirror of the reference API (constructor resolution, attribute surface, KMPPI
+operators, shard arithmetic, Philox restatement) -- no kernel is launched here."""
+import numpy as np
+import pytest
+import torch
+
+import pytorch_mppi_amd as pm
+from pytorch_mppi_amd import models
+from pytorch_mppi_amd.dist import ShardPlan, combine_records_host
+from oracle import mppi_oracle as orc
+from oracle import philox as oph
+
+
+def _lin():
+    return models.LinearGoal(torch.tensor([[1.0, 0.0], [0.0, -1.0]], dtype=torch.double),
+                             torch.tensor([2.0, 2.0], dtype=torch.double))
+
+
+def test_constructor_resolution_matches_reference_rules():
+    m = _lin()
+    sigma = torch.tensor([[1.0, 0.4], [0.4, 0.5]], dtype=torch.double)
+    c = pm.MPPI(m.dynamics, m.running_cost, 2, sigma, num_samples=128, horizon=12, u_max=torch.tensor([1.5, 1.0], dtype=torch.double),
+                lambda_=2.5, noise_mu=torch.tensor([0.1, -0.2], dtype=torch.double), U_init=torch.zeros(12, 2, dtype=torch.double))
+    p = orc.Problem(dynamics=m.dynamics, running_cost=m.running_cost, nx=2, noise_sigma=sigma, K=128, T=12,
+                    u_max=torch.tensor([1.5, 1.0], dtype=torch.double))
+    assert c.nu == 2 and c.dtype == torch.double and (c.K, c.T) == (128, 12)
+    assert torch.equal(c.u_min, -c.u_max) and torch.equal(c.u_min, p.u_min)       # mppi.py:112-119
+    assert not c._diagonal_sigma
+    assert torch.equal(c._noise_L, p.fac["chol"]) and torch.equal(c.noise_sigma_inv, p.fac["sigma_inv"])
+    assert c._model is m
+    d = pm.MPPI(m.dynamics, m.running_cost, 2, torch.diag(torch.tensor([1.0, 4.0], dtype=torch.double)), U_init=torch.zeros(15, 2, dtype=torch.double))
+    assert d._diagonal_sigma and torch.equal(d._noise_L, torch.diag(torch.tensor([1.0, 2.0], dtype=torch.double)))
+    assert torch.isinf(d.u_min) and torch.isinf(d.u_max)                           # :124-126
+
+
+def test_zero_dim_sigma_and_bounds():
+    """reference tests/pendulum.py:25,76-77 and test_mppi.py:276-291"""
+    m = models.Pendulum()
+    c = pm.MPPI(m.dynamics, m.running_cost, 2, torch.tensor(10.0, dtype=torch.double), num_samples=100, horizon=15,
+                u_min=torch.tensor(-2.0, dtype=torch.double), u_max=torch.tensor(2.0, dtype=torch.double))
+    assert c.nu == 1 and c.noise_sigma.shape == (1, 1) and c.U.shape == (15, 1)
+    assert c._vec(c.u_min).shape == (1,)
+
+
+def test_get_params_format_and_horizon_shift():
+    m = _lin()
+    c = pm.MPPI(m.dynamics, m.running_cost, 2, torch.eye(2, dtype=torch.double), num_samples=100, horizon=10)
+    s = c.get_params()
+    assert "K=100" in s and "T=10" in s and "lambda=1.0" in s                      # test_mppi.py:324-328
+    U0 = c.U.clone()
+    c.u_init = torch.tensor([0.5, -0.5], dtype=torch.double)
+    c.shift_nominal_trajectory()                                                   # test_mppi.py:293-303
+    assert torch.equal(c.U[:-1], U0[1:]) and torch.equal(c.U[-1], c.u_init)
+    c.change_horizon(5)
+    assert c.T == 5 and c.U.shape == (5, 2)
+    c.change_horizon(8)
+    assert c.U.shape == (8, 2) and torch.equal(c.U[5:], c.u_init.repeat(3, 1))
+    c.reset()
+    assert c.U.shape == (8, 2)
+
+
+def test_generator_consumption_matches_reference():
+    """mppi.py:144-145: construction without U_init consumes exactly randn(T,nu)."""
+    m = _lin()
+    torch.manual_seed(3)
+    c = pm.MPPI(m.dynamics, m.running_cost, 2, torch.eye(2, dtype=torch.double), horizon=7)
+    after = torch.randn(1)
+    torch.manual_seed(3)
+    ref = torch.randn(7, 2, dtype=torch.double)
+    after_ref = torch.randn(1)
+    assert torch.equal(c.U, ref) and torch.equal(after, after_ref)
+
+
+def test_native_model_detection():
+    m = _lin()
+    f = lambda s, a: s + a
+    assert models.native_model_of(m.dynamics, m.running_cost) is m
+    assert models.native_model_of(m, m.running_cost) is m
+    assert models.native_model_of(m.dynamics, m.running_cost, m.terminal_state_cost) is m
+    assert models.native_model_of(f, m.running_cost) is None
+    assert models.native_model_of(m.dynamics, lambda s, a: s.sum(-1)) is None
+    assert models.native_model_of(m.dynamics, _lin().running_cost) is None          # different object
+    assert models.native_model_of(models.Pendulum().dynamics, models.Pendulum().running_cost, lambda s, a: 0) is None
+    c = pm.MPPI(m.dynamics, m.running_cost, 2, torch.eye(2, dtype=torch.double), step_dependent_dynamics=True)
+    assert c._model is None
+
+
+def test_native_models_equal_oracle_callables():
+    from oracle import dynamics as dyn
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(50, 2, generator=g, dtype=torch.double) * 3
+    u = torch.randn(50, 1, generator=g, dtype=torch.double) * 3
+    P = models.Pendulum()
+    assert torch.allclose(P.dynamics(x, u), dyn.pendulum_dynamics(x, u), rtol=0, atol=1e-15)
+    assert torch.allclose(P.running_cost(P.dynamics(x, u), u), dyn.pendulum_cost(dyn.pendulum_dynamics(x, u), u), rtol=0, atol=1e-15)
+    x6 = torch.randn(20, 6, generator=g)
+    u4 = torch.randn(20, 4, generator=g)
+    f, q = dyn.make_quadtoy(6, 4)
+    I = models.Integrator(6, 4)
+    assert torch.equal(I.dynamics(x6, u4), f(x6, u4)) and torch.equal(I.running_cost(x6, u4), q(x6, u4))
+    W = dyn.make_mlp_weights(16, 4, 32, seed=2)
+    M = models.MLPResidual(*W, 16, 4)
+    fm, qm = dyn.make_mlp(*W)
+    x16, u4b = torch.randn(9, 16, generator=g), torch.randn(9, 4, generator=g)
+    assert torch.equal(M.dynamics(x16, u4b), fm(x16, u4b))
+    M2 = models.MLPResidual.random(16, 4, 32, seed=2)
+    assert torch.equal(M2.W1, W[0]) and torch.equal(M2.b2, W[3])
+    blob = M.param_blob("cpu", torch.float32)
+    assert blob.numel() == 32 * 20 + 32 + 16 * 32 + 16 + 1
+
+
+def test_cpu_device_has_no_compute_path():
+    m = _lin()
+    c = pm.MPPI(m.dynamics, m.running_cost, 2, torch.eye(2, dtype=torch.double))
+    with pytest.raises(RuntimeError, match="MI355X"):
+        c.command(torch.zeros(2, dtype=torch.double))
+
+
+def test_unbuilt_features_fail_loudly():
+    m = _lin()
+    c = pm.MPPI(m.dynamics, m.running_cost, 2, torch.eye(2, dtype=torch.double), rollout_samples=3, device="cpu")
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        c.command(torch.zeros(2, dtype=torch.double))
+    with pytest.raises(ValueError):
+        pm.MPPI(m.dynamics, m.running_cost, 2, torch.eye(2, dtype=torch.double), rng="mt19937")
+
+
+def test_kmppi_operators_and_rbf():
+    """constant-W form == the reference's per-sample solve; RBF KAT test_mppi.py:560-570"""
+    m = _lin()
+    c = pm.KMPPI(m.dynamics, m.running_cost, 2, torch.eye(2, dtype=torch.double), num_samples=10, horizon=10,
+                 U_init=torch.zeros(10, 2, dtype=torch.double))
+    assert c.num_support_pts == 5 and c.theta.shape == (5, 2)
+    W, Wsh, Tk, Hs = orc.kmppi_matrices(10, 5, torch.double)
+    assert torch.allclose(c._W, W, atol=1e-12) and torch.allclose(c._W_shift, Wsh, atol=1e-12)
+    assert torch.equal(c.Tk[0], Tk) and torch.equal(c.Hs[0], Hs) and c.Tk.shape == (10, 5)
+    theta = torch.randn(5, 2, dtype=torch.double)
+    traj, _ = c.deparameterize_to_trajectory_single(theta)
+    assert torch.allclose(traj, W @ theta, atol=1e-10)
+    tb, _ = c.deparameterize_to_trajectory_batch(theta.expand(10, -1, -1).contiguous())
+    assert torch.allclose(tb[3], traj, atol=1e-10)
+    k = pm.RBFKernel(sigma=1.0)
+    tt = torch.tensor([[0.0], [1.0]], dtype=torch.double)
+    kk = k(tt, tt)
+    assert torch.allclose(kk.diag(), torch.ones(2, dtype=torch.double), atol=1e-6)
+    assert abs(float(kk[0, 1]) - np.exp(-0.5)) < 1e-6
+    assert "num_support_pts=5" in c.get_params() and "RBFKernel(sigma=1)" in c.get_params()
+    c.theta = theta.clone()
+    c.shift_nominal_trajectory()
+    assert torch.allclose(c.theta, Wsh @ theta, atol=1e-12)
+    c.change_horizon(12)                 # the reference leaves Tk/Hs stale here (SURVEY A-15)
+    assert c._W.shape == (12, 5)
+    c.reset()
+    assert float(c.theta.abs().sum()) == 0.0
+
+
+def test_sampler_slice_bookkeeping():
+    s = pm.SpecificActionSampler()
+    s.register_sample_start_end(1, 4)
+    assert (s.start_idx, s.end_idx, s.slice) == (1, 4, slice(1, 4))
+    x = torch.zeros(3)
+    assert s.specific_dynamics(x, x, x, 0) is x
+
+
+@pytest.mark.parametrize("K,G", [(65536, 8), (100, 3), (7, 7), (524288, 8)])
+def test_shard_plan_partitions_contiguously(K, G):
+    lo_prev = 0
+    for r in range(G):
+        sp = ShardPlan(K, r, G)
+        assert sp.k_offset == lo_prev and sp.K_local >= 1
+        assert sp.bounds(r) == (sp.k_offset, sp.k_offset + sp.K_local)
+        lo_prev += sp.K_local
+    assert lo_prev == K
+    with pytest.raises(ValueError):
+        ShardPlan(2, 0, 3)
+
+
+def test_combine_records_equals_global_softmax():
+    """the shard records {beta_g, eta_g, P_g} combined in rank order == one global softmax update"""
+    g = torch.Generator().manual_seed(1)
+    K, T, nu, lam = 200, 6, 3, 4.0
+    cost = torch.randn(K, generator=g, dtype=torch.double) * 10 + 50
+    noise = torch.randn(K, T, nu, generator=g, dtype=torch.double)
+    U = torch.randn(T, nu, generator=g, dtype=torch.double)
+    omega, w, beta, eta = orc.weights(cost, lam)
+    U_ref = U + torch.einsum("k,ktn->tn", omega, noise)
+    recs = []
+    for r in range(3):
+        lo, hi = ShardPlan(K, r, 3).bounds(r)
+        b = cost[lo:hi].min()
+        wg = torch.exp(-(1 / lam) * (cost[lo:hi] - b))
+        recs.append(torch.cat([b.view(1), wg.sum().view(1), torch.einsum("k,ktn->tn", wg, noise[lo:hi]).reshape(-1)]))
+    U_new, beta2, eta2 = combine_records_host(torch.stack(recs), U, lam)
+    assert torch.allclose(U_new, U_ref, rtol=1e-12, atol=1e-12)
+    assert float(beta2) == float(beta) and abs(float(eta2) - float(eta)) < 1e-9 * float(eta)
+
+
+def test_philox_known_answers_and_moments():
+    """Random123 KATs for Philox4x32-10 + N(0,1) moments + layout map."""
+    r = oph.philox4x32_10([0], [0], [0], [0], 0, 0)
+    assert [int(x[0]) for x in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    r = oph.philox4x32_10([0xffffffff], [0xffffffff], [0xffffffff], [0xffffffff], 0xffffffff, 0xffffffff)
+    assert [int(x[0]) for x in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    r = oph.philox4x32_10([0x243f6a88], [0x85a308d3], [0x13198a2e], [0x03707344], 0xa4093822, 0x299f31d0)
+    assert [int(x[0]) for x in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    z = oph.normals_ktn(seed=42, call=1, K=4096, T=16, nu=3)
+    assert z.shape == (4096, 16, 3)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    assert abs(np.mean(z ** 4) - 3.0) < 0.1
+    # shard independence: rows of a shard == the same global rows
+    z2 = oph.normals_ktn(seed=42, call=1, K=100, T=16, nu=3, k_offset=1000)
+    assert np.array_equal(z2, z[1000:1100])
+    assert not np.array_equal(oph.normals_ktn(42, 2, 8, 16, 3), z[:8])
