@@ -140,13 +140,16 @@ def main():
     shard = (rank, world) if world > 1 else None
     ctrl, x0, _ = make_controller(pm, args.workload, device, args.rng, shard, Kglobal)
 
-    # healthy softmax: lambda ~ std of the cost, from one untimed command
-    ctrl.command(x0)
+    # healthy softmax: lambda ~ std of the rollout cost, measured by a throw-away
+    # probe controller (its first update, made at lambda=1, is an argmin copy and is discarded)
     if kind != "pendulum":
-        lam = ctrl.cost_total.float().std()
+        probe, _, _ = make_controller(pm, args.workload, device, args.rng, shard, Kglobal)
+        probe.command(x0)
+        lam = probe.cost_total.float().std()
         if world > 1:
             dist.all_reduce(lam, op=dist.ReduceOp.AVG)
         ctrl.lambda_ = float(lam)
+        del probe
 
     def barrier():
         if world > 1:

@@ -21,39 +21,113 @@
 
 namespace mppi {
 
+// Per-block tables in LDS, one entry per (t,n) of the horizon (J = T*nu each):
+//   Ue[j]  nominal sequence with the shift applied                         (mppi.py:232-238)
+//   Um[j]  Ue[j] + mu[n]                    -> v = fma(z, sqrt(diag), Um)   (:201-206, :380)
+//   G[j]   lambda * (Sigma^-1 Ue[t])[n]     -> pert += G * e                (:186-199, :415)
+// G folds lambda*e*Sigma^-1 . U into ONE fma per control dimension (for a full Sigma it removes
+// the nu x nu product from the time loop entirely); the association differs from the
+// reference's ((lambda*e)*Sigma^-1)*U by rounding only (parity tests: 1e-5 fp32 / 1e-9 fp64).
+template <typename T>
+struct StepTables {
+  const T* Ue;
+  const T* Um;
+  const T* G;
+};
+
 // one timestep: actions from z, action cost, dynamics, running cost
 template <class Model, typename T, int NOISE, bool DIAG, bool SLOW>
 __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionConsts<T, Model::NU>& ac,
-                                             const Model& model, const T* __restrict__ Ue, int k,
+                                             const Model& model, const StepTables<T>& tb, int k,
                                              bool active, int orow, int t, const T* zt,
                                              T (&x)[Model::NX], T& rollout, T& pert) {
   constexpr int NX = Model::NX, NU = Model::NU;
   constexpr bool SRC_ACTIONS = NOISE == MPPI_NOISE_ACTIONS;
-  T z[NU], v[NU], e[NU], u[NU];
+  T z[NU], v[NU], u[NU];
 #pragma unroll
   for (int n = 0; n < NU; ++n) z[n] = zt[n];
-  const T* srow = nullptr;
-  if constexpr (SLOW) srow = orow >= 0 ? a.sampler + ((long long)orow * a.Tn + t) * NU : nullptr;
-  make_action<T, NU, DIAG, SRC_ACTIONS>(ac, Ue + t * NU, srow, z, SLOW ? orow : -2, v, e);
-  pert += action_cost_dot<T, NU, DIAG>(ac, Ue + t * NU, e);
+#ifdef MPPI_K1_STREAM_ONLY   // experiment: memory pipeline only (tools/k1_sweep.py), never shipped
 #pragma unroll
-  for (int n = 0; n < NU; ++n) u[n] = a.u_scale * v[n];          // mppi.py:313
-  model.step(x, u, t);                                           // :314
-  rollout += model.cost(x, u, t);                                // :318-319
+  for (int n = 0; n < NU; ++n) rollout += z[n];
+  return;
+#endif
+  const T* __restrict__ Ut = tb.Ue + t * NU;
+  const T* __restrict__ Umt = tb.Um + t * NU;
+  const T* __restrict__ Gt = tb.G + t * NU;
+  if constexpr (SRC_ACTIONS) {
+#pragma unroll
+    for (int n = 0; n < NU; ++n) v[n] = z[n];
+  } else if constexpr (DIAG) {
+#pragma unroll
+    for (int n = 0; n < NU; ++n) v[n] = m_fma(z[n], ac.sd[n], Umt[n]);
+  } else {
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+      T s = Umt[n];
+#pragma unroll
+      for (int m = 0; m <= n; ++m) s = m_fma(z[m], ac.Lm[n * NU + m], s);   // L is lower triangular
+      v[n] = s;
+    }
+  }
+  if constexpr (SLOW) {
+    if (orow == -1) {
+#pragma unroll
+      for (int n = 0; n < NU; ++n) v[n] = T(0);                            // mppi.py:390-392
+    } else if (orow >= 0) {
+      const T* __restrict__ srow = a.sampler + ((long long)orow * a.Tn + t) * NU;
+#pragma unroll
+      for (int n = 0; n < NU; ++n) v[n] = srow[n];                         // :393-399
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NU; ++n) {
+    v[n] = clampT(v[n], ac.lo[n], ac.hi[n]);                               // :383
+    const T e = v[n] - Ut[n];                                              // :385
+    pert = m_fma(Gt[n], ac.abs_cost ? m_abs(e) : e, pert);                 // :409, :415
+    u[n] = a.u_scale * v[n];                                               // :313
+  }
+  model.step(x, u, t);                                                     // :314
+  rollout += model.cost(x, u, t);                                          // :318-319
   if constexpr (SLOW) {
     if (a.states != nullptr && active) {
       T* __restrict__ so = a.states + ((long long)k * a.Tn + t) * NX;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) so[i] = x[i];                 // :321
+      for (int i = 0; i < NX; ++i) so[i] = x[i];                           // :321
     }
+  }
+}
+
+#ifndef MPPI_K1_ROWS
+#define MPPI_K1_ROWS 24     // rows-of-4 (16 B each) a lane keeps in flight; fp64 uses half
+#endif
+
+// depth (in super-steps) of the register ring for a given control width / element type
+template <int NU, typename T>
+struct Ring {
+  static constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
+  static constexpr int DROWS = (sizeof(T) == 4 ? MPPI_K1_ROWS : MPPI_K1_ROWS / 2) / P4;
+  static constexpr int DSTEP = 16 / TT;                  // at most 16 timesteps ahead
+  static constexpr int D0 = DROWS < DSTEP ? DROWS : DSTEP;
+  static constexpr int D = D0 < 2 ? 2 : D0;
+};
+
+template <typename T, int NOISE, int NU>
+__device__ __forceinline__ void ring_fetch(const KArgs<T>& a, int ss, int k, T (&dst)[Stream<NU>::P4 * 4]) {
+  constexpr int P4 = Stream<NU>::P4;
+#pragma unroll
+  for (int i = 0; i < P4; ++i) {
+    T r[4];
+    noise4<T, NOISE>(a, (long long)ss * P4 + i, k, r);
+    dst[4 * i + 0] = r[0]; dst[4 * i + 1] = r[1]; dst[4 * i + 2] = r[2]; dst[4 * i + 3] = r[3];
   }
 }
 
 template <class Model, typename T, int NOISE, bool DIAG, bool SLOW>
 __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionConsts<T, Model::NU>& ac,
-                                               const Model& model, const T* __restrict__ Ue, int k,
-                                               bool active, int orow, T (&x)[Model::NX], T& rollout,
-                                               T& pert) {
+                                               const Model& model, const StepTables<T>& tb, int k,
+                                               bool active, int orow,
+                                               T (&ring)[Ring<Model::NU, T>::D][Stream<Model::NU>::P4 * 4],
+                                               T (&x)[Model::NX], T& rollout, T& pert) {
   constexpr int NU = Model::NU;
   constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
   const int nss = (a.Tn + TT - 1) / TT;
@@ -72,31 +146,17 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
       for (int tt = 0; tt < TT; ++tt) {
         const int t = ss * TT + tt;
         if (t < a.Tn)
-          rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, Ue, k, active, orow, t, zc + tt * NU, x,
+          rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, tb, k, active, orow, t, zc + tt * NU, x,
                                                     rollout, pert);
       }
     }
     return;
   } else {
-    // ring depth: ~24 rows-of-4 in flight per lane, at most 16 timesteps ahead
-    constexpr int DROWS = (sizeof(T) == 4 ? 24 : 12) / P4;
-    constexpr int DSTEP = 16 / TT;
-    constexpr int D0 = DROWS < DSTEP ? DROWS : DSTEP;
-    constexpr int D = D0 < 2 ? 2 : D0;
+    constexpr int D = Ring<NU, T>::D;
     const int last = nss - 1;
     const int nss_full = a.Tn / TT;          // super-steps whose TT timesteps all exist
-    T ring[D][P4 * 4];
     int kf = k;                              // sample index as seen by the refill loads
-    auto fetch = [&](int ss, T (&dst)[P4 * 4]) {
-#pragma unroll
-      for (int i = 0; i < P4; ++i) {
-        T r[4];
-        noise4<T, NOISE>(a, (long long)ss * P4 + i, kf, r);
-        dst[4 * i + 0] = r[0]; dst[4 * i + 1] = r[1]; dst[4 * i + 2] = r[2]; dst[4 * i + 3] = r[3];
-      }
-    };
-#pragma unroll
-    for (int d = 0; d < D; ++d) fetch(d < last ? d : last, ring[d]);
+    auto fetch = [&](int ss, T (&dst)[P4 * 4]) { ring_fetch<T, NOISE, NU>(a, ss, kf, dst); };
 
     int ss0 = 0;
     // ---- main loop: whole groups of D complete super-steps, no branch, no conditional VMEM ----
@@ -110,9 +170,13 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
 #pragma unroll
         for (int i = 0; i < P4 * 4; ++i) asm volatile("" : "+v"(ring[d][i]) : "v"(rollout));
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-          rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, Ue, k, active, orow, ss * TT + tt,
+        for (int tt = 0; tt < TT; ++tt) {
+          int t = ss * TT + tt;
+          // same pin for the LDS table reads of this step (their addresses depend only on t)
+          asm volatile("" : "+s"(t) : "v"(rollout));
+          rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, tb, k, active, orow, t,
                                                     &ring[d][tt * NU], x, rollout, pert);
+        }
         // Refill slot d only AFTER it has been consumed (the address is made to depend on the
         // step's result): the load then lands in the same registers, the loop carries no copy of
         // a just-loaded value and therefore no wait on the youngest loads at the back edge.
@@ -129,7 +193,7 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
         for (int tt = 0; tt < TT; ++tt) {
           const int t = ss * TT + tt;
           if (t < a.Tn)
-            rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, Ue, k, active, orow, t,
+            rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, tb, k, active, orow, t,
                                                       &ring[d][tt * NU], x, rollout, pert);
         }
       }
@@ -143,13 +207,10 @@ __global__ void __launch_bounds__(BLOCK) rollout_cost_kernel(const KArgs<T> a) {
   constexpr int NX = Model::NX, NU = Model::NU;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ue = reinterpret_cast<T*>(smem_raw);   // [J] nominal sequence, shift applied
-  T* red = Ue + a.J;                        // [BLOCK/WAVE]
+  T* Um = Ue + a.J;                         // [J] Ue + mu
+  T* G = Um + a.J;                          // [J] lambda * Sigma^-1 Ue[t]
+  T* red = G + a.J;                         // [BLOCK/WAVE]
   T* fac = red + BLOCK / WAVE;              // [2*NU*NU] full-Sigma factors (only if !DIAG)
-
-  ActionConsts<T, NU> ac;
-  ac.load(a, DIAG ? nullptr : fac);
-  for (int j = threadIdx.x; j < a.J; j += BLOCK) Ue[j] = u_eff(a, j);
-  __syncthreads();
 
   const int kraw = blockIdx.x * BLOCK + threadIdx.x;
   const bool active = kraw < a.K;
@@ -157,6 +218,16 @@ __global__ void __launch_bounds__(BLOCK) rollout_cost_kernel(const KArgs<T> a) {
   const long long kg = a.k_offset + k;
   const int orow = overwrite_row(a, kg);
 
+  // Issue order matters (loads retire in order): first the few loads the set-up needs (nominal
+  // sequence, initial state), then the ring prologue, so that the set-up's waits do not sit
+  // behind 24 KiB of noise per wave and the noise latency overlaps the LDS fill + barrier.
+  T uload[8];
+  constexpr int UL = 8;
+#pragma unroll
+  for (int q = 0; q < UL; ++q) {
+    const int j = threadIdx.x + q * BLOCK;
+    uload[q] = j < a.J ? u_eff(a, j) : T(0);
+  }
   const Model model(a);
   T x[NX];
   {
@@ -164,14 +235,47 @@ __global__ void __launch_bounds__(BLOCK) rollout_cost_kernel(const KArgs<T> a) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = s0[i];      // mppi.py:302-305
   }
+  ActionConsts<T, NU> ac;
+  ac.load(a, DIAG ? nullptr : fac);
+
+  constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT, D = Ring<NU, T>::D;
+  T ring[D][P4 * 4];
+  if constexpr (NOISE != MPPI_NOISE_PHILOX) {
+    const int last = (a.Tn + TT - 1) / TT - 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring_fetch<T, NOISE, NU>(a, d < last ? d : last, k, ring[d]);
+  }
+
+#pragma unroll
+  for (int q = 0; q < UL; ++q) {
+    const int j = threadIdx.x + q * BLOCK;
+    if (j < a.J) Ue[j] = uload[q];
+  }
+  for (int j = threadIdx.x + UL * BLOCK; j < a.J; j += BLOCK) Ue[j] = u_eff(a, j);   // very long horizons
+  __syncthreads();
+  for (int j = threadIdx.x; j < a.J; j += BLOCK) {
+    const int n = j % NU, t0 = j - n;
+    const T uj = Ue[j];
+    Um[j] = uj + a.mu[n];
+    T g;
+    if constexpr (DIAG) {
+      g = uj * a.sinv[n * NU + n];
+    } else {
+      g = T(0);
+      for (int m = 0; m < NU; ++m) g = m_fma(ac.Sm[n * NU + m], Ue[t0 + m], g);   // Sigma^-1 symmetric
+    }
+    G[j] = a.lambda_ * g;
+  }
+  __syncthreads();
+  const StepTables<T> tb{Ue, Um, G};
 
   T rollout = T(0), pert = T(0);
   // wave-uniform choice: does this wave own overwritten rows, or must it store the states?
   const bool slow = __any(orow != -2) || a.states != nullptr;
   if (slow)
-    rollout_stream<Model, T, NOISE, DIAG, true>(a, ac, model, Ue, k, active, orow, x, rollout, pert);
+    rollout_stream<Model, T, NOISE, DIAG, true>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
   else
-    rollout_stream<Model, T, NOISE, DIAG, false>(a, ac, model, Ue, k, active, orow, x, rollout, pert);
+    rollout_stream<Model, T, NOISE, DIAG, false>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
 
   if (a.use_terminal) rollout += model.terminal(x);                    // :324-328
   const T total = rollout + pert;                                      // :416
@@ -187,7 +291,7 @@ template <class Model, typename T>
 static int launch_rollout(const KArgs<T>& a, hipStream_t st) {
   constexpr int NU = Model::NU;
   const bool diag = a.diag != 0;
-  const size_t smem = (size_t)(a.J + BLOCK / WAVE + (diag ? 0 : 2 * NU * NU)) * sizeof(T);
+  const size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (diag ? 0 : 2 * NU * NU)) * sizeof(T);
   const dim3 grid((a.K + BLOCK - 1) / BLOCK), block(BLOCK);
 #define MPPI_LAUNCH(NOISE_)                                                                        \
   do {                                                                                             \

@@ -185,6 +185,7 @@ class MPPI:
             self.K_local = self._shard.K_local
         self._ws = None
         self._z_native = None
+        self._vec_cache = {}
         self._profile = None       # bench.py: {"rollout_cost": [(ev0, ev1), ...]} HIP events around K1
 
     # ------------------------------------------------------------------------------------------
@@ -265,9 +266,21 @@ class MPPI:
         return (self.K_local, self.T, self.nu)
 
     def _vec(self, t):
-        """(nu,) parameter on device in dtype (0-dim bounds broadcast, mppi.py:124-126)."""
-        t = torch.as_tensor(t).to(device=self.d, dtype=self.dtype)
-        return t.reshape(-1).expand(self.nu).contiguous() if t.numel() == 1 else t.reshape(-1).contiguous()
+        """(nu,) parameter on device in dtype (0-dim bounds broadcast, mppi.py:124-126).  Cached on
+        (tensor identity, in-place version) so that a steady-state command() launches no copy
+        kernels for parameters, while assignments / in-place edits by the caller are picked up."""
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(t)
+        key = (id(t), t._version, self.nu, self.dtype, str(self.d))
+        hit = self._vec_cache.get(key)
+        if hit is not None and hit[0] is t:
+            return hit[1]
+        v = t.detach().to(device=self.d, dtype=self.dtype)
+        v = v.reshape(-1).expand(self.nu).contiguous() if v.numel() == 1 else v.reshape(-1).contiguous()
+        if len(self._vec_cache) > 64:
+            self._vec_cache.clear()
+        self._vec_cache[key] = (t, v)
+        return v
 
     def _problem(self, Tn=None, U=None):
         """Fill the static part of an MppiProblem for this controller."""
