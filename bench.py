@@ -10,8 +10,9 @@ nx=16, nu=12, fp32) -- the configuration the north_star's roofline target is quo
 per GPU (weak scaling: the sample axis is sharded, K_global = N*65536).
 Prints ONE JSON line (rank 0).  `roofline` is for K1 = rollout_cost_kernel (HBM-bound: it streams
 the K*T*nu standard normals once): algorithmic bytes 4*K*T*nu + 4*K per launch
-divided by its average duration, measured with HIP events around every K1 launch inside the
-timed region (the engine launches on torch's current stream, so torch.cuda.Event brackets it).
+divided by its average duration, measured with HIP events attached to every K1 launch of the
+timed region (hipExtLaunchKernelGGL start/stop events on the kernel itself, on the stream the engine
+launches on = torch's current stream; C-ABI mppi_profile_enable / mppi_profile_read).
 `cpu_baseline` times the oracle (CPU restatement of the reference path, kind "port") on a bounded
 sample of the same workload on the host cores.
 """
@@ -156,17 +157,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from pytorch_mppi_amd import _native as N
+    import ctypes as C
+    lib = N.lib()
     for _ in range(args.warmup):
         ctrl.command(x0)
-    ctrl._profile = {}
+    lib.mppi_profile_enable(1)      # kernel-attached HIP events on every K1 launch of the timed region
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctrl.command(x0)
     barrier()
     dt = time.perf_counter() - t0
-    prof = ctrl._profile
-    ctrl._profile = None
+    k1_sum, k1_n = C.c_double(0), C.c_int64(0)
+    N.check(lib.mppi_profile_read(C.byref(k1_sum), C.byref(k1_n)), "mppi_profile_read")
+    lib.mppi_profile_enable(0)
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -176,8 +181,8 @@ def main():
     n_eff = 1.0 / float((ctrl.omega.double() ** 2).sum()) if ctrl.omega is not None else None
 
     # ---- roofline of K1 from the HIP events recorded inside the timed region ----
-    k1 = [a.elapsed_time(b) for a, b in prof.get("rollout_cost", [])]
-    k1_ms = sum(k1) / max(1, len(k1))
+    k1 = k1_n.value
+    k1_ms = k1_sum.value / max(1, k1)
     Klocal = ctrl.K_local
     alg_bytes = 4 * Klocal * T * nu + 4 * Klocal
     roofline = None

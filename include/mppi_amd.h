@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 3
+#define MPPI_ABI_VERSION 4
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -171,6 +171,14 @@ int mppi_finalize(const MppiProblem* p, int apply, void* stream);
  * on every rank: beta = min beta_g; s_g = exp(-(beta_g-beta)/lambda); eta = sum s_g eta_g;
  * U_out = shift(U) + sum s_g P_g / eta; rescales this shard's omega. */
 int mppi_combine(const MppiProblem* p, const void* records, int32_t n_shards, void* stream);
+
+/* Measurement hooks (bench.py).  While enabled, every K1 launch (mppi_rollout_cost) is made with
+ * hipExtLaunchKernelGGL start/stop events attached to the KERNEL ITSELF (not to the stream around
+ * it), so the elapsed time is the kernel's own duration -- what `rocprofv3 --kernel-trace`
+ * reports.  mppi_profile_read synchronises on the recorded events, returns their count and the
+ * sum of durations in milliseconds, and clears the record. */
+int mppi_profile_enable(int on);
+int mppi_profile_read(double* sum_ms, int64_t* count);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS = 0, 1, 2
@@ -60,6 +60,8 @@ SYMBOLS = {
     "mppi_weights_partial": (C.c_int, [_PP, _vp]),
     "mppi_finalize": (C.c_int, [_PP, C.c_int, _vp]),
     "mppi_combine": (C.c_int, [_PP, _vp, C.c_int32, _vp]),
+    "mppi_profile_enable": (C.c_int, [C.c_int]),
+    "mppi_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

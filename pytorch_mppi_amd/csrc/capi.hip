@@ -119,6 +119,48 @@ int do_rollout(const MppiProblem* p, hipStream_t st) {
    : (p)->dtype == MPPI_F64 ? (expr_f64)                                \
                             : fail(MPPI_E_BADARG, "bad dtype"))
 
+// ---- measurement hook -------------------------------------------------------------------------
+namespace {
+constexpr int PROF_MAX = 8192;
+bool g_prof_on = false;
+int g_prof_n = 0;
+hipEvent_t g_prof_ev[PROF_MAX][2];
+int g_prof_created = 0;
+}  // namespace
+namespace mppi {
+bool profile_next_events(hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_prof_on || g_prof_n >= PROF_MAX) return false;
+  if (g_prof_n >= g_prof_created) {
+    if (hipEventCreate(&g_prof_ev[g_prof_n][0]) != hipSuccess) return false;
+    if (hipEventCreate(&g_prof_ev[g_prof_n][1]) != hipSuccess) return false;
+    g_prof_created = g_prof_n + 1;
+  }
+  *start = g_prof_ev[g_prof_n][0];
+  *stop = g_prof_ev[g_prof_n][1];
+  ++g_prof_n;
+  return true;
+}
+}  // namespace mppi
+extern "C" int mppi_profile_enable(int on) {
+  g_prof_on = on != 0;
+  if (on) g_prof_n = 0;
+  return 0;
+}
+extern "C" int mppi_profile_read(double* sum_ms, int64_t* count) {
+  double s = 0;
+  for (int i = 0; i < g_prof_n; ++i) {
+    hipError_t e = hipEventSynchronize(g_prof_ev[i][1]);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]);
+    if (e != hipSuccess) return hipfail((int)e, "mppi_profile_read");
+    s += ms;
+  }
+  if (sum_ms) *sum_ms = s;
+  if (count) *count = g_prof_n;
+  g_prof_n = 0;
+  return 0;
+}
+
 extern "C" int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
 extern "C" int64_t mppi_problem_size(void) { return (int64_t)sizeof(MppiProblem); }
 extern "C" const char* mppi_last_error(void) { return g_err; }

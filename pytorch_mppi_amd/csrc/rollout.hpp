@@ -16,7 +16,9 @@
 // memory traffic (sampler rows, `states` stores) lives in a separate instantiation (SLOW) chosen
 // per wave.
 #pragma once
+#include <hip/hip_ext.h>
 #include "actions.hpp"
+#include "dispatch.hpp"
 #include "models.hpp"
 
 namespace mppi {
@@ -293,12 +295,16 @@ static int launch_rollout(const KArgs<T>& a, hipStream_t st) {
   const bool diag = a.diag != 0;
   const size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (diag ? 0 : 2 * NU * NU)) * sizeof(T);
   const dim3 grid((a.K + BLOCK - 1) / BLOCK), block(BLOCK);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  profile_next_events(&ev0, &ev1);   // null events == plain launch
 #define MPPI_LAUNCH(NOISE_)                                                                        \
   do {                                                                                             \
     if (diag)                                                                                      \
-      hipLaunchKernelGGL((rollout_cost_kernel<Model, T, NOISE_, true>), grid, block, smem, st, a); \
+      hipExtLaunchKernelGGL((rollout_cost_kernel<Model, T, NOISE_, true>), grid, block, smem, st,  \
+                            ev0, ev1, 0, a);                                                       \
     else                                                                                           \
-      hipLaunchKernelGGL((rollout_cost_kernel<Model, T, NOISE_, false>), grid, block, smem, st, a);\
+      hipExtLaunchKernelGGL((rollout_cost_kernel<Model, T, NOISE_, false>), grid, block, smem, st, \
+                            ev0, ev1, 0, a);                                                       \
   } while (0)
   if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCH(MPPI_NOISE_PHILOX);
   else if (a.noise_src == MPPI_NOISE_ACTIONS) MPPI_LAUNCH(MPPI_NOISE_ACTIONS);

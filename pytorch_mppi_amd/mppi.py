@@ -186,7 +186,6 @@ class MPPI:
         self._ws = None
         self._z_native = None
         self._vec_cache = {}
-        self._profile = None       # bench.py: {"rollout_cost": [(ev0, ev1), ...]} HIP events around K1
 
     # ------------------------------------------------------------------------------------------
     # parameter resolution (host, once per change)
@@ -401,6 +400,17 @@ class MPPI:
         return not p_ok
 
     def _command(self, state, shift):
+        p = self._begin(state, shift)
+        if self._sharded():
+            self._combine(p, self._shard.all_gather(p._keep["record"]))
+        return self._end(p)
+
+    def _sharded(self):
+        return self._shard is not None and self._shard.world_size > 1
+
+    def _begin(self, state, shift):
+        """Everything local to this shard: noise, K1 (or the generic callback loop), K3, K4.
+        Single shard: K4 also applies the update.  Sharded: K4 only writes the shard record."""
         lib = N.lib()
         self.state = self._to_state(state)
         if self.M != 1:
@@ -423,14 +433,7 @@ class MPPI:
             p._keep["state"] = s0
             p.state_per_sample = int(per_sample)
             p.use_terminal = int(self.terminal_state_cost is not None)
-            prof = self._profile
-            if prof is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
             N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
-            if prof is not None:
-                e1.record()
-                prof.setdefault("rollout_cost", []).append((e0, e1))
         else:
             self._generic_total_cost(p, cost_total, st)
 
@@ -440,19 +443,23 @@ class MPPI:
         U_new = torch.empty(self.T, self.nu, device=self.d, dtype=self.dtype)
         record = torch.empty(2 + self.T * self.nu, device=self.d, dtype=self.dtype)
         p.omega, p.cost_total_non_zero, p.U_out, p.record = _ptr(omega), _ptr(wnz), _ptr(U_new), _ptr(record)
+        p._keep.update(omega=omega, wnz=wnz, U_new=U_new, record=record)
         N.check(lib.mppi_weights_partial(C.byref(p), st), "mppi_weights_partial")
-        if self._shard is None or self._shard.world_size == 1:
-            N.check(lib.mppi_finalize(C.byref(p), 1, st), "mppi_finalize")
-        else:
-            N.check(lib.mppi_finalize(C.byref(p), 0, st), "mppi_finalize")
-            records = self._shard.all_gather(record)
-            p._keep["records"] = records
-            N.check(lib.mppi_combine(C.byref(p), _ptr(records), self._shard.world_size, st), "mppi_combine")
-        self.omega = omega
-        self.cost_total_non_zero = wnz
-        self._record = record
+        N.check(lib.mppi_finalize(C.byref(p), 0 if self._sharded() else 1, st), "mppi_finalize")
+        return p
+
+    def _combine(self, p, records):
+        """K5: identical rank-order combination of the all-gathered shard records on every rank."""
+        p._keep["records"] = records
+        N.check(N.lib().mppi_combine(C.byref(p), _ptr(records), int(records.shape[0]), self._stream()),
+                "mppi_combine")
+
+    def _end(self, p):
+        self.omega = p._keep["omega"]
+        self.cost_total_non_zero = p._keep["wnz"]
+        self._record = p._keep["record"]
         self._last = p                # keeps z / U / sampler tensors alive for the lazy attributes
-        self.U = U_new                                                    # mppi.py:270 (new tensor)
+        self.U = p._keep["U_new"]                                         # mppi.py:270 (new tensor)
         action = self.U[:self.u_per_command]
         if self.u_per_command == 1:
             action = action[0]                                            # :271-275
@@ -738,13 +745,11 @@ class KMPPI(MPPI):
         pt.omega, pt.cost_total_non_zero, pt.U_out, pt.record = _ptr(omega), _ptr(wnz), _ptr(theta_new), _ptr(record)
         pt.u_per_command = 0
         N.check(lib.mppi_weights_partial(C.byref(pt), st), "mppi_weights_partial")
-        if self._shard is None or self._shard.world_size == 1:
+        if not self._sharded():
             N.check(lib.mppi_finalize(C.byref(pt), 1, st), "mppi_finalize")
         else:
             N.check(lib.mppi_finalize(C.byref(pt), 0, st), "mppi_finalize")
-            records = self._shard.all_gather(record)
-            pt._keep["records"] = records
-            N.check(lib.mppi_combine(C.byref(pt), _ptr(records), self._shard.world_size, st), "mppi_combine")
+            self._combine(pt, self._shard.all_gather(record))
         self.omega, self.cost_total_non_zero = omega, wnz
         self._record = record
         self._last, self._last_theta = p, pt

@@ -1,0 +1,114 @@
+"""GPU: the multi-GPU path emulated on one device.  gpurun boxes have ONE GPU (RCCL refuses two
+ranks on a device), so the shards run back to back on cuda:0 and the all-gather is a torch.stack;
+everything else -- contiguous shard plan, per-shard K1/K3/K4 against the shard's own beta, record
+layout, rank-order combine kernel K5 -- is the product code.  The collective itself is
+smoke-tested with nccl(=RCCL) at world_size 1."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pytorch_mppi_amd as pm
+from pytorch_mppi_amd.dist import ShardPlan, combine_records_host
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(K, T, nx, nu, rng, shard, dtype=torch.float32, **kw):
+    m = pm.models.Integrator(nx, nu)
+    g = torch.Generator().manual_seed(3)
+    U0 = torch.randn(T, nu, generator=g, dtype=dtype) * 0.05
+    return pm.MPPI(m.dynamics, m.running_cost, nx, torch.eye(nu, dtype=dtype) * 0.5, num_samples=K, horizon=T,
+                   device="cuda", lambda_=40.0, U_init=U0, rng=rng, seed=99, shard=shard, **kw)
+
+
+def _run_sharded(K, T, nx, nu, world, rng, z=None, dtype=torch.float32, **kw):
+    ctrls = [_mk(K, T, nx, nu, rng, (r, world), dtype, **kw) for r in range(world)]
+    x0 = torch.linspace(-1, 1, nx, dtype=dtype).cuda()
+    ps = []
+    for c in ctrls:
+        if z is not None:
+            c.inject_noise(z)                     # global draw; each shard takes its own rows
+        ps.append(c._begin(x0, True))
+    records = torch.stack([p._keep["record"] for p in ps])      # = all_gather_into_tensor, rank order
+    for c, p in zip(ctrls, ps):
+        c._combine(p, records)
+    acts = [c._end(p) for c, p in zip(ctrls, ps)]
+    return ctrls, acts, records, x0
+
+
+@pytest.mark.parametrize("K,world,dtype", [(4096, 2, torch.float32), (1000, 3, torch.float32), (1536, 8, torch.float64)])
+def test_sharded_equals_unsharded_with_injected_noise(K, world, dtype):
+    T, nx, nu = 12, 6, 4
+    z = torch.randn(K, T, nu, generator=torch.Generator().manual_seed(1), dtype=dtype)
+    ctrls, acts, records, x0 = _run_sharded(K, T, nx, nu, world, "torch", z, dtype, sample_null_action=True)
+    full = _mk(K, T, nx, nu, "torch", None, dtype, sample_null_action=True)
+    full.inject_noise(z)
+    a_full = full.command(x0)
+    tol = 1e-5 if dtype == torch.float32 else 1e-11
+    for c, a in zip(ctrls, acts):
+        assert torch.equal(c.U, ctrls[0].U), "ranks must hold bit-identical U"
+        assert torch.allclose(a, a_full, rtol=tol, atol=tol)
+        assert torch.allclose(c.U, full.U, rtol=tol, atol=tol)
+        lo, hi = c._shard.bounds(c._shard.rank)
+        assert (c.k_offset, c.K_local) == (lo, hi - lo)
+        assert torch.allclose(c.cost_total, full.cost_total[lo:hi], rtol=tol, atol=tol * float(full.cost_total.abs().max()))
+        assert torch.allclose(c.omega, full.omega[lo:hi], rtol=10 * tol, atol=tol)
+    assert abs(sum(float(c.omega.sum()) for c in ctrls) - 1.0) < 1e-5
+    # K5 against its host restatement
+    Ush = torch.roll(full._last._keep["U"], -1, 0)
+    Ush[-1] = 0
+    U_host, beta, eta = combine_records_host(records.double().cpu(), Ush.double().cpu(), 40.0)
+    assert torch.allclose(ctrls[0].U.double().cpu(), U_host, rtol=tol, atol=tol)
+    assert float(beta) == float(full.cost_total.min())
+
+
+def test_philox_stream_is_independent_of_the_number_of_shards():
+    K, T, nx, nu = 3000, 10, 6, 4
+    c2, a2, _, x0 = _run_sharded(K, T, nx, nu, 2, "philox")
+    c5, a5, _, _ = _run_sharded(K, T, nx, nu, 5, "philox")
+    full = _mk(K, T, nx, nu, "philox", None)
+    af = full.command(x0)
+    for a in a2 + a5:
+        assert torch.allclose(a, af, rtol=1e-5, atol=1e-6)
+    # the shards regenerate exactly the rows of the global stream
+    lo, hi = c5[3]._shard.bounds(3)
+    assert torch.equal(c5[3].noise, full.noise[lo:hi])
+    assert torch.equal(c5[3].cost_total, full.cost_total[lo:hi])
+
+
+def test_sampler_rows_live_on_shard_zero_only():
+    """global row bookkeeping (mppi.py:387-400) under sharding"""
+    K, T, nx, nu, world = 512, 8, 6, 4, 4
+    sa = torch.randn(3, T, nu, generator=torch.Generator().manual_seed(5)) * 0.3
+
+    class S(pm.SpecificActionSampler):
+        def sample_trajectories(self, state, info):
+            return sa.clone()
+
+    z = torch.randn(K, T, nu, generator=torch.Generator().manual_seed(2))
+    ctrls, acts, _, x0 = _run_sharded(K, T, nx, nu, world, "torch", z, sample_null_action=True,
+                                      specific_action_sampler=S())
+    full = _mk(K, T, nx, nu, "torch", None, sample_null_action=True, specific_action_sampler=S())
+    full.inject_noise(z)
+    af = full.command(x0)
+    assert torch.allclose(acts[0], af, rtol=1e-5, atol=1e-6)
+    assert torch.equal(ctrls[0].perturbed_action[0], torch.zeros(T, nu, device="cuda"))
+    assert torch.allclose(ctrls[0].perturbed_action[1:4].cpu(), sa, atol=0)
+    assert torch.equal(ctrls[1].perturbed_action, full.perturbed_action[128:256])
+    assert (ctrls[2].specific_action_sampler.start_idx, ctrls[2].specific_action_sampler.end_idx) == (1, 4)
+
+
+def test_record_all_gather_over_rccl_world_size_one():
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rec = torch.arange(2 + 64 * 12, device="cuda", dtype=torch.float32)
+        out = ShardPlan(65536, 0, 1).all_gather(rec)
+        torch.cuda.synchronize()
+        assert out.shape == (1, rec.numel()) and torch.equal(out[0], rec)
+    finally:
+        dist.destroy_process_group()
