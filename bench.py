@@ -197,8 +197,18 @@ def main():
                                 "external-z-equivalent bytes / time, not HBM traffic"}
         else:
             ach = alg_bytes / (k1_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: separate
+            # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 note); null if not collected
+            # for this exact workload/mode
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                if world == 1:
+                    traffic = pmc[f"{args.workload}/{args.rng}"]["rollout_cost_kernel"]["traffic_bytes"]
+            except Exception:
+                traffic = None
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                         "kernel": "rollout_cost_kernel", "avg_launch_us": k1_ms * 1e3,
                         "algorithmic_bytes": alg_bytes,
                         "frac_of_measured_copy_ceiling": ach / HBM_COPY_CEILING_GBS}
