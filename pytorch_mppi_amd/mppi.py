@@ -391,7 +391,7 @@ class MPPI:
         p._keep["sampler"] = actions
 
     def _needs_generic(self):
-        if self._model is None:
+        if self._model is None or self.M != 1:
             return True
         s = self.specific_action_sampler
         if s is not None and type(s).specific_dynamics is not SpecificActionSampler.specific_dynamics:
@@ -413,8 +413,6 @@ class MPPI:
         Single shard: K4 also applies the update.  Sharded: K4 only writes the shard record."""
         lib = N.lib()
         self.state = self._to_state(state)
-        if self.M != 1:
-            raise NotImplementedError("rollout_samples > 1 is not built yet (SURVEY.md 8f-3)")
         p = self._problem()
         p.shift = int(shift)
         st = self._stream()
@@ -483,8 +481,40 @@ class MPPI:
         torch.add(rollout_cost, pert, out=cost_total)                     # mppi.py:416
         N.check(lib.mppi_cost_block_min(C.byref(p), st), "mppi_cost_block_min")
 
+    def _compute_rollout_costs_multi(self, perturbed_actions):
+        """M > 1 state rollouts per action sequence with the discounted variance cost, as
+        mppi.py:334-373 (callbacks see M*K rows); generic path only."""
+        K, T, nu = perturbed_actions.shape
+        M = self.M
+        cost_samples = torch.zeros(M, K, device=self.d, dtype=self.dtype)
+        cost_var = torch.zeros(K, device=self.d, dtype=self.dtype)
+        if tuple(self.state.shape) == (K, self.nx):
+            state0 = self.state
+        else:
+            state0 = self.state.view(1, -1).expand(K, -1)
+        state0 = state0.repeat(M, 1, 1)
+        states = torch.empty(M, K, T, self.nx, device=self.d, dtype=self.dtype)
+        actions = torch.empty(M, K, T, nu, device=self.d, dtype=self.dtype)
+        flat = state0.reshape(M * K, self.nx)
+        sampler = self.specific_action_sampler
+        for t in range(T):
+            u = self.u_scale * perturbed_actions[:, t].expand(M, -1, -1)
+            flat = self._dynamics_fn(flat, u.reshape(M * K, nu), t)
+            if sampler is not None:
+                flat = sampler.specific_dynamics(flat.reshape(M, K, -1), state0.reshape(M, K, -1), u, t).reshape(M * K, -1)
+            c = self._running_cost_fn(flat, u.reshape(M * K, nu), t).reshape(M, K)
+            cost_samples = cost_samples + c
+            cost_var += c.var(dim=0) * self._var_discount_factors[t]
+            states[:, :, t] = flat.reshape(M, K, -1)[:, :, :self.nx]
+            actions[:, :, t] = u
+        cost_samples = cost_samples + self._terminal_state_cost_fn(states, actions)
+        cost_total = cost_samples.mean(dim=0) + cost_var * self.rollout_var_cost
+        return cost_total, states, actions
+
     def _compute_rollout_costs(self, perturbed_actions):
         """The user-callback T-loop, as mppi.py:297-332 (M == 1)."""
+        if self.M > 1:
+            return self._compute_rollout_costs_multi(perturbed_actions)
         K, T, nu = perturbed_actions.shape
         cost_total = torch.zeros(K, device=self.d, dtype=self.dtype)
         if tuple(self.state.shape) == (K, self.nx):
@@ -691,8 +721,6 @@ class KMPPI(MPPI):
     def _command(self, state, shift):
         lib = N.lib()
         self.state = self._to_state(state)
-        if self.M != 1:
-            raise NotImplementedError("rollout_samples > 1 is not built yet (SURVEY.md 8f-3)")
         if shift:
             # explicit shift (tiny (T,nu)/(S,S) host-launched ops) so that theta and U move together
             self.shift_nominal_trajectory()
