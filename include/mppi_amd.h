@@ -20,7 +20,10 @@
  *   MPPI_NOISE_PHILOX no array: the float4 at [jb][k] is generated in-kernel from
  *                     Philox4x32-10(counter = (k_global, jb, call_lo, call_hi), key = seed)
  *                     + Box-Muller, so results do not depend on launch geometry or on the
- *                     number of shards.
+ *                     number of shards.  If p->z is non-NULL in this mode, mppi_rollout_cost /
+ *                     mppi_prepare also STORE the rows they generate there (TNK4), so that the
+ *                     update pass can re-read them (noise_src = TNK4) instead of regenerating:
+ *                     one Philox pass per command, identical numbers either way.
  * The reference's own layout (K,T,nu) (mppi.py:203) is converted with mppi_noise_from_ktn.
  *
  * KMPPI (mppi.py:593-688): mppi_kmppi_interp turns support-point noise (K,S,nu) into raw

@@ -25,6 +25,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
          "-Wno-unused-result"] + os.environ.get("MPPI_EXTRA_HIPCC_FLAGS", "").split()
 
 
+# per-source extras: the Philox instantiations of K3 only stay scratch-free when their 16-row
+# tile loop is fully unrolled (static accumulator indices), which needs a higher pragma-unroll budget
+EXTRA = {"update.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
+
+
 def _hipcc():
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -41,6 +46,7 @@ def _deps_hash():
             h.update(open(os.path.join(CSRC, n), "rb").read())
     h.update(open(os.path.join(INCLUDE, "mppi_amd.h"), "rb").read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA.items())).encode())
     return h.hexdigest()
 
 
@@ -59,7 +65,7 @@ def build(force=False, verbose=True):
 
     def one(src):
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

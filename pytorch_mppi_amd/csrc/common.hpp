@@ -117,6 +117,22 @@ __device__ __forceinline__ void load4<double>(const double* __restrict__ z, long
   out[0] = a.x; out[1] = a.y; out[2] = b.x; out[3] = b.y;
 }
 
+// store one generated row-of-4 into the TNK4 array (Philox "generate once, re-read in K3" mode)
+template <typename T>
+__device__ __forceinline__ void store4(T* __restrict__ z, long long K, long long jb, int k, const T (&v)[4]);
+template <>
+__device__ __forceinline__ void store4<float>(float* __restrict__ z, long long K, long long jb, int k,
+                                              const float (&v)[4]) {
+  *reinterpret_cast<float4*>(z + (jb * K + k) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ __forceinline__ void store4<double>(double* __restrict__ z, long long K, long long jb, int k,
+                                               const double (&v)[4]) {
+  double2* p = reinterpret_cast<double2*>(z + (jb * K + k) * 4);
+  p[0] = make_double2(v[0], v[1]);
+  p[1] = make_double2(v[2], v[3]);
+}
+
 template <typename T, int NOISE>
 __device__ __forceinline__ void noise4(const KArgs<T>& a, long long jb, int k, T (&out)[4]) {
   if constexpr (NOISE == MPPI_NOISE_PHILOX) {

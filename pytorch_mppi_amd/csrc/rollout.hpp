@@ -135,21 +135,34 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
   const int nss = (a.Tn + TT - 1) / TT;
 
   if constexpr (NOISE == MPPI_NOISE_PHILOX) {
-    // generated in registers: no memory pipeline to manage
-    for (int ss = 0; ss < nss; ++ss) {
-      T zc[P4 * 4];
+    // Generated in registers: no memory pipeline, but Philox4x32-10 is a chain of 10 dependent
+    // 32x32->64 multiplies and this wave is alone on its SIMD, so PB super-steps are generated
+    // together (independent counters -> the chains interleave) before they are consumed.
+    constexpr int PB0 = 16 / (P4 * 4) > 0 ? 64 / (P4 * 4) : 1;       // ~64 normals per batch
+    constexpr int PB = PB0 < 2 ? 2 : (PB0 > 8 ? 8 : PB0);
+    for (int ss0 = 0; ss0 < nss; ss0 += PB) {
+      T zb[PB][P4 * 4];
 #pragma unroll
-      for (int i = 0; i < P4; ++i) {
-        T r[4];
-        noise4<T, NOISE>(a, (long long)ss * P4 + i, k, r);
-        zc[4 * i + 0] = r[0]; zc[4 * i + 1] = r[1]; zc[4 * i + 2] = r[2]; zc[4 * i + 3] = r[3];
+      for (int b = 0; b < PB; ++b) {
+#pragma unroll
+        for (int i = 0; i < P4; ++i) {
+          T r[4];
+          const long long jb = (long long)(ss0 + b) * P4 + i;
+          noise4<T, NOISE>(a, jb, k, r);   // rows past the horizon: unused
+          // "generate once": keep the stream for K3 to re-read instead of regenerating it
+          if (a.z != nullptr && active && jb < a.J4) store4<T>(const_cast<T*>(a.z), a.K, jb, k, r);
+          zb[b][4 * i + 0] = r[0]; zb[b][4 * i + 1] = r[1]; zb[b][4 * i + 2] = r[2]; zb[b][4 * i + 3] = r[3];
+        }
       }
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        const int t = ss * TT + tt;
-        if (t < a.Tn)
-          rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, tb, k, active, orow, t, zc + tt * NU, x,
-                                                    rollout, pert);
+      for (int b = 0; b < PB; ++b) {
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          const int t = (ss0 + b) * TT + tt;
+          if (t < a.Tn)
+            rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, tb, k, active, orow, t, &zb[b][tt * NU], x,
+                                                      rollout, pert);
+        }
       }
     }
     return;

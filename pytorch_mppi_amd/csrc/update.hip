@@ -155,6 +155,9 @@ __global__ void __launch_bounds__(BLOCK) prepare_kernel(const KArgs<T> a) {
     for (int i = 0; i < P4; ++i) {
       T r[4];
       noise4<T, NOISE>(a, (long long)ss * P4 + i, k, r);
+      if constexpr (NOISE == MPPI_NOISE_PHILOX) {
+        if (a.z != nullptr) store4<T>(const_cast<T*>(a.z), a.K, (long long)ss * P4 + i, k, r);
+      }
       zc[4 * i] = r[0]; zc[4 * i + 1] = r[1]; zc[4 * i + 2] = r[2]; zc[4 * i + 3] = r[3];
     }
 #pragma unroll

@@ -165,6 +165,7 @@ class MPPI:
         if rng not in ("torch", "torch-native", "philox"):
             raise ValueError("rng must be 'torch', 'torch-native' or 'philox'")
         self.rng = rng
+        self.philox_store = True   # rng="philox": K1 stores the generated rows, K3 re-reads them
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self._call = 0
         self._injected = []
@@ -355,6 +356,13 @@ class MPPI:
             p.noise_src = N.NOISE_PHILOX
             p.call = self._call
             p.z = None
+            if self.philox_store:
+                # generate once in K1 (or mppi_prepare), keep the rows for K3 to re-read: Philox +
+                # Box-Muller costs more per element than an HBM read
+                rows4 = N.noise_rows4(Tn, nu)
+                zn = torch.empty(rows4 * K * 4, device=self.d, dtype=self.dtype)
+                p.z = _ptr(zn)
+                p._keep["z"] = zn
             return
         rows4 = N.noise_rows4(Tn, nu)
         zn = torch.empty(rows4 * K * 4, device=self.d, dtype=self.dtype)
@@ -436,6 +444,8 @@ class MPPI:
             self._generic_total_cost(p, cost_total, st)
 
         self.cost_total = cost_total
+        if p.noise_src == N.NOISE_PHILOX and p.z:
+            p.noise_src = N.NOISE_TNK4        # the rows K1 / mppi_prepare generated are in p.z now
         omega = torch.empty(K, device=self.d, dtype=self.dtype)
         wnz = torch.empty(K, device=self.d, dtype=self.dtype)
         U_new = torch.empty(self.T, self.nu, device=self.d, dtype=self.dtype)
@@ -733,6 +743,8 @@ class KMPPI(MPPI):
         pt.sample_null_action = 0
         self._attach_workspace(pt)
         self._draw_noise(pt, self._noise_shape())
+        if pt.noise_src == N.NOISE_PHILOX:
+            pt.z = None       # support-point stream is tiny: interp and the theta update regenerate it
         # --- trajectory problem ---
         p = self._problem()
         p.shift = 0
