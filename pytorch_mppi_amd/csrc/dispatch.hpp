@@ -16,4 +16,7 @@ MPPI_DECL_MODEL(integrator)
 MPPI_DECL_MODEL(linear_goal)
 MPPI_DECL_MODEL(mlp)
 #undef MPPI_DECL_MODEL
+// fp32 MFMA formulation of the MLP rollout (rollout_mlp_mfma.hip)
+bool mlp_mfma_supported(int nx, int nu, int hidden);
+int rollout_mlp_mfma(const KArgs<float>& a, hipStream_t st);
 }  // namespace mppi

@@ -1,5 +1,6 @@
 // K1 instantiations: 2-layer MLP residual dynamics, per-lane VALU form (any hidden width, f32/f64).
 // BASELINE.json configs[3..4] are (nx,nu,H)=(16,4,256).
+#include <cstdlib>
 #include "dispatch.hpp"
 #include "rollout.hpp"
 namespace mppi {
@@ -18,6 +19,13 @@ template <typename T> static int go(const KArgs<T>& a, hipStream_t st) {
 #undef X
   return MPPI_E_UNSUPPORTED;
 }
-int rollout_mlp(const KArgs<float>& a, hipStream_t st) { return go(a, st); }
+int rollout_mlp(const KArgs<float>& a, hipStream_t st) {
+  // fp32 + (nx,nu)=(16,4) + hidden in {64,128,256}: matrix-core kernel; MPPI_MLP_VALU=1 forces the
+  // per-lane form (A/B measurements, tools/)
+  const char* fv = getenv("MPPI_MLP_VALU");
+  const bool force_valu = fv != nullptr && fv[0] == '1';
+  if (!force_valu && a.states == nullptr && mlp_mfma_supported(a.nx, a.nu, a.hidden)) return rollout_mlp_mfma(a, st);
+  return go(a, st);
+}
 int rollout_mlp(const KArgs<double>& a, hipStream_t st) { return go(a, st); }
 }  // namespace mppi

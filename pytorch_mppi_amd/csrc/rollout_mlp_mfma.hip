@@ -1,0 +1,246 @@
+// K1 for the 2-layer MLP residual model on the matrix cores (fp32, exact: v_mfma_f32_16x16x4_f32
+// is an fmaf chain) -- BASELINE.json configs[3..4]: nx=16, nu=4, hidden=256.
+//
+//   x' = x + s * (W2 tanh(W1 [x;u] + b1) + b2),   cost = sum x^2
+//
+// Transposed chain, samples on the MFMA column axis (16 samples per tile, NT tiles per wave):
+//   layer 1   H^T (H x 16)  = W1 (H x 20)  . [x;u]^T (20 x 16)     A = W1 tile, B = inputs
+//   layer 2   O^T (16 x 16) = W2 (16 x H)  . tanh(H)^T (H x 16)    A = W2 tile, B = tanh(H)
+// D layout of 16x16x4: lane (g = lane>>4, s = lane&15) holds rows 4g+r (r<4) of column s.
+// B layout: lane (g, s) supplies k-index g of the current k-step for column s.
+// So a layer-1 accumulator register r of hidden tile m (rows 16m+4g+r) IS the B operand of the
+// layer-2 k-step "(m, r)" if W2's columns are fetched in that order, and the layer-2 output
+// (state rows 4g+r) IS the B operand of the next timestep's layer-1 k-step "r" if W1's columns
+// are fetched as 4g+r: no lane permutes, no LDS round trip, between layers or between steps.
+// All weights stay in registers for the whole horizon: H/16*5 + H/4 VGPRs per lane (144 at H=256).
+// tanh runs on the VALU in the shadow of the MFMAs (1 - 2/(exp(2x)+1), v_exp + v_rcp).
+#include <hip/hip_ext.h>
+#include "actions.hpp"
+#include "dispatch.hpp"
+
+namespace mppi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float fast_tanh(float x) {
+  // tanh(x) = 1 - 2/(e^{2x}+1); exp2 argument clamped so that e^{2x} stays finite
+  const float t = __builtin_amdgcn_exp2f(fminf(x * 2.8853900817779268f, 126.0f));   // 2*log2(e)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+
+constexpr int MLP_NX = 16, MLP_NU = 4, MLP_NI = 20, MLP_NT = 4;   // NT sample tiles of 16 per wave
+
+template <int HT /* hidden / 16 */, int NOISE, bool DIAG>
+__global__ void __launch_bounds__(BLOCK) rollout_mlp_mfma_kernel(const KArgs<float> a) {
+  constexpr int NU = MLP_NU, NX = MLP_NX, NT = MLP_NT, H = HT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* Ue = reinterpret_cast<float*>(smem_raw);   // [J]
+  float* Um = Ue + a.J;                             // [J]
+  float* G = Um + a.J;                              // [J]
+  float* red = G + a.J;                             // [BLOCK/WAVE]
+  float* b1s = red + BLOCK / WAVE;                  // [H]
+  float* fac = b1s + H;                             // [2*NU*NU]
+
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int g = lane >> 4, s = lane & 15;
+
+  // ---- parameters: blob = W1 (H,20) | b1 (H) | W2 (16,H) | b2 (16) | res_scale ----
+  const float* __restrict__ W1 = a.mp;
+  const float* __restrict__ b1 = W1 + H * MLP_NI;
+  const float* __restrict__ W2 = b1 + H;
+  const float* __restrict__ b2 = W2 + NX * H;
+  const float rs = b2[NX];
+  float w1r[HT][5], w2r[HT][4], b2r[4];
+#pragma unroll
+  for (int m = 0; m < HT; ++m) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w1r[m][q] = W1[(16 * m + s) * MLP_NI + 4 * g + q];
+    w1r[m][4] = W1[(16 * m + s) * MLP_NI + NX + g];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w2r[m][r] = W2[s * H + 16 * m + 4 * g + r];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b2r[r] = b2[4 * g + r];
+
+  ActionConsts<float, NU> ac;
+  ac.load(a, DIAG ? nullptr : fac);
+  for (int j = threadIdx.x; j < a.J; j += BLOCK) Ue[j] = u_eff(a, j);
+  for (int h = threadIdx.x; h < H; h += BLOCK) b1s[h] = b1[h];
+  __syncthreads();
+  for (int j = threadIdx.x; j < a.J; j += BLOCK) {
+    const int n = j % NU, t0 = j - n;
+    const float uj = Ue[j];
+    Um[j] = uj + a.mu[n];
+    float gg;
+    if constexpr (DIAG) {
+      gg = uj * a.sinv[n * NU + n];
+    } else {
+      gg = 0.f;
+      for (int m = 0; m < NU; ++m) gg = fmaf(ac.Sm[n * NU + m], Ue[t0 + m], gg);
+    }
+    G[j] = a.lambda_ * gg;
+  }
+  __syncthreads();
+  // this lane's own control dimension g: constants as scalars
+  const float sd_g = a.L[g * NU + g], lo_g = a.umin[g], hi_g = a.umax[g];
+  float Lrow[NU];
+  if constexpr (!DIAG) {
+#pragma unroll
+    for (int m = 0; m < NU; ++m) Lrow[m] = ac.Lm[g * NU + m];
+  }
+
+  // ---- samples of this wave: tile i covers k = kbase + 16 i + s ----
+  const int kbase = blockIdx.x * BLOCK + wv * (NT * 16);
+  int kk[NT], orow[NT];
+  bool act[NT];
+  float x[NT][4], cpart[NT], ppart[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int kraw = kbase + 16 * i + s;
+    act[i] = kraw < a.K;
+    kk[i] = act[i] ? kraw : a.K - 1;
+    orow[i] = overwrite_row(a, a.k_offset + kk[i]);
+    const float* __restrict__ s0 = a.state_per_sample ? a.state + (long long)kk[i] * NX : a.state;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[i][r] = s0[4 * g + r];
+    cpart[i] = 0.f;
+    ppart[i] = 0.f;
+  }
+
+  float zc[NT][4], zn[NT][4];
+  auto fetch = [&](int t, float (&dst)[NT][4]) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) noise4<float, NOISE == MPPI_NOISE_ACTIONS ? MPPI_NOISE_TNK4 : NOISE>(a, t, kk[i], dst[i]);
+  };
+  fetch(0, zn);   // nu = 4: one row-of-4 per (timestep, sample)
+
+  for (int t = 0; t < a.Tn; ++t) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) zc[i][c] = zn[i][c];
+    }
+    if constexpr (NOISE == MPPI_NOISE_PHILOX) {
+      if (a.z != nullptr && g == 0) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+          if (act[i]) store4<float>(const_cast<float*>(a.z), a.K, t, kk[i], zc[i]);
+      }
+    }
+    fetch(t + 1 < a.Tn ? t + 1 : t, zn);   // prefetch the next step's rows (compute >> latency here)
+
+    const float Ut = Ue[t * NU + g], Umt = Um[t * NU + g], Gt = G[t * NU + g];
+    float ub[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      float v;
+      if constexpr (NOISE == MPPI_NOISE_ACTIONS) {
+        v = g == 0 ? zc[i][0] : (g == 1 ? zc[i][1] : (g == 2 ? zc[i][2] : zc[i][3]));
+      } else if constexpr (DIAG) {
+        const float zg = g == 0 ? zc[i][0] : (g == 1 ? zc[i][1] : (g == 2 ? zc[i][2] : zc[i][3]));
+        v = fmaf(zg, sd_g, Umt);
+      } else {
+        float acc = Umt;
+#pragma unroll
+        for (int m = 0; m < NU; ++m) acc = fmaf(zc[i][m], Lrow[m], acc);
+        v = acc;
+      }
+      if (orow[i] == -1) v = 0.f;
+      else if (orow[i] >= 0) v = a.sampler[((long long)orow[i] * a.Tn + t) * NU + g];
+      v = clampT(v, lo_g, hi_g);
+      const float e = v - Ut;
+      ppart[i] = fmaf(Gt, ac.abs_cost ? fabsf(e) : e, ppart[i]);
+      ub[i] = a.u_scale * v;
+    }
+
+    f32x4 O[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < HT; ++m) {
+      const float4 bb = *reinterpret_cast<const float4*>(b1s + 16 * m + 4 * g);
+      f32x4 Hc[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) Hc[i] = f32x4{bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+          Hc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[m][q], x[i][q], Hc[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        Hc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[m][4], ub[i], Hc[i], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+          O[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[m][r], fast_tanh(Hc[i][r]), O[i], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        x[i][r] = fmaf(rs, O[i][r] + b2r[r], x[i][r]);
+        cpart[i] = fmaf(x[i][r], x[i][r], cpart[i]);
+      }
+    }
+  }
+
+  // ---- per-sample totals: sum the 4 lane groups (dims 4g..4g+3 / control dim g) ----
+  float bm = inf_v<float>();
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    float c = cpart[i], p = ppart[i];
+    c += __shfl_xor(c, 16, WAVE); c += __shfl_xor(c, 32, WAVE);
+    p += __shfl_xor(p, 16, WAVE); p += __shfl_xor(p, 32, WAVE);
+    const float total = c + p;
+    if (act[i] && g == 0) {
+      a.cost[kk[i]] = total;
+      if (a.pert != nullptr) a.pert[kk[i]] = p;
+    }
+    if (act[i]) bm = fminf(bm, total);
+  }
+  const float bmin = block_min<float>(bm, red);
+  if (threadIdx.x == 0) a.block_min[blockIdx.x] = bmin;
+}
+
+template <int HT>
+static int launch_ht(const KArgs<float>& a, hipStream_t st) {
+  const bool diag = a.diag != 0;
+  const size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + HT * 16 + 2 * MLP_NU * MLP_NU) * sizeof(float);
+  const dim3 grid((a.K + BLOCK - 1) / BLOCK), block(BLOCK);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  profile_next_events(&ev0, &ev1);
+#define MPPI_LAUNCH(NOISE_)                                                                          \
+  do {                                                                                               \
+    if (diag)                                                                                        \
+      hipExtLaunchKernelGGL((rollout_mlp_mfma_kernel<HT, NOISE_, true>), grid, block, smem, st, ev0, \
+                            ev1, 0, a);                                                              \
+    else                                                                                             \
+      hipExtLaunchKernelGGL((rollout_mlp_mfma_kernel<HT, NOISE_, false>), grid, block, smem, st,     \
+                            ev0, ev1, 0, a);                                                         \
+  } while (0)
+  if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCH(MPPI_NOISE_PHILOX);
+  else if (a.noise_src == MPPI_NOISE_ACTIONS) MPPI_LAUNCH(MPPI_NOISE_ACTIONS);
+  else MPPI_LAUNCH(MPPI_NOISE_TNK4);
+#undef MPPI_LAUNCH
+  return (int)hipGetLastError();
+}
+
+bool mlp_mfma_supported(int nx, int nu, int hidden) {
+  return nx == MLP_NX && nu == MLP_NU && (hidden == 64 || hidden == 128 || hidden == 256);
+}
+
+int rollout_mlp_mfma(const KArgs<float>& a, hipStream_t st) {
+  if (a.mp == nullptr) return MPPI_E_BADARG;
+  if (!mlp_mfma_supported(a.nx, a.nu, a.hidden) || a.states != nullptr) return MPPI_E_UNSUPPORTED;
+  switch (a.hidden) {
+    case 64: return launch_ht<4>(a, st);
+    case 128: return launch_ht<8>(a, st);
+    default: return launch_ht<16>(a, st);
+  }
+}
+
+}  // namespace mppi

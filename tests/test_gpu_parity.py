@@ -205,3 +205,44 @@ def test_size_independent_properties_at_full_size():
     # einsum restatement of the update from the engine's own public outputs (mppi.py:268)
     P = torch.einsum("k,ktn->tn", c.omega.double(), noise.double()).float().cpu()
     assert torch.allclose(dU, P, rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("H,K,full_sigma,per_sample,rng", [(256, 1000, False, False, "torch"), (128, 257, True, True, "torch"),
+                                                            (64, 4096, False, False, "philox")])
+def test_mlp_mfma_kernel_matches_valu_kernel_and_fp64_oracle(H, K, full_sigma, per_sample, rng, monkeypatch):
+    """fp32 MFMA formulation of the MLP rollout (csrc/rollout_mlp_mfma.hip) against (a) the per-lane
+    VALU kernel of the same model and (b) the fp64 oracle; ragged K (tail tiles), full Sigma,
+    per-sample initial states, null-action row, Philox generate-once."""
+    import pytorch_mppi_amd as pm
+    from oracle import mppi_oracle as orc, dynamics as dyn, philox as oph
+    T, nx, nu = 12, 16, 4
+    g = torch.Generator().manual_seed(H + K)
+    model = pm.models.MLPResidual.random(nx, nu, H, seed=2)
+    U0 = torch.randn(T, nu, generator=g) * 0.05
+    x0 = torch.randn((K, nx) if per_sample else (nx,), generator=g)
+    sig = torch.tensor([[1.0, 0.3, 0, 0], [0.3, 0.8, 0, 0], [0, 0, 0.5, 0.1], [0, 0, 0.1, 1.2]]) if full_sigma else torch.eye(nu)
+    umax = torch.tensor([1.5] * nu)
+
+    def run(force_valu):
+        monkeypatch.setenv("MPPI_MLP_VALU", "1" if force_valu else "0")
+        c = pm.MPPI(model.dynamics, model.running_cost, nx, sig, num_samples=K, horizon=T, device="cuda", lambda_=5.0,
+                    U_init=U0.clone(), u_min=-umax, u_max=umax, sample_null_action=True, rng=rng, seed=77)
+        if rng == "torch":
+            c.inject_noise(z)
+        a = c.command(x0.cuda())
+        return c, a
+
+    z = torch.randn(K, T, nu, generator=g) if rng == "torch" else torch.from_numpy(oph.normals_ktn(77, 1, K, T, nu))
+    c_m, a_m = run(False)
+    c_v, a_v = run(True)
+    f, q = dyn.make_mlp(*[t.double() for t in (model.W1, model.b1, model.W2, model.b2)])
+    p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=sig.double(), K=K, T=T, lambda_=5.0,
+                    u_min=-umax.double(), u_max=umax.double(), sample_null_action=True)
+    r = orc.command(p, U0.double(), x0.double(), z.double(), True)
+    tol = 1e-5 if rng == "torch" else 5e-5       # Philox: hardware log/sin/cos in Box-Muller vs numpy
+    for c, a, name in ((c_m, a_m, "mfma"), (c_v, a_v, "valu")):
+        _assert_close(c.cost_total, r["cost_total"].numpy(), tol, f"{name} cost_total")
+        _assert_close(a, r["action"].numpy(), tol, f"{name} action")
+        _assert_close(c.U, r["U"].numpy(), tol, f"{name} U")
+    assert torch.allclose(c_m.cost_total, c_v.cost_total, rtol=2e-6, atol=0)
+    assert torch.equal(c_m.perturbed_action, c_v.perturbed_action)
