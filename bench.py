@@ -37,6 +37,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
 
 
 def make_controller(pm, wl, device, rng, shard, K):
@@ -186,7 +187,15 @@ def main():
     Klocal = ctrl.K_local
     alg_bytes = 4 * Klocal * T * nu + 4 * Klocal
     roofline = None
-    if k1:
+    if k1 and kind == "mlp":
+        # C4/C5: the rollout is a chain of two dense layers per state evaluation -> fp32 MFMA bound
+        flops = 2.0 * ((nx + nu) * 256 + 256 * nx) * Klocal * T
+        ach = flops / (k1_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "kernel": "rollout_mlp_mfma_kernel", "avg_launch_us": k1_ms * 1e3,
+                    "algorithmic_flops": flops}
+    elif k1:
         if args.rng == "philox":
             # no-HBM mode: the normals never exist in memory; report the time against the
             # external-z byte count for orientation only

@@ -74,13 +74,21 @@ def lib():
         return _lib
     path = _build.LIB
     if not _build.is_current():
-        try:
-            _build.build(verbose=False)
-        except Exception as e:  # stale-but-present library on a box without hipcc is still usable
-            if not os.path.exists(path):
-                raise RuntimeError(
-                    "pytorch_mppi_amd: the HIP engine library is missing and could not be built "
-                    f"({e}); there is no CPU fallback") from e
+        # one builder at a time (torch.distributed.run starts N ranks at once): the others wait on
+        # the lock and then find the library current
+        import fcntl
+        with open(path + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if not _build.is_current():
+                    _build.build(verbose=False)
+            except Exception as e:  # stale-but-present library on a box without hipcc is still usable
+                if not os.path.exists(path):
+                    raise RuntimeError(
+                        "pytorch_mppi_amd: the HIP engine library is missing and could not be built "
+                        f"({e}); there is no CPU fallback") from e
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     try:
         l = C.CDLL(path)
     except OSError as e:

@@ -156,26 +156,48 @@ __global__ void __launch_bounds__(BLOCK) rollout_mlp_mfma_kernel(const KArgs<flo
     f32x4 O[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Software pipeline over the hidden tiles.  A wave issues in order, so VALU work only
+    // overlaps the matrix pipe if it sits BETWEEN MFMAs in the instruction stream.  Stage 1 of
+    // tile m therefore alternates one layer-1 MFMA of tile m+1 with one tanh of tile m (pinned
+    // with sched_barrier so the compiler keeps that order); stage 2 is the 16 layer-2 MFMAs.
+    f32x4 Hc[2][NT];
+    {
+      const float4 bb = *reinterpret_cast<const float4*>(b1s + 4 * g);
 #pragma unroll
-    for (int m = 0; m < HT; ++m) {
-      const float4 bb = *reinterpret_cast<const float4*>(b1s + 16 * m + 4 * g);
-      f32x4 Hc[NT];
+      for (int i = 0; i < NT; ++i) Hc[0][i] = f32x4{bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-      for (int i = 0; i < NT; ++i) Hc[i] = f32x4{bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 5; ++q) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
-          Hc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[m][q], x[i][q], Hc[i], 0, 0, 0);
+          Hc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[0][q], q < 4 ? x[i][q] : ub[i], Hc[0][i], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < HT; ++m) {
+      float th[NT][4];
+      const bool more = m + 1 < HT;
+      if (more) {
+        const float4 bb = *reinterpret_cast<const float4*>(b1s + 16 * (m + 1) + 4 * g);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) Hc[(m + 1) & 1][i] = f32x4{bb.x, bb.y, bb.z, bb.w};
       }
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
-        Hc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[m][4], ub[i], Hc[i], 0, 0, 0);
+      for (int q = 0; q < 5; ++q) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const int slot = q * NT + i;          // 20 MFMA slots, the first 16 also carry one tanh
+          if (more)
+            Hc[(m + 1) & 1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                w1r[more ? m + 1 : m][q], q < 4 ? x[i][q] : ub[i], Hc[(m + 1) & 1][i], 0, 0, 0);
+          if (slot < 4 * NT) th[slot % NT][slot / NT] = fast_tanh(Hc[m & 1][slot % NT][slot / NT]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
-          O[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[m][r], fast_tanh(Hc[i][r]), O[i], 0, 0, 0);
+          O[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[m][r], th[i][r], O[i], 0, 0, 0);
       }
     }
 #pragma unroll
