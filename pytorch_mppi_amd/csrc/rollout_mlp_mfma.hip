@@ -23,22 +23,35 @@ namespace mppi {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float fast_tanh(float x) {
-  // tanh(x) = 1 - 2/(e^{2x}+1); exp2 argument clamped so that e^{2x} stays finite
-  const float t = __builtin_amdgcn_exp2f(fminf(x * 2.8853900817779268f, 126.0f));   // 2*log2(e)
+#ifdef MPPI_MLP_NOTANH   // experiment only (tools/): MFMA pipe alone
+  return x;
+#endif
+  // tanh(x) = 1 - 2/(e^{2x}+1).  No clamp needed: e^{2x} -> inf gives rcp(inf) = 0 -> 1, and
+  // e^{2x} -> 0 gives 1 - 2 = -1.  Every VALU cycle here is additive to the kernel time: the fp32
+  // MFMA runs at the fp32 vector rate and (measured, tools/run_c4_variants.sh) does not overlap
+  // VALU work -- 597 us without tanh, 857 us with it at C4.
+  const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // 2*log2(e)
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
 }
 
-constexpr int MLP_NX = 16, MLP_NU = 4, MLP_NI = 20, MLP_NT = 4;   // NT sample tiles of 16 per wave
+constexpr int MLP_NX = 16, MLP_NU = 4, MLP_NI = 20;
+#ifndef MPPI_MLP_NT
+#define MPPI_MLP_NT 2     // sample tiles (of 16) per wave; a workgroup always covers 256 samples
+#endif
+// NT = 2 -> 8 waves per workgroup = TWO waves per SIMD: one wave's tanh (VALU) runs while the other
+// wave's MFMAs occupy the matrix pipe; each wave still has 2 independent accumulator chains.
+constexpr int MLP_NT = MPPI_MLP_NT;
+constexpr int MLP_THREADS = 256 / (16 * MLP_NT) * WAVE;
 
 template <int HT /* hidden / 16 */, int NOISE, bool DIAG>
-__global__ void __launch_bounds__(BLOCK) rollout_mlp_mfma_kernel(const KArgs<float> a) {
+__global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KArgs<float> a) {
   constexpr int NU = MLP_NU, NX = MLP_NX, NT = MLP_NT, H = HT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* Ue = reinterpret_cast<float*>(smem_raw);   // [J]
   float* Um = Ue + a.J;                             // [J]
   float* G = Um + a.J;                              // [J]
-  float* red = G + a.J;                             // [BLOCK/WAVE]
-  float* b1s = red + BLOCK / WAVE;                  // [H]
+  float* red = G + a.J;                             // [waves per workgroup]
+  float* b1s = red + MLP_THREADS / WAVE;            // [H]
   float* fac = b1s + H;                             // [2*NU*NU]
 
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
@@ -64,10 +77,10 @@ __global__ void __launch_bounds__(BLOCK) rollout_mlp_mfma_kernel(const KArgs<flo
 
   ActionConsts<float, NU> ac;
   ac.load(a, DIAG ? nullptr : fac);
-  for (int j = threadIdx.x; j < a.J; j += BLOCK) Ue[j] = u_eff(a, j);
-  for (int h = threadIdx.x; h < H; h += BLOCK) b1s[h] = b1[h];
+  for (int j = threadIdx.x; j < a.J; j += MLP_THREADS) Ue[j] = u_eff(a, j);
+  for (int h = threadIdx.x; h < H; h += MLP_THREADS) b1s[h] = b1[h];
   __syncthreads();
-  for (int j = threadIdx.x; j < a.J; j += BLOCK) {
+  for (int j = threadIdx.x; j < a.J; j += MLP_THREADS) {
     const int n = j % NU, t0 = j - n;
     const float uj = Ue[j];
     Um[j] = uj + a.mu[n];
@@ -90,7 +103,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_mlp_mfma_kernel(const KArgs<flo
   }
 
   // ---- samples of this wave: tile i covers k = kbase + 16 i + s ----
-  const int kbase = blockIdx.x * BLOCK + wv * (NT * 16);
+  const int kbase = blockIdx.x * 256 + wv * (NT * 16);
   int kk[NT], orow[NT];
   bool act[NT];
   float x[NT][4], cpart[NT], ppart[NT];
@@ -190,7 +203,9 @@ __global__ void __launch_bounds__(BLOCK) rollout_mlp_mfma_kernel(const KArgs<flo
             Hc[(m + 1) & 1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                 w1r[more ? m + 1 : m][q], q < 4 ? x[i][q] : ub[i], Hc[(m + 1) & 1][i], 0, 0, 0);
           if (slot < 4 * NT) th[slot % NT][slot / NT] = fast_tanh(Hc[m & 1][slot % NT][slot / NT]);
+#ifndef MPPI_MLP_NOSB
           __builtin_amdgcn_sched_barrier(0);
+#endif
         }
       }
 #pragma unroll
@@ -224,15 +239,22 @@ __global__ void __launch_bounds__(BLOCK) rollout_mlp_mfma_kernel(const KArgs<flo
     }
     if (act[i]) bm = fminf(bm, total);
   }
-  const float bmin = block_min<float>(bm, red);
-  if (threadIdx.x == 0) a.block_min[blockIdx.x] = bmin;
+  bm = wave_min(bm);
+  if (lane == 0) red[wv] = bm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float r = red[0];
+#pragma unroll
+    for (int i = 1; i < MLP_THREADS / WAVE; ++i) r = fminf(r, red[i]);
+    a.block_min[blockIdx.x] = r;
+  }
 }
 
 template <int HT>
 static int launch_ht(const KArgs<float>& a, hipStream_t st) {
   const bool diag = a.diag != 0;
-  const size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + HT * 16 + 2 * MLP_NU * MLP_NU) * sizeof(float);
-  const dim3 grid((a.K + BLOCK - 1) / BLOCK), block(BLOCK);
+  const size_t smem = (size_t)(3 * a.J + MLP_THREADS / WAVE + HT * 16 + 2 * MLP_NU * MLP_NU) * sizeof(float);
+  const dim3 grid((a.K + 255) / 256), block(MLP_THREADS);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   profile_next_events(&ev0, &ev1);
 #define MPPI_LAUNCH(NOISE_)                                                                          \
