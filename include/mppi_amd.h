@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 4
+#define MPPI_ABI_VERSION 5
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -85,6 +85,11 @@ typedef struct MppiProblem {
   double lambda_;             /* mppi.py:96, read live                                     */
   double u_scale;             /* mppi.py:313                                               */
   uint64_t seed, call;        /* Philox key / per-command counter word                     */
+  /* SMPPI (mppi.py:451-570), lifted control: v = clamp(A + (U+eps)*dt), noise = (v-A)/dt - U.
+   * The host passes base_seq = A + U*dt, noise_L/noise_mu pre-multiplied by dt and the ACTION
+   * bounds in u_min/u_max; the kernels then only need 1/dt and the smoothness weight.         */
+  double noise_rescale;       /* 1/dt (SMPPI) -- multiplies the bounded noise; 1 for MPPI   */
+  double smooth_weight;       /* w_action_seq_cost * u_scale^2 (mppi.py:559-562); 0 = off   */
   /* ---- inputs (device) ---- */
   const void* state;          /* (nx) or (K,nx)                                            */
   const void* U;              /* (T,nu) nominal sequence BEFORE this command's shift       */
@@ -99,6 +104,8 @@ typedef struct MppiProblem {
   const void* sampler_actions;/* (n_sampler_rows,T,nu)                               [opt] */
   const void* W;              /* KMPPI (T,S) interpolation operator                  [opt] */
   const void* theta;          /* KMPPI (S,nu) control points (after shift)           [opt] */
+  const void* base_seq;       /* (T,nu) sequence the noise is added to and measured from;
+                                 NULL = the (shifted) nominal U itself (MPPI/KMPPI)    [opt] */
   /* ---- outputs (device) ---- */
   void* cost_total;           /* (K)                                                       */
   void* omega;                /* (K) normalised weights (mppi.py:258)                [opt] */
@@ -107,7 +114,8 @@ typedef struct MppiProblem {
   void* action_out;           /* (u_per_command,nu)                                  [opt] */
   void* perturbed_action;     /* (K,T,nu) row-major, only written by mppi_prepare    [opt] */
   void* noise;                /* (K,T,nu) row-major, only written by mppi_prepare    [opt] */
-  void* pert_cost;            /* (K) action perturbation cost (mppi.py:415)          [opt] */
+  void* pert_cost;            /* (K) action perturbation cost (mppi.py:415), plus the
+                                 smoothness cost when smooth_weight != 0               [opt] */
   void* states;               /* (K,T,nx) visited states (mppi.py:321)               [opt] */
   void* record;               /* (2 + J) shard record {beta, eta, P[J]} for the exchange   */
   /* ---- scratch ---- */

@@ -25,12 +25,14 @@ OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 def _np(x):
     if x is None:
         return np.zeros(0)
-    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+    # copy: SMPPI updates `action_sequence` in place (mppi.py:515), a numpy VIEW recorded at step s
+    # would silently change at step s+1
+    return x.detach().cpu().numpy().copy() if torch.is_tensor(x) else np.array(x)
 
 
 def run_case(name, *, model, model_args, nx, nu, K, T, dtype, sigma, steps=2, state=None,
              per_sample_state=False, kmppi=False, S=None, sampler_rows=0, terminal=False,
-             seed=0, **ctor):
+             seed=0, smppi=None, **ctor):
     mod, proxy = load_reference()
     tdt = {"f32": torch.float32, "f64": torch.float64}[dtype]
     g = torch.Generator().manual_seed(seed)
@@ -70,9 +72,12 @@ def run_case(name, *, model, model_args, nx, nu, K, T, dtype, sigma, steps=2, st
         sampler = _S()
         kw["specific_action_sampler"] = sampler
     U0 = torch.randn(T, nu, generator=g, dtype=tdt) * 0.3
-    cls = mod.KMPPI if kmppi else mod.MPPI
+    cls = mod.KMPPI if kmppi else (mod.SMPPI if smppi is not None else mod.MPPI)
     if kmppi and S is not None:
         kw["num_support_pts"] = S
+    if smppi is not None:
+        for k2, v2 in smppi.items():
+            kw[k2] = torch.tensor(v2, dtype=tdt) if isinstance(v2, (list, tuple)) else v2
     ctrl = cls(f, q, nx, sigma_t, num_samples=K, horizon=T, device="cpu", U_init=U0.clone(), **kw)
     if state is None:
         state = torch.randn((K, nx) if per_sample_state else (nx,), generator=g, dtype=tdt)
@@ -96,6 +101,8 @@ def run_case(name, *, model, model_args, nx, nu, K, T, dtype, sigma, steps=2, st
         out[f"omega{s}"] = _np(ctrl.omega)
         out[f"noise{s}"] = _np(ctrl.noise)
         out[f"perturbed_action{s}"] = _np(ctrl.perturbed_action)
+        if smppi is not None:
+            out[f"action_sequence{s}"] = _np(ctrl.action_sequence)
         if kmppi:
             out[f"theta{s}"] = _np(ctrl.theta)
             out[f"noise_theta{s}"] = _np(ctrl.noise_theta)
@@ -104,7 +111,7 @@ def run_case(name, *, model, model_args, nx, nu, K, T, dtype, sigma, steps=2, st
     cfg = dict(name=name, model=model, model_args=model_args, nx=nx, nu=nu, K=K, T=T, dtype=dtype,
                sigma=sigma, steps=steps, per_sample_state=per_sample_state, kmppi=kmppi,
                S=(int(ctrl.num_support_pts) if kmppi else None), sampler_rows=sampler_rows,
-               terminal=terminal, ctor=ctor, reference="UM-ARM-Lab/pytorch_mppi v0.9.1",
+               terminal=terminal, ctor=ctor, smppi=smppi, reference="UM-ARM-Lab/pytorch_mppi v0.9.1",
                torch=torch.__version__)
     out["config"] = np.array(json.dumps(cfg))
     os.makedirs(OUT, exist_ok=True)
@@ -142,6 +149,13 @@ def main():
              sigma=np.eye(4).tolist(), steps=2, lambda_=3.0, seed=7)
     run_case("mlp_f64", model="mlp", model_args=dict(hidden=256), nx=16, nu=4, K=64, T=8, dtype="f64",
              sigma=np.eye(4).tolist(), steps=1, lambda_=3.0, seed=7)
+    # SMPPI (lifted control): action bounds, delta_t, smoothness weight; U_init = initial action sequence
+    run_case("smppi_linear_f64", model="linear_goal", model_args=dict(B=Bt, goal=[2.0, 2.0]), nx=2, nu=2,
+             K=100, T=10, dtype="f64", sigma=I2, state=[-3.0, -2.0], steps=3, lambda_=1.0,
+             smppi=dict(w_action_seq_cost=0.7, delta_t=0.5, action_max=[1.0, 0.8]), u_max=[2.0, 2.0], seed=10)
+    run_case("smppi_quadtoy_f32", model="quadtoy", model_args={}, nx=6, nu=4, K=128, T=12, dtype="f32",
+             sigma=[[1, 0.2, 0, 0], [0.2, 2, 0, 0], [0, 0, 0.5, 0], [0, 0, 0, 1.5]], steps=2, lambda_=25.0,
+             smppi=dict(w_action_seq_cost=2.0, delta_t=1.0), sample_null_action=True, u_scale=0.5, seed=11)
     run_case("kmppi_linear_f64", model="linear_goal", model_args=dict(B=Bt, goal=[2.0, 2.0]), nx=2, nu=2,
              K=100, T=10, dtype="f64", sigma=I2, state=[-3.0, -2.0], steps=3, lambda_=1.0, kmppi=True,
              u_max=[1.0, 1.0], seed=8)

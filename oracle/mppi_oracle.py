@@ -232,3 +232,48 @@ def kmppi_command(p: Problem, theta, U, state, z, W, W_shift, shift_nominal_traj
     return dict(U=U_new, theta=theta_new, action=action, cost_total=cost_total, omega=omega,
                 cost_total_non_zero=w, noise=noise, noise_theta=noise_theta,
                 perturbed_action=perturbed, sampler_slice=slc)
+
+
+# ---------------------------------------------------------------------------------------------
+# SMPPI (mppi.py:451-570): lifted control space
+# ---------------------------------------------------------------------------------------------
+def smppi_shift(U, A, u_init):
+    """mppi.py:488-492"""
+    U = torch.roll(U, -1, dims=0)
+    U[-1] = u_init
+    A = torch.roll(A, -1, dims=0)
+    A[-1] = A[-2]
+    return U, A
+
+
+def smppi_command(p: Problem, U, A, state, z, action_min, action_max, w_action_seq_cost=1.0, delta_t=1.0,
+                  shift_nominal_trajectory=True, sampler_actions=None):
+    """One `SMPPI.command()` with injected z (K,T,nu) (mppi.py:488-492, :523-570).  U is the lifted
+    control (action derivative), A the action sequence.  Note the reference quirk kept here: the
+    d-action clamp result is stored (`perturbed_control`) but the UNCLAMPED sum feeds
+    `perturbed_action` (:536-540)."""
+    state = torch.as_tensor(state).to(dtype=p.dtype)
+    U, A = U.clone(), A.clone()
+    if shift_nominal_trajectory:
+        U, A = smppi_shift(U, A, p.u_init)
+    noise = colour_noise(z, p.fac, p.noise_mu)              # :533
+    perturbed_control = U + noise                           # :535
+    perturbed_control_bounded = torch.clamp(perturbed_control, p.u_min, p.u_max)   # :537 (unused below)
+    perturbed = A + perturbed_control * delta_t             # :540
+    perturbed, slc = overwrite_specific(perturbed, p.sample_null_action, sampler_actions, p.T, p.nu)
+    perturbed = torch.clamp(perturbed, action_min, action_max)   # :542
+    noise = (perturbed - A) / delta_t - U                   # :544
+    ac = action_cost(noise, p.fac, p.lambda_, p.noise_abs_cost)   # :548
+    diff = p.u_scale * torch.diff(perturbed, dim=-2)        # :551
+    smooth = torch.sum(torch.square(diff), dim=(1, 2)) * w_action_seq_cost   # :552-554
+    rollout_cost, states, actions = rollout_costs(p, state, perturbed)       # :556
+    pert_cost = torch.sum(U * ac, dim=(1, 2))               # :560
+    cost_total = rollout_cost + pert_cost + smooth          # :561
+    omega, w, beta, eta = weights(cost_total, p.lambda_)
+    U_new = U + torch.einsum("k,ktn->tn", omega, noise)     # :511-513
+    A_new = A + U_new * delta_t                             # :515
+    action = A_new[:p.u_per_command]
+    if p.u_per_command == 1:
+        action = action[0]
+    return dict(U=U_new, action_sequence=A_new, action=action, cost_total=cost_total, omega=omega, noise=noise,
+                perturbed_action=perturbed, perturbed_control=perturbed_control_bounded, sampler_slice=slc)

@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS = 0, 1, 2
@@ -31,9 +31,10 @@ class MppiProblem(C.Structure):
         ("hidden", C.c_int32),
         ("lambda_", C.c_double), ("u_scale", C.c_double),
         ("seed", C.c_uint64), ("call", C.c_uint64),
+        ("noise_rescale", C.c_double), ("smooth_weight", C.c_double),
         ("state", _vp), ("U", _vp), ("u_init", _vp), ("noise_mu", _vp), ("noise_L", _vp),
         ("sigma_inv", _vp), ("u_min", _vp), ("u_max", _vp), ("model_params", _vp), ("z", _vp),
-        ("sampler_actions", _vp), ("W", _vp), ("theta", _vp),
+        ("sampler_actions", _vp), ("W", _vp), ("theta", _vp), ("base_seq", _vp),
         ("cost_total", _vp), ("omega", _vp), ("cost_total_non_zero", _vp), ("U_out", _vp),
         ("action_out", _vp), ("perturbed_action", _vp), ("noise", _vp), ("pert_cost", _vp),
         ("states", _vp), ("record", _vp),

@@ -22,6 +22,13 @@ __device__ __forceinline__ T u_eff(const KArgs<T>& a, int j) {
   return jn < a.J ? a.U[jn] : a.u_init[jn - a.J];
 }
 
+// the sequence the noise is added to and measured from: the (shifted) nominal U, or -- SMPPI --
+// the host-provided base A + U*dt (mppi.py:540)
+template <typename T>
+__device__ __forceinline__ T u_base(const KArgs<T>& a, int j) {
+  return a.B != nullptr ? a.B[j] : u_eff(a, j);
+}
+
 // which overwrite row (if any) global sample kg is: -2 none, -1 null action, >=0 sampler row
 template <typename T>
 __device__ __forceinline__ int overwrite_row(const KArgs<T>& a, long long kg) {
@@ -36,7 +43,7 @@ struct ActionConsts {
   T sd[NU], mu[NU], lo[NU], hi[NU], ci[NU];   // sqrt(diag), mu, bounds, 1/diag
   const T* Lm;                                // (NU,NU) chol(Sigma), row-major   (full Sigma only)
   const T* Sm;                                // (NU,NU) Sigma^-1
-  T lambda_;
+  T lambda_, e_scale;
   int abs_cost;
   // elements of LDS the full-Sigma factors need
   static constexpr int LDS_ELEMS = 2 * NU * NU;
@@ -52,6 +59,7 @@ struct ActionConsts {
       ci[n] = a.sinv[n * NU + n];
     }
     lambda_ = a.lambda_;
+    e_scale = a.e_scale;
     abs_cost = a.abs_cost;
     Lm = lds;
     Sm = lds + NU * NU;
@@ -96,7 +104,7 @@ __device__ __forceinline__ void make_action(const ActionConsts<T, NU>& c, const 
 #pragma unroll
   for (int n = 0; n < NU; ++n) {
     v[n] = clampT(v[n], c.lo[n], c.hi[n]);
-    e[n] = v[n] - Ut[n];
+    e[n] = (v[n] - Ut[n]) * c.e_scale;       // e_scale = 1 (MPPI) | 1/dt (SMPPI, mppi.py:544)
   }
 }
 
@@ -137,11 +145,13 @@ __device__ __forceinline__ void make_action_rt(const KArgs<T>& a, const ActionCo
   else if (a.diag) make_action<T, NU, true, false>(c, Ut, srow, z, orow, v, e);
   else make_action<T, NU, false, false>(c, Ut, srow, z, orow, v, e);
 }
+// `Un` = the true nominal sequence (shift applied): U * action_cost uses U even when the noise
+// is measured from another base (SMPPI)
 template <typename T, int NU>
 __device__ __forceinline__ T action_cost_dot_rt(const KArgs<T>& a, const ActionConsts<T, NU>& c,
-                                                const T* __restrict__ Ue, int t, const T (&e)[NU]) {
-  return a.diag ? action_cost_dot<T, NU, true>(c, Ue + t * NU, e)
-                : action_cost_dot<T, NU, false>(c, Ue + t * NU, e);
+                                                const T* __restrict__ Un, int t, const T (&e)[NU]) {
+  return a.diag ? action_cost_dot<T, NU, true>(c, Un + t * NU, e)
+                : action_cost_dot<T, NU, false>(c, Un + t * NU, e);
 }
 
 // compile-time layout of the TNK4 stream for a given NU: a super-step of TT timesteps consumes

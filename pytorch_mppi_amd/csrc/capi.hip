@@ -72,12 +72,13 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.state_per_sample = p->state_per_sample; a.shift = p->shift; a.use_terminal = p->use_terminal;
   a.noise_src = p->noise_src; a.u_per_command = p->u_per_command; a.hidden = p->hidden;
   a.lambda_ = (T)p->lambda_; a.u_scale = (T)p->u_scale;
+  a.e_scale = (T)(p->noise_rescale == 0.0 ? 1.0 : p->noise_rescale); a.smooth_w = (T)p->smooth_weight;
   a.seed = p->seed; a.call = p->call;
   a.state = (const T*)p->state; a.U = (const T*)p->U; a.u_init = (const T*)p->u_init;
   a.mu = (const T*)p->noise_mu; a.L = (const T*)p->noise_L; a.sinv = (const T*)p->sigma_inv;
   a.umin = (const T*)p->u_min; a.umax = (const T*)p->u_max; a.mp = (const T*)p->model_params;
   a.z = (const T*)p->z; a.sampler = (const T*)p->sampler_actions; a.W = (const T*)p->W;
-  a.theta = (const T*)p->theta;
+  a.theta = (const T*)p->theta; a.B = (const T*)p->base_seq;
   a.cost = (T*)p->cost_total; a.omega = (T*)p->omega; a.wnz = (T*)p->cost_total_non_zero;
   a.U_out = (T*)p->U_out; a.action_out = (T*)p->action_out; a.pa = (T*)p->perturbed_action;
   a.noise = (T*)p->noise; a.pert = (T*)p->pert_cost; a.states = (T*)p->states;
@@ -210,6 +211,7 @@ static int do_interp(const MppiProblem* p, void* out, hipStream_t st) {
   if (p == nullptr || p->S <= 0 || !p->theta || !p->W || !out) return fail(MPPI_E_BADARG, "kmppi_interp needs S, theta, W");
   MppiProblem q = *p;
   q.T = p->S; q.U = p->theta; q.shift = 0; q.sample_null_action = 0; q.n_sampler_rows = 0;
+  q.base_seq = nullptr; q.noise_rescale = 1.0; q.smooth_weight = 0.0;
   KArgs<T> a;
   if (int e = make_args<T>(&q, a)) return e;
   if (int e = need_noise(a)) return e;

@@ -19,9 +19,9 @@ struct KArgs {
   long long k_offset;
   int model_id, diag, abs_cost, null_action, n_sampler, state_per_sample, shift, use_terminal,
       noise_src, u_per_command, hidden;
-  T lambda_, u_scale;
+  T lambda_, u_scale, e_scale, smooth_w;
   unsigned long long seed, call;
-  const T *state, *U, *u_init, *mu, *L, *sinv, *umin, *umax, *mp, *z, *sampler, *W, *theta;
+  const T *state, *U, *u_init, *mu, *L, *sinv, *umin, *umax, *mp, *z, *sampler, *W, *theta, *B;
   T *cost, *omega, *wnz, *U_out, *action_out, *pa, *noise, *pert, *states, *record;
   // workspace carve-up
   T* block_min;   // [nb1]

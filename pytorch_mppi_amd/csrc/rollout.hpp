@@ -24,9 +24,10 @@
 namespace mppi {
 
 // Per-block tables in LDS, one entry per (t,n) of the horizon (J = T*nu each):
-//   Ue[j]  nominal sequence with the shift applied                         (mppi.py:232-238)
+//   Ue[j]  base sequence: nominal U with the shift applied (mppi.py:232-238); SMPPI: A + U*dt
 //   Um[j]  Ue[j] + mu[n]                    -> v = fma(z, sqrt(diag), Um)   (:201-206, :380)
-//   G[j]   lambda * (Sigma^-1 Ue[t])[n]     -> pert += G * e                (:186-199, :415)
+//   G[j]   lambda * (Sigma^-1 U[t])[n]      -> pert += G * e                (:186-199, :415)
+//          (always from the true nominal U, also when the base is something else)
 // G folds lambda*e*Sigma^-1 . U into ONE fma per control dimension (for a full Sigma it removes
 // the nu x nu product from the time loop entirely); the association differs from the
 // reference's ((lambda*e)*Sigma^-1)*U by rounding only (parity tests: 1e-5 fp32 / 1e-9 fp64).
@@ -42,7 +43,8 @@ template <class Model, typename T, int NOISE, bool DIAG, bool SLOW>
 __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionConsts<T, Model::NU>& ac,
                                              const Model& model, const StepTables<T>& tb, int k,
                                              bool active, int orow, int t, const T* zt,
-                                             T (&x)[Model::NX], T& rollout, T& pert) {
+                                             T (&x)[Model::NX], T (&vprev)[Model::NU], T& rollout,
+                                             T& pert) {
   constexpr int NX = Model::NX, NU = Model::NU;
   constexpr bool SRC_ACTIONS = NOISE == MPPI_NOISE_ACTIONS;
   T z[NU], v[NU], u[NU];
@@ -84,9 +86,20 @@ __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionCons
 #pragma unroll
   for (int n = 0; n < NU; ++n) {
     v[n] = clampT(v[n], ac.lo[n], ac.hi[n]);                               // :383
-    const T e = v[n] - Ut[n];                                              // :385
+    const T e = (v[n] - Ut[n]) * ac.e_scale;                               // :385 (SMPPI :544)
     pert = m_fma(Gt[n], ac.abs_cost ? m_abs(e) : e, pert);                 // :409, :415
     u[n] = a.u_scale * v[n];                                               // :313
+  }
+  if (a.smooth_w != T(0)) {
+    // SMPPI smoothness cost w * |u_scale * (v[t] - v[t-1])|^2 (mppi.py:559-562); vprev = v at t = 0
+    T d2 = T(0);
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+      const T d = v[n] - vprev[n];
+      d2 = m_fma(d, d, d2);
+      vprev[n] = v[n];
+    }
+    if (t > 0) rollout = m_fma(a.smooth_w, d2, rollout);
   }
   model.step(x, u, t);                                                     // :314
   rollout += model.cost(x, u, t);                                          // :318-319
@@ -130,6 +143,9 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
                                                bool active, int orow,
                                                T (&ring)[Ring<Model::NU, T>::D][Stream<Model::NU>::P4 * 4],
                                                T (&x)[Model::NX], T& rollout, T& pert) {
+  T vprev[Model::NU];
+#pragma unroll
+  for (int n = 0; n < Model::NU; ++n) vprev[n] = T(0);
   constexpr int NU = Model::NU;
   constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
   const int nss = (a.Tn + TT - 1) / TT;
@@ -161,7 +177,7 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
           const int t = (ss0 + b) * TT + tt;
           if (t < a.Tn)
             rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, tb, k, active, orow, t, &zb[b][tt * NU], x,
-                                                      rollout, pert);
+                                                      vprev, rollout, pert);
         }
       }
     }
@@ -190,7 +206,7 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
           // same pin for the LDS table reads of this step (their addresses depend only on t)
           asm volatile("" : "+s"(t) : "v"(rollout));
           rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, tb, k, active, orow, t,
-                                                    &ring[d][tt * NU], x, rollout, pert);
+                                                    &ring[d][tt * NU], x, vprev, rollout, pert);
         }
         // Refill slot d only AFTER it has been consumed (the address is made to depend on the
         // step's result): the load then lands in the same registers, the loop carries no copy of
@@ -209,7 +225,7 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
           const int t = ss * TT + tt;
           if (t < a.Tn)
             rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, tb, k, active, orow, t,
-                                                      &ring[d][tt * NU], x, rollout, pert);
+                                                      &ring[d][tt * NU], x, vprev, rollout, pert);
         }
       }
     }
@@ -241,7 +257,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_cost_kernel(const KArgs<T> a) {
 #pragma unroll
   for (int q = 0; q < UL; ++q) {
     const int j = threadIdx.x + q * BLOCK;
-    uload[q] = j < a.J ? u_eff(a, j) : T(0);
+    uload[q] = j < a.J ? u_base(a, j) : T(0);
   }
   const Model model(a);
   T x[NX];
@@ -266,18 +282,17 @@ __global__ void __launch_bounds__(BLOCK) rollout_cost_kernel(const KArgs<T> a) {
     const int j = threadIdx.x + q * BLOCK;
     if (j < a.J) Ue[j] = uload[q];
   }
-  for (int j = threadIdx.x + UL * BLOCK; j < a.J; j += BLOCK) Ue[j] = u_eff(a, j);   // very long horizons
+  for (int j = threadIdx.x + UL * BLOCK; j < a.J; j += BLOCK) Ue[j] = u_base(a, j);   // very long horizons
   __syncthreads();
   for (int j = threadIdx.x; j < a.J; j += BLOCK) {
     const int n = j % NU, t0 = j - n;
-    const T uj = Ue[j];
-    Um[j] = uj + a.mu[n];
+    Um[j] = Ue[j] + a.mu[n];
     T g;
     if constexpr (DIAG) {
-      g = uj * a.sinv[n * NU + n];
+      g = u_eff(a, j) * a.sinv[n * NU + n];
     } else {
       g = T(0);
-      for (int m = 0; m < NU; ++m) g = m_fma(ac.Sm[n * NU + m], Ue[t0 + m], g);   // Sigma^-1 symmetric
+      for (int m = 0; m < NU; ++m) g = m_fma(ac.Sm[n * NU + m], u_eff(a, t0 + m), g);   // Sigma^-1 symmetric
     }
     G[j] = a.lambda_ * g;
   }

@@ -24,7 +24,9 @@ int rollout_mlp(const KArgs<float>& a, hipStream_t st) {
   // per-lane form (A/B measurements, tools/)
   const char* fv = getenv("MPPI_MLP_VALU");
   const bool force_valu = fv != nullptr && fv[0] == '1';
-  if (!force_valu && a.states == nullptr && mlp_mfma_supported(a.nx, a.nu, a.hidden)) return rollout_mlp_mfma(a, st);
+  if (!force_valu && a.states == nullptr && a.B == nullptr && a.smooth_w == 0.f &&
+      mlp_mfma_supported(a.nx, a.nu, a.hidden))
+    return rollout_mlp_mfma(a, st);
   return go(a, st);
 }
 int rollout_mlp(const KArgs<double>& a, hipStream_t st) { return go(a, st); }

@@ -138,17 +138,20 @@ template <typename T, int NU, int NOISE>
 __global__ void __launch_bounds__(BLOCK) prepare_kernel(const KArgs<T> a) {
   constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* Ue = reinterpret_cast<T*>(smem_raw);
-  T* fac = Ue + a.J;
+  T* Ue = reinterpret_cast<T*>(smem_raw);   // [J] base sequence (noise is added to / measured from)
+  T* Un = Ue + a.J;                         // [J] true nominal sequence (action cost)
+  T* fac = Un + a.J;
   ActionConsts<T, NU> ac;
   ac.load(a, fac);
-  for (int j = threadIdx.x; j < a.J; j += BLOCK) Ue[j] = u_eff(a, j);
+  for (int j = threadIdx.x; j < a.J; j += BLOCK) { Ue[j] = u_base(a, j); Un[j] = u_eff(a, j); }
   __syncthreads();
   const int k = blockIdx.x * BLOCK + threadIdx.x;
   if (k >= a.K) return;
   const int orow = overwrite_row(a, a.k_offset + k);
   const int nss = (a.Tn + TT - 1) / TT;
-  T pert = T(0);
+  T pert = T(0), smooth = T(0), vprev[NU];
+#pragma unroll
+  for (int n = 0; n < NU; ++n) vprev[n] = T(0);
   for (int ss = 0; ss < nss; ++ss) {
     T zc[P4 * 4];
 #pragma unroll
@@ -168,7 +171,13 @@ __global__ void __launch_bounds__(BLOCK) prepare_kernel(const KArgs<T> a) {
 #pragma unroll
         for (int n = 0; n < NU; ++n) z[n] = zc[tt * NU + n];
         make_action_rt<T, NU>(a, ac, Ue, t, z, orow, v, e);
-        pert += action_cost_dot_rt<T, NU>(a, ac, Ue, t, e);
+        pert += action_cost_dot_rt<T, NU>(a, ac, Un, t, e);
+        if (a.smooth_w != T(0)) {                       // mppi.py:559-562
+          T d2 = T(0);
+#pragma unroll
+          for (int n = 0; n < NU; ++n) { const T d = v[n] - vprev[n]; d2 += d * d; vprev[n] = v[n]; }
+          if (t > 0) smooth += d2;
+        }
         const long long o = ((long long)k * a.Tn + t) * NU;
 #pragma unroll
         for (int n = 0; n < NU; ++n) {
@@ -178,7 +187,7 @@ __global__ void __launch_bounds__(BLOCK) prepare_kernel(const KArgs<T> a) {
       }
     }
   }
-  if (a.pert != nullptr) a.pert[k] = pert;
+  if (a.pert != nullptr) a.pert[k] = pert + a.smooth_w * smooth;
 }
 
 template <typename T>
@@ -245,7 +254,7 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs
     const int j = j0 + threadIdx.x;
     const bool ok = j < a.J;
     const int n = ok ? j % a.nu : 0;
-    cU[threadIdx.x] = ok ? u_eff(a, j) : T(0);
+    cU[threadIdx.x] = ok ? u_base(a, j) : T(0);
     cS[threadIdx.x] = ok ? a.L[n * a.nu + n] : T(0);
     cM[threadIdx.x] = ok ? a.mu[n] : T(0);
     cLo[threadIdx.x] = ok ? a.umin[n] : T(0);
@@ -314,7 +323,7 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs
       s += overwrite_correction<T>(a, kbeg, kend, j, cU[threadIdx.x], cLo[threadIdx.x], cHi[threadIdx.x],
                                    beta, inv_lambda);
     }
-    if (j < a.Jpad) a.P_part[(long long)kc * a.Jpad + j] = s;
+    if (j < a.Jpad) a.P_part[(long long)kc * a.Jpad + j] = s * a.e_scale;   // 1 | 1/dt (SMPPI)
   }
   if (jt == 0 && threadIdx.x == 0) a.eta_part[kc] = eta_b;
 }
@@ -334,7 +343,7 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_full_kernel(const KArgs
   const int kc = blockIdx.x, jt = blockIdx.y;
   ActionConsts<T, NU> ac;
   ac.load(a, fac);
-  for (int j = threadIdx.x; j < a.J; j += BLOCK) Ue[j] = u_eff(a, j);
+  for (int j = threadIdx.x; j < a.J; j += BLOCK) Ue[j] = u_base(a, j);
   const T beta = shard_beta(a, red);
   const T inv_lambda = T(1) / a.lambda_;
 
@@ -529,7 +538,7 @@ int launch_kmppi_interp(const KArgs<T>& a, const T* W, int Thor, int J4out, T* o
 
 template <typename T>
 int launch_prepare(const KArgs<T>& a, hipStream_t st) {
-  const size_t smem = ((size_t)a.J + 2 * a.nu * a.nu) * sizeof(T);
+  const size_t smem = ((size_t)2 * a.J + 2 * a.nu * a.nu) * sizeof(T);
   const dim3 grid((a.K + BLOCK - 1) / BLOCK), block(BLOCK);
 #define X(N)                                                                                      \
   if (a.nu == N) {                                                                                \

@@ -645,6 +645,132 @@ class MPPI:
         return states[:, 1:]
 
 
+class SMPPI(MPPI):
+    """Smooth MPPI (mppi.py:451-570): the sampled quantity U is the action DERIVATIVE, the commanded
+    `action_sequence` integrates it, and the cost gains w * |u_scale * diff_t(action)|^2.
+
+    Same kernels as MPPI: the host hands them the base sequence B = action_sequence + U*dt, the
+    colouring factors pre-multiplied by dt and the ACTION bounds; the kernels measure the bounded
+    noise from B, rescale it by 1/dt ((v - A)/dt - U, :544) and add the smoothness term.
+    Reference behaviour kept: the d-action bounds u_min/u_max only shape the stored
+    `perturbed_control`, not the rollouts (:536-540).  Deviation: `action_sequence` is re-bound to a
+    new tensor per command (the reference updates it in place, :515, which silently rewrites
+    actions returned by earlier calls)."""
+
+    def __init__(self, *args, w_action_seq_cost=1., delta_t=1., U_init=None, action_min=None, action_max=None,
+                 **kwargs):
+        self.w_action_seq_cost = w_action_seq_cost
+        self.delta_t = delta_t
+        super().__init__(*args, U_init=U_init, **kwargs)
+        if action_min is not None and action_max is None:                 # :464-471
+            if not torch.is_tensor(action_min):
+                action_min = torch.tensor(action_min)
+            action_max = -action_min
+        if action_max is not None and action_min is None:
+            if not torch.is_tensor(action_max):
+                action_max = torch.tensor(action_max)
+            action_min = -action_max
+        if action_min is not None:
+            self.action_min = action_min.to(device=self.d)
+            self.action_max = action_max.to(device=self.d)
+        else:
+            self.action_min = torch.tensor(float('-inf'), device=self.d)
+            self.action_max = torch.tensor(float('inf'), device=self.d)
+        if U_init is None:                                                # :479-483
+            self.action_sequence = torch.zeros_like(self.U)
+        else:
+            self.action_sequence = self.U.clone()
+        self.U = torch.zeros_like(self.U)
+        self._perturbed_control = None
+
+    def get_params(self):
+        return f"{super().get_params()} w={self.w_action_seq_cost} t={self.delta_t}"
+
+    def shift_nominal_trajectory(self):
+        self.U = torch.roll(self.U, -1, dims=0)
+        self.U[-1] = self.u_init
+        self.action_sequence = torch.roll(self.action_sequence, -1, dims=0)
+        self.action_sequence[-1] = self.action_sequence[-2]               # :491-492
+
+    def get_action_sequence(self):
+        return self.action_sequence
+
+    def reset(self):
+        self.U = torch.zeros_like(self.U)
+        self.action_sequence = torch.zeros_like(self.U)
+
+    def change_horizon(self, horizon):
+        if horizon < self.U.shape[0]:
+            self.U = self.U[:horizon]
+            self.action_sequence = self.action_sequence[:horizon]
+        elif horizon > self.U.shape[0]:
+            extend_for = horizon - self.U.shape[0]
+            self.U = torch.cat((self.U, self.u_init.repeat(extend_for, 1)))
+            self.action_sequence = torch.cat((self.action_sequence, self.action_sequence[-1].repeat(extend_for, 1)))
+        self.T = horizon
+        self._ws = None
+
+    def _bound_d_action(self, control):
+        return torch.clamp(control, self.u_min, self.u_max)
+
+    def _bound_action(self, action):
+        return torch.clamp(action, self.action_min, self.action_max)
+
+    def _problem(self, Tn=None, U=None):
+        p = super()._problem(Tn, U)
+        dt = float(self.delta_t)
+        keep = p._keep
+        A = self.action_sequence.to(device=self.d, dtype=self.dtype)
+        keep["B"] = (A + keep["U"] * dt).contiguous()                     # base of :540
+        keep["L_dt"] = (keep["L"] * dt).contiguous()
+        keep["mu_dt"] = (keep["mu"] * dt).contiguous()
+        keep["amin"], keep["amax"] = self._vec(self.action_min), self._vec(self.action_max)
+        p.base_seq = _ptr(keep["B"])
+        p.noise_L, p.noise_mu = _ptr(keep["L_dt"]), _ptr(keep["mu_dt"])
+        p.u_min, p.u_max = _ptr(keep["amin"]), _ptr(keep["amax"])
+        p.noise_rescale = 1.0 / dt
+        p.smooth_weight = float(self.w_action_seq_cost) * float(self.u_scale) ** 2
+        return p
+
+    def _begin(self, state, shift):
+        if shift:
+            self.shift_nominal_trajectory()       # U and the action sequence move together (host, tiny)
+        self._perturbed_control = None
+        return super()._begin(state, False)
+
+    def _end(self, p):
+        super()._end(p)
+        self.action_sequence = self.action_sequence + self.U * self.delta_t       # :515 (new tensor)
+        action = self.action_sequence[:self.u_per_command]
+        if self.u_per_command == 1:
+            action = action[0]
+        return action
+
+    @property
+    def perturbed_control(self):
+        """clamp(U + eps, u_min, u_max) of the last command (mppi.py:537) -- stored only, unused by
+        the rollouts, exactly like the reference."""
+        if self._perturbed_control is None and self._last is not None:
+            lib = N.lib()
+            q = MPPI._problem(self, U=self._last._keep["U"])          # plain-MPPI view of the same draw
+            q.shift = 0
+            q.noise_src, q.z, q.call = self._last.noise_src, self._last.z, self._last.call
+            q.sample_null_action, q.n_sampler_rows = 0, 0
+            self._attach_workspace(q)
+            pc = torch.empty(self.K_local, self.T, self.nu, device=self.d, dtype=self.dtype)
+            q.perturbed_action = _ptr(pc)
+            z_save = None
+            if q.noise_src == N.NOISE_PHILOX:
+                q.z = None
+            N.check(lib.mppi_prepare(C.byref(q), self._stream()), "mppi_prepare")
+            self._perturbed_control = pc
+        return self._perturbed_control
+
+    @perturbed_control.setter
+    def perturbed_control(self, v):
+        self._perturbed_control = v
+
+
 class TimeKernel:
     """mppi.py:573-577"""
 

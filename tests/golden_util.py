@@ -79,6 +79,18 @@ def oracle_run(cfg, d, dtype=None):
     state = t(d, "state", dtype)
     sampler = t(d, "sampler_actions", dtype) if cfg["sampler_rows"] else None
     outs = []
+    if cfg.get("smppi"):
+        sm = dict(cfg["smppi"])
+        amax = torch.tensor(sm["action_max"], dtype=dtype) if "action_max" in sm else torch.tensor(float("inf"))
+        amin = -amax
+        A = U.clone()                       # U_init = initial action sequence (mppi.py:479-483)
+        U = torch.zeros_like(U)
+        for s in range(cfg["steps"]):
+            r = orc.smppi_command(p, U, A, state, t(d, f"z{s}", dtype), amin, amax, sm.get("w_action_seq_cost", 1.0),
+                                  sm.get("delta_t", 1.0), bool(d[f"shift{s}"]), sampler)
+            U, A = r["U"], r["action_sequence"]
+            outs.append(r)
+        return outs
     if cfg["kmppi"]:
         W, W_shift, _, _ = orc.kmppi_matrices(cfg["T"], cfg["S"], dtype)
         theta = torch.zeros(cfg["S"], cfg["nu"], dtype=dtype)
@@ -135,7 +147,10 @@ def engine_controller(cfg, d, *, native=True, device="cuda", dtype=None, **extra
 
         kw["specific_action_sampler"] = _S()
     kw.update(extra)
-    cls = pm.KMPPI if cfg["kmppi"] else pm.MPPI
+    if cfg.get("smppi"):
+        for k2, v2 in cfg["smppi"].items():
+            kw[k2] = torch.tensor(v2, dtype=dtype) if isinstance(v2, list) else v2
+    cls = pm.KMPPI if cfg["kmppi"] else (pm.SMPPI if cfg.get("smppi") else pm.MPPI)
     if cfg["kmppi"]:
         kw["num_support_pts"] = cfg["S"]
     return cls(f, q, cfg["nx"], torch.tensor(cfg["sigma"], dtype=dtype), num_samples=cfg["K"],

@@ -346,3 +346,51 @@ class TestSolutionQuality:                                   # :813-948 (MPPI / 
         umax = torch.tensor([0.3, 0.3], dtype=DT)
         r = _closed_loop(make(path, num_samples=300, u_min=-umax, u_max=umax))
         assert float(r["actions"].abs().max()) <= 0.3 + 1e-6
+
+
+@pytest.mark.parametrize("path", PATHS)
+class TestSMPPIBehaviour:                                    # reference TestSMPPI :334-462
+    def test_basic_goal_and_action_bounds(self, path):       # :349-377
+        torch.manual_seed(42)
+        amax = torch.tensor([0.5, 0.5], dtype=DT)
+        c = make(path, cls=pm.SMPPI, num_samples=500, action_min=-amax, action_max=amax)
+        s = st([-3.0, -2.0])
+        d0 = float((st([2.0, 2.0]) - s).norm())
+        for _ in range(10):
+            a = c.command(s)
+            assert a.shape == (2,) and (a.abs().cpu() <= amax + 1e-6).all()
+            s = step(s, a)
+        assert float((st([2.0, 2.0]) - s).norm()) < d0
+
+    def test_smoother_than_mppi(self, path):                 # :379-407, :916-936
+        def smooth(cls, **kw):
+            torch.manual_seed(42)
+            c = make(path, cls=cls, num_samples=300, horizon=15, **kw)
+            s = st([-3.0, -2.0])
+            acts = []
+            for _ in range(15):
+                a = c.command(s)
+                acts.append(a.clone())
+                s = step(s, a)
+            return float(torch.stack(acts).diff(dim=0).abs().sum())
+        assert smooth(pm.SMPPI, w_action_seq_cost=10.0) < smooth(MPPI)
+
+    def test_weights_dt_reset_horizon_params(self, path):    # :409-462
+        torch.manual_seed(42)
+        assert make(path, cls=pm.SMPPI, w_action_seq_cost=5.0).command(st([0.0, 0.0])).shape == (2,)
+        c = make(path, cls=pm.SMPPI, delta_t=0.1)
+        s = st([0.0, 0.0])
+        c.command(s)
+        assert c.get_action_sequence().shape == (10, 2) and c.get_action_sequence() is c.action_sequence
+        assert "w=1.0" in c.get_params() and "t=0.1" in c.get_params()
+        c.change_horizon(5)
+        assert c.U.shape == (5, 2) and c.action_sequence.shape == (5, 2) and c.command(s).shape == (2,)
+        c.change_horizon(12)
+        assert c.U.shape == (12, 2) and c.action_sequence.shape == (12, 2) and c.command(s).shape == (2,)
+        c.reset()
+        assert float(c.U.abs().sum()) == 0.0 and float(c.action_sequence.abs().sum()) == 0.0
+        # noise bookkeeping of the lifted space (mppi.py:540-544)
+        c.command(s)
+        A = c._last._keep["B"] - c._last._keep["U"] * c.delta_t
+        assert torch.allclose((c.perturbed_action - A) / c.delta_t - c._last._keep["U"], c.noise, atol=1e-10)
+        assert c.perturbed_control.shape == (100, 12, 2)

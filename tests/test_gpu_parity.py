@@ -43,6 +43,8 @@ def _run_fixture(name, native):
         if cfg["kmppi"]:
             got["theta"] = ctrl.theta
             got["noise_theta"] = ctrl.noise_theta
+        if cfg.get("smppi"):
+            got["action_sequence"] = ctrl.action_sequence
         for k, v in got.items():
             kr = rtol
             if cfg["kmppi"] and cfg["dtype"] == "f32":

@@ -20,7 +20,7 @@ def test_oracle_matches_reference_fixture(name):
     if cfg["kmppi"]:
         rtol = 1e-9 if cfg["dtype"] == "f64" else 1e-4   # constant-W form vs vmap(solve), SURVEY 3.3
     for s, r in enumerate(outs):
-        for k in KEYS + (["theta", "noise_theta"] if cfg["kmppi"] else []):
+        for k in KEYS + (["theta", "noise_theta"] if cfg["kmppi"] else []) + (["action_sequence"] if cfg.get("smppi") else []):
             ref = np.array(d[f"{k}{s}"])
             got = r[k].numpy()
             scale = max(1.0, float(np.abs(ref).max()))
