@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 5
+#define MPPI_ABI_VERSION 6
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -82,6 +82,12 @@ typedef struct MppiProblem {
   int32_t u_per_command;      /* mppi.py:271                                               */
   int32_t step_offset;        /* reserved (0)                                              */
   int32_t hidden;             /* MLP hidden width                                          */
+  int32_t num_envs;           /* MPPI_Batched (mppi.py:691-873): N independent controllers that
+                                 share ONE noise draw; 0/1 = single.  state (N,nx), U / U_out
+                                 (N,T,nu), cost_total / omega / cost_total_non_zero (N,K), record
+                                 (N,2+J), perturbed_action / noise (N,K,T,nu), pert_cost (N,K);
+                                 the environment is the z axis of every launch grid          */
+  int32_t reserved0;
   double lambda_;             /* mppi.py:96, read live                                     */
   double u_scale;             /* mppi.py:313                                               */
   uint64_t seed, call;        /* Philox key / per-command counter word                     */

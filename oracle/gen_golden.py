@@ -119,6 +119,36 @@ def run_case(name, *, model, model_args, nx, nu, K, T, dtype, sigma, steps=2, st
     print(f"{name}: action0={out['action0']}")
 
 
+def run_batched_case(name, *, N, K, T, dtype, sigma, steps=2, seed=0, **ctor):
+    """MPPI_Batched (mppi.py:691-873) on the linear-goal environment: U (N,T,nu), shared z per command."""
+    mod, proxy = load_reference()
+    tdt = {"f32": torch.float32, "f64": torch.float64}[dtype]
+    g = torch.Generator().manual_seed(seed)
+    B = torch.tensor([[1.0, 0.0], [0.0, -1.0]], dtype=tdt)
+    goal = torch.tensor([2.0, 2.0], dtype=tdt)
+    f, q, _ = dyn.make_linear_goal(B, goal)
+    kw = {k: (torch.tensor(v, dtype=tdt) if isinstance(v, (list, tuple)) else v) for k, v in ctor.items()}
+    nu = 2
+    U0 = torch.randn(N, T, nu, generator=g, dtype=tdt) * 0.3
+    proxy.queue.append(torch.zeros(N, T, nu, dtype=tdt))          # the constructor's own draw (:797), replaced below
+    ctrl = mod.MPPI_Batched(f, q, 2, torch.tensor(sigma, dtype=tdt), N, num_samples=K, horizon=T, device="cpu", **kw)
+    ctrl.U = U0.clone()
+    states = torch.randn(N, 2, generator=g, dtype=tdt) * 2
+    out = dict(U_init=_np(U0), state=_np(states), B=_np(B), goal=_np(goal))
+    for s in range(steps):
+        z = torch.randn(K, T, nu, generator=g, dtype=tdt)
+        proxy.queue.append(z)
+        shift = (s % 2 == 0)
+        act = ctrl.command(states, shift_nominal_trajectory=shift)
+        assert not proxy.queue
+        out[f"z{s}"], out[f"shift{s}"], out[f"action{s}"], out[f"U{s}"] = _np(z), np.array(shift), _np(act), _np(ctrl.U)
+    cfg = dict(name=name, model="linear_goal", nx=2, nu=nu, N=N, K=K, T=T, dtype=dtype, sigma=sigma, steps=steps,
+               ctor=ctor, batched=True, reference="UM-ARM-Lab/pytorch_mppi v0.9.1", torch=torch.__version__)
+    out["config"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: action0={out['action0'][0]}")
+
+
 def main():
     I2 = [[1.0, 0.0], [0.0, 1.0]]
     Bt = [[1.0, 0.0], [0.0, -1.0]]
@@ -156,6 +186,10 @@ def main():
     run_case("smppi_quadtoy_f32", model="quadtoy", model_args={}, nx=6, nu=4, K=128, T=12, dtype="f32",
              sigma=[[1, 0.2, 0, 0], [0.2, 2, 0, 0], [0, 0, 0.5, 0], [0, 0, 0, 1.5]], steps=2, lambda_=25.0,
              smppi=dict(w_action_seq_cost=2.0, delta_t=1.0), sample_null_action=True, u_scale=0.5, seed=11)
+    run_batched_case("batched_linear_f64", N=3, K=100, T=10, dtype="f64", sigma=[[1.0, 0.0], [0.0, 1.0]], steps=3,
+                     lambda_=1.0, u_max=[1.5, 1.0], seed=12)
+    run_batched_case("batched_linear_full_f32", N=5, K=128, T=8, dtype="f32", sigma=[[1.0, 0.3], [0.3, 0.6]], steps=2,
+                     lambda_=4.0, noise_mu=[0.05, -0.1], u_scale=0.5, u_per_command=2, noise_abs_cost=True, seed=13)
     run_case("kmppi_linear_f64", model="linear_goal", model_args=dict(B=Bt, goal=[2.0, 2.0]), nx=2, nu=2,
              K=100, T=10, dtype="f64", sigma=I2, state=[-3.0, -2.0], steps=3, lambda_=1.0, kmppi=True,
              u_max=[1.0, 1.0], seed=8)

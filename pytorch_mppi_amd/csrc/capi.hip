@@ -50,7 +50,8 @@ Carve carve(const MppiProblem* p) {
   if (const char* e = getenv("MPPI_K3_R")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) R = v; }
   c.R = R;
   c.nkc = (p->K + BLOCK * R - 1) / (BLOCK * R);
-  c.total = (int64_t)c.nb1 + c.nkc + (int64_t)c.nkc * c.Jpad;
+  const int64_t ne = p->num_envs > 1 ? p->num_envs : 1;
+  c.total = ne * ((int64_t)c.nb1 + c.nkc + (int64_t)c.nkc * c.Jpad);
   return c;
 }
 
@@ -84,7 +85,14 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.noise = (T*)p->noise; a.pert = (T*)p->pert_cost; a.states = (T*)p->states;
   a.record = (T*)p->record;
   T* ws = (T*)p->workspace;
-  a.block_min = ws; a.eta_part = ws + c.nb1; a.P_part = ws + c.nb1 + c.nkc;
+  a.n_env = p->num_envs > 1 ? p->num_envs : 1;
+  if (a.n_env > 1 && (p->state_per_sample || p->n_sampler_rows > 0 || p->states != nullptr || p->base_seq != nullptr ||
+                      p->S > 0 || p->noise_src == MPPI_NOISE_ACTIONS))
+    return fail(MPPI_E_UNSUPPORTED, "num_envs > 1 supports the plain MPPI path only");
+  if (a.n_env > 65535) return fail(MPPI_E_BADARG, "num_envs > 65535");
+  // per-environment workspace blocks: [n_env][nb1] | [n_env][nkc] | [n_env][nkc][Jpad]
+  a.block_min = ws; a.eta_part = ws + (int64_t)a.n_env * c.nb1;
+  a.P_part = a.eta_part + (int64_t)a.n_env * c.nkc;
   a.nb1 = c.nb1; a.nkc = c.nkc; a.Jpad = c.Jpad; a.R = c.R;
   return 0;
 }

@@ -28,7 +28,33 @@ struct KArgs {
   T* eta_part;    // [nkc]
   T* P_part;      // [nkc][Jpad]
   int nb1, nkc, Jpad, R;
+  int n_env;      // MPPI_Batched: environments on grid.z (1 = single controller)
 };
+
+// MPPI_Batched: the view of the argument block for environment blockIdx.z.  The noise (z), all
+// parameters and the model are shared; state, nominal sequence, costs, weights, workspace and
+// outputs are per environment.
+template <typename T>
+__device__ __forceinline__ KArgs<T> env_view(const KArgs<T>& a) {
+  if (a.n_env <= 1) return a;
+  const long long e = blockIdx.z;
+  KArgs<T> b = a;
+  b.state = a.state + e * a.nx;
+  b.U = a.U + e * a.J;
+  b.cost = a.cost + e * a.K;
+  if (a.omega) b.omega = a.omega + e * a.K;
+  if (a.wnz) b.wnz = a.wnz + e * a.K;
+  if (a.U_out) b.U_out = a.U_out + e * a.J;
+  if (a.action_out) b.action_out = a.action_out + e * a.u_per_command * a.nu;
+  if (a.pa) b.pa = a.pa + e * a.K * a.J;
+  if (a.noise) b.noise = a.noise + e * a.K * a.J;
+  if (a.pert) b.pert = a.pert + e * a.K;
+  if (a.record) b.record = a.record + e * (2 + a.J);
+  b.block_min = a.block_min + e * a.nb1;
+  b.eta_part = a.eta_part + e * a.nkc;
+  b.P_part = a.P_part + e * (long long)a.nkc * a.Jpad;
+  return b;
+}
 
 // ---------------------------------------------------------------------------------------------
 // scalar math overloads (accurate ocml forms: parity against the CPU oracle is the first gate)

@@ -234,8 +234,9 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
 
 // NOISE: MPPI_NOISE_TNK4 | _PHILOX | _ACTIONS (compile-time);  DIAG: diagonal Sigma
 template <class Model, typename T, int NOISE, bool DIAG>
-__global__ void __launch_bounds__(BLOCK) rollout_cost_kernel(const KArgs<T> a) {
+__global__ void __launch_bounds__(BLOCK) rollout_cost_kernel(const KArgs<T> a_in) {
   constexpr int NX = Model::NX, NU = Model::NU;
+  const KArgs<T> a = env_view(a_in);        // MPPI_Batched: environment = blockIdx.z
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ue = reinterpret_cast<T*>(smem_raw);   // [J] nominal sequence, shift applied
   T* Um = Ue + a.J;                         // [J] Ue + mu
@@ -322,7 +323,7 @@ static int launch_rollout(const KArgs<T>& a, hipStream_t st) {
   constexpr int NU = Model::NU;
   const bool diag = a.diag != 0;
   const size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (diag ? 0 : 2 * NU * NU)) * sizeof(T);
-  const dim3 grid((a.K + BLOCK - 1) / BLOCK), block(BLOCK);
+  const dim3 grid((a.K + BLOCK - 1) / BLOCK, 1, a.n_env), block(BLOCK);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   profile_next_events(&ev0, &ev1);   // null events == plain launch
 #define MPPI_LAUNCH(NOISE_)                                                                        \

@@ -44,8 +44,9 @@ constexpr int MLP_NT = MPPI_MLP_NT;
 constexpr int MLP_THREADS = 256 / (16 * MLP_NT) * WAVE;
 
 template <int HT /* hidden / 16 */, int NOISE, bool DIAG>
-__global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KArgs<float> a) {
+__global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KArgs<float> a_in) {
   constexpr int NU = MLP_NU, NX = MLP_NX, NT = MLP_NT, H = HT * 16;
+  const KArgs<float> a = env_view(a_in);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* Ue = reinterpret_cast<float*>(smem_raw);   // [J]
   float* Um = Ue + a.J;                             // [J]
@@ -254,7 +255,7 @@ template <int HT>
 static int launch_ht(const KArgs<float>& a, hipStream_t st) {
   const bool diag = a.diag != 0;
   const size_t smem = (size_t)(3 * a.J + MLP_THREADS / WAVE + HT * 16 + 2 * MLP_NU * MLP_NU) * sizeof(float);
-  const dim3 grid((a.K + 255) / 256), block(MLP_THREADS);
+  const dim3 grid((a.K + 255) / 256, 1, a.n_env), block(MLP_THREADS);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   profile_next_events(&ev0, &ev1);
 #define MPPI_LAUNCH(NOISE_)                                                                          \

@@ -135,7 +135,8 @@ __global__ void __launch_bounds__(64) kmppi_interp_kernel(const KArgs<T> a, cons
 // prepare: perturbed_action / noise (K,T,nu) + pert_cost (K)
 // =============================================================================================
 template <typename T, int NU, int NOISE>
-__global__ void __launch_bounds__(BLOCK) prepare_kernel(const KArgs<T> a) {
+__global__ void __launch_bounds__(BLOCK) prepare_kernel(const KArgs<T> a_in) {
+  const KArgs<T> a = env_view(a_in);
   constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ue = reinterpret_cast<T*>(smem_raw);   // [J] base sequence (noise is added to / measured from)
@@ -191,7 +192,8 @@ __global__ void __launch_bounds__(BLOCK) prepare_kernel(const KArgs<T> a) {
 }
 
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) cost_block_min_kernel(const KArgs<T> a) {
+__global__ void __launch_bounds__(BLOCK) cost_block_min_kernel(const KArgs<T> a_in) {
+  const KArgs<T> a = env_view(a_in);
   __shared__ T red[BLOCK / WAVE];
   const int k = blockIdx.x * BLOCK + threadIdx.x;
   const T bm = block_min<T>(k < a.K ? a.cost[k] : inf_v<T>(), red);
@@ -244,7 +246,8 @@ __device__ __forceinline__ T overwrite_correction(const KArgs<T>& a, int kbeg, i
 }
 
 template <typename T, int NOISE, int R>
-__global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs<T> a) {
+__global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs<T> a_in) {
+  const KArgs<T> a = env_view(a_in);
   __shared__ __attribute__((aligned(16))) T cU[UPD_TJ], cS[UPD_TJ], cM[UPD_TJ], cLo[UPD_TJ], cHi[UPD_TJ];
   __shared__ T red[BLOCK / WAVE];
   __shared__ T wsum[BLOCK / WAVE][UPD_TJ];
@@ -330,7 +333,8 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs
 
 // full-Sigma variant: one tile = SSB super-steps of NU-aligned timesteps, at most 64 columns
 template <typename T, int NU, int NOISE>
-__global__ void __launch_bounds__(BLOCK) weights_partial_full_kernel(const KArgs<T> a) {
+__global__ void __launch_bounds__(BLOCK) weights_partial_full_kernel(const KArgs<T> a_in) {
+  const KArgs<T> a = env_view(a_in);
   constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
   constexpr int SSB = (16 / P4) > 0 ? (16 / P4) : 1;     // super-steps per tile
   constexpr int TJ = SSB * P4 * 4;                      // columns per tile (<= 64)
@@ -438,7 +442,8 @@ __device__ __forceinline__ T column_sum(const KArgs<T>& a, int j, T (*part)[WAVE
 
 // grid.x = ceil(J/64) column blocks (+ extra blocks that only write omega)
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) finalize_kernel(const KArgs<T> a, int apply, int ncolblocks) {
+__global__ void __launch_bounds__(BLOCK) finalize_kernel(const KArgs<T> a_in, int apply, int ncolblocks) {
+  const KArgs<T> a = env_view(a_in);
   __shared__ T red[BLOCK / WAVE];
   __shared__ T part[BLOCK / WAVE][WAVE];
   const T beta = shard_beta(a, red);
@@ -539,7 +544,7 @@ int launch_kmppi_interp(const KArgs<T>& a, const T* W, int Thor, int J4out, T* o
 template <typename T>
 int launch_prepare(const KArgs<T>& a, hipStream_t st) {
   const size_t smem = ((size_t)2 * a.J + 2 * a.nu * a.nu) * sizeof(T);
-  const dim3 grid((a.K + BLOCK - 1) / BLOCK), block(BLOCK);
+  const dim3 grid((a.K + BLOCK - 1) / BLOCK, 1, a.n_env), block(BLOCK);
 #define X(N)                                                                                      \
   if (a.nu == N) {                                                                                \
     if (a.noise_src == MPPI_NOISE_PHILOX)                                                         \
@@ -555,7 +560,7 @@ int launch_prepare(const KArgs<T>& a, hipStream_t st) {
 
 template <typename T>
 int launch_cost_block_min(const KArgs<T>& a, hipStream_t st) {
-  hipLaunchKernelGGL(cost_block_min_kernel<T>, dim3(a.nb1), dim3(BLOCK), 0, st, a);
+  hipLaunchKernelGGL(cost_block_min_kernel<T>, dim3(a.nb1, 1, a.n_env), dim3(BLOCK), 0, st, a);
   return (int)hipGetLastError();
 }
 
@@ -563,7 +568,7 @@ template <typename T>
 int launch_weights_partial(const KArgs<T>& a, hipStream_t st) {
   if (a.noise_src == MPPI_NOISE_ACTIONS) return MPPI_E_BADARG;
   if (a.diag) {
-    const dim3 grid(a.nkc, (a.J4 * 4 + UPD_TJ - 1) / UPD_TJ), block(BLOCK);
+    const dim3 grid(a.nkc, (a.J4 * 4 + UPD_TJ - 1) / UPD_TJ, a.n_env), block(BLOCK);
 #define LAUNCH_R(RR)                                                                              \
   if (a.R == RR) {                                                                                \
     if (a.noise_src == MPPI_NOISE_PHILOX)                                                         \
@@ -584,7 +589,7 @@ int launch_weights_partial(const KArgs<T>& a, hipStream_t st) {
     constexpr int P4 = Stream<N>::P4, TT = Stream<N>::TT;                                         \
     constexpr int SSB = (16 / P4) > 0 ? (16 / P4) : 1;                                            \
     const int nss = (a.Tn + TT - 1) / TT;                                                         \
-    const dim3 grid(a.nkc, (nss + SSB - 1) / SSB), block(BLOCK);                                  \
+    const dim3 grid(a.nkc, (nss + SSB - 1) / SSB, a.n_env), block(BLOCK);                                  \
     if (a.noise_src == MPPI_NOISE_PHILOX)                                                         \
       hipLaunchKernelGGL((weights_partial_full_kernel<T, N, MPPI_NOISE_PHILOX>), grid, block,     \
                          smem, st, a);                                                            \
@@ -607,12 +612,13 @@ int launch_finalize(const KArgs<T>& a, int apply, hipStream_t st) {
     if (nbk > 256) nbk = 256;
     nb = nbk > nb ? nbk : nb;
   }
-  hipLaunchKernelGGL(finalize_kernel<T>, dim3(nb), dim3(BLOCK), 0, st, a, apply, ncol);
+  hipLaunchKernelGGL(finalize_kernel<T>, dim3(nb, 1, a.n_env), dim3(BLOCK), 0, st, a, apply, ncol);
   return (int)hipGetLastError();
 }
 
 template <typename T>
 int launch_combine(const KArgs<T>& a, const T* rec, int G, hipStream_t st) {
+  if (a.n_env > 1) return MPPI_E_UNSUPPORTED;   // sharded MPPI_Batched: not built
   int nb = (a.J + BLOCK - 1) / BLOCK;
   if (a.omega != nullptr) {
     const int nbk = (a.K + BLOCK - 1) / BLOCK;

@@ -771,6 +771,115 @@ class SMPPI(MPPI):
         self._perturbed_control = v
 
 
+class MPPI_Batched:
+    """MPPI for N parallel environments (mppi.py:691-873): N nominal sequences U (N,T,nu), ONE shared
+    noise draw per command, independent softmax per environment.
+
+    Here the environment is the z axis of every launch grid: K1/K3/K4 run once for all N
+    environments (fused path: native model; generic path: the reference's single (N*K, nx)
+    callback batch per timestep around `mppi_prepare`).  Constructor and `command(states)` as in
+    the reference; `rng` / `seed` are the same additive extras as on `MPPI`."""
+
+    def __init__(self, dynamics, running_cost, nx, noise_sigma, num_envs,
+                 num_samples=100, horizon=15, device="cpu",
+                 lambda_=1.,
+                 noise_mu=None,
+                 u_min=None,
+                 u_max=None,
+                 u_init=None,
+                 u_scale=1,
+                 u_per_command=1,
+                 step_dependent_dynamics=False,
+                 noise_abs_cost=False,
+                 *, rng="torch", seed=None):
+        # parameter resolution is MPPI's (identical rules, mppi.py:730-790); the inner controller is
+        # never commanded itself -- it is the parameter block + launch plumbing for all N envs
+        self._c = MPPI(dynamics, running_cost, nx, noise_sigma, num_samples=num_samples, horizon=horizon,
+                       device=device, lambda_=lambda_, noise_mu=noise_mu, u_min=u_min, u_max=u_max, u_init=u_init,
+                       U_init=torch.zeros(horizon, 1 if len(noise_sigma.shape) == 0 else noise_sigma.shape[0],
+                                          dtype=noise_sigma.dtype),
+                       u_scale=u_scale, u_per_command=u_per_command, step_dependent_dynamics=step_dependent_dynamics,
+                       noise_abs_cost=noise_abs_cost, rng=rng, seed=seed)
+        c = self._c
+        self.d, self.dtype = c.d, c.dtype
+        self.N, self.K, self.T, self.nx, self.nu = num_envs, c.K, c.T, c.nx, c.nu
+        self.u_per_command = u_per_command
+        self.U = self._sample_noise((self.N, self.T))                     # :796-797
+        self.cost_total = self.omega = None
+
+    # attribute surface shared with the inner parameter block
+    lambda_ = property(lambda self: self._c.lambda_, lambda self, v: setattr(self._c, "lambda_", v))
+    u_scale = property(lambda self: self._c.u_scale, lambda self, v: setattr(self._c, "u_scale", v))
+    u_min = property(lambda self: self._c.u_min, lambda self, v: setattr(self._c, "u_min", v))
+    u_max = property(lambda self: self._c.u_max, lambda self, v: setattr(self._c, "u_max", v))
+    u_init = property(lambda self: self._c.u_init, lambda self, v: setattr(self._c, "u_init", v))
+    noise_mu = property(lambda self: self._c.noise_mu)
+    noise_sigma = property(lambda self: self._c.noise_sigma)
+    noise_abs_cost = property(lambda self: self._c.noise_abs_cost)
+
+    def _sample_noise(self, shape):
+        return self._c._sample_noise(shape)
+
+    def compile(self, **kwargs):
+        self._c.compile(**kwargs)
+
+    def reset(self):
+        self.U = self._sample_noise((self.N, self.T))
+
+    def inject_noise(self, z):
+        self._c.inject_noise(z)
+
+    def command(self, states, shift_nominal_trajectory=True):
+        """states (N,nx) -> actions (N,nu) or (N,u_per_command,nu)   (mppi.py:811-873)"""
+        lib = N.lib()
+        c = self._c
+        if not torch.is_tensor(states):
+            states = torch.tensor(states)
+        states = states.to(dtype=self.dtype, device=self.d).reshape(self.N, self.nx).contiguous()
+        Nn, K, T, nu = self.N, self.K, self.T, self.nu
+        p = c._problem(U=self.U.reshape(Nn * T, nu))
+        p.num_envs = Nn
+        p.shift = int(bool(shift_nominal_trajectory))
+        st = c._stream()
+        c._attach_workspace(p)
+        c._draw_noise(p, (K, T, nu))                                      # shared across environments (:838)
+        cost_total = torch.empty(Nn, K, device=self.d, dtype=self.dtype)
+        p.cost_total = _ptr(cost_total)
+        p.state = _ptr(states)
+        p._keep["state"] = states
+        if not c._needs_generic():
+            N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
+        else:
+            pa = torch.empty(Nn, K, T, nu, device=self.d, dtype=self.dtype)
+            pert = torch.empty(Nn, K, device=self.d, dtype=self.dtype)
+            p.perturbed_action, p.pert_cost = _ptr(pa), _ptr(pert)
+            N.check(lib.mppi_prepare(C.byref(p), st), "mppi_prepare")
+            p.perturbed_action = p.pert_cost = None
+            NK = Nn * K
+            state = states.unsqueeze(1).expand(Nn, K, self.nx).reshape(NK, self.nx)   # :848-850
+            rollout = torch.zeros(Nn, K, device=self.d, dtype=self.dtype)
+            for t in range(T):
+                u = c.u_scale * pa[:, :, t].reshape(NK, nu)
+                state = c._dynamics_fn(state, u, t)
+                rollout = rollout + c._running_cost_fn(state, u, t).reshape(Nn, K)
+            torch.add(rollout, pert, out=cost_total)                      # :861
+            N.check(lib.mppi_cost_block_min(C.byref(p), st), "mppi_cost_block_min")
+        if p.noise_src == N.NOISE_PHILOX and p.z:
+            p.noise_src = N.NOISE_TNK4
+        omega = torch.empty(Nn, K, device=self.d, dtype=self.dtype)
+        U_new = torch.empty(Nn, T, nu, device=self.d, dtype=self.dtype)
+        record = torch.empty(Nn, 2 + T * nu, device=self.d, dtype=self.dtype)
+        p.omega, p.U_out, p.record = _ptr(omega), _ptr(U_new), _ptr(record)
+        N.check(lib.mppi_weights_partial(C.byref(p), st), "mppi_weights_partial")   # per-env beta/eta (:863-866)
+        N.check(lib.mppi_finalize(C.byref(p), 1, st), "mppi_finalize")
+        self.cost_total, self.omega, self._last = cost_total, omega, p
+        self.U = U_new                                                    # :869
+        action = self.U[:, :self.u_per_command]
+        if self.u_per_command == 1:
+            action = action[:, 0]
+        return action
+
+
 class TimeKernel:
     """mppi.py:573-577"""
 

@@ -14,8 +14,28 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TDT = {"f32": torch.float32, "f64": torch.float64}
 
 
-def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+def golden_names(batched=False):
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [n for n in names if n.startswith("batched_") == batched]
+
+
+def oracle_run_batched(cfg, d, dtype=None):
+    """MPPI_Batched == N independent MPPI commands that share one z (mppi.py:838-869)."""
+    dtype = dtype or TDT[cfg["dtype"]]
+    f, q, _ = dyn.make_linear_goal(t(d, "B", dtype), t(d, "goal", dtype))
+    p = orc.Problem(dynamics=f, running_cost=q, nx=2, noise_sigma=torch.tensor(cfg["sigma"], dtype=dtype),
+                    K=cfg["K"], T=cfg["T"], **ctor_tensors(cfg, dtype))
+    U = t(d, "U_init", dtype)
+    states = t(d, "state", dtype)
+    outs = []
+    for s in range(cfg["steps"]):
+        z = t(d, f"z{s}", dtype)
+        rs = [orc.command(p, U[n], states[n], z, bool(d[f"shift{s}"])) for n in range(cfg["N"])]
+        U = torch.stack([r["U"] for r in rs])
+        outs.append(dict(U=U, action=torch.stack([r["action"] for r in rs]),
+                         cost_total=torch.stack([r["cost_total"] for r in rs]),
+                         omega=torch.stack([r["omega"] for r in rs])))
+    return outs
 
 
 def load(name):

@@ -399,3 +399,54 @@ class TestSMPPIBehaviour:                                    # reference TestSMP
         A = c._last._keep["B"] - c._last._keep["U"] * c.delta_t
         assert torch.allclose((c.perturbed_action - A) / c.delta_t - c._last._keep["U"], c.noise, atol=1e-10)
         assert c.perturbed_control.shape == (100, 12, 2)
+
+
+@pytest.mark.parametrize("path", PATHS)
+class TestMPPIBatchedBehaviour:                              # reference TestMPPIBatched :704-780
+    def _make(self, path, N=4, **kw):
+        B, goal, f, q, _ = _env()
+        if path == "fused":
+            m = models.LinearGoal(B.cpu(), goal.cpu())
+            f, q = m.dynamics, m.running_cost
+        args = dict(dynamics=f, running_cost=q, nx=2, noise_sigma=torch.eye(2, dtype=DT), num_envs=N,
+                    num_samples=100, horizon=10, device=DEV, lambda_=1.0)
+        args.update(kw)
+        return pm.MPPI_Batched(**args)
+
+    def test_shapes_goal_bounds(self, path):                 # :720-752
+        torch.manual_seed(42)
+        c = self._make(path, num_samples=300)
+        s = torch.tensor([[-3.0, -2.0], [0.0, 0.0], [3.0, 3.0], [-1.0, 4.0]], dtype=DT, device=DEV)
+        a = c.command(s)
+        assert a.shape == (4, 2) and a.dtype == DT
+        goal = st([2.0, 2.0])
+        d0 = (goal - s).norm(dim=1)
+        for _ in range(5):
+            s = step(s, c.command(s))
+        assert ((goal - s).norm(dim=1) < d0 + 1e-9).all()
+        umax = torch.tensor([0.5, 0.5], dtype=DT)
+        cb = self._make(path, u_min=-umax, u_max=umax)
+        for _ in range(5):
+            assert (cb.command(s).abs().cpu() <= umax + 1e-6).all()
+        assert self._make(path, u_per_command=3).command(s).shape == (4, 3, 2)
+
+    def test_environments_are_independent(self, path):       # :754-762
+        """same seed: env 0 of a 2-env batch == the single-env controller fed the same noise"""
+        z = torch.randn(100, 10, 2, dtype=DT)
+        s2 = torch.tensor([[-3.0, -2.0], [5.0, 5.0]], dtype=DT, device=DEV)
+        c2 = self._make(path, N=2)
+        c1 = make(path, num_samples=100, horizon=10, U_init=c2.U[0].clone())
+        c2.inject_noise(z)
+        c1.inject_noise(z)
+        a2 = c2.command(s2)
+        a1 = c1.command(s2[0])
+        assert torch.allclose(a2[0], a1, atol=1e-10)
+
+    def test_reset_and_compile(self, path):                  # :764-780
+        torch.manual_seed(42)
+        c = self._make(path)
+        U0 = c.U.clone()
+        c.reset()
+        assert c.U.shape == (4, 10, 2) and not torch.equal(c.U, U0)
+        c.compile()
+        assert torch.isfinite(c.command(torch.zeros(4, 2, dtype=DT, device=DEV))).all()

@@ -248,3 +248,33 @@ def test_mlp_mfma_kernel_matches_valu_kernel_and_fp64_oracle(H, K, full_sigma, p
         _assert_close(c.U, r["U"].numpy(), tol, f"{name} U")
     assert torch.allclose(c_m.cost_total, c_v.cost_total, rtol=2e-6, atol=0)
     assert torch.equal(c_m.perturbed_action, c_v.perturbed_action)
+
+
+@pytest.mark.parametrize("name", gu.golden_names(batched=True))
+@pytest.mark.parametrize("native", [True, False])
+def test_mppi_batched_matches_reference_fixture(name, native):
+    """MPPI_Batched (environment = grid z) vs the live-reference fixture and the per-env oracle."""
+    import pytorch_mppi_amd as pm
+    from oracle import dynamics as dyn
+    cfg, d = gu.load(name)
+    dtype = gu.TDT[cfg["dtype"]]
+    if native:
+        m = pm.models.LinearGoal(gu.t(d, "B", dtype), gu.t(d, "goal", dtype))
+        f, q = m.dynamics, m.running_cost
+    else:
+        f, q, _ = dyn.make_linear_goal(gu.t(d, "B", dtype).cuda(), gu.t(d, "goal", dtype).cuda())
+    ctrl = pm.MPPI_Batched(f, q, 2, torch.tensor(cfg["sigma"], dtype=dtype), cfg["N"], num_samples=cfg["K"],
+                           horizon=cfg["T"], device="cuda", **gu.ctor_tensors(cfg, dtype))
+    assert (ctrl._c._model is not None) == native
+    ctrl.U = gu.t(d, "U_init", dtype).cuda()
+    states = gu.t(d, "state", dtype).cuda()
+    outs = gu.oracle_run_batched(cfg, d)
+    rtol = 1e-9 if cfg["dtype"] == "f64" else 1e-5
+    for s, r in enumerate(outs):
+        ctrl.inject_noise(gu.t(d, f"z{s}", dtype))
+        act = ctrl.command(states, shift_nominal_trajectory=bool(d[f"shift{s}"]))
+        _assert_close(act, d[f"action{s}"], rtol, f"{name} step {s} action")
+        _assert_close(ctrl.U, d[f"U{s}"], rtol, f"{name} step {s} U")
+        _assert_close(ctrl.cost_total, r["cost_total"].numpy(), rtol, f"{name} step {s} cost_total")
+        _assert_close(ctrl.omega, r["omega"].numpy(), rtol, f"{name} step {s} omega")
+        assert torch.allclose(ctrl.omega.sum(dim=1), torch.ones(cfg["N"], dtype=dtype, device="cuda"), atol=1e-5)

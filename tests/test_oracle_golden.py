@@ -43,3 +43,16 @@ def test_rbf_kernel_known_answers():
     k = rbf_kernel(tt, tt, sigma=1.0)
     assert torch.allclose(k.diag(), torch.ones(2, dtype=torch.double), atol=1e-6)
     assert torch.allclose(k[0, 1], torch.tensor(np.exp(-0.5), dtype=torch.double), atol=1e-6)
+
+
+@pytest.mark.parametrize("name", gu.golden_names(batched=True))
+def test_oracle_batched_matches_reference_fixture(name):
+    """MPPI_Batched (mppi.py:691-873) == N independent oracle commands sharing one z."""
+    cfg, d = gu.load(name)
+    outs = gu.oracle_run_batched(cfg, d)
+    rtol = 1e-12 if cfg["dtype"] == "f64" else 2e-6
+    for s, r in enumerate(outs):
+        for k in ("action", "U"):
+            ref = np.array(d[f"{k}{s}"])
+            np.testing.assert_allclose(r[k].numpy(), ref, rtol=rtol, atol=rtol * max(1.0, np.abs(ref).max()),
+                                       err_msg=f"{name} step {s} {k}")
