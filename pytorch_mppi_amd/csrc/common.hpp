@@ -109,7 +109,9 @@ __host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned
 __device__ __forceinline__ void box_muller(unsigned a, unsigned b, float& z0, float& z1) {
   float u1 = fmaf((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);  // 2^-32, 2^-33
   float u2 = (float)b * 2.3283064365386963e-10f;
-  float r = sqrtf(-2.0f * __logf(u1));
+  // r = sqrt(-2 ln u1) = sqrt(-2 ln2 * log2 u1): raw v_log_f32 / v_sqrt_f32 (1 ulp each; the
+  // argument is in [0, 44.4], never denormal, so the slow-path fix-ups of sqrtf/logf are dead weight)
+  float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
   z0 = r * __builtin_amdgcn_cosf(u2);
   z1 = r * __builtin_amdgcn_sinf(u2);
 }

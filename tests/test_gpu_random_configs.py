@@ -1,0 +1,137 @@
+"""GPU: randomized configurations of the generic (callback) and fused paths against the fp64 oracle
+driven with the same callables and the same injected noise -- breadth over (K, T, nu, diagonal/full
+Sigma, mu, bounds, u_scale, abs cost, null action, shift, fp32/fp64), i.e. over the kernel
+instantiations that the golden fixtures do not reach (prepare / K3 for nu = 1..8, full-Sigma K3, ragged K)."""
+import numpy as np
+import pytest
+import torch
+
+import pytorch_mppi_amd as pm
+from oracle import mppi_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    nu = [1, 2, 3, 4, 5, 6, 7, 8][seed % 8]
+    nx = nu + r(0, 3)
+    K = [1, 37, 100, 256, 300, 1000, 2049][r(0, 6)]
+    T = [1, 2, 5, 9, 16, 33][r(0, 5)]
+    full = seed % 3 == 0 and nu > 1
+    dtype = torch.float64 if seed % 2 == 0 else torch.float32
+    A = torch.randn(nu, nu, generator=g, dtype=torch.float64) * 0.3
+    sigma = (A @ A.T + torch.eye(nu, dtype=torch.float64) * 0.5) if full else torch.diag(torch.rand(nu, generator=g, dtype=torch.float64) + 0.3)
+    kw = dict(lambda_=float(torch.rand(1, generator=g)) * 20 + 2.0)
+    if seed % 4 != 1:
+        umax = torch.rand(nu, generator=g, dtype=torch.float64) + 0.5
+        kw["u_max"] = umax
+        if seed % 5 == 0:
+            kw["u_min"] = -umax * 0.5
+    if seed % 3 == 1:
+        kw["noise_mu"] = torch.randn(nu, generator=g, dtype=torch.float64) * 0.2
+    if seed % 4 == 2:
+        kw["u_scale"] = 0.7
+    if seed % 5 == 2:
+        kw["noise_abs_cost"] = True
+    if seed % 3 == 2 and K > 1:
+        kw["sample_null_action"] = True
+    if seed % 7 == 3:
+        kw["u_per_command"] = min(2, T)
+    if seed % 6 == 4:
+        kw["u_init"] = torch.randn(nu, generator=g, dtype=torch.float64) * 0.1
+    Bm = torch.randn(nx, nu, generator=g, dtype=torch.float64) * 0.5
+    goal = torch.randn(nx, generator=g, dtype=torch.float64)
+    U0 = torch.randn(T, nu, generator=g, dtype=torch.float64) * 0.1
+    x0 = torch.randn(nx, generator=g, dtype=torch.float64)
+    z = [torch.randn(K, T, nu, generator=g, dtype=torch.float64) for _ in range(2)]
+    return dict(nx=nx, nu=nu, K=K, T=T, dtype=dtype, sigma=sigma, kw=kw, B=Bm, goal=goal, U0=U0, x0=x0, z=z)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_generic_path_random_config_vs_fp64_oracle(seed):
+    c = _case(seed)
+    dt = c["dtype"]
+    cast = lambda t: t.to(dt) if torch.is_tensor(t) and t.is_floating_point() else t
+    kw64 = c["kw"]
+    kw = {k: cast(v) for k, v in kw64.items()}
+    # fp64 oracle with CPU callables
+    f64 = lambda s, a: s + torch.tanh(a @ c["B"].T)
+    q64 = lambda s, a: ((c["goal"] - s) ** 2).sum(-1) + 0.01 * (a ** 2).sum(-1)
+    p = orc.Problem(dynamics=f64, running_cost=q64, nx=c["nx"], noise_sigma=c["sigma"], K=c["K"], T=c["T"], **kw64)
+    # engine with the same formulas on device tensors
+    Bd, gd = c["B"].to(dt).cuda(), c["goal"].to(dt).cuda()
+    f = lambda s, a: s + torch.tanh(a @ Bd.T)
+    q = lambda s, a: ((gd - s) ** 2).sum(-1) + 0.01 * (a ** 2).sum(-1)
+    ctrl = pm.MPPI(f, q, c["nx"], c["sigma"].to(dt), num_samples=c["K"], horizon=c["T"], device="cuda",
+                   U_init=c["U0"].to(dt), **kw)
+    U = c["U0"]
+    tol = 1e-9 if dt == torch.float64 else 2e-5
+    # fp32 runs: the bar is err <= max(tol, 2 * err(oracle_fp32 vs oracle_fp64)) -- the
+    # reference's own fp32 arithmetic sits at that floor for ill-conditioned softmaxes
+    B32, g32 = c["B"].float(), c["goal"].float()
+    p32 = orc.Problem(dynamics=lambda s, a: s + torch.tanh(a @ B32.T),
+                      running_cost=lambda s, a: ((g32 - s) ** 2).sum(-1) + 0.01 * (a ** 2).sum(-1), nx=c["nx"],
+                      noise_sigma=c["sigma"].float(), K=c["K"], T=c["T"],
+                      **{k: (v.float() if torch.is_tensor(v) else v) for k, v in kw64.items()})
+    U32 = c["U0"].float()
+    for s, z in enumerate(c["z"]):
+        shift = s == 0
+        r = orc.command(p, U, c["x0"], z, shift)
+        U = r["U"]
+        floor = {}
+        if dt == torch.float32:
+            r32 = orc.command(p32, U32, c["x0"].float(), z.float(), shift)
+            U32 = r32["U"]
+            floor = {k: float((r32[k].double() - r[k]).abs().max()) for k in ("action", "U", "cost_total", "omega", "noise", "perturbed_action")}
+        ctrl.inject_noise(z.to(dt))
+        a = ctrl.command(c["x0"].to(dt).cuda(), shift_nominal_trajectory=shift)
+        for name, got, ref in (("action", a, r["action"]), ("U", ctrl.U, r["U"]), ("cost_total", ctrl.cost_total, r["cost_total"]),
+                               ("omega", ctrl.omega, r["omega"]), ("noise", ctrl.noise, r["noise"]),
+                               ("perturbed_action", ctrl.perturbed_action, r["perturbed_action"])):
+            got = got.detach().cpu().double().numpy()
+            ref = ref.numpy()
+            scale = max(1.0, float(np.abs(ref).max()))
+            np.testing.assert_allclose(got, ref, rtol=tol, atol=max(tol * scale, 2 * floor.get(name, 0.0)),
+                                       err_msg=f"seed {seed} step {s} {name} {c['K']}x{c['T']}x{c['nu']}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_integrator_random_config_vs_fp64_oracle(seed):
+    """same sweep on the fused kernel (Integrator instantiations: (2,2) (4,2) (6,4) (8,4) (12,6) (16,12))"""
+    from oracle import dynamics as dyn
+    nx, nu = [(2, 2), (4, 2), (6, 4), (8, 4), (12, 6), (16, 12)][seed % 6]
+    c = _case(100 + seed)
+    g = torch.Generator().manual_seed(seed)
+    K, T = c["K"], c["T"]
+    dt = c["dtype"]
+    full = seed % 2 == 1
+    A = torch.randn(nu, nu, generator=g, dtype=torch.float64) * 0.3
+    sigma = (A @ A.T + torch.eye(nu, dtype=torch.float64) * 0.5) if full else torch.diag(torch.rand(nu, generator=g, dtype=torch.float64) + 0.3)
+    umax = torch.rand(nu, generator=g, dtype=torch.float64) + 0.5
+    kw64 = dict(lambda_=15.0, u_max=umax, noise_mu=torch.randn(nu, generator=g, dtype=torch.float64) * 0.1,
+                sample_null_action=K > 1, u_scale=0.8)
+    U0 = torch.randn(T, nu, generator=g, dtype=torch.float64) * 0.1
+    x0 = torch.randn(nx, generator=g, dtype=torch.float64)
+    f64, q64 = dyn.make_quadtoy(nx, nu)
+    p = orc.Problem(dynamics=f64, running_cost=q64, nx=nx, noise_sigma=sigma, K=K, T=T, **kw64)
+    m = pm.models.Integrator(nx, nu)
+    cast = lambda t: t.to(dt) if torch.is_tensor(t) else t
+    ctrl = pm.MPPI(m.dynamics, m.running_cost, nx, sigma.to(dt), num_samples=K, horizon=T, device="cuda", U_init=U0.to(dt),
+                   **{k: cast(v) for k, v in kw64.items()})
+    assert not ctrl._needs_generic()
+    tol = 1e-9 if dt == torch.float64 else 2e-5
+    U = U0
+    for s in range(2):
+        z = torch.randn(K, T, nu, generator=g, dtype=torch.float64)
+        r = orc.command(p, U, x0, z, s == 0)
+        U = r["U"]
+        ctrl.inject_noise(z.to(dt))
+        a = ctrl.command(x0.to(dt).cuda(), shift_nominal_trajectory=(s == 0))
+        for name, got, ref in (("action", a, r["action"]), ("U", ctrl.U, r["U"]), ("cost_total", ctrl.cost_total, r["cost_total"]),
+                               ("omega", ctrl.omega, r["omega"])):
+            got = got.detach().cpu().double().numpy()
+            ref = ref.numpy()
+            np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())),
+                                       err_msg=f"seed {seed} step {s} {name} ({nx},{nu}) K={K} T={T} full={full}")
