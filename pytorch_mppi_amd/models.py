@@ -30,6 +30,7 @@ class NativeModel:
 
     def __init__(self):
         self._blob_cache = {}
+        self._param_version = 0
 
     # -- torch callables in the reference's plugin convention ----------------------------------
     def dynamics(self, state, action):
@@ -60,6 +61,7 @@ class NativeModel:
     def invalidate(self):
         """Call after mutating parameters in place (e.g. re-trained MLP weights)."""
         self._blob_cache.clear()
+        self._param_version += 1
 
 
 class Pendulum(NativeModel):

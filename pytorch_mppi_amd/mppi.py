@@ -187,6 +187,10 @@ class MPPI:
         self._ws = None
         self._z_native = None
         self._vec_cache = {}
+        self._problem_cache = {}
+        self._ws_need = {}
+        self._dev_index = (self.d.index if self.d.index is not None else
+                           (torch.cuda.current_device() if self.d.type == "cuda" and torch.cuda.is_available() else 0))
 
     # ------------------------------------------------------------------------------------------
     # parameter resolution (host, once per change)
@@ -250,6 +254,7 @@ class MPPI:
         self.T = horizon
         self._ws = None
         self._z_native = None
+        self._problem_cache = {}
 
     def reset(self):
         self.U = self._sample_noise((self.T,))
@@ -282,50 +287,78 @@ class MPPI:
         self._vec_cache[key] = (t, v)
         return v
 
+    def _static_key(self, Tn):
+        """Identity + in-place version of everything the static part of the problem block is built
+        from: a steady-state command() re-uses the cached block and parameter tensors, while
+        attribute assignments / in-place edits by the caller (autotune, tests) are picked up."""
+        tv = lambda t: (id(t), t._version) if torch.is_tensor(t) else t
+        m = self._model
+        return (Tn, self.K_local, self.nx, self.nu, self.k_offset, id(m), m.hidden if m is not None else 0,
+                bool(self.noise_abs_cost), bool(self.sample_null_action), int(self.u_per_command),
+                float(self.lambda_), float(self.u_scale), self.seed, tv(self.u_init), tv(self.noise_mu),
+                tv(self.noise_sigma), tv(self.noise_sigma_inv), tv(self._noise_L), tv(self.u_min), tv(self.u_max),
+                m._param_version if m is not None else 0)
+
     def _problem(self, Tn=None, U=None):
-        """Fill the static part of an MppiProblem for this controller."""
+        """MppiProblem for this controller: static part cached (see _static_key), U bound fresh."""
         if self.d.type != "cuda":
             raise RuntimeError("pytorch_mppi_amd runs on the MI355X only: construct the controller with "
                                "device='cuda' (there is no CPU compute path)")
-        p = N.MppiProblem()
-        p.K, p.T, p.nx, p.nu = self.K_local, (Tn or self.T), self.nx, self.nu
-        p.S = 0
-        p.dtype = _DT[self.dtype]
-        p.k_offset = self.k_offset
-        p.model_id = self._model.model_id if self._model is not None else N.MODEL_NONE
-        p.hidden = self._model.hidden if self._model is not None else 0
-        p.sigma_diagonal = int(self._diagonal_sigma)
-        p.noise_abs_cost = int(bool(self.noise_abs_cost))
-        p.sample_null_action = int(bool(self.sample_null_action))
-        p.u_per_command = int(self.u_per_command)
-        p.lambda_ = float(self.lambda_)
-        p.u_scale = float(self.u_scale)
-        p.seed = self.seed
-        keep = dict(
-            U=(self.U if U is None else U).to(device=self.d, dtype=self.dtype).contiguous(),
-            u_init=self._vec(self.u_init), mu=self._vec(self.noise_mu),
-            L=self._noise_L.to(device=self.d, dtype=self.dtype).contiguous(),
-            sinv=self.noise_sigma_inv.to(device=self.d, dtype=self.dtype).contiguous(),
-            umin=self._vec(self.u_min), umax=self._vec(self.u_max))
-        p.U, p.u_init, p.noise_mu = _ptr(keep["U"]), _ptr(keep["u_init"]), _ptr(keep["mu"])
-        p.noise_L, p.sigma_inv = _ptr(keep["L"]), _ptr(keep["sinv"])
-        p.u_min, p.u_max = _ptr(keep["umin"]), _ptr(keep["umax"])
-        if self._model is not None:
-            keep["mp"] = self._model.param_blob(self.d, self.dtype)
-            p.model_params = _ptr(keep["mp"])
+        Tn = Tn or self.T
+        key = self._static_key(Tn)
+        hit = self._problem_cache.get(Tn)
+        if hit is None or hit[0] != key:
+            p = N.MppiProblem()
+            p.K, p.T, p.nx, p.nu = self.K_local, Tn, self.nx, self.nu
+            p.S = 0
+            p.dtype = _DT[self.dtype]
+            p.k_offset = self.k_offset
+            p.model_id = self._model.model_id if self._model is not None else N.MODEL_NONE
+            p.hidden = self._model.hidden if self._model is not None else 0
+            p.sigma_diagonal = int(self._diagonal_sigma)
+            p.noise_abs_cost = int(bool(self.noise_abs_cost))
+            p.sample_null_action = int(bool(self.sample_null_action))
+            p.u_per_command = int(self.u_per_command)
+            p.lambda_ = float(self.lambda_)
+            p.u_scale = float(self.u_scale)
+            p.seed = self.seed
+            keep = dict(
+                u_init=self._vec(self.u_init), mu=self._vec(self.noise_mu),
+                L=self._noise_L.to(device=self.d, dtype=self.dtype).contiguous(),
+                sinv=self.noise_sigma_inv.to(device=self.d, dtype=self.dtype).contiguous(),
+                umin=self._vec(self.u_min), umax=self._vec(self.u_max))
+            p.u_init, p.noise_mu = _ptr(keep["u_init"]), _ptr(keep["mu"])
+            p.noise_L, p.sigma_inv = _ptr(keep["L"]), _ptr(keep["sinv"])
+            p.u_min, p.u_max = _ptr(keep["umin"]), _ptr(keep["umax"])
+            if self._model is not None:
+                keep["mp"] = self._model.param_blob(self.d, self.dtype)
+                p.model_params = _ptr(keep["mp"])
+            hit = (key, p, keep)
+            self._problem_cache[Tn] = hit
+        # a fresh struct per command (the previous one stays valid for the lazy attributes)
+        p = N.MppiProblem.from_buffer_copy(hit[1])
+        keep = dict(hit[2])
+        Ut = self.U if U is None else U
+        if Ut.device != self.d or Ut.dtype != self.dtype or not Ut.is_contiguous():
+            Ut = Ut.to(device=self.d, dtype=self.dtype).contiguous()
+        keep["U"] = Ut
+        p.U = Ut.data_ptr()
         p._keep = keep      # keep the tensors alive as long as the struct
         return p
 
     def _attach_workspace(self, p):
-        lib = N.lib()
-        need = int(lib.mppi_workspace_elems(C.byref(p)))
+        key = (p.K, p.T, p.nu, p.num_envs)
+        need = self._ws_need.get(key)
+        if need is None:
+            need = self._ws_need[key] = int(N.lib().mppi_workspace_elems(C.byref(p)))
         if self._ws is None or self._ws.numel() < need or self._ws.dtype != self.dtype:
             self._ws = torch.empty(max(need, 1), device=self.d, dtype=self.dtype)
-        p.workspace = _ptr(self._ws)
+        p.workspace = self._ws.data_ptr()
         p.workspace_elems = self._ws.numel()
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.d).cuda_stream)
+        """The caller's current HIP stream (raw handle; torch.cuda.current_stream() costs ~10 us)."""
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(self._dev_index))
 
     def _draw_noise(self, p, shape):
         """Bind this command's standard normals to the problem: injected / torch.randn (reference
