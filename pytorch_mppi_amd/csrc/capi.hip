@@ -42,7 +42,7 @@ Carve carve(const MppiProblem* p) {
   const int64_t J4 = mppi_noise_rows4(p->T, p->nu);
   c.Jpad = (int)(J4 * 4);
   if (c.Jpad % UPD_TJ) c.Jpad += UPD_TJ - c.Jpad % UPD_TJ;
-  c.nb1 = (p->K + BLOCK - 1) / BLOCK;
+  c.nb1 = (p->K + WAVE - 1) / WAVE;            // one cost minimum per wave of 64 samples
   // samples per lane in K3: enough k-chunks to fill the chip, at most 8 loads in flight per lane
   int R = 4;
   const int njt = c.Jpad / UPD_TJ;

@@ -24,7 +24,7 @@ struct KArgs {
   const T *state, *U, *u_init, *mu, *L, *sinv, *umin, *umax, *mp, *z, *sampler, *W, *theta, *B;
   T *cost, *omega, *wnz, *U_out, *action_out, *pa, *noise, *pert, *states, *record;
   // workspace carve-up
-  T* block_min;   // [nb1]
+  T* block_min;   // [nb1] minima of cost_total per 64 consecutive samples
   T* eta_part;    // [nkc]
   T* P_part;      // [nkc][Jpad]
   int nb1, nkc, Jpad, R;

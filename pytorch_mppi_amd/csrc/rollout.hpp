@@ -112,6 +112,11 @@ __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionCons
   }
 }
 
+#ifndef MPPI_K1_BLOCK
+#define MPPI_K1_BLOCK 256   // threads per K1 workgroup (multiple of 64)
+#endif
+constexpr int K1_BLOCK = MPPI_K1_BLOCK;
+
 #ifndef MPPI_K1_ROWS
 #define MPPI_K1_ROWS 24     // rows-of-4 (16 B each) a lane keeps in flight; fp64 uses half
 #endif
@@ -234,7 +239,7 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
 
 // NOISE: MPPI_NOISE_TNK4 | _PHILOX | _ACTIONS (compile-time);  DIAG: diagonal Sigma
 template <class Model, typename T, int NOISE, bool DIAG>
-__global__ void __launch_bounds__(BLOCK) rollout_cost_kernel(const KArgs<T> a_in) {
+__global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a_in) {
   constexpr int NX = Model::NX, NU = Model::NU;
   const KArgs<T> a = env_view(a_in);        // MPPI_Batched: environment = blockIdx.z
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -244,7 +249,7 @@ __global__ void __launch_bounds__(BLOCK) rollout_cost_kernel(const KArgs<T> a_in
   T* red = G + a.J;                         // [BLOCK/WAVE]
   T* fac = red + BLOCK / WAVE;              // [2*NU*NU] full-Sigma factors (only if !DIAG)
 
-  const int kraw = blockIdx.x * BLOCK + threadIdx.x;
+  const int kraw = blockIdx.x * K1_BLOCK + threadIdx.x;
   const bool active = kraw < a.K;
   const int k = active ? kraw : a.K - 1;   // tail lanes shadow the last sample, never store
   const long long kg = a.k_offset + k;
@@ -253,12 +258,17 @@ __global__ void __launch_bounds__(BLOCK) rollout_cost_kernel(const KArgs<T> a_in
   // Issue order matters (loads retire in order): first the few loads the set-up needs (nominal
   // sequence, initial state), then the ring prologue, so that the set-up's waits do not sit
   // behind 24 KiB of noise per wave and the noise latency overlaps the LDS fill + barrier.
-  T uload[8];
   constexpr int UL = 8;
+  T uload[UL], umload[UL], gload[UL];
 #pragma unroll
   for (int q = 0; q < UL; ++q) {
-    const int j = threadIdx.x + q * BLOCK;
-    uload[q] = j < a.J ? u_base(a, j) : T(0);
+    const int j = threadIdx.x + q * K1_BLOCK;
+    const bool ok = j < a.J;
+    const int n = ok ? j % NU : 0;
+    uload[q] = ok ? u_base(a, j) : T(0);
+    umload[q] = ok ? a.mu[n] : T(0);
+    // diagonal Sigma: G = lambda * U / sigma^2 needs no neighbours -> built in the same pass
+    if constexpr (DIAG) gload[q] = ok ? (a.B != nullptr ? u_eff(a, j) : uload[q]) * a.sinv[n * NU + n] : T(0);
   }
   const Model model(a);
   T x[NX];
@@ -280,24 +290,31 @@ __global__ void __launch_bounds__(BLOCK) rollout_cost_kernel(const KArgs<T> a_in
 
 #pragma unroll
   for (int q = 0; q < UL; ++q) {
-    const int j = threadIdx.x + q * BLOCK;
-    if (j < a.J) Ue[j] = uload[q];
-  }
-  for (int j = threadIdx.x + UL * BLOCK; j < a.J; j += BLOCK) Ue[j] = u_base(a, j);   // very long horizons
-  __syncthreads();
-  for (int j = threadIdx.x; j < a.J; j += BLOCK) {
-    const int n = j % NU, t0 = j - n;
-    Um[j] = Ue[j] + a.mu[n];
-    T g;
-    if constexpr (DIAG) {
-      g = u_eff(a, j) * a.sinv[n * NU + n];
-    } else {
-      g = T(0);
-      for (int m = 0; m < NU; ++m) g = m_fma(ac.Sm[n * NU + m], u_eff(a, t0 + m), g);   // Sigma^-1 symmetric
+    const int j = threadIdx.x + q * K1_BLOCK;
+    if (j < a.J) {
+      Ue[j] = uload[q];
+      Um[j] = uload[q] + umload[q];
+      if constexpr (DIAG) G[j] = a.lambda_ * gload[q];
     }
-    G[j] = a.lambda_ * g;
+  }
+  for (int j = threadIdx.x + UL * K1_BLOCK; j < a.J; j += K1_BLOCK) {   // very long horizons
+    const int n = j % NU;
+    const T ub = u_base(a, j);
+    Ue[j] = ub;
+    Um[j] = ub + a.mu[n];
+    if constexpr (DIAG) G[j] = a.lambda_ * (u_eff(a, j) * a.sinv[n * NU + n]);
   }
   __syncthreads();
+  if constexpr (!DIAG) {
+    // full Sigma: G[t,n] = lambda * sum_m Sigma^-1[n,m] U[t,m] needs the whole row -> second pass
+    for (int j = threadIdx.x; j < a.J; j += K1_BLOCK) {
+      const int n = j % NU, t0 = j - n;
+      T g = T(0);
+      for (int m = 0; m < NU; ++m) g = m_fma(ac.Sm[n * NU + m], u_eff(a, t0 + m), g);   // Sigma^-1 symmetric
+      G[j] = a.lambda_ * g;
+    }
+    __syncthreads();
+  }
   const StepTables<T> tb{Ue, Um, G};
 
   T rollout = T(0), pert = T(0);
@@ -314,8 +331,8 @@ __global__ void __launch_bounds__(BLOCK) rollout_cost_kernel(const KArgs<T> a_in
     a.cost[k] = total;
     if (a.pert != nullptr) a.pert[k] = pert;
   }
-  const T bm = block_min<T>(active ? total : inf_v<T>(), red);
-  if (threadIdx.x == 0) a.block_min[blockIdx.x] = bm;
+  const T bm = wave_min<T>(active ? total : inf_v<T>());      // one minimum per 64 samples
+  if ((threadIdx.x & (WAVE - 1)) == 0 && kraw < a.K) a.block_min[kraw / WAVE] = bm;
 }
 
 template <class Model, typename T>
@@ -323,7 +340,7 @@ static int launch_rollout(const KArgs<T>& a, hipStream_t st) {
   constexpr int NU = Model::NU;
   const bool diag = a.diag != 0;
   const size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (diag ? 0 : 2 * NU * NU)) * sizeof(T);
-  const dim3 grid((a.K + BLOCK - 1) / BLOCK, 1, a.n_env), block(BLOCK);
+  const dim3 grid((a.K + K1_BLOCK - 1) / K1_BLOCK, 1, a.n_env), block(K1_BLOCK);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   profile_next_events(&ev0, &ev1);   // null events == plain launch
 #define MPPI_LAUNCH(NOISE_)                                                                        \

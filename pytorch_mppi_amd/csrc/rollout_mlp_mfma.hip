@@ -247,7 +247,10 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
     float r = red[0];
 #pragma unroll
     for (int i = 1; i < MLP_THREADS / WAVE; ++i) r = fminf(r, red[i]);
-    a.block_min[blockIdx.x] = r;
+    // workgroup covers 256 samples = 4 slots of the per-64-sample minima array
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if ((int)blockIdx.x * 4 + q < a.nb1) a.block_min[blockIdx.x * 4 + q] = r;
   }
 }
 

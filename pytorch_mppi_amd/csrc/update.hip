@@ -194,10 +194,9 @@ __global__ void __launch_bounds__(BLOCK) prepare_kernel(const KArgs<T> a_in) {
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) cost_block_min_kernel(const KArgs<T> a_in) {
   const KArgs<T> a = env_view(a_in);
-  __shared__ T red[BLOCK / WAVE];
   const int k = blockIdx.x * BLOCK + threadIdx.x;
-  const T bm = block_min<T>(k < a.K ? a.cost[k] : inf_v<T>(), red);
-  if (threadIdx.x == 0) a.block_min[blockIdx.x] = bm;
+  const T bm = wave_min<T>(k < a.K ? a.cost[k] : inf_v<T>());
+  if ((threadIdx.x & (WAVE - 1)) == 0 && k < a.K) a.block_min[k / WAVE] = bm;
 }
 
 // =============================================================================================
@@ -560,7 +559,7 @@ int launch_prepare(const KArgs<T>& a, hipStream_t st) {
 
 template <typename T>
 int launch_cost_block_min(const KArgs<T>& a, hipStream_t st) {
-  hipLaunchKernelGGL(cost_block_min_kernel<T>, dim3(a.nb1, 1, a.n_env), dim3(BLOCK), 0, st, a);
+  hipLaunchKernelGGL(cost_block_min_kernel<T>, dim3((a.K + BLOCK - 1) / BLOCK, 1, a.n_env), dim3(BLOCK), 0, st, a);
   return (int)hipGetLastError();
 }
 
