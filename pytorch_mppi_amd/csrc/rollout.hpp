@@ -6,7 +6,7 @@
 //
 // Memory pipeline (the part that decides the HBM fraction): at K = 65536 the chip holds ONE wave
 // per SIMD, so latency must be covered by loads in flight from that wave alone.  The noise rows
-// go through a register ring of D super-steps (~24 rows-of-4 = 384 B per lane outstanding).
+// go through a register ring of D super-steps (9 rows-of-4 = 144 B per lane outstanding).
 // gfx950 retires vector-memory ops in order behind ONE counter (vmcnt), and the compiler can
 // only wait for "all but the N youngest": any load or store under a branch between two ring
 // slots makes N unknowable and every wait collapses to vmcnt(0), which serialises the ring.
@@ -118,7 +118,11 @@ __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionCons
 constexpr int K1_BLOCK = MPPI_K1_BLOCK;
 
 #ifndef MPPI_K1_ROWS
-#define MPPI_K1_ROWS 24     // rows-of-4 (16 B each) a lane keeps in flight; fp64 uses half
+// rows-of-4 (16 B each) a lane keeps in flight; fp64 uses half.  Measured at C3 (tools/run_k1_rows.sh,
+// K1 inside the command pipeline): 24 rows 42.1 us | 16: 36.4 | 12: 37.6 | 9: 35.9 | 6: 39.2.  A deeper
+// ring does NOT help: beyond ~150 B per lane in flight the kernel is not latency-bound any more,
+// and the extra 60+ VGPRs push the allocator into AGPR copies inside the loop.
+#define MPPI_K1_ROWS 9
 #endif
 
 // depth (in super-steps) of the register ring for a given control width / element type
@@ -258,7 +262,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
   // Issue order matters (loads retire in order): first the few loads the set-up needs (nominal
   // sequence, initial state), then the ring prologue, so that the set-up's waits do not sit
   // behind 24 KiB of noise per wave and the noise latency overlaps the LDS fill + barrier.
-  constexpr int UL = 8;
+  constexpr int UL = 4;     // staged in registers: J <= 4*K1_BLOCK (e.g. T=64, nu=12 -> 3 per thread)
   T uload[UL], umload[UL], gload[UL];
 #pragma unroll
   for (int q = 0; q < UL; ++q) {
