@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 6
+#define MPPI_ABI_VERSION 7
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -196,6 +196,10 @@ int mppi_combine(const MppiProblem* p, const void* records, int32_t n_shards, vo
  * sum of durations in milliseconds, and clears the record. */
 int mppi_profile_enable(int on);
 int mppi_profile_read(double* sum_ms, int64_t* count);
+/* Same record, plus the kernels' own time span on the device wall clock: every K1 workgroup stamps
+ * wall_clock64() at entry and exit, min(entry)/max(exit) per launch.  This excludes the dispatch
+ * packets that bracket an event-attached launch and is what rocprofv3 --kernel-trace reports. */
+int mppi_profile_read2(double* sum_ms_events, double* sum_ms_device, int64_t* count);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS = 0, 1, 2
@@ -63,6 +63,7 @@ SYMBOLS = {
     "mppi_combine": (C.c_int, [_PP, _vp, C.c_int32, _vp]),
     "mppi_profile_enable": (C.c_int, [C.c_int]),
     "mppi_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "mppi_profile_read2": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -85,6 +85,7 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.noise = (T*)p->noise; a.pert = (T*)p->pert_cost; a.states = (T*)p->states;
   a.record = (T*)p->record;
   T* ws = (T*)p->workspace;
+  a.tstamp = nullptr;
   a.n_env = p->num_envs > 1 ? p->num_envs : 1;
   if (a.n_env > 1 && (p->state_per_sample || p->n_sampler_rows > 0 || p->states != nullptr || p->base_seq != nullptr ||
                       p->S > 0 || p->noise_src == MPPI_NOISE_ACTIONS))
@@ -135,9 +136,11 @@ bool g_prof_on = false;
 int g_prof_n = 0;
 hipEvent_t g_prof_ev[PROF_MAX][2];
 int g_prof_created = 0;
+unsigned long long* g_prof_ts = nullptr;   // device: PROF_MAX x {min entry, max exit}
 }  // namespace
 namespace mppi {
-bool profile_next_events(hipEvent_t* start, hipEvent_t* stop) {
+bool profile_next_events(hipEvent_t* start, hipEvent_t* stop, unsigned long long** tstamp) {
+  if (tstamp) *tstamp = nullptr;
   if (!g_prof_on || g_prof_n >= PROF_MAX) return false;
   if (g_prof_n >= g_prof_created) {
     if (hipEventCreate(&g_prof_ev[g_prof_n][0]) != hipSuccess) return false;
@@ -146,14 +149,42 @@ bool profile_next_events(hipEvent_t* start, hipEvent_t* stop) {
   }
   *start = g_prof_ev[g_prof_n][0];
   *stop = g_prof_ev[g_prof_n][1];
+  if (tstamp && g_prof_ts) *tstamp = g_prof_ts + 2 * (size_t)g_prof_n;
   ++g_prof_n;
   return true;
 }
 }  // namespace mppi
+extern "C" int mppi_profile_read(double* sum_ms, int64_t* count);
 extern "C" int mppi_profile_enable(int on) {
   g_prof_on = on != 0;
-  if (on) g_prof_n = 0;
+  if (on) {
+    g_prof_n = 0;
+    // measurement set-up (outside any timed region): stamp slots {min = ~0, max = 0}
+    if (!g_prof_ts && hipMalloc((void**)&g_prof_ts, sizeof(unsigned long long) * 2 * PROF_MAX) != hipSuccess) g_prof_ts = nullptr;
+    if (g_prof_ts) {
+      static unsigned long long init[2 * PROF_MAX];
+      for (int i = 0; i < PROF_MAX; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+      if (hipMemcpy(g_prof_ts, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(g_prof_ts); g_prof_ts = nullptr; }
+    }
+  }
   return 0;
+}
+extern "C" int mppi_profile_read2(double* sum_ms_events, double* sum_ms_device, int64_t* count) {
+  const int n = g_prof_n;
+  double dev = 0;
+  if (g_prof_ts && n > 0) {
+    static unsigned long long host[2 * PROF_MAX];
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(host, g_prof_ts, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hipfail((int)e, "mppi_profile_read2");
+    int dev_id = 0, khz = 100000;
+    (void)hipGetDevice(&dev_id);
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev_id);
+    for (int i = 0; i < n; ++i)
+      if (host[2 * i + 1] > host[2 * i]) dev += (double)(host[2 * i + 1] - host[2 * i]) / (double)khz;   // ticks / kHz = ms
+  }
+  if (sum_ms_device) *sum_ms_device = dev;
+  return mppi_profile_read(sum_ms_events, count);
 }
 extern "C" int mppi_profile_read(double* sum_ms, int64_t* count) {
   double s = 0;

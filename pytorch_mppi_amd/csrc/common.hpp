@@ -29,6 +29,7 @@ struct KArgs {
   T* P_part;      // [nkc][Jpad]
   int nb1, nkc, Jpad, R;
   int n_env;      // MPPI_Batched: environments on grid.z (1 = single controller)
+  unsigned long long* tstamp;   // measurement hook: {min entry, max exit} on wall_clock64, or null
 };
 
 // MPPI_Batched: the view of the argument block for environment blockIdx.z.  The noise (z), all

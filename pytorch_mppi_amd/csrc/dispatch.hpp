@@ -6,7 +6,7 @@
 namespace mppi {
 // measurement hook (capi.hip): when profiling is on, hands out a start/stop event pair for the
 // next K1 launch; returns false when profiling is off
-bool profile_next_events(hipEvent_t* start, hipEvent_t* stop);
+bool profile_next_events(hipEvent_t* start, hipEvent_t* stop, unsigned long long** tstamp = nullptr);
 #define MPPI_DECL_MODEL(name)                                          \
   int rollout_##name(const KArgs<float>& a, hipStream_t st);            \
   int rollout_##name(const KArgs<double>& a, hipStream_t st);           \

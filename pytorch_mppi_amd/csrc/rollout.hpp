@@ -246,6 +246,7 @@ template <class Model, typename T, int NOISE, bool DIAG>
 __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a_in) {
   constexpr int NX = Model::NX, NU = Model::NU;
   const KArgs<T> a = env_view(a_in);        // MPPI_Batched: environment = blockIdx.z
+  if (a.tstamp != nullptr && threadIdx.x == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ue = reinterpret_cast<T*>(smem_raw);   // [J] nominal sequence, shift applied
   T* Um = Ue + a.J;                         // [J] Ue + mu
@@ -337,16 +338,18 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
   }
   const T bm = wave_min<T>(active ? total : inf_v<T>());      // one minimum per 64 samples
   if ((threadIdx.x & (WAVE - 1)) == 0 && kraw < a.K) a.block_min[kraw / WAVE] = bm;
+  if (a.tstamp != nullptr && threadIdx.x == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
 }
 
 template <class Model, typename T>
-static int launch_rollout(const KArgs<T>& a, hipStream_t st) {
+static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
   constexpr int NU = Model::NU;
+  KArgs<T> a = a_in;
   const bool diag = a.diag != 0;
   const size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (diag ? 0 : 2 * NU * NU)) * sizeof(T);
   const dim3 grid((a.K + K1_BLOCK - 1) / K1_BLOCK, 1, a.n_env), block(K1_BLOCK);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  profile_next_events(&ev0, &ev1);   // null events == plain launch
+  profile_next_events(&ev0, &ev1, &a.tstamp);   // null events == plain launch
 #define MPPI_LAUNCH(NOISE_)                                                                        \
   do {                                                                                             \
     if (diag)                                                                                      \

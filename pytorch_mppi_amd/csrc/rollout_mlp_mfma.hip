@@ -47,6 +47,7 @@ template <int HT /* hidden / 16 */, int NOISE, bool DIAG>
 __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KArgs<float> a_in) {
   constexpr int NU = MLP_NU, NX = MLP_NX, NT = MLP_NT, H = HT * 16;
   const KArgs<float> a = env_view(a_in);
+  if (a.tstamp != nullptr && threadIdx.x == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* Ue = reinterpret_cast<float*>(smem_raw);   // [J]
   float* Um = Ue + a.J;                             // [J]
@@ -251,16 +252,18 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if ((int)blockIdx.x * 4 + q < a.nb1) a.block_min[blockIdx.x * 4 + q] = r;
+    if (a.tstamp != nullptr) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
   }
 }
 
 template <int HT>
-static int launch_ht(const KArgs<float>& a, hipStream_t st) {
+static int launch_ht(const KArgs<float>& a_in, hipStream_t st) {
+  KArgs<float> a = a_in;
   const bool diag = a.diag != 0;
   const size_t smem = (size_t)(3 * a.J + MLP_THREADS / WAVE + HT * 16 + 2 * MLP_NU * MLP_NU) * sizeof(float);
   const dim3 grid((a.K + 255) / 256, 1, a.n_env), block(MLP_THREADS);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  profile_next_events(&ev0, &ev1);
+  profile_next_events(&ev0, &ev1, &a.tstamp);
 #define MPPI_LAUNCH(NOISE_)                                                                          \
   do {                                                                                               \
     if (diag)                                                                                        \
