@@ -28,26 +28,37 @@ __global__ void __launch_bounds__(BLOCK) noise_fill_philox_kernel(const KArgs<T>
 }
 
 // (K, J) row-major -> [J4][K][4].  Tile: 64 samples x 64 columns through LDS so that both the
-// read (along j) and the write (along k) are coalesced.
-template <typename T>
+// read (along j: 16 lanes x 16 B = one 256-B run per sample) and the write (along k: 64 lanes x
+// 16 B = 1 KiB) are coalesced 16-byte accesses.  VEC = false: J % 4 != 0 (rows not 16-B aligned).
+template <typename T, bool VEC>
 __global__ void __launch_bounds__(BLOCK) noise_from_ktn_kernel(const KArgs<T> a, const T* __restrict__ in,
                                                                T* __restrict__ out) {
-  __shared__ T tile[64][65];
+  __shared__ __attribute__((aligned(16))) T tile[64][68];   // 68: rows stay 16-B aligned, 4-way -> conflict-light
   const int k0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
-  for (int r = ty; r < 64; r += 4) {
-    const int k = k0 + r, j = j0 + tx;
-    tile[r][tx] = (k < a.K && j < a.J) ? in[(long long)k * a.J + j] : T(0);
+  if constexpr (VEC) {
+    const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;   // 16 column-quads x 16 rows per pass
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = r0 + 16 * p, k = k0 + r, j = j0 + 4 * c4;
+      T v[4] = {T(0), T(0), T(0), T(0)};
+      if (k < a.K && j < a.J) load4<T>(in + (long long)k * a.J + j, 0, 0, 0, v);   // J % 4 == 0: whole quad valid
+      tile[r][4 * c4 + 0] = v[0]; tile[r][4 * c4 + 1] = v[1]; tile[r][4 * c4 + 2] = v[2]; tile[r][4 * c4 + 3] = v[3];
+    }
+  } else {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+    for (int r = ty; r < 64; r += 4) {
+      const int k = k0 + r, j = j0 + tx;
+      tile[r][tx] = (k < a.K && j < a.J) ? in[(long long)k * a.J + j] : T(0);
+    }
   }
   __syncthreads();
-  // each thread writes rows-of-4: 16 rows-of-4 per tile column block x 64 samples
+  // rows-of-4: 16 per tile x 64 samples, one 16-B store each
   for (int q = threadIdx.x; q < 16 * 64; q += BLOCK) {
     const int jbl = q >> 6, kl = q & 63;
     const int k = k0 + kl, jb = (j0 >> 2) + jbl;
     if (k < a.K && jb < a.J4) {
-      T* o = out + ((long long)jb * a.K + k) * 4;
-      o[0] = tile[kl][4 * jbl + 0]; o[1] = tile[kl][4 * jbl + 1];
-      o[2] = tile[kl][4 * jbl + 2]; o[3] = tile[kl][4 * jbl + 3];
+      const T v[4] = {tile[kl][4 * jbl + 0], tile[kl][4 * jbl + 1], tile[kl][4 * jbl + 2], tile[kl][4 * jbl + 3]};
+      store4<T>(out, a.K, jb, k, v);
     }
   }
 }
@@ -509,7 +520,11 @@ int launch_noise_fill_philox(const KArgs<T>& a, T* out, hipStream_t st) {
 template <typename T>
 int launch_noise_from_ktn(const KArgs<T>& a, const T* in, T* out, hipStream_t st) {
   const dim3 grid((a.K + 63) / 64, (a.J4 * 4 + 63) / 64);
-  hipLaunchKernelGGL(noise_from_ktn_kernel<T>, grid, dim3(BLOCK), 0, st, a, in, out);
+  const bool vec = a.J % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL((noise_from_ktn_kernel<T, true>), grid, dim3(BLOCK), 0, st, a, in, out);
+  else
+    hipLaunchKernelGGL((noise_from_ktn_kernel<T, false>), grid, dim3(BLOCK), 0, st, a, in, out);
   return (int)hipGetLastError();
 }
 
