@@ -347,22 +347,29 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
   KArgs<T> a = a_in;
   const bool diag = a.diag != 0;
   const size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (diag ? 0 : 2 * NU * NU)) * sizeof(T);
+  if (smem > 160 * 1024) return MPPI_E_UNSUPPORTED;   // T*nu beyond the LDS tables: not built
   const dim3 grid((a.K + K1_BLOCK - 1) / K1_BLOCK, 1, a.n_env), block(K1_BLOCK);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   profile_next_events(&ev0, &ev1, &a.tstamp);   // null events == plain launch
+  // event-attached launch only while measuring; the plain launch is what hipGraph capture records
+#define MPPI_LAUNCH1(KERNEL)                                                                       \
+  do {                                                                                             \
+    if (smem > 64 * 1024) /* long horizons: the LDS tables need the opt-in limit (160 KiB/CU) */   \
+      (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)smem);                                                        \
+    if (ev0 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a);      \
+    else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, a);                                     \
+  } while (0)
 #define MPPI_LAUNCH(NOISE_)                                                                        \
   do {                                                                                             \
-    if (diag)                                                                                      \
-      hipExtLaunchKernelGGL((rollout_cost_kernel<Model, T, NOISE_, true>), grid, block, smem, st,  \
-                            ev0, ev1, 0, a);                                                       \
-    else                                                                                           \
-      hipExtLaunchKernelGGL((rollout_cost_kernel<Model, T, NOISE_, false>), grid, block, smem, st, \
-                            ev0, ev1, 0, a);                                                       \
+    if (diag) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, NOISE_, true>));                         \
+    else MPPI_LAUNCH1((rollout_cost_kernel<Model, T, NOISE_, false>));                             \
   } while (0)
   if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCH(MPPI_NOISE_PHILOX);
   else if (a.noise_src == MPPI_NOISE_ACTIONS) MPPI_LAUNCH(MPPI_NOISE_ACTIONS);
   else MPPI_LAUNCH(MPPI_NOISE_TNK4);
 #undef MPPI_LAUNCH
+#undef MPPI_LAUNCH1
   return (int)hipGetLastError();
 }
 

@@ -264,19 +264,21 @@ static int launch_ht(const KArgs<float>& a_in, hipStream_t st) {
   const dim3 grid((a.K + 255) / 256, 1, a.n_env), block(MLP_THREADS);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   profile_next_events(&ev0, &ev1, &a.tstamp);
+#define MPPI_LAUNCH1(KERNEL)                                                                         \
+  do {                                                                                               \
+    if (ev0 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a);        \
+    else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, a);                                       \
+  } while (0)
 #define MPPI_LAUNCH(NOISE_)                                                                          \
   do {                                                                                               \
-    if (diag)                                                                                        \
-      hipExtLaunchKernelGGL((rollout_mlp_mfma_kernel<HT, NOISE_, true>), grid, block, smem, st, ev0, \
-                            ev1, 0, a);                                                              \
-    else                                                                                             \
-      hipExtLaunchKernelGGL((rollout_mlp_mfma_kernel<HT, NOISE_, false>), grid, block, smem, st,     \
-                            ev0, ev1, 0, a);                                                         \
+    if (diag) MPPI_LAUNCH1((rollout_mlp_mfma_kernel<HT, NOISE_, true>));                             \
+    else MPPI_LAUNCH1((rollout_mlp_mfma_kernel<HT, NOISE_, false>));                                 \
   } while (0)
   if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCH(MPPI_NOISE_PHILOX);
   else if (a.noise_src == MPPI_NOISE_ACTIONS) MPPI_LAUNCH(MPPI_NOISE_ACTIONS);
   else MPPI_LAUNCH(MPPI_NOISE_TNK4);
 #undef MPPI_LAUNCH
+#undef MPPI_LAUNCH1
   return (int)hipGetLastError();
 }
 

@@ -559,12 +559,20 @@ template <typename T>
 int launch_prepare(const KArgs<T>& a, hipStream_t st) {
   const size_t smem = ((size_t)2 * a.J + 2 * a.nu * a.nu) * sizeof(T);
   const dim3 grid((a.K + BLOCK - 1) / BLOCK, 1, a.n_env), block(BLOCK);
+  if (smem > 160 * 1024) return MPPI_E_UNSUPPORTED;
 #define X(N)                                                                                      \
   if (a.nu == N) {                                                                                \
-    if (a.noise_src == MPPI_NOISE_PHILOX)                                                         \
+    if (a.noise_src == MPPI_NOISE_PHILOX) {                                                       \
+      if (smem > 64 * 1024)                                                                       \
+        (void)hipFuncSetAttribute((const void*)prepare_kernel<T, N, MPPI_NOISE_PHILOX>,           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);        \
       hipLaunchKernelGGL((prepare_kernel<T, N, MPPI_NOISE_PHILOX>), grid, block, smem, st, a);    \
-    else                                                                                          \
+    } else {                                                                                      \
+      if (smem > 64 * 1024)                                                                       \
+        (void)hipFuncSetAttribute((const void*)prepare_kernel<T, N, MPPI_NOISE_TNK4>,             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);        \
       hipLaunchKernelGGL((prepare_kernel<T, N, MPPI_NOISE_TNK4>), grid, block, smem, st, a);      \
+    }                                                                                             \
     return (int)hipGetLastError();                                                                \
   }
   MPPI_NU_LIST(X)
@@ -604,12 +612,19 @@ int launch_weights_partial(const KArgs<T>& a, hipStream_t st) {
     constexpr int SSB = (16 / P4) > 0 ? (16 / P4) : 1;                                            \
     const int nss = (a.Tn + TT - 1) / TT;                                                         \
     const dim3 grid(a.nkc, (nss + SSB - 1) / SSB, a.n_env), block(BLOCK);                                  \
-    if (a.noise_src == MPPI_NOISE_PHILOX)                                                         \
+    if (a.noise_src == MPPI_NOISE_PHILOX) {                                                       \
+      if (smem > 64 * 1024)                                                                       \
+        (void)hipFuncSetAttribute((const void*)weights_partial_full_kernel<T, N, MPPI_NOISE_PHILOX>, \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);        \
       hipLaunchKernelGGL((weights_partial_full_kernel<T, N, MPPI_NOISE_PHILOX>), grid, block,     \
                          smem, st, a);                                                            \
-    else                                                                                          \
+    } else {                                                                                      \
+      if (smem > 64 * 1024)                                                                       \
+        (void)hipFuncSetAttribute((const void*)weights_partial_full_kernel<T, N, MPPI_NOISE_TNK4>, \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);        \
       hipLaunchKernelGGL((weights_partial_full_kernel<T, N, MPPI_NOISE_TNK4>), grid, block, smem, \
                          st, a);                                                                  \
+    }                                                                                             \
     return (int)hipGetLastError();                                                                \
   }
   MPPI_NU_LIST(X)

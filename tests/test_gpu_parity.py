@@ -278,3 +278,26 @@ def test_mppi_batched_matches_reference_fixture(name, native):
         _assert_close(ctrl.cost_total, r["cost_total"].numpy(), rtol, f"{name} step {s} cost_total")
         _assert_close(ctrl.omega, r["omega"].numpy(), rtol, f"{name} step {s} omega")
         assert torch.allclose(ctrl.omega.sum(dim=1), torch.ones(cfg["N"], dtype=dtype, device="cuda"), atol=1e-5)
+
+
+@pytest.mark.parametrize("K,T,nx,nu", [(300, 1, 2, 2), (64, 512, 16, 12), (1 << 20, 4, 6, 4), (5, 700, 2, 2)])
+def test_extreme_shapes_fused_vs_generic(K, T, nx, nu):
+    """shape extremes: T = 1, long horizons (LDS tables beyond the default 64 KiB dynamic limit), a
+    million samples, K smaller than a wave -- fused kernel vs the callback path on the same noise."""
+    import pytorch_mppi_amd as pm
+    m = pm.models.Integrator(nx, nu)
+    g = torch.Generator().manual_seed(K + T)
+    U0 = torch.randn(T, nu, generator=g, dtype=torch.float64) * 0.05
+    x0 = torch.randn(nx, generator=g, dtype=torch.float64).cuda()
+    z = torch.randn(K, T, nu, generator=g, dtype=torch.float64)
+    outs = []
+    for fused in (True, False):
+        f, q = (m.dynamics, m.running_cost) if fused else ((lambda s, a: m.dynamics(s, a)), (lambda s, a: m.running_cost(s, a)))
+        c = pm.MPPI(f, q, nx, torch.eye(nu, dtype=torch.float64) * 0.3, num_samples=K, horizon=T, device="cuda",
+                    lambda_=5.0, U_init=U0.clone(), u_max=torch.tensor([1.0] * nu, dtype=torch.float64))
+        assert (c._model is not None) == fused and c._needs_generic() != fused
+        c.inject_noise(z)
+        a = c.command(x0)
+        outs.append((a, c.U, c.cost_total))
+    for got, ref in zip(outs[0], outs[1]):
+        assert torch.allclose(got, ref, rtol=1e-9, atol=1e-9 * max(1.0, float(ref.abs().max())))
