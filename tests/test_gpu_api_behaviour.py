@@ -479,3 +479,45 @@ def test_hip_graph_captured_command_matches_eager(path):
     # closed loop quality equals eager within sampling noise (different draws are consumed during capture)
     goal = st([2.0, 2.0])
     assert float((goal - (st([-3.0, -2.0]) + ga.sum(0) * torch.tensor([1.0, -1.0], dtype=DT, device=DEV))).norm()) < 2.5
+
+
+def test_parameter_edits_between_commands_are_picked_up():
+    """The static problem block is cached between commands; assignments and in-place edits of the
+    public parameters (autotune does this, reference autotune.py:151-219) must invalidate it."""
+    z = [torch.randn(200, 8, 2, dtype=DT, generator=torch.Generator().manual_seed(i)) for i in range(4)]
+    s = st([-1.0, 0.5])
+    U0 = torch.zeros(8, 2, dtype=DT)
+
+    def fresh(**kw):
+        return make("fused", num_samples=200, horizon=8, U_init=U0.clone(), **kw)
+
+    c = fresh()
+    c.inject_noise(z[0]); c.command(s, shift_nominal_trajectory=False)
+    # 1) scalar attribute
+    c.lambda_ = 7.5
+    c.U = U0.clone().cuda()
+    c.inject_noise(z[1]); a = c.command(s, shift_nominal_trajectory=False)
+    r = fresh(lambda_=7.5); r.inject_noise(z[1]); b = r.command(s, shift_nominal_trajectory=False)
+    assert torch.allclose(a, b, atol=1e-12)
+    # 2) tensor re-assignment (bounds)
+    c.u_min, c.u_max = torch.tensor([-0.2, -0.3], dtype=DT, device=DEV), torch.tensor([0.2, 0.3], dtype=DT, device=DEV)
+    c.U = U0.clone().cuda()
+    c.inject_noise(z[2]); a = c.command(s, shift_nominal_trajectory=False)
+    r = fresh(lambda_=7.5, u_min=torch.tensor([-0.2, -0.3], dtype=DT), u_max=torch.tensor([0.2, 0.3], dtype=DT))
+    r.inject_noise(z[2]); b = r.command(s, shift_nominal_trajectory=False)
+    assert torch.allclose(a, b, atol=1e-12) and float(c.perturbed_action[..., 0].abs().max()) <= 0.2 + 1e-12
+    # 3) in-place edit of a parameter tensor
+    c.noise_mu[0] = 0.4
+    c.u_init[1] = -0.1
+    c.U = U0.clone().cuda()
+    c.inject_noise(z[3]); a = c.command(s, shift_nominal_trajectory=True)
+    r = fresh(lambda_=7.5, u_min=torch.tensor([-0.2, -0.3], dtype=DT), u_max=torch.tensor([0.2, 0.3], dtype=DT),
+              noise_mu=torch.tensor([0.4, 0.0], dtype=DT), u_init=torch.tensor([0.0, -0.1], dtype=DT))
+    r.inject_noise(z[3]); b = r.command(s, shift_nominal_trajectory=True)
+    assert torch.allclose(a, b, atol=1e-12) and torch.allclose(c.U, r.U, atol=1e-12)
+    # 4) set_noise refreshes the derived factors (documented deviation, SURVEY 8f-4)
+    c.set_noise(noise_sigma=torch.diag(torch.tensor([4.0, 0.25], dtype=DT)))
+    assert torch.allclose(c._noise_L.cpu(), torch.diag(torch.tensor([2.0, 0.5], dtype=DT)))
+    c.U = U0.clone().cuda()
+    c.inject_noise(z[0]); c.command(s)
+    assert torch.isfinite(c.U).all()
