@@ -155,6 +155,9 @@ def main():
         ctrl.lambda_ = float(lam)
         del probe
 
+    # torch-generator modes: every rank draws its own shard, so the ranks need distinct streams
+    torch.manual_seed(1234 + rank)
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -179,9 +182,22 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
+    ranks_identical = None
+    if world > 1:
+        # every rank must hold bit-identical U after the rank-order combine (K5)
+        mine = ctrl.U.detach().reshape(-1).contiguous()
+        allU = torch.empty(world * mine.numel(), device=device, dtype=mine.dtype)
+        dist.all_gather_into_tensor(allU, mine)
+        allU = allU.view(world, -1)
+        ranks_identical = bool(all(torch.equal(allU[0], allU[r]) for r in range(world)))
     ms_per_step = dt / args.steps * 1e3
     value = Kglobal * args.steps / dt
-    n_eff = 1.0 / float((ctrl.omega.double() ** 2).sum()) if ctrl.omega is not None else None
+    n_eff = None
+    if ctrl.omega is not None:
+        s2 = (ctrl.omega.double() ** 2).sum()
+        if world > 1:
+            dist.all_reduce(s2, op=dist.ReduceOp.SUM)      # omega is normalised globally by K5
+        n_eff = 1.0 / float(s2)
 
     # ---- roofline of K1 from the HIP events recorded inside the timed region ----
     k1 = k1_n.value
@@ -238,7 +254,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "K_per_gpu": Kper, "K_global": Kglobal, "T": T, "nx": nx, "nu": nu,
                    "rng": args.rng, "lambda": float(ctrl.lambda_), "n_eff": n_eff,
-                   "sharding": f"samples/{world}" if world > 1 else "none"},
+                   "sharding": f"samples/{world}" if world > 1 else "none",
+                   "ranks_hold_identical_U": ranks_identical},
         "state_evals_per_s": value * T,
         "roofline": roofline,
     }
