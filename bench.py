@@ -130,12 +130,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
     dist = None
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # MPPI_BENCH_BACKEND=gloo: test rig for the N>1 code path on a 1-GPU box (ranks share cuda:0 and
+    # the record all-gather is staged through the host); the driver's runs use nccl = RCCL over xGMI
+    backend = os.environ.get("MPPI_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import pytorch_mppi_amd as pm
 
@@ -151,7 +158,9 @@ def main():
         probe.command(x0)
         lam = probe.cost_total.float().std()
         if world > 1:
-            dist.all_reduce(lam, op=dist.ReduceOp.AVG)
+            lam = lam.cpu() if backend != "nccl" else lam
+            dist.all_reduce(lam, op=dist.ReduceOp.SUM)
+            lam = lam / world
         ctrl.lambda_ = float(lam)
         del probe
 
@@ -179,14 +188,16 @@ def main():
     N.check(lib.mppi_profile_read2(C.byref(k1_sum), C.byref(k1_dev), C.byref(k1_n)), "mppi_profile_read2")
     lib.mppi_profile_enable(0)
     if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     ranks_identical = None
     if world > 1:
         # every rank must hold bit-identical U after the rank-order combine (K5)
         mine = ctrl.U.detach().reshape(-1).contiguous()
-        allU = torch.empty(world * mine.numel(), device=device, dtype=mine.dtype)
+        if backend != "nccl":
+            mine = mine.cpu()
+        allU = torch.empty(world * mine.numel(), device=mine.device, dtype=mine.dtype)
         dist.all_gather_into_tensor(allU, mine)
         allU = allU.view(world, -1)
         ranks_identical = bool(all(torch.equal(allU[0], allU[r]) for r in range(world)))
@@ -196,6 +207,7 @@ def main():
     if ctrl.omega is not None:
         s2 = (ctrl.omega.double() ** 2).sum()
         if world > 1:
+            s2 = s2.cpu() if backend != "nccl" else s2
             dist.all_reduce(s2, op=dist.ReduceOp.SUM)      # omega is normalised globally by K5
         n_eff = 1.0 / float(s2)
 

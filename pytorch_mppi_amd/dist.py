@@ -34,6 +34,12 @@ class ShardPlan:
     def all_gather(self, record):
         """(2+J,) shard record -> (world_size, 2+J), rank order.  The single collective."""
         n = record.numel()
+        if record.is_cuda and dist.get_backend(self.group) == "gloo":
+            # test rigs only (several ranks sharing ONE GPU, where RCCL refuses to run): stage the
+            # record through the host.  Production = nccl (RCCL), device to device.
+            host = torch.empty(self.world_size * n, dtype=record.dtype)
+            dist.all_gather_into_tensor(host, record.detach().cpu().contiguous().view(-1), group=self.group)
+            return host.to(record.device).view(self.world_size, n)
         out = torch.empty(self.world_size * n, device=record.device, dtype=record.dtype)
         dist.all_gather_into_tensor(out, record.contiguous().view(-1), group=self.group)
         return out.view(self.world_size, n)

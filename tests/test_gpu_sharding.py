@@ -112,3 +112,34 @@ def test_record_all_gather_over_rccl_world_size_one():
         assert out.shape == (1, rec.numel()) and torch.equal(out[0], rec)
     finally:
         dist.destroy_process_group()
+
+
+def _torchrun(args, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547"] + args
+    return subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_processes_sharded_command_matches_unsharded():
+    """the real N>1 path end to end: 2 PROCESSES (sharing cuda:0, gloo), record all-gather, K5"""
+    r = _torchrun([os.path.join("tests", "dist_worker.py")])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("OK") == 2
+
+
+def test_bench_two_ranks_prints_one_valid_json_line():
+    """bench.py under torch.distributed.run with 2 ranks (gloo test rig): weak scaling bookkeeping"""
+    import json
+    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--workload", "c2"],
+                  env_extra={"MPPI_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["K_global"] == 2 * d["config"]["K_per_gpu"]
+    assert d["config"]["ranks_hold_identical_U"] is True and d["value"] > 0 and "cpu_baseline" not in d
