@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 7
+#define MPPI_ABI_VERSION 8
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -52,7 +52,8 @@ enum {
   MPPI_MODEL_PENDULUM = 1,    /* reference tests/pendulum.py:30-60                        */
   MPPI_MODEL_INTEGRATOR = 2,  /* "quad-toy": reference tests/benchmark_mppi.py:65-78      */
   MPPI_MODEL_LINEAR_GOAL = 3, /* reference tests/test_mppi.py:25-51                       */
-  MPPI_MODEL_MLP = 4          /* x + s*(W2 tanh(W1[x;u]+b1)+b2), tests/pendulum_approximate.py:47-67 */
+  MPPI_MODEL_MLP = 4,         /* x + s*(W2 tanh(W1[x;u]+b1)+b2), tests/pendulum_approximate.py:47-67 */
+  MPPI_MODEL_CUSTOM_BASE = 100 /* 100 + slot: user dynamics/cost compiled at run time (jit.py)  */
 };
 
 enum {
@@ -188,6 +189,14 @@ int mppi_finalize(const MppiProblem* p, int apply, void* stream);
  * on every rank: beta = min beta_g; s_g = exp(-(beta_g-beta)/lambda); eta = sum s_g eta_g;
  * U_out = shift(U) + sum s_g P_g / eta; rescales this shard's omega. */
 int mppi_combine(const MppiProblem* p, const void* records, int32_t n_shards, void* stream);
+
+/* User models.  The reference's plugin API is "any Python callable" (mppi.py:63-64); the fused
+ * equivalent is a device functor {step, cost, terminal} that pytorch_mppi_amd/jit.py wraps around
+ * the user's C++ snippets, compiles with hipcc against csrc/rollout.hpp into its own shared object
+ * and registers here.  `rollout_f32` / `rollout_f64`: int (*)(const void* kargs, void* stream), the
+ * object's own instantiation of K1 (kargs = the engine-internal typed argument block that
+ * mppi_rollout_cost builds).  model_id = MPPI_MODEL_CUSTOM_BASE + slot, slot in [0, 64). */
+int mppi_register_model(int32_t model_id, int32_t nx, int32_t nu, void* rollout_f32, void* rollout_f64);
 
 /* Measurement hooks (bench.py).  While enabled, every K1 launch (mppi_rollout_cost) is made with
  * hipExtLaunchKernelGGL start/stop events attached to the KERNEL ITSELF (not to the stream around

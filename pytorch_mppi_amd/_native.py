@@ -9,11 +9,12 @@ import os
 
 from . import _build
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS = 0, 1, 2
 MODEL_NONE, MODEL_PENDULUM, MODEL_INTEGRATOR, MODEL_LINEAR_GOAL, MODEL_MLP = 0, 1, 2, 3, 4
+MODEL_CUSTOM_BASE = 100
 
 _vp = C.c_void_p
 
@@ -61,6 +62,7 @@ SYMBOLS = {
     "mppi_weights_partial": (C.c_int, [_PP, _vp]),
     "mppi_finalize": (C.c_int, [_PP, C.c_int, _vp]),
     "mppi_combine": (C.c_int, [_PP, _vp, C.c_int32, _vp]),
+    "mppi_register_model": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "mppi_profile_enable": (C.c_int, [C.c_int]),
     "mppi_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mppi_profile_read2": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

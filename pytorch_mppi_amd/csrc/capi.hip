@@ -35,6 +35,12 @@ extern "C" int64_t mppi_noise_rows4(int32_t T, int32_t nu) {
 }
 
 namespace {
+// run-time registered (JIT-compiled) models: see mppi_register_model
+typedef int (*custom_rollout_fn)(const void* kargs, void* stream);
+struct CustomModel { int nx, nu; custom_rollout_fn f32, f64; };
+constexpr int MAX_CUSTOM = 64;
+CustomModel g_custom[MAX_CUSTOM] = {};
+
 struct Carve { int nb1, nkc, Jpad, R; int64_t total; };
 
 Carve carve(const MppiProblem* p) {
@@ -117,7 +123,15 @@ int do_rollout(const MppiProblem* p, hipStream_t st) {
     case MPPI_MODEL_INTEGRATOR: r = rollout_integrator(a, st); break;
     case MPPI_MODEL_LINEAR_GOAL: r = rollout_linear_goal(a, st); break;
     case MPPI_MODEL_MLP: r = rollout_mlp(a, st); break;
-    default: return fail(MPPI_E_UNSUPPORTED, "mppi_rollout_cost: model has no fused kernel");
+    default: {
+      const int slot = p->model_id - MPPI_MODEL_CUSTOM_BASE;
+      if (slot < 0 || slot >= MAX_CUSTOM) return fail(MPPI_E_UNSUPPORTED, "mppi_rollout_cost: model has no fused kernel");
+      const CustomModel& cm = g_custom[slot];
+      custom_rollout_fn fn = sizeof(T) == 4 ? cm.f32 : cm.f64;
+      if (fn == nullptr || cm.nx != p->nx || cm.nu != p->nu)
+        return fail(MPPI_E_UNSUPPORTED, "mppi_rollout_cost: custom model not registered for this (nx, nu, dtype)");
+      r = fn((const void*)&a, (void*)st);
+    }
   }
   return hipfail(r, "mppi_rollout_cost");
 }
@@ -217,8 +231,21 @@ extern "C" int mppi_model_supported(int32_t model_id, int32_t nx, int32_t nu, in
     case MPPI_MODEL_INTEGRATOR: return supported_integrator(nx, nu, hidden);
     case MPPI_MODEL_LINEAR_GOAL: return supported_linear_goal(nx, nu, hidden);
     case MPPI_MODEL_MLP: return supported_mlp(nx, nu, hidden);
-    default: return 0;
+    default: {
+      const int slot = model_id - MPPI_MODEL_CUSTOM_BASE;
+      if (slot < 0 || slot >= MAX_CUSTOM) return 0;
+      const CustomModel& cm = g_custom[slot];
+      return cm.nx == nx && cm.nu == nu && (dtype == MPPI_F32 ? cm.f32 != nullptr : cm.f64 != nullptr);
+    }
   }
+}
+
+extern "C" int mppi_register_model(int32_t model_id, int32_t nx, int32_t nu, void* f32, void* f64) {
+  const int slot = model_id - MPPI_MODEL_CUSTOM_BASE;
+  if (slot < 0 || slot >= MAX_CUSTOM) return fail(MPPI_E_BADARG, "custom model id out of range");
+  if (nx <= 0 || nu <= 0 || (f32 == nullptr && f64 == nullptr)) return fail(MPPI_E_BADARG, "bad custom model");
+  g_custom[slot] = CustomModel{nx, nu, (custom_rollout_fn)f32, (custom_rollout_fn)f64};
+  return 0;
 }
 
 template <typename T>

@@ -62,6 +62,8 @@ __device__ __forceinline__ KArgs<T> env_view(const KArgs<T>& a) {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float m_sin(float x) { return sinf(x); }
 __device__ __forceinline__ double m_sin(double x) { return sin(x); }
+__device__ __forceinline__ float m_cos(float x) { return cosf(x); }
+__device__ __forceinline__ double m_cos(double x) { return cos(x); }
 __device__ __forceinline__ float m_exp(float x) { return expf(x); }
 __device__ __forceinline__ double m_exp(double x) { return exp(x); }
 __device__ __forceinline__ float m_tanh(float x) { return tanhf(x); }
