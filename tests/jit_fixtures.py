@@ -1,0 +1,45 @@
+"""User models used by tests/test_gpu_jit_models.py.  Defined here (not in the test) so that
+`__graft_entry__.build()` can compile them in the build container: the objects land in
+pytorch_mppi_amd/_jit/ (in-tree, hash-named) and travel to the GPU box with the snapshot."""
+import torch
+
+import pytorch_mppi_amd as pm
+from pytorch_mppi_amd import jit
+
+DT_, GX, GY, WT = 0.1, 1.5, -0.5, 3.0
+
+
+def pendulum_user():
+    builtin = pm.models.Pendulum()
+    return builtin, jit.compile_model(
+        "pendulum_user", 2, 1, dynamics=builtin.dynamics, running_cost=builtin.running_cost,
+        step="const T uc = clampT(u[0], T(-2), T(2));"
+             "T nthd = x[1] + (T(15) * m_sin(x[0]) + T(3) * uc) * T(0.05);"
+             "nthd = clampT(nthd, T(-8), T(8)); x[0] = x[0] + nthd * T(0.05); x[1] = nthd;",
+        cost="const T pi = T(3.141592653589793), two_pi = T(6.283185307179586);"
+             "T r = m_fmod(x[0] + pi, two_pi); if (r != T(0) && r < T(0)) r += two_pi;"
+             "const T an = r - pi; return an * an + T(0.1) * (x[1] * x[1]);")
+
+
+def unicycle_callables():
+    def f(s, a):
+        return torch.stack((s[:, 0] + DT_ * a[:, 0] * torch.cos(s[:, 2]), s[:, 1] + DT_ * a[:, 0] * torch.sin(s[:, 2]),
+                            s[:, 2] + DT_ * a[:, 1]), dim=1)
+
+    def q(s, a):
+        return (s[:, 0] - GX) ** 2 + (s[:, 1] - GY) ** 2 + 0.01 * (a ** 2).sum(-1)
+
+    def term(states, actions):
+        last = states[..., -1, :]
+        return WT * ((last[..., 0] - GX) ** 2 + (last[..., 1] - GY) ** 2)
+
+    return f, q, term
+
+
+def unicycle():
+    f, q, term = unicycle_callables()
+    return jit.compile_model(
+        "unicycle", 3, 2, dynamics=f, running_cost=q, terminal_state_cost=term, params=[DT_, GX, GY, WT],
+        step="const T c = m_cos(x[2]), s = m_sin(x[2]); x[0] += p[0] * u[0] * c; x[1] += p[0] * u[0] * s; x[2] += p[0] * u[1];",
+        cost="const T dx = x[0] - p[1], dy = x[1] - p[2]; return dx * dx + dy * dy + T(0.01) * (u[0] * u[0] + u[1] * u[1]);",
+        terminal="const T dx = x[0] - p[1], dy = x[1] - p[2]; return p[3] * (dx * dx + dy * dy);")

@@ -6,22 +6,14 @@ import numpy as np
 import pytest
 import torch
 
+import jit_fixtures as jf
 import pytorch_mppi_amd as pm
-from pytorch_mppi_amd import jit
 
 pytestmark = pytest.mark.gpu
 
 
 def test_jit_pendulum_is_bitwise_the_builtin_kernel():
-    builtin = pm.models.Pendulum()
-    user = jit.compile_model(
-        "pendulum_user", 2, 1, dynamics=builtin.dynamics, running_cost=builtin.running_cost,
-        step="const T uc = clampT(u[0], T(-2), T(2));"
-             "T nthd = x[1] + (T(15) * m_sin(x[0]) + T(3) * uc) * T(0.05);"
-             "nthd = clampT(nthd, T(-8), T(8)); x[0] = x[0] + nthd * T(0.05); x[1] = nthd;",
-        cost="const T pi = T(3.141592653589793), two_pi = T(6.283185307179586);"
-             "T r = m_fmod(x[0] + pi, two_pi); if (r != T(0) && r < T(0)) r += two_pi;"
-             "const T an = r - pi; return an * an + T(0.1) * (x[1] * x[1]);")
+    builtin, user = jf.pendulum_user()
     z = torch.randn(1000, 20, 1, generator=torch.Generator().manual_seed(0))
     outs = []
     for m in (builtin, user):
@@ -37,24 +29,8 @@ def test_jit_pendulum_is_bitwise_the_builtin_kernel():
 def test_jit_unicycle_fused_equals_callback_path_and_oracle(dtype):
     """a model the engine has never seen: unicycle with parameters + terminal cost"""
     from oracle import mppi_oracle as orc
-    dt_, gx, gy, wT = 0.1, 1.5, -0.5, 3.0
-
-    def f(s, a):
-        return torch.stack((s[:, 0] + dt_ * a[:, 0] * torch.cos(s[:, 2]), s[:, 1] + dt_ * a[:, 0] * torch.sin(s[:, 2]),
-                            s[:, 2] + dt_ * a[:, 1]), dim=1)
-
-    def q(s, a):
-        return (s[:, 0] - gx) ** 2 + (s[:, 1] - gy) ** 2 + 0.01 * (a ** 2).sum(-1)
-
-    def term(states, actions):
-        last = states[..., -1, :]
-        return wT * ((last[..., 0] - gx) ** 2 + (last[..., 1] - gy) ** 2)
-
-    model = jit.compile_model(
-        "unicycle", 3, 2, dynamics=f, running_cost=q, terminal_state_cost=term, params=[dt_, gx, gy, wT],
-        step="const T c = m_cos(x[2]), s = m_sin(x[2]); x[0] += p[0] * u[0] * c; x[1] += p[0] * u[0] * s; x[2] += p[0] * u[1];",
-        cost="const T dx = x[0] - p[1], dy = x[1] - p[2]; return dx * dx + dy * dy + T(0.01) * (u[0] * u[0] + u[1] * u[1]);",
-        terminal="const T dx = x[0] - p[1], dy = x[1] - p[2]; return p[3] * (dx * dx + dy * dy);")
+    f, q, term = jf.unicycle_callables()
+    model = jf.unicycle()
     K, T = 777, 25
     g = torch.Generator().manual_seed(3)
     U0 = torch.randn(T, 2, generator=g, dtype=torch.float64) * 0.1
