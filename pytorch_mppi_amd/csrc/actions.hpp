@@ -45,9 +45,6 @@ struct ActionConsts {
   const T* Sm;                                // (NU,NU) Sigma^-1
   T lambda_, e_scale;
   int abs_cost;
-  // elements of LDS the full-Sigma factors need
-  static constexpr int LDS_ELEMS = 2 * NU * NU;
-
   // `lds` may be nullptr when Sigma is diagonal.  Caller must __syncthreads() afterwards.
   __device__ __forceinline__ void load(const KArgs<T>& a, T* lds) {
 #pragma unroll

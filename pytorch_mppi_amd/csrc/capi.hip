@@ -72,7 +72,7 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   const Carve c = carve(p);
   if (!p->workspace || p->workspace_elems < c.total) return fail(MPPI_E_WORKSPACE, "workspace too small");
   a.K = p->K; a.Tn = p->T; a.nx = p->nx; a.nu = p->nu; a.J = p->T * p->nu;
-  a.J4 = (int)mppi_noise_rows4(p->T, p->nu); a.S = p->S;
+  a.J4 = (int)mppi_noise_rows4(p->T, p->nu);
   a.k_offset = p->k_offset;
   a.model_id = p->model_id; a.diag = p->sigma_diagonal; a.abs_cost = p->noise_abs_cost;
   a.null_action = p->sample_null_action; a.n_sampler = p->n_sampler_rows;
@@ -84,8 +84,7 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.state = (const T*)p->state; a.U = (const T*)p->U; a.u_init = (const T*)p->u_init;
   a.mu = (const T*)p->noise_mu; a.L = (const T*)p->noise_L; a.sinv = (const T*)p->sigma_inv;
   a.umin = (const T*)p->u_min; a.umax = (const T*)p->u_max; a.mp = (const T*)p->model_params;
-  a.z = (const T*)p->z; a.sampler = (const T*)p->sampler_actions; a.W = (const T*)p->W;
-  a.theta = (const T*)p->theta; a.B = (const T*)p->base_seq;
+  a.z = (const T*)p->z; a.sampler = (const T*)p->sampler_actions; a.B = (const T*)p->base_seq;
   a.cost = (T*)p->cost_total; a.omega = (T*)p->omega; a.wnz = (T*)p->cost_total_non_zero;
   a.U_out = (T*)p->U_out; a.action_out = (T*)p->action_out; a.pa = (T*)p->perturbed_action;
   a.noise = (T*)p->noise; a.pert = (T*)p->pert_cost; a.states = (T*)p->states;

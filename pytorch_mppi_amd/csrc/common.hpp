@@ -15,13 +15,13 @@ constexpr int UPD_TJ = 64;            // j-columns per K3 tile (= one value per 
 // typed, by-value kernel argument block (lives in kernarg memory -> SGPRs)
 template <typename T>
 struct KArgs {
-  int K, Tn, nx, nu, J, J4, S;
+  int K, Tn, nx, nu, J, J4;
   long long k_offset;
   int model_id, diag, abs_cost, null_action, n_sampler, state_per_sample, shift, use_terminal,
       noise_src, u_per_command, hidden;
   T lambda_, u_scale, e_scale, smooth_w;
   unsigned long long seed, call;
-  const T *state, *U, *u_init, *mu, *L, *sinv, *umin, *umax, *mp, *z, *sampler, *W, *theta, *B;
+  const T *state, *U, *u_init, *mu, *L, *sinv, *umin, *umax, *mp, *z, *sampler, *B;
   T *cost, *omega, *wnz, *U_out, *action_out, *pa, *noise, *pert, *states, *record;
   // workspace carve-up
   T* block_min;   // [nb1] minima of cost_total per 64 consecutive samples

@@ -185,7 +185,6 @@ class MPPI:
             self.k_offset = self._shard.k_offset
             self.K_local = self._shard.K_local
         self._ws = None
-        self._z_native = None
         self._vec_cache = {}
         self._problem_cache = {}
         self._ws_need = {}
@@ -253,7 +252,6 @@ class MPPI:
             self.U = torch.cat((self.U, self.u_init.repeat(horizon - self.U.shape[0], 1)))
         self.T = horizon
         self._ws = None
-        self._z_native = None
         self._problem_cache = {}
 
     def reset(self):
