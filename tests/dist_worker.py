@@ -44,6 +44,23 @@ def main():
         both = torch.empty(world * mine.numel())
         dist.all_gather_into_tensor(both, mine)
         ok &= bool(torch.equal(both[:mine.numel()], both[mine.numel():2 * mine.numel()]))
+    # KMPPI and SMPPI under sharding (theta / lifted-control updates go through the same record exchange)
+    lin = pm.models.LinearGoal(torch.tensor([[1.0, 0.0], [0.0, -1.0]]), torch.tensor([2.0, 2.0]))
+    xs = torch.tensor([-3.0, -2.0]).cuda()
+    for cls, extra, zshape in ((pm.KMPPI, dict(num_support_pts=5), (K, 5, 2)),
+                               (pm.SMPPI, dict(w_action_seq_cost=2.0, delta_t=0.5, action_max=torch.tensor([1.0, 1.0])), (K, T, 2))):
+        kw = dict(num_samples=K, horizon=T, device="cuda", lambda_=5.0, U_init=torch.zeros(T, 2), rng="torch", **extra)
+        sharded = cls(lin.dynamics, lin.running_cost, 2, torch.eye(2), shard=(rank, world), **kw)
+        full = cls(lin.dynamics, lin.running_cost, 2, torch.eye(2), **kw)
+        for step in range(3):
+            z = torch.randn(*zshape, generator=g)
+            sharded.inject_noise(z)
+            full.inject_noise(z)
+            a_s, a_f = sharded.command(xs), full.command(xs)
+            ok &= bool(torch.allclose(a_s, a_f, rtol=1e-5, atol=1e-6))
+            ok &= bool(torch.allclose(sharded.U, full.U, rtol=1e-5, atol=1e-6))
+        if not ok:
+            print(f"rank {rank}: {cls.__name__} sharded mismatch")
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
