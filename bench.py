@@ -235,8 +235,10 @@ def main():
             ach = alg_bytes / (k1_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                        "note": "rng=philox generates z in registers: K1 is VALU-bound, 'achieved' is "
-                                "external-z-equivalent bytes / time, not HBM traffic"}
+                        "kernel": "rollout_cost_kernel<..., PHILOX>", "avg_launch_us": k1_ms * 1e3,
+                        "avg_launch_us_hip_events": k1_ms_events * 1e3,
+                        "note": "rng=philox: K1 generates the normals (Philox4x32-10 + Box-Muller) and WRITES them "
+                                "once for K3 -- it is VALU/RNG-bound, 'achieved' is those bytes / time"}
         else:
             ach = alg_bytes / (k1_ms * 1e-3) / 1e9
             # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: separate
