@@ -1137,3 +1137,33 @@ class KMPPI(MPPI):
     @noise_theta.setter
     def noise_theta(self, v):
         self._noise_theta = v
+
+
+def run_mppi(mppi, env, retrain_dynamics, retrain_after_iter=50, iter=1000, render=True):
+    """Closed-loop helper with the reference's contract (mppi.py:876-898): step a gym-style `env`
+    `iter` times with `mppi.command(env.unwrapped.state)`, keep the last `retrain_after_iter`
+    (state, action) rows in a device tensor, hand that tensor to `retrain_dynamics` every
+    `retrain_after_iter` steps, return (total reward, dataset).  Host glue around `command()`;
+    the only device->host transfer per step is the action the environment needs."""
+    import time
+    rows = retrain_after_iter
+    dataset = torch.zeros((rows, mppi.nx + mppi.nu), dtype=mppi.U.dtype, device=mppi.d)
+    total_reward = 0
+    for i in range(iter):
+        state = env.unwrapped.state.copy()
+        t0 = time.perf_counter()
+        action = mppi.command(state)
+        dt = time.perf_counter() - t0
+        step_result = env.step(action.cpu().numpy())
+        reward = step_result[1]
+        total_reward += reward
+        logger.debug("step %d: reward %.4f, command() %.5fs", i, float(reward), dt)
+        if render:
+            env.render()
+        row = i % rows
+        if row == 0 and i > 0:
+            retrain_dynamics(dataset)
+            dataset.zero_()
+        dataset[row, :mppi.nx] = torch.as_tensor(state, dtype=mppi.U.dtype)
+        dataset[row, mppi.nx:] = action
+    return total_reward, dataset

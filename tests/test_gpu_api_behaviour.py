@@ -521,3 +521,38 @@ def test_parameter_edits_between_commands_are_picked_up():
     c.U = U0.clone().cuda()
     c.inject_noise(z[0]); c.command(s)
     assert torch.isfinite(c.U).all()
+
+
+def test_run_mppi_closed_loop_helper():
+    """reference mppi.py:876-898 with a minimal gym-style pendulum env (no gym in this image)"""
+    import math
+
+    class Env:
+        def __init__(self):
+            self.state = np.array([math.pi, 1.0])
+            self.unwrapped = self
+            self.steps = 0
+
+        def step(self, u):
+            th, thd = self.state
+            u = float(np.clip(u, -2, 2)[0])
+            thd = float(np.clip(thd + (15.0 * math.sin(th) + 3.0 * u) * 0.05, -8, 8))
+            th = th + thd * 0.05
+            self.state = np.array([th, thd])
+            self.steps += 1
+            an = ((th + math.pi) % (2 * math.pi)) - math.pi
+            return self.state, -(an ** 2 + 0.1 * thd ** 2 + 0.001 * u ** 2), False, {}
+
+        def render(self):
+            raise AssertionError("render=False must not render")
+
+    torch.manual_seed(0)
+    m = models.Pendulum()
+    ctrl = MPPI(m.dynamics, m.running_cost, 2, torch.tensor(10.0, dtype=DT), num_samples=1000, horizon=15, device=DEV,
+                u_min=torch.tensor(-2.0, dtype=DT), u_max=torch.tensor(2.0, dtype=DT))
+    seen = []
+    env = Env()
+    total, data = pm.run_mppi(ctrl, env, lambda d: seen.append(d.clone()), retrain_after_iter=10, iter=35, render=False)
+    assert env.steps == 35 and len(seen) == 3 and seen[0].shape == (10, 3) and data.shape == (10, 3)
+    assert data.is_cuda and np.isfinite(total)
+    assert float(seen[0][:, 2].abs().max()) <= 2.0 + 1e-9          # stored actions respect the bounds
