@@ -208,6 +208,11 @@ class MPPI:
             self.noise_sigma_inv = torch.linalg.inv(self.noise_sigma)
             self._noise_sigma_chol = torch.linalg.cholesky(self.noise_sigma)
             self._noise_L = self._noise_sigma_chol.contiguous()
+        # what the kernels read.  Like the reference's action-cost closure (mppi.py:189-199, values
+        # captured at construction), later assignments to the PUBLIC `noise_sigma` /
+        # `noise_sigma_inv` attributes (reference autotune.py:158-162) do not reach the hot path;
+        # `set_noise()` is the coherent way to change Sigma.
+        self._sigma_inv_kernel = self.noise_sigma_inv
 
     def set_noise(self, noise_sigma=None, noise_mu=None):
         """Replace Sigma / mu and refresh every derived factor (in the reference
@@ -294,7 +299,7 @@ class MPPI:
         return (Tn, self.K_local, self.nx, self.nu, self.k_offset, id(m), m.hidden if m is not None else 0,
                 bool(self.noise_abs_cost), bool(self.sample_null_action), int(self.u_per_command),
                 float(self.lambda_), float(self.u_scale), self.seed, tv(self.u_init), tv(self.noise_mu),
-                tv(self.noise_sigma), tv(self.noise_sigma_inv), tv(self._noise_L), tv(self.u_min), tv(self.u_max),
+                tv(self._sigma_inv_kernel), tv(self._noise_L), tv(self.u_min), tv(self.u_max),
                 m._param_version if m is not None else 0)
 
     def _problem(self, Tn=None, U=None):
@@ -323,7 +328,7 @@ class MPPI:
             keep = dict(
                 u_init=self._vec(self.u_init), mu=self._vec(self.noise_mu),
                 L=self._noise_L.to(device=self.d, dtype=self.dtype).contiguous(),
-                sinv=self.noise_sigma_inv.to(device=self.d, dtype=self.dtype).contiguous(),
+                sinv=self._sigma_inv_kernel.to(device=self.d, dtype=self.dtype).contiguous(),
                 umin=self._vec(self.u_min), umax=self._vec(self.u_max))
             p.u_init, p.noise_mu = _ptr(keep["u_init"]), _ptr(keep["mu"])
             p.noise_L, p.sigma_inv = _ptr(keep["L"]), _ptr(keep["sinv"])
