@@ -294,6 +294,41 @@ def main():
             extras[mode] = {"rollouts_per_s": Kglobal * n / d2, "ms_per_step": d2 / n * 1e3}
             del c2
         out["other_rng_modes"] = extras
+        # the other single-GPU BASELINE.json configurations, short runs (parity-test cases, not the
+        # headline): C2 pendulum 8192x32 and C4 MLP 65536x64 (fp32 MFMA rollout)
+        others = {}
+        for wl in ("c2", "c4"):
+            if wl == args.workload:
+                continue
+            d_, kind_, nx_, nu_, K_, T_ = WORKLOADS[wl]
+            cw, xw, _ = make_controller(pm, wl, device, args.rng, None, K_)
+            if kind_ != "pendulum":
+                pr, _, _ = make_controller(pm, wl, device, args.rng, None, K_)
+                pr.command(xw)
+                cw.lambda_ = float(pr.cost_total.float().std())
+                del pr
+            nw = 100 if wl == "c2" else 8
+            for _ in range(3):
+                cw.command(xw)
+            lib.mppi_profile_enable(1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nw):
+                cw.command(xw)
+            torch.cuda.synchronize()
+            dw = time.perf_counter() - t1
+            e_, d2_, n_ = C.c_double(0), C.c_double(0), C.c_int64(0)
+            N.check(lib.mppi_profile_read2(C.byref(e_), C.byref(d2_), C.byref(n_)), "mppi_profile_read2")
+            lib.mppi_profile_enable(0)
+            k1us = d2_.value / max(1, n_.value) * 1e3
+            rec = {"workload": d_, "rollouts_per_s": K_ * nw / dw, "ms_per_step": dw / nw * 1e3, "k1_avg_us": k1us}
+            if kind_ == "mlp" and k1us > 0:
+                fl = 2.0 * ((nx_ + nu_) * 256 + 256 * nx_) * K_ * T_
+                rec["k1_tflops"] = fl / (k1us * 1e-6) / 1e12
+                rec["k1_frac_of_fp32_mfma_peak"] = rec["k1_tflops"] / MFMA_F32_PEAK_TFLOPS
+            others[wl] = rec
+            del cw
+        out["other_workloads"] = others
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:
