@@ -5,7 +5,7 @@
  * below names the reference lines it replaces.  Every function
  *   - is `extern "C"`, takes plain pointers/sizes (device pointers are raw HIP addresses),
  *   - launches on the HIP stream it is handed and never synchronises the device,
- *   - allocates nothing (all workspace is caller-provided, see mppi_workspace_floats),
+ *   - allocates nothing (all workspace is caller-provided, see mppi_workspace_elems; the measurement hook owns its event pool),
  *   - returns 0 on success, a negative MPPI_E_* code for an engine-side refusal, or a
  *     positive hipError_t value; mppi_last_error() returns a thread-local message.
  *
