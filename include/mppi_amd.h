@@ -40,11 +40,15 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 8
+#define MPPI_ABI_VERSION 9
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
-       MPPI_NOISE_ACTIONS = 2 /* p->z holds pre-made raw actions (TNK4), KMPPI; K1/prepare only */ };
+       MPPI_NOISE_ACTIONS = 2 /* p->z holds pre-made raw actions (TNK4), KMPPI; K1/prepare only */,
+       MPPI_NOISE_KTN = 3     /* p->z is the reference's own (K,T,nu) row-major fp32 draw (mppi.py:203), read in
+                                 place by mppi_rollout_cost (LDS-transposed 128-B lines) and mppi_weights_partial
+                                 (lane = column).  fp32, diagonal Sigma, T*nu % 4 == 0, nu in {4,8,12,16};
+                                 anything else returns MPPI_E_UNSUPPORTED -> convert with mppi_noise_from_ktn */ };
 
 /* native dynamics/cost models (device functors in pytorch_mppi_amd/csrc/models.hpp) */
 enum {

@@ -9,10 +9,11 @@ import os
 
 from . import _build
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 F32, F64 = 0, 1
-NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS = 0, 1, 2
+NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
+E_UNSUPPORTED = -2
 MODEL_NONE, MODEL_PENDULUM, MODEL_INTEGRATOR, MODEL_LINEAR_GOAL, MODEL_MLP = 0, 1, 2, 3, 4
 MODEL_CUSTOM_BASE = 100
 

@@ -53,11 +53,14 @@ Carve carve(const MppiProblem* p) {
   int R = 4;
   const int njt = c.Jpad / UPD_TJ;
   while (R > 1 && (int64_t)((p->K + BLOCK * R - 1) / (BLOCK * R)) * njt < 512) R >>= 1;
+  if (p->noise_src == MPPI_NOISE_KTN) R = 1;   // lane-per-column K3: blocks come from the k axis (J/256 column groups only)
   if (const char* e = getenv("MPPI_K3_R")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) R = v; }
   c.R = R;
   c.nkc = (p->K + BLOCK * R - 1) / (BLOCK * R);
   const int64_t ne = p->num_envs > 1 ? p->num_envs : 1;
-  c.total = ne * ((int64_t)c.nb1 + c.nkc + (int64_t)c.nkc * c.Jpad);
+  // sized for the finest chunking (R = 1) so one workspace serves every noise_src of the same problem
+  const int64_t nkc_max = (p->K + BLOCK - 1) / BLOCK;
+  c.total = ne * ((int64_t)c.nb1 + nkc_max + nkc_max * c.Jpad);
   return c;
 }
 
@@ -106,7 +109,10 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
 template <typename T>
 int need_noise(const KArgs<T>& a) {
   if (a.noise_src != MPPI_NOISE_PHILOX && a.z == nullptr) return fail(MPPI_E_BADARG, "noise_src needs p->z");
-  if (a.noise_src < 0 || a.noise_src > MPPI_NOISE_ACTIONS) return fail(MPPI_E_BADARG, "bad noise_src");
+  if (a.noise_src < 0 || a.noise_src > MPPI_NOISE_KTN) return fail(MPPI_E_BADARG, "bad noise_src");
+  if (a.noise_src == MPPI_NOISE_KTN &&
+      (sizeof(T) != 4 || !a.diag || a.J % 4 != 0 || (reinterpret_cast<uintptr_t>(a.z) & 15) != 0 || a.n_env > 1))
+    return fail(MPPI_E_UNSUPPORTED, "MPPI_NOISE_KTN: fp32, diagonal Sigma, T*nu % 4 == 0, 16-byte aligned, single env");
   return 0;
 }
 

@@ -166,6 +166,7 @@ __device__ __forceinline__ void store4<double>(double* __restrict__ z, long long
 
 template <typename T, int NOISE>
 __device__ __forceinline__ void noise4(const KArgs<T>& a, long long jb, int k, T (&out)[4]) {
+  static_assert(NOISE != MPPI_NOISE_KTN, "the (K,T,nu) layout has its own loaders");
   if constexpr (NOISE == MPPI_NOISE_PHILOX) {
     philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, out);
   } else {

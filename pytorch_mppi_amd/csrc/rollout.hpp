@@ -36,6 +36,7 @@ struct StepTables {
   const T* Ue;
   const T* Um;
   const T* G;
+  T* ktn_lds;      // MPPI_NOISE_KTN: wave-private transposition tiles (else unused)
 };
 
 // one timestep: actions from z, action cost, dynamics, running cost
@@ -135,6 +136,39 @@ struct Ring {
   static constexpr int D = D0 < 2 ? 2 : D0;
 };
 
+// MPPI_NOISE_KTN: the reference's (K,T,nu) row-major draw read in place.  Lane k needs its own
+// contiguous stream, which one-lane-per-sample loads would fetch as 64 separate cache lines per
+// instruction.  Instead a wave reads 128-B lines cooperatively (8 lanes x 16 B per sample line,
+// 8 sample lines per instruction), transposes them through a wave-private LDS tile (XOR-swizzled
+// 16-B slots: conflict-free on the write and on the read side) and ends up with exactly the
+// rows-of-4 the TNK4 path would have read.  A macro-step = PL lines = MS whole timesteps.
+template <int NU>
+struct Ktn {
+  static constexpr int G = (NU % 32 == 0) ? 32 : (NU % 16 == 0) ? 16 : (NU % 8 == 0) ? 8 : (NU % 4 == 0) ? 4 : (NU % 2 == 0) ? 2 : 1;
+  static constexpr int PL = NU / G;            // 128-B lines (32 floats) per macro-step
+  static constexpr int MS = 32 * PL / NU;      // timesteps per macro-step
+  static constexpr bool OK = NU % 4 == 0 && MS <= 16 && PL <= 3;   // nu in {4, 8, 12, 16, 32}
+  static constexpr int LDS_FLOATS_PER_WAVE = PL * 64 * 32;
+};
+
+// the PL x 8 coalesced 16-B loads of macro-step m: instruction (q,i) covers 8 sample lines
+template <int NU, typename T>
+__device__ __forceinline__ void ktn_issue(const KArgs<T>& a, int m, int kwave0, int c, int sl,
+                                          float (&lreg)[Ktn<NU>::PL][8][4]) {
+  constexpr int PL = Ktn<NU>::PL;
+#pragma unroll
+  for (int q = 0; q < PL; ++q) {
+    long long off = (long long)(m * PL + q) * 32 + c * 4;        // float offset inside the sample's stream
+    off = off + 4 <= a.J ? off : (long long)a.J - 4;              // tail: stay inside the row (masked by t < T)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int ks = kwave0 + 8 * i + sl;
+      ks = ks < a.K ? ks : a.K - 1;
+      load4<float>(reinterpret_cast<const float*>(a.z) + (long long)ks * a.J + off, 0, 0, 0, lreg[q][i]);
+    }
+  }
+}
+
 template <typename T, int NOISE, int NU>
 __device__ __forceinline__ void ring_fetch(const KArgs<T>& a, int ss, int k, T (&dst)[Stream<NU>::P4 * 4]) {
   constexpr int P4 = Stream<NU>::P4;
@@ -159,7 +193,51 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
   constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
   const int nss = (a.Tn + TT - 1) / TT;
 
-  if constexpr (NOISE == MPPI_NOISE_PHILOX) {
+  if constexpr (NOISE == MPPI_NOISE_KTN) {
+    if constexpr (Ktn<NU>::OK && sizeof(T) == 4) {
+      constexpr int PL = Ktn<NU>::PL, MS = Ktn<NU>::MS;
+      const int lane = threadIdx.x & (WAVE - 1);
+      const int kw0 = k - lane;                         // first sample of this wave (k is clamped: recompute below)
+      const int kwave0 = (blockIdx.x * K1_BLOCK + (int)threadIdx.x) - lane;
+      (void)kw0;
+      float* ldsw = reinterpret_cast<float*>(tb.ktn_lds) + (threadIdx.x / WAVE) * Ktn<NU>::LDS_FLOATS_PER_WAVE;
+      const int nmacro = (a.Tn + MS - 1) / MS;
+      const int c = lane & 7, sl = lane >> 3;
+      float lreg[PL][8][4];      // plain scalars: a float4 array is not promoted to registers here
+      ktn_issue<NU>(a, 0, kwave0, c, sl, lreg);
+      for (int m = 0; m < nmacro; ++m) {
+        // stage macro-step m: registers -> swizzled LDS tile (wave-private: LDS ops of one wave execute
+        // in order, no barrier).  The tile then serves the MS steps directly (NU/4 ds_read_b128 each),
+        // so the only long-lived registers are the lines of macro-step m+1 in flight.
+#pragma unroll
+        for (int q = 0; q < PL; ++q) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int s = 8 * i + sl;
+            store4<float>(ldsw + q * 2048, 0, 0, 8 * s + (c ^ (s & 7)), lreg[q][i]);
+          }
+        }
+        ktn_issue<NU>(a, m + 1 < nmacro ? m + 1 : m, kwave0, c, sl, lreg);   // unconditional prefetch of the next macro-step
+#pragma unroll
+        for (int st = 0; st < MS; ++st) {
+          const int t = m * MS + st;
+          if (t < a.Tn) {
+            T zt[NU];
+#pragma unroll
+            for (int r = 0; r < NU / 4; ++r) {
+              const int f = st * NU + 4 * r;               // float offset inside the macro-step (static)
+              const int q = f / 32, c2 = (f % 32) / 4;
+              const float4 v4 = *reinterpret_cast<const float4*>(ldsw + q * 2048 + (8 * lane + (c2 ^ (lane & 7))) * 4);
+              zt[4 * r] = v4.x; zt[4 * r + 1] = v4.y; zt[4 * r + 2] = v4.z; zt[4 * r + 3] = v4.w;
+            }
+            rollout_step<Model, T, MPPI_NOISE_TNK4, DIAG, SLOW>(a, ac, model, tb, k, active, orow, t, zt, x, vprev,
+                                                                rollout, pert);
+          }
+        }
+      }
+    }
+    return;
+  } else if constexpr (NOISE == MPPI_NOISE_PHILOX) {
     // Generated in registers: no memory pipeline, but Philox4x32-10 is a chain of 10 dependent
     // 32x32->64 multiplies and this wave is alone on its SIMD, so PB super-steps are generated
     // together (independent counters -> the chains interleave) before they are consumed.
@@ -287,7 +365,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
 
   constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT, D = Ring<NU, T>::D;
   T ring[D][P4 * 4];
-  if constexpr (NOISE != MPPI_NOISE_PHILOX) {
+  if constexpr (NOISE != MPPI_NOISE_PHILOX && NOISE != MPPI_NOISE_KTN) {
     const int last = (a.Tn + TT - 1) / TT - 1;
 #pragma unroll
     for (int d = 0; d < D; ++d) ring_fetch<T, NOISE, NU>(a, d < last ? d : last, k, ring[d]);
@@ -320,7 +398,10 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
     }
     __syncthreads();
   }
-  const StepTables<T> tb{Ue, Um, G};
+  // KTN tiles start 16-B aligned behind the tables
+  T* ktn_lds = fac + (DIAG ? 0 : 2 * NU * NU);
+  ktn_lds += (4 - ((ktn_lds - Ue) & 3)) & 3;
+  const StepTables<T> tb{Ue, Um, G, ktn_lds};
 
   T rollout = T(0), pert = T(0);
   // wave-uniform choice: does this wave own overwritten rows, or must it store the states?
@@ -346,7 +427,11 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
   constexpr int NU = Model::NU;
   KArgs<T> a = a_in;
   const bool diag = a.diag != 0;
-  const size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (diag ? 0 : 2 * NU * NU)) * sizeof(T);
+  size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (diag ? 0 : 2 * NU * NU)) * sizeof(T);
+  if (a.noise_src == MPPI_NOISE_KTN) {
+    if (!(Ktn<NU>::OK && sizeof(T) == 4 && diag)) return MPPI_E_UNSUPPORTED;
+    smem += (size_t)(4 + (K1_BLOCK / WAVE) * Ktn<NU>::LDS_FLOATS_PER_WAVE) * sizeof(T);
+  }
   if (smem > 160 * 1024) return MPPI_E_UNSUPPORTED;   // T*nu beyond the LDS tables: not built
   const dim3 grid((a.K + K1_BLOCK - 1) / K1_BLOCK, 1, a.n_env), block(K1_BLOCK);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -367,7 +452,9 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
   } while (0)
   if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCH(MPPI_NOISE_PHILOX);
   else if (a.noise_src == MPPI_NOISE_ACTIONS) MPPI_LAUNCH(MPPI_NOISE_ACTIONS);
-  else MPPI_LAUNCH(MPPI_NOISE_TNK4);
+  else if (a.noise_src == MPPI_NOISE_KTN) {
+    if constexpr (Ktn<NU>::OK && sizeof(T) == 4) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_KTN, true>));
+  } else MPPI_LAUNCH(MPPI_NOISE_TNK4);
 #undef MPPI_LAUNCH
 #undef MPPI_LAUNCH1
   return (int)hipGetLastError();

@@ -25,8 +25,11 @@ int rollout_mlp(const KArgs<float>& a, hipStream_t st) {
   const char* fv = getenv("MPPI_MLP_VALU");
   const bool force_valu = fv != nullptr && fv[0] == '1';
   if (!force_valu && a.states == nullptr && a.B == nullptr && a.smooth_w == 0.f &&
-      mlp_mfma_supported(a.nx, a.nu, a.hidden))
+      mlp_mfma_supported(a.nx, a.nu, a.hidden)) {
+    // the matrix-core kernel reads the engine's own layout: ask the caller to convert a (K,T,nu) draw
+    if (a.noise_src == MPPI_NOISE_KTN) return MPPI_E_UNSUPPORTED;
     return rollout_mlp_mfma(a, st);
+  }
   return go(a, st);
 }
 int rollout_mlp(const KArgs<double>& a, hipStream_t st) { return go(a, st); }

@@ -341,6 +341,85 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs
   if (jt == 0 && threadIdx.x == 0) a.eta_part[kc] = eta_b;
 }
 
+// (K,T,nu)-layout variant (MPPI_NOISE_KTN, fp32, diagonal Sigma): the draw is row-major in the
+// flat column j, so here a LANE owns 4 columns and walks the samples: every wave load is one
+// contiguous 1 KiB of a sample's row, the per-column constants sit in registers, and there is no
+// cross-lane reduction at all -- just a fixed-order sum over the 4 waves and the k-chunks.
+// grid = (nkc, ceil(J/256), n_env); block (kc, cg): samples [kc*BLOCK*R, +BLOCK*R), columns [cg*256, +256).
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) weights_partial_ktn_kernel(const KArgs<T> a_in) {
+  const KArgs<T> a = env_view(a_in);
+  __shared__ T red[BLOCK / WAVE];
+  __shared__ T wsum[BLOCK / WAVE][WAVE][4];
+  const int kc = blockIdx.x, cg = blockIdx.y;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int j0 = cg * 256 + lane * 4;
+  const bool cols = j0 < a.J;                     // J % 4 == 0: the quad is valid as a whole
+  T cU[4], cS[4], cM[4], cLo[4], cHi[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int j = cols ? j0 + c : 0, n = j % a.nu;
+    cU[c] = u_base(a, j); cS[c] = a.L[n * a.nu + n]; cM[c] = a.mu[n]; cLo[c] = a.umin[n]; cHi[c] = a.umax[n];
+  }
+  const T beta = shard_beta(a, red);
+  const T inv_lambda = T(1) / a.lambda_;
+  const long long n_over = (a.null_action ? 1 : 0) + (long long)a.n_sampler;
+  const int per_wave = a.R * BLOCK / (BLOCK / WAVE);            // samples of this chunk per wave
+  const int kbeg = kc * a.R * BLOCK + wv * per_wave;
+  T acc[4] = {T(0), T(0), T(0), T(0)};
+  T eta = T(0);
+  constexpr int UN = 8;                       // rows in flight per lane
+  for (int i0 = 0; i0 < per_wave; i0 += UN) {
+    T zz[UN][4], w[UN];
+    int orow[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int k = kbeg + i0 + u;
+      const bool ok = k < a.K;
+      const int kq = ok ? k : a.K - 1;
+      w[u] = ok ? weight_of<T>(a.cost[kq], beta, inv_lambda) : T(0);
+      orow[u] = (ok && a.k_offset + k < n_over) ? overwrite_row(a, a.k_offset + k) : -2;
+      if (cols) load4<T>(a.z + (long long)kq * a.J + j0, 0, 0, 0, zz[u]);
+      if (ok && cg == 0 && lane == 0 && a.wnz != nullptr) a.wnz[k] = w[u];
+      eta += w[u];
+    }
+    if (cols) {
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          T v = cU[c] + (zz[u][c] * cS[c] + cM[c]);
+          if (orow[u] == -1) v = T(0);                                               // wave-uniform
+          else if (orow[u] >= 0) v = a.sampler[(long long)orow[u] * a.J + j0 + c];
+          v = clampT(v, cLo[c], cHi[c]);
+          acc[c] += w[u] * (v - cU[c]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) wsum[wv][lane][c] = acc[c];
+  const T eta_w = eta;                      // identical in every lane of the wave
+  __syncthreads();
+  if (wv == 0 && cols) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      T s = wsum[0][lane][c];
+#pragma unroll
+      for (int q = 1; q < BLOCK / WAVE; ++q) s += wsum[q][lane][c];
+      a.P_part[(long long)kc * a.Jpad + j0 + c] = s * a.e_scale;
+    }
+  }
+  if (lane == 0) red[wv] = eta_w;
+  __syncthreads();
+  if (cg == 0 && threadIdx.x == 0) {
+    T e = red[0];
+#pragma unroll
+    for (int q = 1; q < BLOCK / WAVE; ++q) e += red[q];
+    a.eta_part[kc] = e;
+  }
+}
+
 // full-Sigma variant: one tile = SSB super-steps of NU-aligned timesteps, at most 64 columns
 template <typename T, int NU, int NOISE>
 __global__ void __launch_bounds__(BLOCK) weights_partial_full_kernel(const KArgs<T> a_in) {
@@ -530,6 +609,7 @@ int launch_noise_from_ktn(const KArgs<T>& a, const T* in, T* out, hipStream_t st
 
 template <typename T>
 int launch_kmppi_interp(const KArgs<T>& a, const T* W, int Thor, int J4out, T* out, hipStream_t st) {
+  if (a.noise_src == MPPI_NOISE_KTN) return MPPI_E_UNSUPPORTED;
   const size_t smem = ((size_t)a.J * 64 + 2 * a.nu * a.nu) * sizeof(T);
   if (smem > 160 * 1024) return MPPI_E_UNSUPPORTED;
   const dim3 grid((a.K + 63) / 64), block(64);
@@ -557,6 +637,7 @@ int launch_kmppi_interp(const KArgs<T>& a, const T* W, int Thor, int J4out, T* o
 
 template <typename T>
 int launch_prepare(const KArgs<T>& a, hipStream_t st) {
+  if (a.noise_src == MPPI_NOISE_KTN) return MPPI_E_UNSUPPORTED;   // convert with mppi_noise_from_ktn first
   const size_t smem = ((size_t)2 * a.J + 2 * a.nu * a.nu) * sizeof(T);
   const dim3 grid((a.K + BLOCK - 1) / BLOCK, 1, a.n_env), block(BLOCK);
   if (smem > 160 * 1024) return MPPI_E_UNSUPPORTED;
@@ -589,6 +670,12 @@ int launch_cost_block_min(const KArgs<T>& a, hipStream_t st) {
 template <typename T>
 int launch_weights_partial(const KArgs<T>& a, hipStream_t st) {
   if (a.noise_src == MPPI_NOISE_ACTIONS) return MPPI_E_BADARG;
+  if (a.noise_src == MPPI_NOISE_KTN) {
+    if (!a.diag || a.J % 4 != 0) return MPPI_E_UNSUPPORTED;
+    const dim3 grid(a.nkc, (a.J + 255) / 256, a.n_env), block(BLOCK);
+    hipLaunchKernelGGL(weights_partial_ktn_kernel<T>, grid, block, 0, st, a);
+    return (int)hipGetLastError();
+  }
   if (a.diag) {
     const dim3 grid(a.nkc, (a.J4 * 4 + UPD_TJ - 1) / UPD_TJ, a.n_env), block(BLOCK);
 #define LAUNCH_R(RR)                                                                              \

@@ -21,6 +21,7 @@ engine's sample-minor layout; "philox": generate in-kernel, no (K,T,nu) array at
 """
 import ctypes as C
 import logging
+import os
 import typing
 
 import torch
@@ -166,6 +167,7 @@ class MPPI:
             raise ValueError("rng must be 'torch', 'torch-native' or 'philox'")
         self.rng = rng
         self.philox_store = True   # rng="philox": K1 stores the generated rows, K3 re-reads them
+        self.ktn_direct = os.environ.get("MPPI_KTN_DIRECT", "1") != "0"   # rng="torch": read (K,T,nu) in place when possible
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self._call = 0
         self._injected = []
@@ -400,9 +402,26 @@ class MPPI:
                 p.z = _ptr(zn)
                 p._keep["z"] = zn
             return
+        p._keep["z_ktn"] = z
+        if self._ktn_direct_ok(p, Tn, nu, z):
+            # fused fp32 path, diagonal Sigma: K1 and K3 read the reference-layout draw in place
+            p.noise_src = N.NOISE_KTN
+            p.z = _ptr(z)
+            return
+        self._convert_noise(p)
+
+    def _ktn_direct_ok(self, p, Tn, nu, z):
+        return (self.ktn_direct and self.dtype == torch.float32 and self._diagonal_sigma and (Tn * nu) % 4 == 0
+                and nu in (4, 8, 12, 16) and z.data_ptr() % 16 == 0 and p.num_envs <= 1 and Tn == self.T
+                and not self._needs_generic())
+
+    def _convert_noise(self, p):
+        """(K,T,nu) draw kept in p._keep['z_ktn'] -> the engine's sample-minor rows-of-4."""
+        z = p._keep["z_ktn"]
+        K, Tn, nu = z.shape
         rows4 = N.noise_rows4(Tn, nu)
         zn = torch.empty(rows4 * K * 4, device=self.d, dtype=self.dtype)
-        N.check(lib.mppi_noise_from_ktn(C.byref(p), _ptr(z), _ptr(zn), self._stream()), "mppi_noise_from_ktn")
+        N.check(N.lib().mppi_noise_from_ktn(C.byref(p), _ptr(z), _ptr(zn), self._stream()), "mppi_noise_from_ktn")
         p.noise_src = N.NOISE_TNK4
         p.z = _ptr(zn)
         p._keep["z"] = zn
@@ -489,7 +508,12 @@ class MPPI:
             p._keep["state"] = s0
             p.state_per_sample = int(per_sample)
             p.use_terminal = int(self.terminal_state_cost is not None)
-            N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
+            rc = lib.mppi_rollout_cost(C.byref(p), st)
+            if rc == N.E_UNSUPPORTED and p.noise_src == N.NOISE_KTN:
+                self.ktn_direct = False            # no in-place instantiation for this model: convert from now on
+                self._convert_noise(p)
+                rc = lib.mppi_rollout_cost(C.byref(p), st)
+            N.check(rc, "mppi_rollout_cost")
         else:
             self._generic_total_cost(p, cost_total, st)
 
@@ -613,6 +637,8 @@ class MPPI:
             return
         lib = N.lib()
         p = self._last
+        if p.noise_src == N.NOISE_KTN:
+            self._convert_noise(p)
         K, T, nu = self.K_local, self.T, self.nu
         pa = torch.empty(K, T, nu, device=self.d, dtype=self.dtype)
         noise = torch.empty(K, T, nu, device=self.d, dtype=self.dtype)
@@ -649,6 +675,8 @@ class MPPI:
                 and not self._needs_generic():
             lib = N.lib()
             p = self._last
+            if p.noise_src == N.NOISE_KTN:
+                self._convert_noise(p)
             K = self.K_local
             states = torch.empty(1, K, self.T, self.nx, device=self.d, dtype=self.dtype)
             scratch = torch.empty(K, device=self.d, dtype=self.dtype)
@@ -842,6 +870,8 @@ class SMPPI(MPPI):
         the rollouts, exactly like the reference."""
         if self._perturbed_control is None and self._last is not None:
             lib = N.lib()
+            if self._last.noise_src == N.NOISE_KTN:
+                self._convert_noise(self._last)
             q = MPPI._problem(self, U=self._last._keep["U"])          # plain-MPPI view of the same draw
             q.shift = 0
             q.noise_src, q.z, q.call = self._last.noise_src, self._last.z, self._last.call
@@ -1003,6 +1033,7 @@ class KMPPI(MPPI):
         self.num_support_pts = num_support_pts or self.T // 2
         self.theta = torch.zeros((self.num_support_pts, self.nu), dtype=self.dtype, device=self.d)
         self.interpolation_kernel = kernel
+        self.ktn_direct = False        # the support-point draw always goes through the layout conversion
         self._noise_theta = None
         self._last_theta = None
         self.prepare_vmap_interpolation()

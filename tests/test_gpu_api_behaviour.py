@@ -556,3 +556,24 @@ def test_run_mppi_closed_loop_helper():
     assert env.steps == 35 and len(seen) == 3 and seen[0].shape == (10, 3) and data.shape == (10, 3)
     assert data.is_cuda and np.isfinite(total)
     assert float(seen[0][:, 2].abs().max()) <= 2.0 + 1e-9          # stored actions respect the bounds
+
+
+@pytest.mark.parametrize("nx,nu,T", [(6, 4, 17), (8, 4, 16), (16, 12, 19), (16, 12, 64)])
+def test_in_place_ktn_draw_equals_converted_draw(nx, nu, T):
+    """rng="torch", fp32: reading the (K,T,nu) draw in place (MPPI_NOISE_KTN) and converting it to the
+    engine layout first are the same controller: same costs, same weights, same action; and the lazy
+    `noise` / `perturbed_action` attributes still materialise after an in-place command."""
+    from pytorch_mppi_amd import _native as N
+    out = []
+    for direct in (True, False):
+        torch.manual_seed(7)
+        m = models.Integrator(nx, nu)
+        c = MPPI(m.dynamics, m.running_cost, nx, 0.5 * torch.eye(nu), num_samples=1000, horizon=T,
+                 device=DEV, lambda_=5.0, u_min=-torch.ones(nu), u_max=torch.ones(nu), sample_null_action=True)
+        c.ktn_direct = direct
+        x = torch.linspace(-1, 1, nx, device=DEV)
+        acts = [c.command(x).clone() for _ in range(3)]
+        assert (c._last.noise_src == N.NOISE_KTN) == direct
+        out.append((torch.stack(acts), c.cost_total.clone(), c.omega.clone(), c.noise.clone(), c.perturbed_action.clone()))
+    for a, b in zip(*out):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
