@@ -168,6 +168,7 @@ class MPPI:
         self.rng = rng
         self.philox_store = True   # rng="philox": K1 stores the generated rows, K3 re-reads them
         self.ktn_direct = os.environ.get("MPPI_KTN_DIRECT", "1") != "0"   # rng="torch": read (K,T,nu) in place when possible
+        self._force_collective = False
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self._call = 0
         self._injected = []
@@ -365,6 +366,9 @@ class MPPI:
         """The caller's current HIP stream (raw handle; torch.cuda.current_stream() costs ~10 us)."""
         return C.c_void_p(torch._C._cuda_getCurrentRawStream(self._dev_index))
 
+    def _randn(self, *shape):
+        return torch.randn(*shape, device=self.d, dtype=self.dtype)
+
     def _draw_noise(self, p, shape):
         """Bind this command's standard normals to the problem: injected / torch.randn (reference
         layout, converted to the engine's sample-minor rows-of-4) or in-kernel Philox."""
@@ -379,12 +383,12 @@ class MPPI:
                 raise ValueError(f"injected noise has shape {tuple(z.shape)}, expected {(K, Tn, nu)}")
             z = z.contiguous()
         elif self.rng == "torch":
-            z = torch.randn(K, Tn, nu, device=self.d, dtype=self.dtype)   # mppi.py:203
+            z = self._randn(K, Tn, nu)                                    # mppi.py:203
         elif self.rng == "torch-native":
             # same generator, drawn straight into the engine's sample-minor layout: no conversion
             # pass; which (k,t,n) gets which draw differs from the reference-layout draw
             rows4 = N.noise_rows4(Tn, nu)
-            zn = torch.randn(rows4 * K * 4, device=self.d, dtype=self.dtype)
+            zn = self._randn(rows4 * K * 4)
             p.noise_src = N.NOISE_TNK4
             p.z = _ptr(zn)
             p._keep["z"] = zn
@@ -483,7 +487,8 @@ class MPPI:
         return self._end(p)
 
     def _sharded(self):
-        return self._shard is not None and self._shard.world_size > 1
+        # _force_collective: measurement seam (tools/shard_overhead.py) -- run record -> all_gather -> K5 at world_size 1
+        return self._shard is not None and (self._shard.world_size > 1 or self._force_collective)
 
     def _begin(self, state, shift):
         """Everything local to this shard: noise, K1 (or the generic callback loop), K3, K4.

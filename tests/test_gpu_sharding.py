@@ -143,3 +143,4 @@ def test_bench_two_ranks_prints_one_valid_json_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["K_global"] == 2 * d["config"]["K_per_gpu"]
     assert d["config"]["ranks_hold_identical_U"] is True and d["value"] > 0 and "cpu_baseline" not in d
+
