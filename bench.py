@@ -69,47 +69,73 @@ def make_controller(pm, wl, device, rng, shard, K):
     return ctrl, x0.to(device), model
 
 
-def cpu_baseline(wl, budget_s=15.0):
-    """The oracle (oracle/mppi_oracle.py, a CPU restatement of the reference's command()) timed on a
-    bounded sample of the same workload: same T/nx/nu/model, fewer samples, incl. torch.randn."""
+def _oracle_problem(wl, K):
     from oracle import dynamics as dyn
     from oracle import mppi_oracle as orc
-    _, kind, nx, nu, Kfull, T = WORKLOADS[wl]
-    K = min(Kfull, 8192)
+    _, kind, nx, nu, _, T = WORKLOADS[wl]
     dtype = torch.float32
     if kind == "pendulum":
         f, q = dyn.pendulum_dynamics, dyn.pendulum_cost
-        p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=torch.tensor(10.0), K=K, T=T,
-                        u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0))
-    elif kind == "integrator":
+        return orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=torch.tensor(10.0), K=K, T=T,
+                           u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0))
+    if kind == "integrator":
         f, q = dyn.make_quadtoy(nx, nu)
-        p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=torch.eye(nu), K=K, T=T)
-    else:
-        W = dyn.make_mlp_weights(nx, nu, 256, seed=2, dtype=dtype)
-        f, q = dyn.make_mlp(*W)
-        p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=torch.eye(nu), K=K, T=T)
+        return orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=torch.eye(nu), K=K, T=T)
+    W = dyn.make_mlp_weights(nx, nu, 256, seed=2, dtype=dtype)
+    W = tuple(w.to(torch.empty(0).device) for w in W)       # follows the ambient default device
+    f, q = dyn.make_mlp(*W)
+    return orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=torch.eye(nu), K=K, T=T)
+
+
+def _time_oracle(wl, K, budget_s, max_calls, sync):
+    from oracle import mppi_oracle as orc
+    _, kind, nx, nu, Kfull, T = WORKLOADS[wl]
+    p = _oracle_problem(wl, K)
     U = torch.randn(T, nu) * 0.3
     x0 = torch.randn(nx)
     times = []
     t_start = time.perf_counter()
     it = 0
     while True:
+        sync()
         t0 = time.perf_counter()
-        z = torch.randn(K, T, nu, dtype=dtype)            # the reference's draw, mppi.py:203
+        z = torch.randn(K, T, nu, dtype=torch.float32)    # the reference's draw, mppi.py:203
         r = orc.command(p, U, x0, z, True)
         U = r["U"]
+        sync()
         dt = time.perf_counter() - t0
         if it > 0:
             times.append(dt)                              # first call = warm-up
         it += 1
-        if time.perf_counter() - t_start > budget_s or len(times) >= 50:
+        if times and (time.perf_counter() - t_start > budget_s or len(times) >= max_calls):
             break
-    t = sorted(times)[len(times) // 2]
-    return {"value": K / t, "unit": "rollouts/s", "cores": torch.get_num_threads(), "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": f"oracle command() incl. randn, K={K} of {Kfull}, T={T}, nx={nx}, nu={nu}, fp32, "
-                      f"median of {len(times)} calls ({t * 1e3:.1f} ms each)",
-            "state_evals_per_s": K * T / t}
+    return sorted(times)[len(times) // 2], len(times)
+
+
+def cpu_baseline(wl, budget_s=15.0):
+    """The oracle (oracle/mppi_oracle.py, a CPU restatement of the reference's command()) timed on a
+    bounded sample of the same workload: same T/nx/nu/model, fewer samples, incl. torch.randn.
+    Beside it, for orientation only: the same restatement with its tensors on cuda:0 at the FULL K
+    -- i.e. the reference's own formulation (one ATen launch per tensor op, ~10 per time step) on
+    this GPU, the comparator SURVEY.md 8(d) asks for next to the CPU number."""
+    _, kind, nx, nu, Kfull, T = WORKLOADS[wl]
+    K = min(Kfull, 8192)
+    t, n = _time_oracle(wl, K, budget_s, 50, lambda: None)
+    out = {"value": K / t, "unit": "rollouts/s", "cores": torch.get_num_threads(), "kind": "port",
+           "host_cpus": os.cpu_count(),
+           "sample": f"oracle command() incl. randn, K={K} of {Kfull}, T={T}, nx={nx}, nu={nu}, fp32, "
+                     f"median of {n} calls ({t * 1e3:.1f} ms each)",
+           "state_evals_per_s": K * T / t}
+    try:
+        with torch.device("cuda"):
+            tg, ng = _time_oracle(wl, Kfull, 5.0, 30, torch.cuda.synchronize)
+        out["same_port_on_gpu"] = {
+            "value": Kfull / tg, "unit": "rollouts/s", "ms_per_command": tg * 1e3,
+            "sample": f"the same torch-op restatement with tensors on cuda:0 (ATen kernels), full K={Kfull}, "
+                      f"median of {ng} calls"}
+    except Exception as e:      # a comparator, never a reason to lose the bench line
+        out["same_port_on_gpu"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
 
 
 def main():
