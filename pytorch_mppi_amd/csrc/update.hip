@@ -143,6 +143,144 @@ __global__ void __launch_bounds__(64) kmppi_interp_kernel(const KArgs<T> a, cons
 }
 
 // =============================================================================================
+// KMPPI interpolation on the matrix cores (fp32, nu % 4 == 0): the operator is one small GEMM per
+// control dimension,  V_n (T x 16 samples) = W (T x S) . Theta'_n (S x 16 samples),
+// v_mfma_f32_16x16x4_f32 (an exact fp32 fma chain).  A = W tile (lane (g,c) supplies W[t0+c][4ks+g]),
+// B = bounded control points (lane (g,c) supplies support point 4ks+g of sample c: exactly the rows
+// that lane loaded from the sample-minor stream, no exchange), D: lane (g,c) holds timesteps
+// t0+4g+r of sample c -> the four n of a row-of-4 sit in the same lane and leave as one 16-byte
+// store.  One wave = 16 samples x ONE row-of-4 column group q (grid.y): 8 row loads, 32 MFMAs and
+// 4 stores per 16-timestep tile, ~64 VGPRs -> 8 waves per SIMD, so the load, MFMA and store phases
+// of different waves overlap.  HBM-bound (reads K*S*nu, writes K*T*nu floats); the LDS kernel
+// above is the general fallback (any nu, fp64).
+// =============================================================================================
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int NU, int NOISE, int SK, bool DIAG>
+__global__ void __launch_bounds__(BLOCK) kmppi_interp_mfma_kernel(const KArgs<float> a,
+                                                                  const float* __restrict__ W, int Thor,
+                                                                  float* __restrict__ out) {
+  static_assert(NU % 4 == 0, "rows-of-4 must not straddle timesteps");
+  constexpr int P4 = NU / 4;
+  constexpr int SP = 4 * SK + 1;            // padded row of the staged operator: conflict-free A fetches
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* Wl = reinterpret_cast<float*>(smem_raw);          // [Tpad][SP], zero outside (Thor, S)
+  const int Tpad = (Thor + 15) & ~15;
+  const int S = a.Tn;
+  float* thl = Wl + Tpad * SP;                             // [S*NU] control points theta
+  float* fac = thl + S * NU;                               // [2*NU*NU] (full Sigma only)
+  const int q = blockIdx.y;
+  // per-control constants of this column group (uniform -> scalar loads)
+  float sd[4], mu[4], lo[4], hi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = 4 * q + i;
+    sd[i] = a.L[n * NU + n]; mu[i] = a.mu[n]; lo[i] = a.umin[n]; hi[i] = a.umax[n];
+  }
+  ActionConsts<float, NU> ac;
+  if constexpr (!DIAG) ac.load(a, fac);
+  // the operator goes through LDS, not through vector memory: on gfx950 loads and stores retire
+  // in order behind ONE counter, so an A fetch from global would wait for the previous tile's stores
+  {
+    constexpr int UN = 4;
+    const int nW = Tpad * SP;
+    for (int base = 0; base < nW; base += BLOCK * UN) {
+      float tmp[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = base + u * BLOCK + threadIdx.x;
+        const int t = i / SP, sp = i - t * SP;
+        const bool ok = i < nW && t < Thor && sp < S;
+        tmp[u] = W[ok ? (long long)t * S + sp : 0];
+        tmp[u] = ok ? tmp[u] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = base + u * BLOCK + threadIdx.x;
+        if (i < nW) Wl[i] = tmp[u];
+      }
+    }
+    for (int i = threadIdx.x; i < S * NU; i += BLOCK) thl[i] = a.U[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int g = lane >> 4, c = lane & 15;
+  const int kraw = blockIdx.x * 64 + wv * 16 + c;
+  const bool active = kraw < a.K;
+  const int k = active ? kraw : a.K - 1;
+
+  // B operands: bounded control points theta' = clamp(theta + eps) (mppi.py:660-663)
+  float B[SK][4];
+  if constexpr (DIAG) {
+    float zr[SK][4];
+#pragma unroll
+    for (int ks = 0; ks < SK; ++ks) {
+      const int sp = 4 * ks + g;
+      const int sl = sp < S ? sp : S - 1;
+      noise4<float, NOISE>(a, (long long)sl * P4 + q, k, zr[ks]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < SK; ++ks) {
+      const int sp = 4 * ks + g;
+      const int sl = sp < S ? sp : S - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = thl[sl * NU + 4 * q + i] + (zr[ks][i] * sd[i] + mu[i]);    // as make_action<DIAG>
+        B[ks][i] = sp < S ? clampT(v, lo[i], hi[i]) : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < SK; ++ks) {
+      const int sp = 4 * ks + g;
+      const int sl = sp < S ? sp : S - 1;
+      float z[NU], v[NU], e[NU];
+#pragma unroll
+      for (int qq = 0; qq < P4; ++qq) {
+        float r[4];
+        noise4<float, NOISE>(a, (long long)sl * P4 + qq, k, r);
+        z[4 * qq] = r[0]; z[4 * qq + 1] = r[1]; z[4 * qq + 2] = r[2]; z[4 * qq + 3] = r[3];
+      }
+      make_action<float, NU, false, false>(ac, thl + sl * NU, nullptr, z, -2, v, e);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float b = v[i];
+#pragma unroll
+        for (int qq = 1; qq < P4; ++qq) b = (qq == q) ? v[4 * qq + i] : b;      // q is wave-uniform
+        B[ks][i] = sp < S ? b : 0.f;
+      }
+    }
+  }
+
+  const int nks = (S + 3) / 4;
+  for (int t0 = 0; t0 < Thor; t0 += 16) {
+    f32x4_t D[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) D[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const float* Wr = Wl + (t0 + c) * SP + g;
+    float aw[SK];
+#pragma unroll
+    for (int ks = 0; ks < SK; ++ks) aw[ks] = Wr[4 * ks];     // zero-padded beyond S
+#pragma unroll
+    for (int ks = 0; ks < SK; ++ks) {
+      if (ks < nks) {                       // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          D[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[ks], B[ks][i], D[i], 0, 0, 0);     // :665
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = t0 + 4 * g + r;
+      if (active && t < Thor) {
+        const float v[4] = {D[0][r], D[1][r], D[2][r], D[3][r]};
+        store4<float>(out, a.K, (long long)t * P4 + q, k, v);
+      }
+    }
+  }
+}
+
+// =============================================================================================
 // prepare: perturbed_action / noise (K,T,nu) + pert_cost (K)
 // =============================================================================================
 template <typename T, int NU, int NOISE>
@@ -607,9 +745,45 @@ int launch_noise_from_ktn(const KArgs<T>& a, const T* in, T* out, hipStream_t st
   return (int)hipGetLastError();
 }
 
+// fp32, nu % 4 == 0, S <= 64: the matrix-core kernel.  Returns 1 when it launched.
+template <typename T>
+bool try_kmppi_interp_mfma(const KArgs<T>&, const T*, int, int, T*, hipStream_t) { return false; }
+template <>
+bool try_kmppi_interp_mfma<float>(const KArgs<float>& a, const float* W, int Thor, int J4out, float* out,
+                                  hipStream_t st) {
+  if (a.nu % 4 != 0 || a.Tn > 64 || J4out != Thor * (a.nu / 4) || getenv("MPPI_KMPPI_NO_MFMA")) return false;
+  const dim3 grid((a.K + 63) / 64, a.nu / 4), block(BLOCK);
+  const int Tpad = (Thor + 15) & ~15;
+#define LK2(N, SKK, NS, DG)                                                                         \
+  hipLaunchKernelGGL((kmppi_interp_mfma_kernel<N, NS, SKK, DG>), grid, block, smem, st, a, W, Thor, out);
+#define LK(N, SKK)                                                                                  \
+  {                                                                                                 \
+    const size_t smem = ((size_t)Tpad * (4 * SKK + 1) + (size_t)a.Tn * N + 2 * N * N) * sizeof(float); \
+    if (smem > 64 * 1024) return false;                                                             \
+    if (a.noise_src == MPPI_NOISE_PHILOX) {                                                         \
+      if (a.diag) LK2(N, SKK, MPPI_NOISE_PHILOX, true) else LK2(N, SKK, MPPI_NOISE_PHILOX, false)   \
+    } else {                                                                                        \
+      if (a.diag) LK2(N, SKK, MPPI_NOISE_TNK4, true) else LK2(N, SKK, MPPI_NOISE_TNK4, false)       \
+    }                                                                                               \
+    return true;                                                                                    \
+  }
+#define LN(N)                    \
+  if (a.nu == N) {               \
+    if (a.Tn <= 16) LK(N, 4)     \
+    if (a.Tn <= 32) LK(N, 8)     \
+    LK(N, 16)                    \
+  }
+  LN(4) LN(8) LN(12) LN(16)
+#undef LN
+#undef LK
+#undef LK2
+  return false;
+}
+
 template <typename T>
 int launch_kmppi_interp(const KArgs<T>& a, const T* W, int Thor, int J4out, T* out, hipStream_t st) {
   if (a.noise_src == MPPI_NOISE_KTN) return MPPI_E_UNSUPPORTED;
+  if (try_kmppi_interp_mfma<T>(a, W, Thor, J4out, out, st)) return (int)hipGetLastError();
   const size_t smem = ((size_t)a.J * 64 + 2 * a.nu * a.nu) * sizeof(T);
   if (smem > 160 * 1024) return MPPI_E_UNSUPPORTED;
   const dim3 grid((a.K + 63) / 64), block(64);

@@ -1,0 +1,49 @@
+"""Per-command time of every controller of the family on C3-sized work (one MI355X):
+MPPI / KMPPI / SMPPI with K=65536, T=64, nx=16, nu=12 and MPPI_Batched with N envs x K/N samples,
+fused path (Integrator native model), rng = torch-native unless given.
+    python tools/variants_bench.py [rng] [name-substring]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import pytorch_mppi_amd as pm
+
+rng = sys.argv[1] if len(sys.argv) > 1 else "torch-native"
+dev = "cuda"
+nx, nu, K, T = 16, 12, 65536, 64
+m = pm.models.Integrator(nx, nu)
+sig = torch.eye(nu)
+torch.manual_seed(0)
+x0 = torch.randn(nx, device=dev)
+
+
+only = sys.argv[2] if len(sys.argv) > 2 else ""
+
+
+def timeit(name, ctrl, state, n=50):
+    if only not in name:
+        return
+    for _ in range(5):
+        ctrl.command(state)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ctrl.command(state)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"{name:34s} {dt * 1e3:8.4f} ms/command   {K / dt:10.3e} rollouts/s", flush=True)
+
+
+kw = dict(num_samples=K, horizon=T, device=dev, lambda_=50.0)
+timeit("MPPI", pm.MPPI(m.dynamics, m.running_cost, nx, sig, rng=rng, **kw), x0)
+timeit("MPPI + u bounds + null action", pm.MPPI(m.dynamics, m.running_cost, nx, sig, rng=rng, u_min=-torch.ones(nu),
+                                               u_max=torch.ones(nu), sample_null_action=True, **kw), x0)
+full = torch.eye(nu) + 0.1 * torch.ones(nu, nu)
+timeit("MPPI full Sigma (Cholesky)", pm.MPPI(m.dynamics, m.running_cost, nx, full, rng=rng, **kw), x0)
+timeit("KMPPI S=32", pm.KMPPI(m.dynamics, m.running_cost, nx, sig, num_support_pts=32,
+                              kernel=pm.RBFKernel(sigma=2.0), rng=rng, **kw), x0)
+timeit("SMPPI", pm.SMPPI(m.dynamics, m.running_cost, nx, sig, rng=rng, action_min=-torch.ones(nu),
+                         action_max=torch.ones(nu), w_action_seq_cost=1.0, delta_t=0.1, **kw), x0)
+for N in (8, 64):
+    b = pm.MPPI_Batched(m.dynamics, m.running_cost, nx, sig, N, num_samples=K // N, horizon=T, device=dev,
+                        lambda_=50.0, rng=rng)
+    timeit(f"MPPI_Batched N={N} x K={K // N}", b, torch.randn(N, nx, device=dev))
