@@ -69,6 +69,31 @@ struct ActionConsts {
   }
 };
 
+// row n of chol(Sigma) (lower triangular: entries 0..n) out of the LDS copy.  One uniform-address
+// ds_read_b128 per 16 bytes when the rows are 16-byte aligned (NU*sizeof(T) % 16 == 0 and the factor
+// block starts on a 16-byte boundary, which every kernel's LDS carve guarantees for such NU):
+// the full-Sigma kernels are LDS-issue-bound on these reads, not FMA-bound.
+template <typename T, int NU>
+__device__ __forceinline__ void chol_row(const T* __restrict__ Lm, int n, T (&row)[NU]) {
+  constexpr int V = 16 / sizeof(T);                     // elements per 16-byte read
+  if constexpr ((NU % V) == 0) {
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    const vec_t* p = reinterpret_cast<const vec_t*>(__builtin_assume_aligned(Lm + n * NU, 16));
+#pragma unroll
+    for (int i = 0; i < NU / V; ++i) {
+      if (i * V <= n) {
+        const vec_t v = p[i];
+#pragma unroll
+        for (int e = 0; e < V; ++e) row[i * V + e] = v[e];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < NU; ++m)
+      if (m <= n) row[m] = Lm[n * NU + m];
+  }
+}
+
 // SRC_ACTIONS: z already holds raw actions (KMPPI), no colouring and no "+U"
 template <typename T, int NU, bool DIAG, bool SRC_ACTIONS>
 __device__ __forceinline__ void make_action(const ActionConsts<T, NU>& c, const T* __restrict__ Ut,
@@ -83,9 +108,12 @@ __device__ __forceinline__ void make_action(const ActionConsts<T, NU>& c, const 
   } else {
 #pragma unroll
     for (int n = 0; n < NU; ++n) {
-      T s = z[0] * c.Lm[n * NU];
+      T Lr[NU];
+      chol_row<T, NU>(c.Lm, n, Lr);
+      T s = z[0] * Lr[0];
 #pragma unroll
-      for (int m = 1; m < NU; ++m) s += z[m] * c.Lm[n * NU + m];
+      for (int m = 1; m < NU; ++m)
+        if (m <= n) s += z[m] * Lr[m];        // L = chol(Sigma) is lower triangular (mppi.py:139)
       v[n] = Ut[n] + (s + c.mu[n]);
     }
   }

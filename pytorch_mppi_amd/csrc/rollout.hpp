@@ -68,9 +68,11 @@ __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionCons
   } else {
 #pragma unroll
     for (int n = 0; n < NU; ++n) {
+      T Lr[NU];
+      chol_row<T, NU>(ac.Lm, n, Lr);
       T s = Umt[n];
 #pragma unroll
-      for (int m = 0; m <= n; ++m) s = m_fma(z[m], ac.Lm[n * NU + m], s);   // L is lower triangular
+      for (int m = 0; m <= n; ++m) s = m_fma(z[m], Lr[m], s);               // L is lower triangular
       v[n] = s;
     }
   }
