@@ -725,6 +725,29 @@ __global__ void __launch_bounds__(BLOCK) combine_kernel(const KArgs<T> a, const 
 // =============================================================================================
 // host-side launchers
 // =============================================================================================
+}  // namespace mppi
+#include "update_dyn.hpp"
+namespace mppi {
+
+// launch one of the runtime-nu kernels (update_dyn.hpp) with its dynamic LDS
+#define MPPI_DYN_LAUNCH(KERN, GRID, SMEM, ...)                                                      \
+  {                                                                                                 \
+    const size_t smem_ = (SMEM);                                                                    \
+    if (smem_ > 160 * 1024) return MPPI_E_UNSUPPORTED;                                              \
+    if (a.noise_src == MPPI_NOISE_PHILOX) {                                                         \
+      if (smem_ > 64 * 1024)                                                                        \
+        (void)hipFuncSetAttribute((const void*)KERN<T, MPPI_NOISE_PHILOX>,                          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_);          \
+      hipLaunchKernelGGL((KERN<T, MPPI_NOISE_PHILOX>), GRID, dim3(DYN_BLOCK), smem_, st, __VA_ARGS__); \
+    } else {                                                                                        \
+      if (smem_ > 64 * 1024)                                                                        \
+        (void)hipFuncSetAttribute((const void*)KERN<T, MPPI_NOISE_TNK4>,                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_);          \
+      hipLaunchKernelGGL((KERN<T, MPPI_NOISE_TNK4>), GRID, dim3(DYN_BLOCK), smem_, st, __VA_ARGS__); \
+    }                                                                                               \
+    return (int)hipGetLastError();                                                                  \
+  }
+
 #define MPPI_NU_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(10) X(12) X(16)
 
 template <typename T>
@@ -806,7 +829,9 @@ int launch_kmppi_interp(const KArgs<T>& a, const T* W, int Thor, int J4out, T* o
   }
   MPPI_NU_LIST(X)
 #undef X
-  return MPPI_E_UNSUPPORTED;
+  // any other control width: runtime-nu kernel (update_dyn.hpp)
+  MPPI_DYN_LAUNCH(kmppi_interp_dyn_kernel, dim3((a.K + DYN_BLOCK - 1) / DYN_BLOCK),
+                  ((size_t)a.J + 3 * a.nu) * DYN_BLOCK * sizeof(T), a, W, Thor, J4out, out)
 }
 
 template <typename T>
@@ -832,7 +857,8 @@ int launch_prepare(const KArgs<T>& a, hipStream_t st) {
   }
   MPPI_NU_LIST(X)
 #undef X
-  return MPPI_E_UNSUPPORTED;
+  MPPI_DYN_LAUNCH(prepare_dyn_kernel, dim3((a.K + DYN_BLOCK - 1) / DYN_BLOCK, 1, a.n_env),
+                  ((size_t)2 * a.J + (size_t)4 * a.nu * DYN_BLOCK) * sizeof(T), a)
 }
 
 template <typename T>
@@ -890,7 +916,8 @@ int launch_weights_partial(const KArgs<T>& a, hipStream_t st) {
   }
   MPPI_NU_LIST(X)
 #undef X
-  return MPPI_E_UNSUPPORTED;
+  MPPI_DYN_LAUNCH(weights_partial_full_dyn_kernel, dim3(a.nkc, a.Tn, a.n_env),
+                  ((size_t)a.J + (size_t)4 * a.nu * DYN_BLOCK) * sizeof(T), a, a.R * BLOCK)
 }
 
 template <typename T>

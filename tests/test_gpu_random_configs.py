@@ -12,10 +12,10 @@ from oracle import mppi_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def _case(seed):
+def _case(seed, nu=None):
     g = torch.Generator().manual_seed(seed)
     r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
-    nu = [1, 2, 3, 4, 5, 6, 7, 8][seed % 8]
+    nu = [1, 2, 3, 4, 5, 6, 7, 8][seed % 8] if nu is None else nu
     nx = nu + r(0, 3)
     K = [1, 37, 100, 256, 300, 1000, 2049][r(0, 6)]
     T = [1, 2, 5, 9, 16, 33][r(0, 5)]
@@ -51,7 +51,17 @@ def _case(seed):
 
 @pytest.mark.parametrize("seed", range(24))
 def test_generic_path_random_config_vs_fp64_oracle(seed):
-    c = _case(seed)
+    _generic_vs_oracle(seed, _case(seed))
+
+
+@pytest.mark.parametrize("seed,nu", [(200, 9), (201, 11), (202, 13), (203, 20), (204, 9), (205, 15), (206, 24), (207, 11)])
+def test_generic_path_any_control_width_vs_fp64_oracle(seed, nu):
+    """control widths without a compiled-in instantiation run the runtime-nu kernels
+    (csrc/update_dyn.hpp: prepare, full-Sigma K3): same bar as the compiled widths"""
+    _generic_vs_oracle(seed, _case(seed, nu))
+
+
+def _generic_vs_oracle(seed, c):
     dt = c["dtype"]
     cast = lambda t: t.to(dt) if torch.is_tensor(t) and t.is_floating_point() else t
     kw64 = c["kw"]
@@ -135,3 +145,63 @@ def test_fused_integrator_random_config_vs_fp64_oracle(seed):
             ref = ref.numpy()
             np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())),
                                        err_msg=f"seed {seed} step {s} {name} ({nx},{nu}) K={K} T={T} full={full}")
+
+
+@pytest.mark.parametrize("nu,dtype,full", [(8, torch.float64, False), (12, torch.float32, True), (9, torch.float64, False),
+                                           (11, torch.float32, True), (20, torch.float64, True)])
+def test_kmppi_and_smppi_any_control_width(nu, dtype, full):
+    """KMPPI (runtime-nu interpolation kernel) and SMPPI with a control width that has no compiled-in
+    instantiation, generic callbacks, against the fp64 oracle with the same injected normals."""
+    g = torch.Generator().manual_seed(nu)
+    nx, K, T, S = nu + 1, 300, 12, 5
+    A = torch.randn(nu, nu, generator=g, dtype=torch.float64) * 0.2
+    sigma = (A @ A.T + 0.5 * torch.eye(nu, dtype=torch.float64)) if full else torch.diag(torch.rand(nu, generator=g, dtype=torch.float64) + 0.4)
+    Bm = torch.randn(nx, nu, generator=g, dtype=torch.float64) * 0.4
+    goal = torch.randn(nx, generator=g, dtype=torch.float64)
+    x0 = torch.randn(nx, generator=g, dtype=torch.float64)
+    umax = torch.rand(nu, generator=g, dtype=torch.float64) + 0.6
+    f64 = lambda s, a: s + a @ Bm.T
+    q64 = lambda s, a: ((goal - s) ** 2).sum(-1)
+    Bd, gd = Bm.to(dtype).cuda(), goal.to(dtype).cuda()
+    f = lambda s, a: s + a @ Bd.T
+    q = lambda s, a: ((gd - s) ** 2).sum(-1)
+    tol = 1e-9 if dtype == torch.float64 else 3e-5
+    kw = dict(lambda_=8.0, u_max=umax)
+    p = orc.Problem(dynamics=f64, running_cost=q64, nx=nx, noise_sigma=sigma, K=K, T=T, **kw)
+
+    def close(name, got, ref):
+        ref = ref.numpy()
+        np.testing.assert_allclose(got.detach().cpu().double().numpy(), ref, rtol=tol,
+                                   atol=tol * max(1.0, float(np.abs(ref).max())), err_msg=name)
+
+    # ---- KMPPI ----
+    W, W_shift, _, _ = orc.kmppi_matrices(T, S, torch.float64)
+    theta, U = torch.zeros(S, nu, dtype=torch.float64), torch.zeros(T, nu, dtype=torch.float64)
+    c = pm.KMPPI(f, q, nx, sigma.to(dtype), num_samples=K, horizon=T, device="cuda", num_support_pts=S,
+                 kernel=pm.RBFKernel(sigma=1.0), lambda_=8.0, u_max=umax.to(dtype),
+                 U_init=torch.zeros(T, nu, dtype=dtype))     # the reference starts KMPPI's U from a random draw
+    for s in range(2):
+        z = torch.randn(K, S, nu, generator=g, dtype=torch.float64)
+        r = orc.kmppi_command(p, theta, U, x0, z, W, W_shift, True)
+        theta, U = r["theta"], r["U"]
+        c.inject_noise(z.to(dtype))
+        a = c.command(x0.to(dtype).cuda())
+        close(f"kmppi action {s}", a, r["action"])
+        close(f"kmppi cost {s}", c.cost_total, r["cost_total"])
+        close(f"kmppi theta {s}", c.theta, r["theta"])
+        close(f"kmppi U {s}", c.U, r["U"])
+    # ---- SMPPI ----
+    amax = torch.full((nu,), 1.5, dtype=torch.float64)
+    U, Aseq = torch.zeros(T, nu, dtype=torch.float64), torch.zeros(T, nu, dtype=torch.float64)
+    c = pm.SMPPI(f, q, nx, sigma.to(dtype), num_samples=K, horizon=T, device="cuda", lambda_=8.0,
+                 u_max=umax.to(dtype), action_max=amax.to(dtype), w_action_seq_cost=0.7, delta_t=0.5,
+                 U_init=torch.zeros(T, nu, dtype=dtype))
+    for s in range(2):
+        z = torch.randn(K, T, nu, generator=g, dtype=torch.float64)
+        r = orc.smppi_command(p, U, Aseq, x0, z, -amax, amax, 0.7, 0.5, True)
+        U, Aseq = r["U"], r["action_sequence"]
+        c.inject_noise(z.to(dtype))
+        a = c.command(x0.to(dtype).cuda())
+        close(f"smppi action {s}", a, r["action"])
+        close(f"smppi cost {s}", c.cost_total, r["cost_total"])
+        close(f"smppi U {s}", c.U, r["U"])
