@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 9
+#define MPPI_ABI_VERSION 10
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -188,6 +188,11 @@ int mppi_weights_partial(const MppiProblem* p, void* stream);
  * (mppi.py:270; KMPPI: theta_out, then U = W theta is applied by the host), action_out
  * (:271-275), omega / cost_total_non_zero (:256-258). */
 int mppi_finalize(const MppiProblem* p, int apply, void* stream);
+
+/* K1 + K3 + K4 in one call (the fused path of one MPPI._command, mppi.py:261-275): exactly
+ * mppi_rollout_cost, then mppi_weights_partial on the rows K1 read or generated, then
+ * mppi_finalize(apply).  Nothing is launched when K1 refuses the problem (negative status). */
+int mppi_command(const MppiProblem* p, int apply, void* stream);
 
 /* K5 -- multi-GPU: combine `n_shards` records (all-gathered, rank order) exactly the same way
  * on every rank: beta = min beta_g; s_g = exp(-(beta_g-beta)/lambda); eta = sum s_g eta_g;

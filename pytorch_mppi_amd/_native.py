@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
@@ -62,6 +62,7 @@ SYMBOLS = {
     "mppi_cost_block_min": (C.c_int, [_PP, _vp]),
     "mppi_weights_partial": (C.c_int, [_PP, _vp]),
     "mppi_finalize": (C.c_int, [_PP, C.c_int, _vp]),
+    "mppi_command": (C.c_int, [_PP, C.c_int, _vp]),
     "mppi_combine": (C.c_int, [_PP, _vp, C.c_int32, _vp]),
     "mppi_register_model": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "mppi_profile_enable": (C.c_int, [C.c_int]),

@@ -54,7 +54,9 @@ Carve carve(const MppiProblem* p) {
   const int njt = c.Jpad / UPD_TJ;
   while (R > 1 && (int64_t)((p->K + BLOCK * R - 1) / (BLOCK * R)) * njt < 512) R >>= 1;
   if (p->noise_src == MPPI_NOISE_KTN) R = 1;   // lane-per-column K3: blocks come from the k axis (J/256 column groups only)
-  if (const char* e = getenv("MPPI_K3_R")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) R = v; }
+  // tuning knob for tools/ sweeps, read once
+  static const int r_env = [] { const char* e = getenv("MPPI_K3_R"); return e ? atoi(e) : 0; }();
+  if (r_env == 1 || r_env == 2 || r_env == 4 || r_env == 8) R = r_env;
   c.R = R;
   c.nkc = (p->K + BLOCK * R - 1) / (BLOCK * R);
   const int64_t ne = p->num_envs > 1 ? p->num_envs : 1;
@@ -343,6 +345,15 @@ static int do_finalize(const MppiProblem* p, int apply, hipStream_t st) {
 extern "C" int mppi_finalize(const MppiProblem* p, int apply, void* stream) {
   return BY_DTYPE(p, do_finalize<float>(p, apply, (hipStream_t)stream),
                   do_finalize<double>(p, apply, (hipStream_t)stream));
+}
+
+extern "C" int mppi_command(const MppiProblem* p, int apply, void* stream) {
+  if (int e = mppi_rollout_cost(p, stream)) return e;
+  MppiProblem q = *p;
+  // "generate once": K1 stored the Philox rows it generated, K3 re-reads them
+  if (q.noise_src == MPPI_NOISE_PHILOX && q.z != nullptr) q.noise_src = MPPI_NOISE_TNK4;
+  if (int e = mppi_weights_partial(&q, stream)) return e;
+  return mppi_finalize(&q, apply, stream);
 }
 
 template <typename T>

@@ -774,7 +774,8 @@ bool try_kmppi_interp_mfma(const KArgs<T>&, const T*, int, int, T*, hipStream_t)
 template <>
 bool try_kmppi_interp_mfma<float>(const KArgs<float>& a, const float* W, int Thor, int J4out, float* out,
                                   hipStream_t st) {
-  if (a.nu % 4 != 0 || a.Tn > 64 || J4out != Thor * (a.nu / 4) || getenv("MPPI_KMPPI_NO_MFMA")) return false;
+  static const bool off = getenv("MPPI_KMPPI_NO_MFMA") != nullptr;      // A/B knob for tools/, read once
+  if (off || a.nu % 4 != 0 || a.Tn > 64 || J4out != Thor * (a.nu / 4)) return false;
   const dim3 grid((a.K + 63) / 64, a.nu / 4), block(BLOCK);
   const int Tpad = (Thor + 15) & ~15;
 #define LK2(N, SKK, NS, DG)                                                                         \

@@ -507,32 +507,36 @@ class MPPI:
         per_sample = tuple(self.state.shape) == (K, self.nx)              # mppi.py:302
         self._states = self._actions = self._noise = self._perturbed_action = None
 
-        if not self._needs_generic():
-            s0 = self.state.contiguous() if per_sample else self.state.reshape(-1).contiguous()
-            p.state = _ptr(s0)
-            p._keep["state"] = s0
-            p.state_per_sample = int(per_sample)
-            p.use_terminal = int(self.terminal_state_cost is not None)
-            rc = lib.mppi_rollout_cost(C.byref(p), st)
-            if rc == N.E_UNSUPPORTED and p.noise_src == N.NOISE_KTN:
-                self.ktn_direct = False            # no in-place instantiation for this model: convert from now on
-                self._convert_noise(p)
-                rc = lib.mppi_rollout_cost(C.byref(p), st)
-            N.check(rc, "mppi_rollout_cost")
-        else:
-            self._generic_total_cost(p, cost_total, st)
-
-        self.cost_total = cost_total
-        if p.noise_src == N.NOISE_PHILOX and p.z:
-            p.noise_src = N.NOISE_TNK4        # the rows K1 / mppi_prepare generated are in p.z now
         omega = torch.empty(K, device=self.d, dtype=self.dtype)
         wnz = torch.empty(K, device=self.d, dtype=self.dtype)
         U_new = torch.empty(self.T, self.nu, device=self.d, dtype=self.dtype)
         record = torch.empty(2 + self.T * self.nu, device=self.d, dtype=self.dtype)
         p.omega, p.cost_total_non_zero, p.U_out, p.record = _ptr(omega), _ptr(wnz), _ptr(U_new), _ptr(record)
         p._keep.update(omega=omega, wnz=wnz, U_new=U_new, record=record)
+        apply = 0 if self._sharded() else 1
+        self.cost_total = cost_total
+
+        if not self._needs_generic():
+            s0 = self.state.contiguous() if per_sample else self.state.reshape(-1).contiguous()
+            p.state = _ptr(s0)
+            p._keep["state"] = s0
+            p.state_per_sample = int(per_sample)
+            p.use_terminal = int(self.terminal_state_cost is not None)
+            rc = lib.mppi_command(C.byref(p), apply, st)                  # K1 + K3 + K4, one call
+            if rc == N.E_UNSUPPORTED and p.noise_src == N.NOISE_KTN:
+                self.ktn_direct = False            # no in-place instantiation for this model: convert from now on
+                self._convert_noise(p)
+                rc = lib.mppi_command(C.byref(p), apply, st)
+            N.check(rc, "mppi_command")
+            if p.noise_src == N.NOISE_PHILOX and p.z:
+                p.noise_src = N.NOISE_TNK4        # the rows K1 generated are in p.z now (lazy attributes)
+            return p
+
+        self._generic_total_cost(p, cost_total, st)
+        if p.noise_src == N.NOISE_PHILOX and p.z:
+            p.noise_src = N.NOISE_TNK4            # the rows mppi_prepare generated are in p.z now
         N.check(lib.mppi_weights_partial(C.byref(p), st), "mppi_weights_partial")
-        N.check(lib.mppi_finalize(C.byref(p), 0 if self._sharded() else 1, st), "mppi_finalize")
+        N.check(lib.mppi_finalize(C.byref(p), apply, st), "mppi_finalize")
         return p
 
     def _combine(self, p, records):
