@@ -972,6 +972,15 @@ class MPPI_Batched:
         st = c._stream()
         c._attach_workspace(p)
         c._draw_noise(p, (K, T, nu))                                      # shared across environments (:838)
+        if p.noise_src == N.NOISE_PHILOX:
+            # ONE draw serves all N environments: generate the rows once, every environment's K1 / K3
+            # block then reads them (in-kernel generation would repeat the Philox work N times)
+            if not p.z:
+                zn = torch.empty(N.noise_rows4(T, nu) * K * 4, device=self.d, dtype=self.dtype)
+                p.z = _ptr(zn)
+                p._keep["z"] = zn
+            N.check(lib.mppi_noise_fill_philox(C.byref(p), p.z, st), "mppi_noise_fill_philox")
+            p.noise_src = N.NOISE_TNK4
         cost_total = torch.empty(Nn, K, device=self.d, dtype=self.dtype)
         p.cost_total = _ptr(cost_total)
         p.state = _ptr(states)

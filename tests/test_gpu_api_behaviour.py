@@ -442,6 +442,17 @@ class TestMPPIBatchedBehaviour:                              # reference TestMPP
         a1 = c1.command(s2[0])
         assert torch.allclose(a2[0], a1, atol=1e-10)
 
+    def test_philox_draw_is_shared_and_equals_single_controller(self, path):
+        """rng="philox": the batch generates ONE set of rows (mppi_noise_fill_philox) that every
+        environment reads -- each environment equals the single controller with the same seed."""
+        s3 = torch.tensor([[-3.0, -2.0], [5.0, 5.0], [0.5, -1.0]], dtype=DT, device=DEV)
+        c3 = self._make(path, N=3, rng="philox", seed=77, num_samples=333)
+        singles = [make(path, num_samples=333, horizon=10, U_init=c3.U[e].clone(), rng="philox", seed=77) for e in range(3)]
+        for _ in range(3):
+            a3 = c3.command(s3)
+            for e, c1 in enumerate(singles):
+                assert torch.allclose(a3[e], c1.command(s3[e]), atol=1e-10)
+
     def test_reset_and_compile(self, path):                  # :764-780
         torch.manual_seed(42)
         c = self._make(path)
