@@ -393,6 +393,43 @@ __device__ __forceinline__ T overwrite_correction(const KArgs<T>& a, int kbeg, i
   return corr;
 }
 
+// the streaming loop of the diagonal K3 over one 64-column tile; SPARSE: 64-sample groups whose
+// weights are all exactly zero (live[r] == false, wave-uniform) are skipped -- no load, no RNG
+template <typename T, int NOISE, int R, bool SPARSE>
+__device__ __forceinline__ void k3_tile_loop(const KArgs<T>& a, int jt, int nrows, const int (&kk)[R],
+                                             const T (&w)[R], const bool (&live)[R], const T* cU,
+                                             const T* cS, const T* cM, const T* cLo, const T* cHi,
+                                             T (&acc)[UPD_TJ]) {
+#pragma unroll
+  for (int jbl = 0; jbl < UPD_TJ / 4; ++jbl) {
+    if (jbl < nrows) {
+      const long long jb = (long long)jt * (UPD_TJ / 4) + jbl;
+      T zz[R][4];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (!SPARSE || live[r]) noise4<T, NOISE>(a, jb, kk[r], zz[r]);
+      }
+      T u4[4], s4[4], m4[4], lo4[4], hi4[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        u4[c] = cU[4 * jbl + c]; s4[c] = cS[4 * jbl + c]; m4[c] = cM[4 * jbl + c];
+        lo4[c] = cLo[4 * jbl + c]; hi4[c] = cHi[4 * jbl + c];
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (!SPARSE || live[r]) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            T v = u4[c] + (zz[r][c] * s4[c] + m4[c]);
+            v = clampT(v, lo4[c], hi4[c]);
+            acc[4 * jbl + c] += w[r] * (v - u4[c]);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int NOISE, int R>
 __global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs<T> a_in) {
   const KArgs<T> a = env_view(a_in);
@@ -433,34 +470,26 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs
 #pragma unroll
   for (int i = 0; i < UPD_TJ; ++i) acc[i] = T(0);
 
-  const int nrows = a.J4 - jt * (UPD_TJ / 4);   // rows-of-4 of this tile that exist (block-uniform)
+  // Samples whose weight is EXACTLY zero (exp underflow: (cost - beta)/lambda > ~104 in fp32) add
+  // exactly nothing to any column, so their rows are neither read nor generated.  With the peaked
+  // softmax of everyday MPPI settings (N_eff of tens to hundreds among 65536) that is almost every
+  // 64-sample group; with a flat softmax every group is live and the dense loop runs unchanged.
+  bool live[R], all_live = true, any_live = false;
 #pragma unroll
-  for (int jbl = 0; jbl < UPD_TJ / 4; ++jbl) {
-    if (jbl < nrows) {
-      const long long jb = (long long)jt * (UPD_TJ / 4) + jbl;
-      T zz[R][4];
-#pragma unroll
-      for (int r = 0; r < R; ++r) noise4<T, NOISE>(a, jb, kk[r], zz[r]);
-      T u4[4], s4[4], m4[4], lo4[4], hi4[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        u4[c] = cU[4 * jbl + c]; s4[c] = cS[4 * jbl + c]; m4[c] = cM[4 * jbl + c];
-        lo4[c] = cLo[4 * jbl + c]; hi4[c] = cHi[4 * jbl + c];
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          T v = u4[c] + (zz[r][c] * s4[c] + m4[c]);
-          v = clampT(v, lo4[c], hi4[c]);
-          acc[4 * jbl + c] += w[r] * (v - u4[c]);
-        }
-      }
-    }
+  for (int r = 0; r < R; ++r) {
+    live[r] = __ballot(w[r] != T(0)) != 0ull;          // wave-uniform
+    all_live = all_live && live[r];
+    any_live = any_live || live[r];
   }
+  const int nrows = a.J4 - jt * (UPD_TJ / 4);   // rows-of-4 of this tile that exist (block-uniform)
+  if (all_live)
+    k3_tile_loop<T, NOISE, R, false>(a, jt, nrows, kk, w, live, cU, cS, cM, cLo, cHi, acc);
+  else if (any_live)
+    k3_tile_loop<T, NOISE, R, true>(a, jt, nrows, kk, w, live, cU, cS, cM, cLo, cHi, acc);
 
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-  const T colsum = wave_reduce_transpose64<T>(acc);   // lane l: this wave's sum of column j0+l
+  // lane l: this wave's sum of column j0+l (all accumulators are still zero without a live group)
+  const T colsum = any_live ? wave_reduce_transpose64<T>(acc) : T(0);
   wsum[wv][lane] = colsum;
   const T eta_b = block_sum<T>(eta, red);             // barriers also publish wsum
   if (threadIdx.x < UPD_TJ) {
@@ -517,7 +546,9 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_ktn_kernel(const KArgs<
       const int kq = ok ? k : a.K - 1;
       w[u] = ok ? weight_of<T>(a.cost[kq], beta, inv_lambda) : T(0);
       orow[u] = (ok && a.k_offset + k < n_over) ? overwrite_row(a, a.k_offset + k) : -2;
-      if (cols) load4<T>(a.z + (long long)kq * a.J + j0, 0, 0, 0, zz[u]);
+      // every lane of the wave looks at the same sample: a zero weight skips the row (see the TNK4 K3)
+      if (cols && w[u] != T(0)) load4<T>(a.z + (long long)kq * a.J + j0, 0, 0, 0, zz[u]);
+      else { zz[u][0] = zz[u][1] = zz[u][2] = zz[u][3] = T(0); }
       if (ok && cg == 0 && lane == 0 && a.wnz != nullptr) a.wnz[k] = w[u];
       eta += w[u];
     }
@@ -590,6 +621,7 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_full_kernel(const KArgs
     const int orow = ok ? overwrite_row(a, a.k_offset + k) : -2;
     eta += w;
     if (ok && jt == 0 && a.wnz != nullptr) a.wnz[k] = w;
+    if (__ballot(w != T(0)) == 0ull) continue;      // nothing to add from these 64 samples (wave-uniform)
 #pragma unroll
     for (int sb = 0; sb < SSB; ++sb) {
       const int ss = jt * SSB + sb;

@@ -205,3 +205,48 @@ def test_kmppi_and_smppi_any_control_width(nu, dtype, full):
         close(f"smppi action {s}", a, r["action"])
         close(f"smppi cost {s}", c.cost_total, r["cost_total"])
         close(f"smppi U {s}", c.U, r["U"])
+
+
+@pytest.mark.parametrize("dtype,full,K", [(torch.float32, False, 5000), (torch.float64, False, 2049), (torch.float32, True, 3000),
+                                          (torch.float64, True, 700)])
+def test_peaked_softmax_skips_zero_weight_groups_exactly(dtype, full, K):
+    """lambda so small that almost every weight underflows to exactly 0: K3 skips whole 64-sample
+    groups (no load, no colouring).  Same bar as the dense case against the fp64 oracle, plus: the
+    number of non-zero weights agrees, i.e. the skipped groups really were all-zero."""
+    from oracle import dynamics as dyn
+    g = torch.Generator().manual_seed(K)
+    nx, nu, T = 8, 4, 12
+    A = torch.randn(nu, nu, generator=g, dtype=torch.float64) * 0.3
+    sigma = (A @ A.T + 0.5 * torch.eye(nu, dtype=torch.float64)) if full else torch.diag(torch.rand(nu, generator=g, dtype=torch.float64) + 0.3)
+    kw64 = dict(lambda_=0.004, u_max=torch.full((nu,), 1.5, dtype=torch.float64), sample_null_action=True)
+    U0 = torch.randn(T, nu, generator=g, dtype=torch.float64) * 0.1
+    x0 = torch.randn(nx, generator=g, dtype=torch.float64)
+    f64, q64 = dyn.make_quadtoy(nx, nu)
+    p = orc.Problem(dynamics=f64, running_cost=q64, nx=nx, noise_sigma=sigma, K=K, T=T, **kw64)
+    m = pm.models.Integrator(nx, nu)
+    ctrl = pm.MPPI(m.dynamics, m.running_cost, nx, sigma.to(dtype), num_samples=K, horizon=T, device="cuda",
+                   U_init=U0.to(dtype), lambda_=0.004, u_max=kw64["u_max"].to(dtype), sample_null_action=True)
+    U = U0
+    for s in range(2):
+        z = torch.randn(K, T, nu, generator=g, dtype=torch.float64)
+        r = orc.command(p, U, x0, z, True)
+        U = r["U"]
+        ctrl.inject_noise(z.to(dtype))
+        a = ctrl.command(x0.to(dtype).cuda())
+        nz_ref = int((r["omega"] > 0).sum())
+        assert nz_ref < K // 10, "test premise: a peaked softmax"
+        if dtype == torch.float64:
+            assert int((ctrl.omega > 0).sum()) == nz_ref
+            np.testing.assert_allclose(a.cpu().numpy(), r["action"].numpy(), rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(ctrl.U.cpu().numpy(), r["U"].numpy(), rtol=1e-9, atol=1e-9)
+        else:
+            # fp32 at this lambda: weights of near-optimal samples are ill-conditioned (d cost / lambda),
+            # so compare against the same arithmetic done by the oracle in fp32
+            p32 = orc.Problem(dynamics=f64, running_cost=q64, nx=nx, noise_sigma=sigma.float(), K=K, T=T, lambda_=0.004,
+                              u_max=kw64["u_max"].float(), sample_null_action=True)
+            r32 = orc.command(p32, (U0 if s == 0 else Uprev32).float(), x0.float(), z.float(), True)
+            floor = float((r32["U"].double() - r["U"]).abs().max())
+            np.testing.assert_allclose(ctrl.U.cpu().double().numpy(), r["U"].numpy(), rtol=0, atol=max(2e-5, 3 * floor))
+        Uprev32 = ctrl.U.detach().cpu()
+        # keep both sides on the same nominal sequence so that step 2 tests the update, not the drift
+        ctrl.U = r["U"].to(dtype).cuda()

@@ -35,6 +35,8 @@ def timeit(name, ctrl, state, n=50):
 
 kw = dict(num_samples=K, horizon=T, device=dev, lambda_=50.0)
 timeit("MPPI", pm.MPPI(m.dynamics, m.running_cost, nx, sig, rng=rng, **kw), x0)
+timeit("MPPI peaked softmax (lambda=0.05)", pm.MPPI(m.dynamics, m.running_cost, nx, sig, rng=rng,
+                                                    **{**kw, "lambda_": 0.05}), x0)
 timeit("MPPI + u bounds + null action", pm.MPPI(m.dynamics, m.running_cost, nx, sig, rng=rng, u_min=-torch.ones(nu),
                                                u_max=torch.ones(nu), sample_null_action=True, **kw), x0)
 full = torch.eye(nu) + 0.1 * torch.ones(nu, nu)
