@@ -167,6 +167,7 @@ class MPPI:
             raise ValueError("rng must be 'torch', 'torch-native' or 'philox'")
         self.rng = rng
         self.philox_store = True   # rng="philox": K1 stores the generated rows, K3 re-reads them
+        self.philox_fill = False   # rng="philox": generate in a separate launch instead of inside K1 (see _draw_noise)
         self.ktn_direct = os.environ.get("MPPI_KTN_DIRECT", "1") != "0"   # rng="torch": read (K,T,nu) in place when possible
         self._force_collective = False
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
@@ -399,12 +400,20 @@ class MPPI:
             p.call = self._call
             p.z = None
             if self.philox_store:
-                # generate once in K1 (or mppi_prepare), keep the rows for K3 to re-read: Philox +
-                # Box-Muller costs more per element than an HBM read
+                # generate once, keep the rows for K3 to re-read: Philox + Box-Muller costs more per
+                # element than an HBM read
                 rows4 = N.noise_rows4(Tn, nu)
-                zn = torch.empty(rows4 * K * 4, device=self.d, dtype=self.dtype)
+                n = rows4 * K * 4
+                zn = torch.empty(n, device=self.d, dtype=self.dtype)
                 p.z = _ptr(zn)
                 p._keep["z"] = zn
+                if self.philox_fill:
+                    # option: a separate generator launch at full occupancy (32 us for C3's 50 M
+                    # normals, write floor 26 us) + K1 as the pure HBM-read kernel.  Measured at C3:
+                    # 0.125 ms per command against 0.112 ms with K1 generating (K1 reads rows that are
+                    # still being written back: 38.5 us instead of 35), so it is not the default.
+                    N.check(lib.mppi_noise_fill_philox(C.byref(p), p.z, self._stream()), "mppi_noise_fill_philox")
+                    p.noise_src = N.NOISE_TNK4
             return
         p._keep["z_ktn"] = z
         if self._ktn_direct_ok(p, Tn, nu, z):

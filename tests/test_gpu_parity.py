@@ -301,3 +301,25 @@ def test_extreme_shapes_fused_vs_generic(K, T, nx, nu):
         outs.append((a, c.U, c.cost_total))
     for got, ref in zip(outs[0], outs[1]):
         assert torch.allclose(got, ref, rtol=1e-9, atol=1e-9 * max(1.0, float(ref.abs().max())))
+
+
+@pytest.mark.parametrize("path", ["fused", "generic"])
+def test_philox_variants_are_one_stream(path):
+    """rng="philox": generating inside K1 (stored for K3), generating in a separate fill launch, and
+    regenerating in K3 (no array at all) are the same stream -- a pure function of (seed, call, k, j)
+    -- so the three variants give the same commands."""
+    import pytorch_mppi_amd as pm
+    m = pm.models.Integrator(6, 4)
+    f, q = (m.dynamics, m.running_cost) if path == "fused" else (lambda s, a: m.dynamics(s, a), lambda s, a: m.running_cost(s, a))
+    outs = []
+    for fill, store in ((False, True), (True, True), (False, False)):
+        c = pm.MPPI(f, q, 6, torch.diag(torch.tensor([1.0, 2.0, 0.5, 1.5])), num_samples=3000, horizon=13, device="cuda",
+                    lambda_=4.0, u_max=torch.ones(4), rng="philox", seed=99, sample_null_action=True)
+        c.philox_fill, c.philox_store = fill, store
+        assert (c._model is not None) == (path == "fused")
+        x = torch.linspace(-1, 1, 6, device="cuda")
+        a = [c.command(x).clone() for _ in range(3)]
+        outs.append((torch.stack(a), c.cost_total.clone(), c.noise.clone()))
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):                    # downstream arithmetic: different kernels contract differently
+            torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-6)
