@@ -28,15 +28,21 @@ def main():
     ctrl = MPPI(model.dynamics, model.running_cost, nx=2, noise_sigma=torch.tensor(10.0), num_samples=args.samples,
                 horizon=args.horizon, lambda_=1.0, device="cuda", u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0),
                 rng=args.rng)
-    state = torch.tensor([[math.pi, 1.0]], device="cuda")     # hanging down, spinning
-    total = 0.0
-    torch.cuda.synchronize()
+
+    def run(steps):
+        state = torch.tensor([[math.pi, 1.0]], device="cuda")     # hanging down, spinning
+        total = torch.zeros((), device="cuda")
+        for _ in range(steps):
+            action = ctrl.command(state[0])                       # device tensor, no host sync inside
+            state = model.dynamics(state, action.view(1, 1))      # the "environment": same true dynamics
+            total = total + model.running_cost(state, action.view(1, 1))[0]      # stays on the device
+        torch.cuda.synchronize()
+        return state, float(total)
+
+    run(5)                                         # warm-up: kernel loading, allocator
+    ctrl.reset()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        action = ctrl.command(state[0])                       # device tensor, no host sync inside
-        state = model.dynamics(state, action.view(1, 1))      # the "environment": same true dynamics
-        total += float(model.running_cost(state, action.view(1, 1)))
-    torch.cuda.synchronize()
+    state, total = run(args.steps)
     dt = time.perf_counter() - t0
     th = ((float(state[0, 0]) + math.pi) % (2 * math.pi)) - math.pi
     print(f"{args.steps} steps in {dt * 1e3:.1f} ms ({dt / args.steps * 1e6:.0f} us per control step incl. env), "
