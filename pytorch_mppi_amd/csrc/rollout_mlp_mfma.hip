@@ -13,7 +13,7 @@
 // (state rows 4g+r) IS the B operand of the next timestep's layer-1 k-step "r" if W1's columns
 // are fetched as 4g+r: no lane permutes, no LDS round trip, between layers or between steps.
 // All weights stay in registers for the whole horizon: H/16*5 + H/4 VGPRs per lane (144 at H=256).
-// tanh runs on the VALU in the shadow of the MFMAs (1 - 2/(exp(2x)+1), v_exp + v_rcp).
+// Only r = 1/(2^x + 1) of tanh = 1 - 2r runs on the VALU (v_exp + v_add + v_rcp); the affine parts live in the weights.
 #include <hip/hip_ext.h>
 #include "actions.hpp"
 #include "dispatch.hpp"
@@ -22,16 +22,20 @@ namespace mppi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float fast_tanh(float x) {
+// tanh(x) = 1 - 2 r(x),  r = 1 / (2^{x * 2 log2 e} + 1).  Every VALU cycle here is additive to the
+// kernel time: the fp32 MFMA runs at the fp32 vector rate and (measured, tools/run_c4_variants.sh)
+// does not overlap VALU work -- 597 us without tanh, 857 us with the five-instruction form at C4.
+// So the affine parts are folded into the weights once per launch and only r is evaluated per
+// hidden unit (v_exp + v_add + v_rcp):
+//   layer 1 is loaded as  (2 log2 e) * [W1 | b1]          -> the pre-activation arrives in exp2 units
+//   layer 2 is loaded as  -2 * W2,  b2 + rowsum(W2)        -> W2 tanh(h) + b2 = (-2 W2) r + (b2 + W2 1)
+// No clamp needed: 2^x -> inf gives rcp(inf) = 0 (tanh = 1), 2^x -> 0 gives r = 1 (tanh = -1).
+constexpr float MLP_EXP2_SCALE = 2.8853900817779268f;   // 2 * log2(e)
+__device__ __forceinline__ float half_one_minus_tanh(float x_exp2_units) {
 #ifdef MPPI_MLP_NOTANH   // experiment only (tools/): MFMA pipe alone
-  return x;
+  return x_exp2_units;
 #endif
-  // tanh(x) = 1 - 2/(e^{2x}+1).  No clamp needed: e^{2x} -> inf gives rcp(inf) = 0 -> 1, and
-  // e^{2x} -> 0 gives 1 - 2 = -1.  Every VALU cycle here is additive to the kernel time: the fp32
-  // MFMA runs at the fp32 vector rate and (measured, tools/run_c4_variants.sh) does not overlap
-  // VALU work -- 597 us without tanh, 857 us with it at C4.
-  const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // 2*log2(e)
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+  return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x_exp2_units) + 1.0f);
 }
 
 constexpr int MLP_NX = 16, MLP_NU = 4, MLP_NI = 20;
@@ -69,18 +73,32 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
 #pragma unroll
   for (int m = 0; m < HT; ++m) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) w1r[m][q] = W1[(16 * m + s) * MLP_NI + 4 * g + q];
-    w1r[m][4] = W1[(16 * m + s) * MLP_NI + NX + g];
+    for (int q = 0; q < 4; ++q) w1r[m][q] = MLP_EXP2_SCALE * W1[(16 * m + s) * MLP_NI + 4 * g + q];
+    w1r[m][4] = MLP_EXP2_SCALE * W1[(16 * m + s) * MLP_NI + NX + g];
 #pragma unroll
     for (int r = 0; r < 4; ++r) w2r[m][r] = W2[s * H + 16 * m + 4 * g + r];
   }
+  // rowsum(W2): this lane holds a quarter of row s; the three other quarters sit in lanes s + 16 g'
+  float rowsum = 0.f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) b2r[r] = b2[4 * g + r];
+  for (int m = 0; m < HT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rowsum += w2r[m][r];
+  }
+  rowsum += __shfl_xor(rowsum, 16, WAVE);
+  rowsum += __shfl_xor(rowsum, 32, WAVE);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b2r[r] = b2[4 * g + r] + __shfl(rowsum, 4 * g + r, WAVE);   // D rows are 4g+r
+#pragma unroll
+  for (int m = 0; m < HT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w2r[m][r] *= -2.0f;
+  }
 
   ActionConsts<float, NU> ac;
   ac.load(a, DIAG ? nullptr : fac);
   for (int j = threadIdx.x; j < a.J; j += MLP_THREADS) Ue[j] = u_eff(a, j);
-  for (int h = threadIdx.x; h < H; h += MLP_THREADS) b1s[h] = b1[h];
+  for (int h = threadIdx.x; h < H; h += MLP_THREADS) b1s[h] = MLP_EXP2_SCALE * b1[h];
   __syncthreads();
   for (int j = threadIdx.x; j < a.J; j += MLP_THREADS) {
     const int n = j % NU, t0 = j - n;
@@ -204,7 +222,7 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
           if (more)
             Hc[(m + 1) & 1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                 w1r[more ? m + 1 : m][q], q < 4 ? x[i][q] : ub[i], Hc[(m + 1) & 1][i], 0, 0, 0);
-          if (slot < 4 * NT) th[slot % NT][slot / NT] = fast_tanh(Hc[m & 1][slot % NT][slot / NT]);
+          if (slot < 4 * NT) th[slot % NT][slot / NT] = half_one_minus_tanh(Hc[m & 1][slot % NT][slot / NT]);
 #ifndef MPPI_MLP_NOSB
           __builtin_amdgcn_sched_barrier(0);
 #endif
