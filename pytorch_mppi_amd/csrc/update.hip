@@ -407,7 +407,7 @@ __device__ __forceinline__ void k3_tile_loop(const KArgs<T>& a, int jt, int nrow
       T zz[R][4];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if (!SPARSE || live[r]) noise4<T, NOISE>(a, jb, kk[r], zz[r]);
+        if (!SPARSE || live[r]) noise4_last<T, NOISE>(a, jb, kk[r], zz[r]);
       }
       T u4[4], s4[4], m4[4], lo4[4], hi4[4];
 #pragma unroll
@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_ktn_kernel(const KArgs<
       w[u] = ok ? weight_of<T>(a.cost[kq], beta, inv_lambda) : T(0);
       orow[u] = (ok && a.k_offset + k < n_over) ? overwrite_row(a, a.k_offset + k) : -2;
       // every lane of the wave looks at the same sample: a zero weight skips the row (see the TNK4 K3)
-      if (cols && w[u] != T(0)) load4<T>(a.z + (long long)kq * a.J + j0, 0, 0, 0, zz[u]);
+      if (cols && w[u] != T(0)) load4_last<T>(a.z + (long long)kq * a.J + j0, 0, 0, 0, zz[u]);
       else { zz[u][0] = zz[u][1] = zz[u][2] = zz[u][3] = T(0); }
       if (ok && cg == 0 && lane == 0 && a.wnz != nullptr) a.wnz[k] = w[u];
       eta += w[u];
@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_full_kernel(const KArgs
 #pragma unroll
         for (int i = 0; i < P4; ++i) {
           T q[4];
-          noise4<T, NOISE>(a, (long long)ss * P4 + i, kq, q);
+          noise4_last<T, NOISE>(a, (long long)ss * P4 + i, kq, q);
           zc[4 * i] = q[0]; zc[4 * i + 1] = q[1]; zc[4 * i + 2] = q[2]; zc[4 * i + 3] = q[3];
         }
 #pragma unroll
