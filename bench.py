@@ -1,10 +1,13 @@
 #!/usr/bin/env python
 """bench.py -- rollouts/sec per `.command()` call (BASELINE.json metric) on N MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2|c4] [--rng torch-native|torch|philox]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2|c4] [--rng philox|philox-fused|torch-native|torch]
 
 A "step" is one full `MPPI.command(state)`: on-device noise draw, fused rollout+cost (K1),
 exp-weighting + weighted update (K3/K4) and, for N>1, the single record all-gather + combine.
+Default noise mode: rng="philox" -- the engine's own Philox4x32-10 + Box-Muller generator on the
+device (for a draw of C3's size: one generator launch, then K1 streams the rows; "philox-fused"
+forces the generation into K1); "torch-native" / "torch" draw with torch.randn instead.
 Default workload = BASELINE.json configs[2] ("c3": 12-DoF quadratic toy dynamics, K=65536, T=64,
 nx=16, nu=12, fp32) -- the configuration the north_star's roofline target is quoted on; K is
 per GPU (weak scaling: the sample axis is sharded, K_global = N*65536).
@@ -65,7 +68,9 @@ def make_controller(pm, wl, device, rng, shard, K):
     # which must stay O(1) for a healthy softmax (N_eff >> 1)
     U0 = torch.randn(T, nu, dtype=dtype) * 0.02
     ctrl = pm.MPPI(model.dynamics, model.running_cost, nx, sigma, num_samples=K, horizon=T, device=device,
-                   U_init=U0, rng=rng, seed=1234, shard=shard, **kw)
+                   U_init=U0, rng="philox" if rng == "philox-fused" else rng, seed=1234, shard=shard, **kw)
+    if rng == "philox-fused":
+        ctrl.philox_fill = False                  # force the generation into K1
     return ctrl, x0.to(device), model
 
 
@@ -144,7 +149,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--rng", default="torch-native", choices=["torch", "torch-native", "philox"])
+    ap.add_argument("--rng", default="philox", choices=["torch", "torch-native", "philox", "philox-fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -255,7 +260,7 @@ def main():
                     "avg_launch_us_hip_events": k1_ms_events * 1e3,
                     "algorithmic_flops": flops}
     elif k1:
-        if args.rng == "philox":
+        if ctrl.last_draw == "philox-k1":
             # no-HBM mode: the normals never exist in memory; report the time against the
             # external-z byte count for orientation only
             ach = alg_bytes / (k1_ms * 1e-3) / 1e9
@@ -293,7 +298,7 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "K_per_gpu": Kper, "K_global": Kglobal, "T": T, "nx": nx, "nu": nu,
-                   "rng": args.rng, "lambda": float(ctrl.lambda_), "n_eff": n_eff,
+                   "rng": args.rng, "draw": ctrl.last_draw or "torch.randn", "lambda": float(ctrl.lambda_), "n_eff": n_eff,
                    "sharding": f"samples/{world}" if world > 1 else "none",
                    "ranks_hold_identical_U": ranks_identical},
         "state_evals_per_s": value * T,
@@ -303,7 +308,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         # other noise modes of the same workload (short runs), for the record
         extras = {}
-        for mode in ("philox", "torch-native", "torch"):
+        for mode in ("philox", "philox-fused", "torch-native", "torch"):
             if mode == args.rng:
                 continue
             c2, x2, _ = make_controller(pm, args.workload, device, mode, None, Kglobal)

@@ -167,7 +167,8 @@ class MPPI:
             raise ValueError("rng must be 'torch', 'torch-native' or 'philox'")
         self.rng = rng
         self.philox_store = True   # rng="philox": K1 stores the generated rows, K3 re-reads them
-        self.philox_fill = False   # rng="philox": generate in a separate launch instead of inside K1 (see _draw_noise)
+        self.last_draw = None      # how the last command got its normals: "philox-fill" | "philox-k1" | None (other modes)
+        self.philox_fill = None    # rng="philox": generate in a separate launch (True) / inside K1 (False) / by size (None)
         self.ktn_direct = os.environ.get("MPPI_KTN_DIRECT", "1") != "0"   # rng="torch": read (K,T,nu) in place when possible
         self._force_collective = False
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
@@ -407,11 +408,13 @@ class MPPI:
                 zn = torch.empty(n, device=self.d, dtype=self.dtype)
                 p.z = _ptr(zn)
                 p._keep["z"] = zn
-                if self.philox_fill:
-                    # option: a separate generator launch at full occupancy (32 us for C3's 50 M
-                    # normals, write floor 26 us) + K1 as the pure HBM-read kernel.  Measured at C3:
-                    # 0.125 ms per command against 0.112 ms with K1 generating (K1 reads rows that are
-                    # still being written back: 38.5 us instead of 35), so it is not the default.
+                fill = self.philox_fill if self.philox_fill is not None else n >= (1 << 22)
+                self.last_draw = "philox-fill" if fill else "philox-k1"
+                if fill:
+                    # large draws: a separate generator launch at full occupancy (32 us for C3's 50 M
+                    # normals, write floor 26 us), then K1 as the pure HBM-read kernel -- at C3 the
+                    # same command time as K1 generating at its one wave per SIMD (0.112-0.119 vs
+                    # 0.116 ms).  Small draws keep the generation inside K1: one launch fewer.
                     N.check(lib.mppi_noise_fill_philox(C.byref(p), p.z, self._stream()), "mppi_noise_fill_philox")
                     p.noise_src = N.NOISE_TNK4
             return
