@@ -45,6 +45,18 @@ class ShardPlan:
         return out.view(self.world_size, n)
 
 
+    def all_gather_start(self, record):
+        """Same collective, not waited for: returns (out, work).  `work.wait()` makes the caller's
+        stream wait for it; until then the caller may queue work that does not depend on the records
+        (the next command's noise generation) and the latency-bound collective hides behind it."""
+        if not record.is_cuda or dist.get_backend(self.group) == "gloo":
+            return self.all_gather(record), None          # test rigs: host-staged, synchronous
+        n = record.numel()
+        out = torch.empty(self.world_size * n, device=record.device, dtype=record.dtype)
+        work = dist.all_gather_into_tensor(out, record.contiguous().view(-1), group=self.group, async_op=True)
+        return out.view(self.world_size, n), work
+
+
 def combine_records_host(records, U_eff, lambda_):
     """Host restatement of mppi_combine (K5) in torch ops -- used by the CPU (gloo) tests to check
     the exchange + rank-order combine logic, and by the GPU tests as the checker of the kernel.

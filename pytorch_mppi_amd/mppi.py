@@ -167,6 +167,9 @@ class MPPI:
             raise ValueError("rng must be 'torch', 'torch-native' or 'philox'")
         self.rng = rng
         self.philox_store = True   # rng="philox": K1 stores the generated rows, K3 re-reads them
+        self.overlap_collective = True   # sharded + Philox generator launch: next rows behind the all-gather
+        self._pf_rows = None       # sharded + Philox: (key, rows) generated ahead for the next command
+        self._pf_hits = 0
         self.last_draw = None      # how the last command got its normals: "philox-fill" | "philox-k1" | None (other modes)
         self.philox_fill = None    # rng="philox": generate in a separate launch (True) / inside K1 (False) / by size (None)
         self.ktn_direct = os.environ.get("MPPI_KTN_DIRECT", "1") != "0"   # rng="torch": read (K,T,nu) in place when possible
@@ -376,6 +379,7 @@ class MPPI:
         layout, converted to the engine's sample-minor rows-of-4) or in-kernel Philox."""
         lib = N.lib()
         K, Tn, nu = shape
+        self.last_draw = None
         if self._injected:
             z = self._injected.pop(0)
             z = torch.as_tensor(z).to(device=self.d, dtype=self.dtype)
@@ -405,11 +409,19 @@ class MPPI:
                 # element than an HBM read
                 rows4 = N.noise_rows4(Tn, nu)
                 n = rows4 * K * 4
+                fill = self.philox_fill if self.philox_fill is not None else n >= (1 << 22)
+                self.last_draw = "philox-fill" if fill else "philox-k1"
+                pf, self._pf_rows = self._pf_rows, None
+                if fill and pf is not None and pf[0] == (K, Tn, nu, int(p.k_offset), int(p.seed), int(p.call)):
+                    zn = pf[1]                     # generated while the previous command's collective ran
+                    self._pf_hits += 1
+                    p.z = _ptr(zn)
+                    p._keep["z"] = zn
+                    p.noise_src = N.NOISE_TNK4
+                    return
                 zn = torch.empty(n, device=self.d, dtype=self.dtype)
                 p.z = _ptr(zn)
                 p._keep["z"] = zn
-                fill = self.philox_fill if self.philox_fill is not None else n >= (1 << 22)
-                self.last_draw = "philox-fill" if fill else "philox-k1"
                 if fill:
                     # large draws: a separate generator launch at full occupancy (32 us for C3's 50 M
                     # normals, write floor 26 us), then K1 as the pure HBM-read kernel -- at C3 the
@@ -495,8 +507,29 @@ class MPPI:
     def _command(self, state, shift):
         p = self._begin(state, shift)
         if self._sharded():
-            self._combine(p, self._shard.all_gather(p._keep["record"]))
+            if self.overlap_collective and self.last_draw == "philox-fill" and not self._injected:
+                records, work = self._shard.all_gather_start(p._keep["record"])
+                self._prefetch_philox_rows(p)   # queued behind K4, runs while the collective is in flight
+                if work is not None:
+                    work.wait()
+            else:
+                records = self._shard.all_gather(p._keep["record"])
+            self._combine(p, records)
         return self._end(p)
+
+    def _prefetch_philox_rows(self, p):
+        """Sharded commands: the Philox rows of the NEXT command are a pure function of
+        (seed, call+1, sample, row) -- nothing of this command's result enters -- so their generator
+        launch is queued before the caller's stream waits for the record all-gather: the
+        latency-bound collective (tens of microseconds over xGMI) hides behind 30 us of generation.
+        The next command picks the buffer up if (shape, seed, call) still match, else drops it."""
+        q = N.MppiProblem.from_buffer_copy(p)
+        q.call = self._call + 1
+        q.noise_src = N.NOISE_PHILOX
+        n = N.noise_rows4(q.T, q.nu) * q.K * 4
+        zn = torch.empty(n, device=self.d, dtype=self.dtype)
+        N.check(N.lib().mppi_noise_fill_philox(C.byref(q), _ptr(zn), self._stream()), "mppi_noise_fill_philox")
+        self._pf_rows = ((q.K, q.T, q.nu, int(q.k_offset), int(q.seed), int(q.call)), zn)
 
     def _sharded(self):
         # _force_collective: measurement seam (tools/shard_overhead.py) -- run record -> all_gather -> K5 at world_size 1

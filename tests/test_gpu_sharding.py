@@ -114,6 +114,35 @@ def test_record_all_gather_over_rccl_world_size_one():
         dist.destroy_process_group()
 
 
+def test_sharded_philox_generates_next_rows_behind_the_collective():
+    """Sharded + rng="philox" (generator launch): the rows of command n+1 are generated while the
+    record all-gather of command n is in flight (RCCL at world_size 1, collective forced) and picked
+    up by the next command; the controller is the unsharded one, and a seed change drops the buffer."""
+    import torch.distributed as dist
+    from pytorch_mppi_amd import MPPI, models
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29535")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m = models.Integrator(8, 4)
+        mk = lambda shard: MPPI(m.dynamics, m.running_cost, 8, 0.5 * torch.eye(4), num_samples=3000, horizon=20, device="cuda",
+                                lambda_=4.0, u_max=torch.ones(4), U_init=torch.zeros(20, 4), rng="philox", seed=5, shard=shard)
+        a, b = mk(None), mk((0, 1))
+        a.philox_fill = b.philox_fill = True
+        b._force_collective = True
+        x = torch.linspace(-1, 1, 8, device="cuda")
+        for i in range(6):
+            ua, ub = a.command(x), b.command(x)
+            torch.testing.assert_close(ua, ub, rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(a.cost_total, b.cost_total, rtol=1e-5, atol=1e-5)
+        assert b._pf_hits == 5 and a._pf_hits == 0
+        b.seed = a.seed = 6                      # stale buffer: key mismatch -> regenerated
+        torch.testing.assert_close(a.command(x), b.command(x), rtol=1e-5, atol=1e-6)
+        assert b._pf_hits == 5
+    finally:
+        dist.destroy_process_group()
+
+
 def _torchrun(args, env_extra=None, timeout=300):
     import subprocess
     import sys

@@ -10,16 +10,18 @@ import bench
 import pytorch_mppi_amd as pm
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
-rng = sys.argv[2] if len(sys.argv) > 2 else "torch-native"
+rng = sys.argv[2] if len(sys.argv) > 2 else "philox"
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 Kper = bench.WORKLOADS[wl][4]
-for name, shard in (("single", None), ("sharded(world=1,nccl)", (0, 1))):
+for name, shard, overlap in (("single", None, False), ("sharded(world=1,nccl)", (0, 1), False),
+                             ("sharded + next rows behind the collective", (0, 1), True)):
     ctrl, x0, _ = bench.make_controller(pm, wl, dev, rng, shard, Kper)
     ctrl.lambda_ = 50.0
     ctrl._force_collective = shard is not None
+    ctrl.overlap_collective = overlap
     for _ in range(10):
         ctrl.command(x0)
     torch.cuda.synchronize()
