@@ -42,6 +42,10 @@ def _worker(rank, world, port, name, out_q):
         w = torch.exp(-(1 / p.lambda_) * (c - b))
         rec = torch.cat([b.view(1), w.sum().view(1), torch.einsum("k,ktn->tn", w, full["noise"][lo:hi]).reshape(-1)])
         recs = plan.all_gather(rec)                       # the one collective of a command
+        recs2, work = plan.all_gather_start(rec)          # the not-waited-for form the controller uses
+        if work is not None:
+            work.wait()
+        assert torch.equal(recs, recs2)
         U_new, beta, eta = combine_records_host(recs, full["U_shifted"], p.lambda_)
         ok = torch.allclose(U_new, full["U"], rtol=1e-10, atol=1e-12) and float(beta) == float(full["beta"])
         # every rank must hold bit-identical results
