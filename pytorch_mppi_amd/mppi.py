@@ -167,7 +167,12 @@ class MPPI:
             raise ValueError("rng must be 'torch', 'torch-native' or 'philox'")
         self.rng = rng
         self.philox_store = True   # rng="philox": K1 stores the generated rows, K3 re-reads them
-        self.overlap_collective = True   # sharded + Philox generator launch: next rows behind the all-gather
+        # sharded + Philox generator launch: queue the next command's rows behind K4 so that they
+        # run while the record all-gather is in flight.  OFF: on this stack a kernel on torch's
+        # default stream and one on a pool stream (RCCL's) do not run concurrently (measured: 42.8 us
+        # spin kernel on a side stream + 32.3 us generator on the default stream = 72.2 us), so there is
+        # nothing to win and the fork/join costs 13 us per command.
+        self.overlap_collective = False
         self._pf_rows = None       # sharded + Philox: (key, rows) generated ahead for the next command
         self._pf_hits = 0
         self.last_draw = None      # how the last command got its normals: "philox-fill" | "philox-k1" | None (other modes)

@@ -130,6 +130,7 @@ def test_sharded_philox_generates_next_rows_behind_the_collective():
         a, b = mk(None), mk((0, 1))
         a.philox_fill = b.philox_fill = True
         b._force_collective = True
+        b.overlap_collective = True
         x = torch.linspace(-1, 1, 8, device="cuda")
         for i in range(6):
             ua, ub = a.command(x), b.command(x)
