@@ -13,11 +13,12 @@ nx=16, nu=12, fp32) -- the configuration the north_star's roofline target is quo
 per GPU (weak scaling: the sample axis is sharded, K_global = N*65536).
 Prints ONE JSON line (rank 0).  `roofline` is for K1 = rollout_cost_kernel (HBM-bound: it streams
 the K*T*nu standard normals once): algorithmic bytes 4*K*T*nu + 4*K per launch
-divided by its average duration over every K1 launch of the timed region, measured two ways through
-the C-ABI hook (mppi_profile_enable / mppi_profile_read2): HIP events attached to the launch itself
-(hipExtLaunchKernelGGL start/stop events, on the stream the engine launches on = torch's current
-stream) and the kernel's own span on the device wall clock (what rocprofv3 --kernel-trace reports;
-the events additionally contain the dispatch packets, ~3 us).
+divided by its average duration over the K1 launches of the timed region, measured two ways through
+the C-ABI hook (mppi_profile_enable / mppi_profile_read2): the kernel's own span on the device wall
+clock on EVERY launch (min workgroup entry .. max exit: what rocprofv3 --kernel-trace reports, free
+of charge) and HIP events attached to the launch itself (hipExtLaunchKernelGGL start/stop events, on
+the stream the engine launches on = torch's current stream) on every 4th launch -- they additionally
+contain the two dispatch packets (~2-3 us) and each costs the stream ~5 us, hence the sampling.
 `cpu_baseline` times the oracle (CPU restatement of the reference path, kind "port") on a bounded
 sample of the same workload on the host cores.
 """
@@ -42,6 +43,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
+EVENT_EVERY = 4            # HIP events on every 4th K1 launch (device-clock stamps on all of them)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
 
 
@@ -208,15 +210,18 @@ def main():
     lib = N.lib()
     for _ in range(args.warmup):
         ctrl.command(x0)
-    lib.mppi_profile_enable(1)      # kernel-attached HIP events on every K1 launch of the timed region
+    # device-clock stamps on every K1 launch of the timed region, kernel-attached HIP events on every
+    # EVENT_EVERY-th (an event-attached launch carries two extra dispatch packets, ~5 us: attaching
+    # them to every launch would cost the timed region 5 %)
+    lib.mppi_profile_enable(EVENT_EVERY)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctrl.command(x0)
     barrier()
     dt = time.perf_counter() - t0
-    k1_sum, k1_dev, k1_n = C.c_double(0), C.c_double(0), C.c_int64(0)
-    N.check(lib.mppi_profile_read2(C.byref(k1_sum), C.byref(k1_dev), C.byref(k1_n)), "mppi_profile_read2")
+    k1_sum, k1_dev, k1_n, k1_ne = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_int64(0)
+    N.check(lib.mppi_profile_read2(C.byref(k1_sum), C.byref(k1_dev), C.byref(k1_n), C.byref(k1_ne)), "mppi_profile_read2")
     lib.mppi_profile_enable(0)
     if world > 1:
         tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -244,7 +249,7 @@ def main():
 
     # ---- roofline of K1 from the HIP events recorded inside the timed region ----
     k1 = k1_n.value
-    k1_ms_events = k1_sum.value / max(1, k1)      # HIP events attached to the launch (incl. dispatch packets)
+    k1_ms_events = k1_sum.value / max(1, k1_ne.value)   # HIP events attached to the launch (incl. dispatch packets)
     k1_ms_device = k1_dev.value / max(1, k1)      # the kernel's own span on the device wall clock
     k1_ms = k1_ms_device if k1_ms_device > 0 else k1_ms_events
     Klocal = ctrl.K_local
@@ -287,8 +292,9 @@ def main():
                         "kernel": "rollout_cost_kernel", "avg_launch_us": k1_ms * 1e3,
                         "avg_launch_us_hip_events": k1_ms_events * 1e3,
                         "timing": "kernel span on the device wall clock (min workgroup entry .. max exit per "
-                                  "launch, every K1 launch of the timed region); HIP events attached to the same "
-                                  "launches are reported beside it and include the dispatch packets",
+                                  "launch, every K1 launch of the timed region); HIP events attached to every "
+                                  f"{EVENT_EVERY}th of those launches are reported beside it and include the "
+                                  "dispatch packets",
                         "algorithmic_bytes": alg_bytes,
                         "frac_of_measured_copy_ceiling": ach / HBM_COPY_CEILING_GBS}
 
@@ -341,15 +347,15 @@ def main():
             nw = 100 if wl == "c2" else 8
             for _ in range(3):
                 cw.command(xw)
-            lib.mppi_profile_enable(1)
+            lib.mppi_profile_enable(EVENT_EVERY)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(nw):
                 cw.command(xw)
             torch.cuda.synchronize()
             dw = time.perf_counter() - t1
-            e_, d2_, n_ = C.c_double(0), C.c_double(0), C.c_int64(0)
-            N.check(lib.mppi_profile_read2(C.byref(e_), C.byref(d2_), C.byref(n_)), "mppi_profile_read2")
+            e_, d2_, n_, ne_ = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_int64(0)
+            N.check(lib.mppi_profile_read2(C.byref(e_), C.byref(d2_), C.byref(n_), C.byref(ne_)), "mppi_profile_read2")
             lib.mppi_profile_enable(0)
             k1us = d2_.value / max(1, n_.value) * 1e3
             rec = {"workload": d_, "rollouts_per_s": K_ * nw / dw, "ms_per_step": dw / nw * 1e3, "k1_avg_us": k1us}

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 10
+#define MPPI_ABI_VERSION 11
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -207,17 +207,19 @@ int mppi_combine(const MppiProblem* p, const void* records, int32_t n_shards, vo
  * mppi_rollout_cost builds).  model_id = MPPI_MODEL_CUSTOM_BASE + slot, slot in [0, 64). */
 int mppi_register_model(int32_t model_id, int32_t nx, int32_t nu, void* rollout_f32, void* rollout_f64);
 
-/* Measurement hooks (bench.py).  While enabled, every K1 launch (mppi_rollout_cost) is made with
- * hipExtLaunchKernelGGL start/stop events attached to the KERNEL ITSELF (not to the stream around
- * it), so the elapsed time is the kernel's own duration -- what `rocprofv3 --kernel-trace`
- * reports.  mppi_profile_read synchronises on the recorded events, returns their count and the
- * sum of durations in milliseconds, and clears the record. */
-int mppi_profile_enable(int on);
-int mppi_profile_read(double* sum_ms, int64_t* count);
-/* Same record, plus the kernels' own time span on the device wall clock: every K1 workgroup stamps
- * wall_clock64() at entry and exit, min(entry)/max(exit) per launch.  This excludes the dispatch
- * packets that bracket an event-attached launch and is what rocprofv3 --kernel-trace reports. */
-int mppi_profile_read2(double* sum_ms_events, double* sum_ms_device, int64_t* count);
+/* Measurement hooks (bench.py).  mppi_profile_enable(every): while enabled (every >= 1), each K1
+ * launch (mppi_rollout_cost) stamps wall_clock64() at workgroup entry and exit -- min(entry) /
+ * max(exit) per launch is the kernel's own span on the device clock, what `rocprofv3
+ * --kernel-trace` reports, and costs nothing measurable -- and every `every`-th launch is
+ * additionally made with hipExtLaunchKernelGGL start/stop events attached to the KERNEL ITSELF (not
+ * to the stream around it).  An event-attached launch carries two extra dispatch packets (~5 us), so
+ * sampling keeps the timed region honest.  mppi_profile_enable(0) switches both off.
+ * mppi_profile_read2 synchronises, returns the sums in milliseconds with the number of launches
+ * stamped (`count`) and of launches with events (`count_events`), and clears the record;
+ * mppi_profile_read returns the event part only. */
+int mppi_profile_enable(int every);
+int mppi_profile_read(double* sum_ms, int64_t* count_events);
+int mppi_profile_read2(double* sum_ms_events, double* sum_ms_device, int64_t* count, int64_t* count_events);
 
 #ifdef __cplusplus
 }

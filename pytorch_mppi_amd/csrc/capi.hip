@@ -153,32 +153,39 @@ int do_rollout(const MppiProblem* p, hipStream_t st) {
 // ---- measurement hook -------------------------------------------------------------------------
 namespace {
 constexpr int PROF_MAX = 8192;
-bool g_prof_on = false;
-int g_prof_n = 0;
-hipEvent_t g_prof_ev[PROF_MAX][2];
+int g_prof_every = 0;                      // 0 = off; N = HIP events on every N-th K1 launch
+int g_prof_n = 0;                          // launches stamped since the last read
+hipEvent_t g_prof_ev[PROF_MAX][2];         // event pairs, created on first use
+bool g_prof_has_ev[PROF_MAX];              // does launch i carry events?
 int g_prof_created = 0;
 unsigned long long* g_prof_ts = nullptr;   // device: PROF_MAX x {min entry, max exit}
 }  // namespace
 namespace mppi {
 bool profile_next_events(hipEvent_t* start, hipEvent_t* stop, unsigned long long** tstamp) {
   if (tstamp) *tstamp = nullptr;
-  if (!g_prof_on || g_prof_n >= PROF_MAX) return false;
-  if (g_prof_n >= g_prof_created) {
-    if (hipEventCreate(&g_prof_ev[g_prof_n][0]) != hipSuccess) return false;
-    if (hipEventCreate(&g_prof_ev[g_prof_n][1]) != hipSuccess) return false;
-    g_prof_created = g_prof_n + 1;
+  *start = *stop = nullptr;
+  if (g_prof_every <= 0 || g_prof_n >= PROF_MAX) return false;
+  const int i = g_prof_n++;
+  if (tstamp && g_prof_ts) *tstamp = g_prof_ts + 2 * (size_t)i;
+  g_prof_has_ev[i] = false;
+  if (i % g_prof_every != 0) return false;
+  if (i >= g_prof_created) {
+    // pairs are created densely up to i so that index == launch number
+    for (int j = g_prof_created; j <= i; ++j) {
+      if (hipEventCreate(&g_prof_ev[j][0]) != hipSuccess) return false;
+      if (hipEventCreate(&g_prof_ev[j][1]) != hipSuccess) return false;
+      g_prof_created = j + 1;
+    }
   }
-  *start = g_prof_ev[g_prof_n][0];
-  *stop = g_prof_ev[g_prof_n][1];
-  if (tstamp && g_prof_ts) *tstamp = g_prof_ts + 2 * (size_t)g_prof_n;
-  ++g_prof_n;
+  *start = g_prof_ev[i][0];
+  *stop = g_prof_ev[i][1];
+  g_prof_has_ev[i] = true;
   return true;
 }
 }  // namespace mppi
-extern "C" int mppi_profile_read(double* sum_ms, int64_t* count);
-extern "C" int mppi_profile_enable(int on) {
-  g_prof_on = on != 0;
-  if (on) {
+extern "C" int mppi_profile_enable(int every) {
+  g_prof_every = every > 0 ? every : 0;
+  if (every > 0) {
     g_prof_n = 0;
     // measurement set-up (outside any timed region): stamp slots {min = ~0, max = 0}
     if (!g_prof_ts && hipMalloc((void**)&g_prof_ts, sizeof(unsigned long long) * 2 * PROF_MAX) != hipSuccess) g_prof_ts = nullptr;
@@ -190,7 +197,7 @@ extern "C" int mppi_profile_enable(int on) {
   }
   return 0;
 }
-extern "C" int mppi_profile_read2(double* sum_ms_events, double* sum_ms_device, int64_t* count) {
+extern "C" int mppi_profile_read2(double* sum_ms_events, double* sum_ms_device, int64_t* count, int64_t* count_events) {
   const int n = g_prof_n;
   double dev = 0;
   if (g_prof_ts && n > 0) {
@@ -205,19 +212,23 @@ extern "C" int mppi_profile_read2(double* sum_ms_events, double* sum_ms_device, 
       if (host[2 * i + 1] > host[2 * i]) dev += (double)(host[2 * i + 1] - host[2 * i]) / (double)khz;   // ticks / kHz = ms
   }
   if (sum_ms_device) *sum_ms_device = dev;
-  return mppi_profile_read(sum_ms_events, count);
+  if (count) *count = n;
+  return mppi_profile_read(sum_ms_events, count_events);
 }
-extern "C" int mppi_profile_read(double* sum_ms, int64_t* count) {
+extern "C" int mppi_profile_read(double* sum_ms, int64_t* count_events) {
   double s = 0;
+  int64_t ne = 0;
   for (int i = 0; i < g_prof_n; ++i) {
+    if (!g_prof_has_ev[i]) continue;
     hipError_t e = hipEventSynchronize(g_prof_ev[i][1]);
     float ms = 0;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]);
     if (e != hipSuccess) return hipfail((int)e, "mppi_profile_read");
     s += ms;
+    ++ne;
   }
   if (sum_ms) *sum_ms = s;
-  if (count) *count = g_prof_n;
+  if (count_events) *count_events = ne;
   g_prof_n = 0;
   return 0;
 }

@@ -176,7 +176,7 @@ class MPPI:
         self._pf_rows = None       # sharded + Philox: (key, rows) generated ahead for the next command
         self._pf_hits = 0
         self.last_draw = None      # how the last command got its normals: "philox-fill" | "philox-k1" | None (other modes)
-        self.philox_fill = None    # rng="philox": generate in a separate launch (True) / inside K1 (False) / by size (None)
+        self.philox_fill = None    # rng="philox": generate in a separate launch (True) / inside K1 (False) / by horizon (None)
         self.ktn_direct = os.environ.get("MPPI_KTN_DIRECT", "1") != "0"   # rng="torch": read (K,T,nu) in place when possible
         self._force_collective = False
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
@@ -414,7 +414,10 @@ class MPPI:
                 # element than an HBM read
                 rows4 = N.noise_rows4(Tn, nu)
                 n = rows4 * K * 4
-                fill = self.philox_fill if self.philox_fill is not None else n >= (1 << 22)
+                # inside K1 every lane generates its own rows one after the other (~0.35 us per
+                # row-of-4, however small K is); the generator launch spreads them over the whole chip
+                # and costs one launch (~4 us): it wins from ~16 rows per sample on (tools/k_sweep.py)
+                fill = self.philox_fill if self.philox_fill is not None else rows4 >= 16
                 self.last_draw = "philox-fill" if fill else "philox-k1"
                 pf, self._pf_rows = self._pf_rows, None
                 if fill and pf is not None and pf[0] == (K, Tn, nu, int(p.k_offset), int(p.seed), int(p.call)):
@@ -428,10 +431,9 @@ class MPPI:
                 p.z = _ptr(zn)
                 p._keep["z"] = zn
                 if fill:
-                    # large draws: a separate generator launch at full occupancy (32 us for C3's 50 M
-                    # normals, write floor 26 us), then K1 as the pure HBM-read kernel -- at C3 the
-                    # same command time as K1 generating at its one wave per SIMD (0.112-0.119 vs
-                    # 0.116 ms).  Small draws keep the generation inside K1: one launch fewer.
+                    # a separate generator launch at full occupancy (32 us for C3's 50 M normals, write
+                    # floor 26 us), then K1 as the pure HBM-read kernel.  Short horizons keep the
+                    # generation inside K1: one launch fewer.
                     N.check(lib.mppi_noise_fill_philox(C.byref(p), p.z, self._stream()), "mppi_noise_fill_philox")
                     p.noise_src = N.NOISE_TNK4
             return
