@@ -40,7 +40,7 @@ struct StepTables {
 };
 
 // one timestep: actions from z, action cost, dynamics, running cost
-template <class Model, typename T, int NOISE, bool DIAG, bool SLOW>
+template <class Model, typename T, int NOISE, bool DIAG, int SLOW>
 __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionConsts<T, Model::NU>& ac,
                                              const Model& model, const StepTables<T>& tb, int k,
                                              bool active, int orow, int t, const T* zt,
@@ -76,7 +76,11 @@ __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionCons
       v[n] = s;
     }
   }
-  if constexpr (SLOW) {
+  if constexpr (SLOW == 1) {
+    // null-action row only: a per-lane select, no memory traffic -> the ring's exact waits survive
+#pragma unroll
+    for (int n = 0; n < NU; ++n) v[n] = orow == -1 ? T(0) : v[n];          // mppi.py:390-392
+  } else if constexpr (SLOW == 2) {
     if (orow == -1) {
 #pragma unroll
       for (int n = 0; n < NU; ++n) v[n] = T(0);                            // mppi.py:390-392
@@ -106,7 +110,7 @@ __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionCons
   }
   model.step(x, u, t);                                                     // :314
   rollout += model.cost(x, u, t);                                          // :318-319
-  if constexpr (SLOW) {
+  if constexpr (SLOW == 2) {
     if (a.states != nullptr && active) {
       T* __restrict__ so = a.states + ((long long)k * a.Tn + t) * NX;
 #pragma unroll
@@ -182,7 +186,7 @@ __device__ __forceinline__ void ring_fetch(const KArgs<T>& a, int ss, int k, T (
   }
 }
 
-template <class Model, typename T, int NOISE, bool DIAG, bool SLOW>
+template <class Model, typename T, int NOISE, bool DIAG, int SLOW>
 __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionConsts<T, Model::NU>& ac,
                                                const Model& model, const StepTables<T>& tb, int k,
                                                bool active, int orow,
@@ -407,11 +411,15 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
 
   T rollout = T(0), pert = T(0);
   // wave-uniform choice: does this wave own overwritten rows, or must it store the states?
-  const bool slow = __any(orow != -2) || a.states != nullptr;
+  // (0 = neither; 1 = only the sample_null_action row: a select, no extra memory traffic; 2 = sampler
+  // rows / states: conditional loads and stores, which cost the wave its exact vmcnt waits)
+  const bool slow = __any(orow >= 0) || a.states != nullptr;
   if (slow)
-    rollout_stream<Model, T, NOISE, DIAG, true>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
+    rollout_stream<Model, T, NOISE, DIAG, 2>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
+  else if (__any(orow == -1))
+    rollout_stream<Model, T, NOISE, DIAG, 1>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
   else
-    rollout_stream<Model, T, NOISE, DIAG, false>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
+    rollout_stream<Model, T, NOISE, DIAG, 0>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
 
   if (a.use_terminal) rollout += model.terminal(x);                    // :324-328
   const T total = rollout + pert;                                      // :416
