@@ -861,15 +861,18 @@ class SMPPI(MPPI):
             self.action_sequence = self.U.clone()
         self.U = torch.zeros_like(self.U)
         self._perturbed_control = None
+        self._dt_cache = None
 
     def get_params(self):
         return f"{super().get_params()} w={self.w_action_seq_cost} t={self.delta_t}"
 
     def shift_nominal_trajectory(self):
-        self.U = torch.roll(self.U, -1, dims=0)
-        self.U[-1] = self.u_init
-        self.action_sequence = torch.roll(self.action_sequence, -1, dims=0)
-        self.action_sequence[-1] = self.action_sequence[-2]               # :491-492
+        # roll(-1) + overwrite of the last row (mppi.py:488-492) as ONE concatenation each: these are
+        # host-launched tiny kernels and a command is only ~100 us long
+        u_last = torch.as_tensor(self.u_init, device=self.U.device, dtype=self.U.dtype).reshape(1, -1).expand(1, self.nu)
+        self.U = torch.cat((self.U[1:], u_last), dim=0)
+        A = self.action_sequence
+        self.action_sequence = torch.cat((A[1:], A[-1:]), dim=0)          # :491-492 (last row repeats)
 
     def get_action_sequence(self):
         return self.action_sequence
@@ -900,9 +903,12 @@ class SMPPI(MPPI):
         dt = float(self.delta_t)
         keep = p._keep
         A = self.action_sequence.to(device=self.d, dtype=self.dtype)
-        keep["B"] = (A + keep["U"] * dt).contiguous()                     # base of :540
-        keep["L_dt"] = (keep["L"] * dt).contiguous()
-        keep["mu_dt"] = (keep["mu"] * dt).contiguous()
+        keep["B"] = torch.add(A, keep["U"], alpha=dt).contiguous()        # base of :540, one kernel
+        # colouring factors x dt: constant between parameter changes -> cached on the parameter tensors
+        ck = (id(keep["L"]), keep["L"]._version, id(keep["mu"]), keep["mu"]._version, dt)
+        if self._dt_cache is None or self._dt_cache[0] != ck:
+            self._dt_cache = (ck, (keep["L"] * dt).contiguous(), (keep["mu"] * dt).contiguous(), keep["L"], keep["mu"])
+        keep["L_dt"], keep["mu_dt"] = self._dt_cache[1], self._dt_cache[2]
         keep["amin"], keep["amax"] = self._vec(self.action_min), self._vec(self.action_max)
         p.base_seq = _ptr(keep["B"])
         p.noise_L, p.noise_mu = _ptr(keep["L_dt"]), _ptr(keep["mu_dt"])
@@ -919,7 +925,7 @@ class SMPPI(MPPI):
 
     def _end(self, p):
         super()._end(p)
-        self.action_sequence = self.action_sequence + self.U * self.delta_t       # :515 (new tensor)
+        self.action_sequence = torch.add(self.action_sequence, self.U, alpha=float(self.delta_t))   # :515 (new tensor)
         action = self.action_sequence[:self.u_per_command]
         if self.u_per_command == 1:
             action = action[0]
