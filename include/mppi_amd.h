@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 11
+#define MPPI_ABI_VERSION 12
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -92,7 +92,8 @@ typedef struct MppiProblem {
                                  (N,T,nu), cost_total / omega / cost_total_non_zero (N,K), record
                                  (N,2+J), perturbed_action / noise (N,K,T,nu), pert_cost (N,K);
                                  the environment is the z axis of every launch grid          */
-  int32_t reserved0;
+  int32_t noise_coloured;     /* p->z already holds eps = L z + mu (mppi_noise_fill_philox_coloured): kernels add U and
+                               * bound only; the action cost still uses the true Sigma^-1 */
   double lambda_;             /* mppi.py:96, read live                                     */
   double u_scale;             /* mppi.py:313                                               */
   uint64_t seed, call;        /* Philox key / per-command counter word                     */
@@ -152,6 +153,12 @@ int mppi_model_supported(int32_t model_id, int32_t nx, int32_t nu, int32_t dtype
 /* replaces torch.randn(K,T,nu) at mppi.py:203 (called from :378 / KMPPI :660): fills
  * p->z (written, despite the const) in TNK4 layout with the Philox stream the fused mode uses */
 int mppi_noise_fill_philox(const MppiProblem* p, void* z_tnk4, void* stream);
+
+/* the same stream with the colouring of mppi.py:201-206 applied by the generator: writes
+ * eps = chol(Sigma) z + mu (full Sigma) in TNK4 layout; run the rest of the command with
+ * p->noise_coloured = 1 and K1 / K3 take their diagonal-Sigma form (no per-sample L z in the
+ * HBM-bound kernels).  MPPI_E_UNSUPPORTED for control widths without a compiled instantiation. */
+int mppi_noise_fill_philox_coloured(const MppiProblem* p, void* eps_tnk4, void* stream);
 
 /* (K,T,nu) row-major standard normals (the reference's layout, mppi.py:203) -> TNK4 */
 int mppi_noise_from_ktn(const MppiProblem* p, const void* z_ktn, void* z_tnk4, void* stream);

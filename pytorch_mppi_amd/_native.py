@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
@@ -30,7 +30,7 @@ class MppiProblem(C.Structure):
         ("sample_null_action", C.c_int32), ("n_sampler_rows", C.c_int32),
         ("state_per_sample", C.c_int32), ("shift", C.c_int32), ("use_terminal", C.c_int32),
         ("noise_src", C.c_int32), ("u_per_command", C.c_int32), ("step_offset", C.c_int32),
-        ("hidden", C.c_int32), ("num_envs", C.c_int32), ("reserved0", C.c_int32),
+        ("hidden", C.c_int32), ("num_envs", C.c_int32), ("noise_coloured", C.c_int32),
         ("lambda_", C.c_double), ("u_scale", C.c_double),
         ("seed", C.c_uint64), ("call", C.c_uint64),
         ("noise_rescale", C.c_double), ("smooth_weight", C.c_double),
@@ -55,6 +55,7 @@ SYMBOLS = {
     "mppi_workspace_elems": (C.c_int64, [_PP]),
     "mppi_model_supported": (C.c_int, [C.c_int32] * 5),
     "mppi_noise_fill_philox": (C.c_int, [_PP, _vp, _vp]),
+    "mppi_noise_fill_philox_coloured": (C.c_int, [_PP, _vp, _vp]),
     "mppi_noise_from_ktn": (C.c_int, [_PP, _vp, _vp, _vp]),
     "mppi_kmppi_interp": (C.c_int, [_PP, _vp, _vp]),
     "mppi_rollout_cost": (C.c_int, [_PP, _vp]),

@@ -49,8 +49,8 @@ struct ActionConsts {
   __device__ __forceinline__ void load(const KArgs<T>& a, T* lds) {
 #pragma unroll
     for (int n = 0; n < NU; ++n) {
-      sd[n] = a.L[n * NU + n];
-      mu[n] = a.mu[n];
+      sd[n] = a.coloured ? T(1) : a.L[n * NU + n];     // coloured stream: eps is in z already
+      mu[n] = a.coloured ? T(0) : a.mu[n];
       lo[n] = a.umin[n];
       hi[n] = a.umax[n];
       ci[n] = a.sinv[n * NU + n];
@@ -167,7 +167,7 @@ __device__ __forceinline__ void make_action_rt(const KArgs<T>& a, const ActionCo
   const T* Ut = Ue + t * NU;
   const T* srow = orow >= 0 ? a.sampler + ((long long)orow * a.Tn + t) * NU : nullptr;
   if (a.noise_src == MPPI_NOISE_ACTIONS) make_action<T, NU, true, true>(c, Ut, srow, z, orow, v, e);
-  else if (a.diag) make_action<T, NU, true, false>(c, Ut, srow, z, orow, v, e);
+  else if (a.diag || a.coloured) make_action<T, NU, true, false>(c, Ut, srow, z, orow, v, e);
   else make_action<T, NU, false, false>(c, Ut, srow, z, orow, v, e);
 }
 // `Un` = the true nominal sequence (shift applied): U * action_cost uses U even when the noise

@@ -83,6 +83,7 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.null_action = p->sample_null_action; a.n_sampler = p->n_sampler_rows;
   a.state_per_sample = p->state_per_sample; a.shift = p->shift; a.use_terminal = p->use_terminal;
   a.noise_src = p->noise_src; a.u_per_command = p->u_per_command; a.hidden = p->hidden;
+  a.coloured = p->noise_coloured != 0;
   a.lambda_ = (T)p->lambda_; a.u_scale = (T)p->u_scale;
   a.e_scale = (T)(p->noise_rescale == 0.0 ? 1.0 : p->noise_rescale); a.smooth_w = (T)p->smooth_weight;
   a.seed = p->seed; a.call = p->call;
@@ -110,6 +111,7 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
 
 template <typename T>
 int need_noise(const KArgs<T>& a) {
+  if (a.coloured && a.noise_src != MPPI_NOISE_TNK4) return fail(MPPI_E_BADARG, "noise_coloured needs an external row stream (MPPI_NOISE_TNK4)");
   if (a.noise_src != MPPI_NOISE_PHILOX && a.z == nullptr) return fail(MPPI_E_BADARG, "noise_src needs p->z");
   if (a.noise_src < 0 || a.noise_src > MPPI_NOISE_KTN) return fail(MPPI_E_BADARG, "bad noise_src");
   if (a.noise_src == MPPI_NOISE_KTN &&
@@ -275,6 +277,18 @@ static int do_fill(const MppiProblem* p, void* z, hipStream_t st) {
 }
 extern "C" int mppi_noise_fill_philox(const MppiProblem* p, void* z, void* stream) {
   return BY_DTYPE(p, do_fill<float>(p, z, (hipStream_t)stream), do_fill<double>(p, z, (hipStream_t)stream));
+}
+
+template <typename T>
+static int do_fill_coloured(const MppiProblem* p, void* z, hipStream_t st) {
+  KArgs<T> a;
+  if (int e = make_args<T>(p, a)) return e;
+  if (!z) return fail(MPPI_E_BADARG, "null eps");
+  return hipfail(launch_noise_fill_philox_coloured<T>(a, (T*)z, st), "mppi_noise_fill_philox_coloured");
+}
+extern "C" int mppi_noise_fill_philox_coloured(const MppiProblem* p, void* z, void* stream) {
+  return BY_DTYPE(p, do_fill_coloured<float>(p, z, (hipStream_t)stream),
+                  do_fill_coloured<double>(p, z, (hipStream_t)stream));
 }
 
 template <typename T>

@@ -18,7 +18,8 @@ struct KArgs {
   int K, Tn, nx, nu, J, J4;
   long long k_offset;
   int model_id, diag, abs_cost, null_action, n_sampler, state_per_sample, shift, use_terminal,
-      noise_src, u_per_command, hidden;
+      noise_src, u_per_command, hidden,
+      coloured;   // z holds eps = L z + mu already (generator-side colouring): add U, bound, done
   T lambda_, u_scale, e_scale, smooth_w;
   unsigned long long seed, call;
   const T *state, *U, *u_init, *mu, *L, *sinv, *umin, *umax, *mp, *z, *sampler, *B;

@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
     const bool ok = j < a.J;
     const int n = ok ? j % NU : 0;
     uload[q] = ok ? u_base(a, j) : T(0);
-    umload[q] = ok ? a.mu[n] : T(0);
+    umload[q] = (ok && !a.coloured) ? a.mu[n] : T(0);
     // diagonal Sigma: G = lambda * U / sigma^2 needs no neighbours -> built in the same pass
     if constexpr (DIAG) gload[q] = ok ? (a.B != nullptr ? u_eff(a, j) : uload[q]) * a.sinv[n * NU + n] : T(0);
   }
@@ -390,10 +390,28 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
     const int n = j % NU;
     const T ub = u_base(a, j);
     Ue[j] = ub;
-    Um[j] = ub + a.mu[n];
+    Um[j] = a.coloured ? ub : ub + a.mu[n];
     if constexpr (DIAG) G[j] = a.lambda_ * (u_eff(a, j) * a.sinv[n * NU + n]);
   }
+  const bool coloured_full = DIAG && a.coloured && !a.diag;
+  if (coloured_full) {
+    // generator-coloured stream of a full Sigma: this (diagonal) form streams it, but the action
+    // cost is still lambda * eps' Sigma^-1 U.  Sigma^-1 goes through LDS (the launch reserved NU*NU
+    // elements at `fac`): one coalesced load per thread instead of every lane of every wave
+    // hammering the same 576 bytes of global memory
+    for (int i = threadIdx.x; i < NU * NU; i += K1_BLOCK) fac[i] = a.sinv[i];
+  }
   __syncthreads();
+  if (coloured_full) {
+    for (int j = threadIdx.x; j < a.J; j += K1_BLOCK) {
+      const int n = j % NU, t0 = j - n;
+      T g = T(0);
+#pragma unroll
+      for (int m = 0; m < NU; ++m) g = m_fma(fac[n * NU + m], a.B != nullptr ? u_eff(a, t0 + m) : Ue[t0 + m], g);
+      G[j] = a.lambda_ * g;
+    }
+    __syncthreads();
+  }
   if constexpr (!DIAG) {
     // full Sigma: G[t,n] = lambda * sum_m Sigma^-1[n,m] U[t,m] needs the whole row -> second pass
     for (int j = threadIdx.x; j < a.J; j += K1_BLOCK) {
@@ -436,8 +454,8 @@ template <class Model, typename T>
 static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
   constexpr int NU = Model::NU;
   KArgs<T> a = a_in;
-  const bool diag = a.diag != 0;
-  size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (diag ? 0 : 2 * NU * NU)) * sizeof(T);
+  const bool diag = a.diag != 0 || a.coloured != 0;   // a coloured stream runs the diagonal instantiation
+  size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (a.diag != 0 ? 0 : 2 * NU * NU)) * sizeof(T);   // factors / Sigma^-1 of a coloured stream
   if (a.noise_src == MPPI_NOISE_KTN) {
     if (!(Ktn<NU>::OK && sizeof(T) == 4 && diag)) return MPPI_E_UNSUPPORTED;
     smem += (size_t)(4 + (K1_BLOCK / WAVE) * Ktn<NU>::LDS_FLOATS_PER_WAVE) * sizeof(T);

@@ -103,10 +103,15 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
   for (int j = threadIdx.x; j < a.J; j += MLP_THREADS) {
     const int n = j % NU, t0 = j - n;
     const float uj = Ue[j];
-    Um[j] = uj + a.mu[n];
+    Um[j] = a.coloured ? uj : uj + a.mu[n];
     float gg;
     if constexpr (DIAG) {
-      gg = uj * a.sinv[n * NU + n];
+      if (a.coloured && !a.diag) {          // generator-coloured full Sigma: whole-row G from global
+        gg = 0.f;
+        for (int m = 0; m < NU; ++m) gg = fmaf(a.sinv[n * NU + m], Ue[t0 + m], gg);
+      } else {
+        gg = uj * a.sinv[n * NU + n];
+      }
     } else {
       gg = 0.f;
       for (int m = 0; m < NU; ++m) gg = fmaf(ac.Sm[n * NU + m], Ue[t0 + m], gg);
@@ -115,7 +120,7 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
   }
   __syncthreads();
   // this lane's own control dimension g: constants as scalars
-  const float sd_g = a.L[g * NU + g], lo_g = a.umin[g], hi_g = a.umax[g];
+  const float sd_g = a.coloured ? 1.f : a.L[g * NU + g], lo_g = a.umin[g], hi_g = a.umax[g];
   float Lrow[NU];
   if constexpr (!DIAG) {
 #pragma unroll
@@ -277,7 +282,7 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
 template <int HT>
 static int launch_ht(const KArgs<float>& a_in, hipStream_t st) {
   KArgs<float> a = a_in;
-  const bool diag = a.diag != 0;
+  const bool diag = a.diag != 0 || a.coloured != 0;
   const size_t smem = (size_t)(3 * a.J + MLP_THREADS / WAVE + HT * 16 + 2 * MLP_NU * MLP_NU) * sizeof(float);
   const dim3 grid((a.K + 255) / 256, 1, a.n_env), block(MLP_THREADS);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -27,6 +27,51 @@ __global__ void __launch_bounds__(BLOCK) noise_fill_philox_kernel(const KArgs<T>
   }
 }
 
+// the same stream, coloured by the generator: eps[t] = chol(Sigma) z[t] + mu (mppi.py:201-206) for
+// whole timesteps -- one thread per (sample, super-step of TT timesteps = P4 rows-of-4).  The
+// factors are uniform (scalar loads); at full occupancy the nu*(nu+1)/2 FMAs per timestep cost a few
+// microseconds, against ~25 us each in K1 and K3 where one wave per SIMD does them behind LDS reads.
+template <typename T, int NU>
+__global__ void __launch_bounds__(BLOCK) noise_fill_philox_coloured_kernel(const KArgs<T> a, T* __restrict__ out) {
+  constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
+  const int k = blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= a.K) return;
+  const int nss = (a.Tn + TT - 1) / TT;
+  // the factors once, before any store: uniform -> scalar loads, live in SGPRs / uniform registers
+  T Lr[NU * (NU + 1) / 2], mr[NU];
+#pragma unroll
+  for (int n = 0; n < NU; ++n) {
+    mr[n] = a.mu[n];
+#pragma unroll
+    for (int m = 0; m <= n; ++m) Lr[n * (n + 1) / 2 + m] = a.L[n * NU + m];
+  }
+  for (int ss = blockIdx.y; ss < nss; ss += gridDim.y) {
+    T zc[P4 * 4], ec[P4 * 4];
+#pragma unroll
+    for (int i = 0; i < P4; ++i) {
+      T r[4];
+      philox_normal4<T>(a.seed, a.call, a.k_offset + k, (long long)ss * P4 + i, r);
+      zc[4 * i] = r[0]; zc[4 * i + 1] = r[1]; zc[4 * i + 2] = r[2]; zc[4 * i + 3] = r[3];
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+      for (int n = 0; n < NU; ++n) {
+        T s = zc[tt * NU] * Lr[n * (n + 1) / 2];
+#pragma unroll
+        for (int m = 1; m < NU; ++m)
+          if (m <= n) s += zc[tt * NU + m] * Lr[n * (n + 1) / 2 + m];     // lower triangular
+        ec[tt * NU + n] = s + mr[n];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < P4; ++i) {
+      const T r[4] = {ec[4 * i], ec[4 * i + 1], ec[4 * i + 2], ec[4 * i + 3]};
+      store4<T>(out, a.K, (long long)ss * P4 + i, k, r);
+    }
+  }
+}
+
 // (K, J) row-major -> [J4][K][4].  Tile: 64 samples x 64 columns through LDS so that both the
 // read (along j: 16 lanes x 16 B = one 256-B run per sample) and the write (along k: 64 lanes x
 // 16 B = 1 KiB) are coalesced 16-byte accesses.  VEC = false: J % 4 != 0 (rows not 16-B aligned).
@@ -443,8 +488,8 @@ __global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs
     const bool ok = j < a.J;
     const int n = ok ? j % a.nu : 0;
     cU[threadIdx.x] = ok ? u_base(a, j) : T(0);
-    cS[threadIdx.x] = ok ? a.L[n * a.nu + n] : T(0);
-    cM[threadIdx.x] = ok ? a.mu[n] : T(0);
+    cS[threadIdx.x] = ok ? (a.coloured ? T(1) : a.L[n * a.nu + n]) : T(0);     // coloured stream: eps is in z
+    cM[threadIdx.x] = (ok && !a.coloured) ? a.mu[n] : T(0);
     cLo[threadIdx.x] = ok ? a.umin[n] : T(0);
     cHi[threadIdx.x] = ok ? a.umax[n] : T(0);
   }
@@ -790,6 +835,20 @@ int launch_noise_fill_philox(const KArgs<T>& a, T* out, hipStream_t st) {
 }
 
 template <typename T>
+int launch_noise_fill_philox_coloured(const KArgs<T>& a, T* out, hipStream_t st) {
+  const int nss = (a.Tn + 3) / 4 + 1;      // >= super-steps for any nu; the kernel strides over the real count
+  const dim3 grid((a.K + BLOCK - 1) / BLOCK, nss < 64 ? nss : 64), block(BLOCK);
+#define X(N)                                                                                       \
+  if (a.nu == N) {                                                                                 \
+    hipLaunchKernelGGL((noise_fill_philox_coloured_kernel<T, N>), grid, block, 0, st, a, out);     \
+    return (int)hipGetLastError();                                                                 \
+  }
+  MPPI_NU_LIST(X)
+#undef X
+  return MPPI_E_UNSUPPORTED;
+}
+
+template <typename T>
 int launch_noise_from_ktn(const KArgs<T>& a, const T* in, T* out, hipStream_t st) {
   const dim3 grid((a.K + 63) / 64, (a.J4 * 4 + 63) / 64);
   const bool vec = a.J % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
@@ -909,7 +968,7 @@ int launch_weights_partial(const KArgs<T>& a, hipStream_t st) {
     hipLaunchKernelGGL(weights_partial_ktn_kernel<T>, grid, block, 0, st, a);
     return (int)hipGetLastError();
   }
-  if (a.diag) {
+  if (a.diag || a.coloured) {
     const dim3 grid(a.nkc, (a.J4 * 4 + UPD_TJ - 1) / UPD_TJ, a.n_env), block(BLOCK);
 #define LAUNCH_R(RR)                                                                              \
   if (a.R == RR) {                                                                                \
@@ -981,6 +1040,7 @@ int launch_combine(const KArgs<T>& a, const T* rec, int G, hipStream_t st) {
 
 #define MPPI_INST(T)                                                                     \
   template int launch_noise_fill_philox<T>(const KArgs<T>&, T*, hipStream_t);             \
+  template int launch_noise_fill_philox_coloured<T>(const KArgs<T>&, T*, hipStream_t);    \
   template int launch_noise_from_ktn<T>(const KArgs<T>&, const T*, T*, hipStream_t);      \
   template int launch_kmppi_interp<T>(const KArgs<T>&, const T*, int, int, T*, hipStream_t); \
   template int launch_prepare<T>(const KArgs<T>&, hipStream_t);                           \

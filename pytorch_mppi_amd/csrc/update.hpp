@@ -3,6 +3,7 @@
 #include "common.hpp"
 namespace mppi {
 template <typename T> int launch_noise_fill_philox(const KArgs<T>& a, T* out, hipStream_t st);
+template <typename T> int launch_noise_fill_philox_coloured(const KArgs<T>& a, T* out, hipStream_t st);
 template <typename T> int launch_noise_from_ktn(const KArgs<T>& a, const T* in, T* out, hipStream_t st);
 template <typename T> int launch_kmppi_interp(const KArgs<T>& a, const T* W, int Thor, int J4out, T* out, hipStream_t st);
 template <typename T> int launch_prepare(const KArgs<T>& a, hipStream_t st);

@@ -45,6 +45,8 @@ __device__ __forceinline__ void make_action_dyn(const KArgs<T>& a, const T* __re
     T v;
     if (a.noise_src == MPPI_NOISE_ACTIONS) {
       v = zc[n * DYN_BLOCK + tid];
+    } else if (a.coloured) {
+      v = Ut[n] + zc[n * DYN_BLOCK + tid];
     } else if (a.diag) {
       v = Ut[n] + (zc[n * DYN_BLOCK + tid] * a.L[n * nu + n] + a.mu[n]);
     } else {

@@ -176,6 +176,7 @@ class MPPI:
         self._pf_rows = None       # sharded + Philox: (key, rows) generated ahead for the next command
         self._pf_hits = 0
         self.last_draw = None      # how the last command got its normals: "philox-fill" | "philox-k1" | None (other modes)
+        self.coloured_fill = True  # rng="philox", full Sigma: let the generator launch apply chol(Sigma) (see _draw_noise)
         self.philox_fill = None    # rng="philox": generate in a separate launch (True) / inside K1 (False) / by horizon (None)
         self.ktn_direct = os.environ.get("MPPI_KTN_DIRECT", "1") != "0"   # rng="torch": read (K,T,nu) in place when possible
         self._force_collective = False
@@ -434,6 +435,16 @@ class MPPI:
                     # a separate generator launch at full occupancy (32 us for C3's 50 M normals, write
                     # floor 26 us), then K1 as the pure HBM-read kernel.  Short horizons keep the
                     # generation inside K1: one launch fewer.
+                    if not self._diagonal_sigma and self.coloured_fill:
+                        # full Sigma: the generator applies chol(Sigma) z + mu itself (full occupancy,
+                        # a few us) and K1 / K3 run their diagonal form on the coloured rows instead of
+                        # doing nu*(nu+1)/2 FMAs per timestep behind LDS reads at one wave per SIMD
+                        rc = lib.mppi_noise_fill_philox_coloured(C.byref(p), p.z, self._stream())
+                        if rc == 0:
+                            p.noise_src, p.noise_coloured = N.NOISE_TNK4, 1
+                            return
+                        if rc != N.E_UNSUPPORTED:
+                            N.check(rc, "mppi_noise_fill_philox_coloured")
                     N.check(lib.mppi_noise_fill_philox(C.byref(p), p.z, self._stream()), "mppi_noise_fill_philox")
                     p.noise_src = N.NOISE_TNK4
             return
@@ -530,6 +541,9 @@ class MPPI:
         launch is queued before the caller's stream waits for the record all-gather: the
         latency-bound collective (tens of microseconds over xGMI) hides behind 30 us of generation.
         The next command picks the buffer up if (shape, seed, call) still match, else drops it."""
+        if p.noise_coloured:
+            self._pf_rows = None
+            return
         q = N.MppiProblem.from_buffer_copy(p)
         q.call = self._call + 1
         q.noise_src = N.NOISE_PHILOX
@@ -841,6 +855,7 @@ class SMPPI(MPPI):
         self.w_action_seq_cost = w_action_seq_cost
         self.delta_t = delta_t
         super().__init__(*args, U_init=U_init, **kwargs)
+        self.coloured_fill = False     # `perturbed_control` re-derives U + eps from the raw normals (:535-537)
         if action_min is not None and action_max is None:                 # :464-471
             if not torch.is_tensor(action_min):
                 action_min = torch.tensor(action_min)
@@ -1110,6 +1125,7 @@ class KMPPI(MPPI):
         self.theta = torch.zeros((self.num_support_pts, self.nu), dtype=self.dtype, device=self.d)
         self.interpolation_kernel = kernel
         self.ktn_direct = False        # the support-point draw always goes through the layout conversion
+        self.coloured_fill = False     # the interpolation kernel colours the support points itself
         self._noise_theta = None
         self._last_theta = None
         self.prepare_vmap_interpolation()

@@ -323,3 +323,61 @@ def test_philox_variants_are_one_stream(path):
     for o in outs[1:]:
         for x, y in zip(outs[0], o):                    # downstream arithmetic: different kernels contract differently
             torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("model_kind,nu,dtype", [("integrator", 4, torch.float32), ("integrator", 12, torch.float64),
+                                                 ("mlp", 4, torch.float32), ("generic", 6, torch.float64)])
+def test_generator_coloured_full_sigma_matches_oracle(model_kind, nu, dtype):
+    """rng="philox" + full Sigma: the generator launch writes eps = chol(Sigma) z + mu and K1 / K3 run
+    their diagonal form on it (`noise_coloured`).  Against the fp64 oracle fed the SAME normals
+    (oracle/philox.py), and against the engine with the colouring left to K1 / K3; fused integrator,
+    matrix-core MLP and the generic callback path; lazy noise / perturbed_action included."""
+    import pytorch_mppi_amd as pm
+    from oracle import mppi_oracle as orc, dynamics as dyn, philox as oph
+    K, T = 1500, 24                                    # T*nu >= 64 -> generator launch
+    g = torch.Generator().manual_seed(nu)
+    A = torch.randn(nu, nu, generator=g, dtype=torch.float64) * 0.3
+    sigma = A @ A.T + 0.5 * torch.eye(nu, dtype=torch.float64)
+    mu = torch.randn(nu, generator=g, dtype=torch.float64) * 0.1
+    umax = torch.full((nu,), 1.2, dtype=torch.float64)
+    U0 = torch.randn(T, nu, generator=g, dtype=torch.float64) * 0.05
+    if model_kind == "mlp":
+        nx = 16
+        m = pm.models.MLPResidual.random(nx, nu, 64, seed=2, dtype=dtype)
+        f64, q64 = dyn.make_mlp(*[t.double() for t in (m.W1, m.b1, m.W2, m.b2)])
+        f, q = m.dynamics, m.running_cost
+    else:
+        nx = {4: 8, 12: 16, 6: 12}[nu]
+        m = pm.models.Integrator(nx, nu)
+        f64, q64 = dyn.make_quadtoy(nx, nu)
+        f, q = m.dynamics, m.running_cost
+        if model_kind == "generic":
+            f, q = (lambda s, a: m.dynamics(s, a)), (lambda s, a: m.running_cost(s, a))
+    x0 = torch.randn(nx, generator=g, dtype=torch.float64)
+    kw = dict(lambda_=6.0, noise_mu=mu, u_max=umax, sample_null_action=True, noise_abs_cost=(nu == 6))
+    p = orc.Problem(dynamics=f64, running_cost=q64, nx=nx, noise_sigma=sigma, K=K, T=T, **kw)
+    cast = lambda t: t.to(dtype) if torch.is_tensor(t) else t
+    ctrls = []
+    for coloured in (True, False):
+        c = pm.MPPI(f, q, nx, sigma.to(dtype), num_samples=K, horizon=T, device="cuda", U_init=U0.to(dtype), rng="philox",
+                    seed=31, **{k: cast(v) for k, v in kw.items()})
+        c.coloured_fill = coloured
+        ctrls.append(c)
+    tol = 1e-9 if dtype == torch.float64 else 5e-5       # Philox: hardware log/sin/cos vs numpy
+    ztol = 1e-5                                          # ... which is also what limits fp64 here
+    U = U0
+    for call in (1, 2):
+        z = torch.from_numpy(oph.normals_ktn(31, call, K, T, nu)).double()
+        r = orc.command(p, U, x0, z, True)
+        U = r["U"]
+        outs = []
+        for c in ctrls:
+            a = c.command(x0.to(dtype).cuda())
+            outs.append((a, c.U, c.cost_total, c.noise, c.perturbed_action))
+            assert int(c._last.noise_coloured) == int(c.coloured_fill and model_kind is not None)
+            _assert_close(a, r["action"].numpy(), max(tol, ztol), f"action call {call}")
+            _assert_close(c.cost_total, r["cost_total"].numpy(), max(tol, ztol), f"cost call {call}")
+            _assert_close(c.perturbed_action, r["perturbed_action"].numpy(), max(tol, ztol), f"perturbed_action call {call}")
+            c.U = r["U"].to(dtype).cuda()                # same nominal sequence on both sides for the next call
+        for x, y in zip(*outs):                          # the two engine variants against each other
+            torch.testing.assert_close(x, y, rtol=2e-5 if dtype == torch.float32 else 1e-10, atol=2e-5 if dtype == torch.float32 else 1e-10)
