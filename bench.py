@@ -19,8 +19,9 @@ clock on EVERY launch (min workgroup entry .. max exit: what rocprofv3 --kernel-
 of charge) and HIP events attached to the launch itself (hipExtLaunchKernelGGL start/stop events, on
 the stream the engine launches on = torch's current stream) on every 4th launch -- they additionally
 contain the two dispatch packets (~2-3 us) and each costs the stream ~5 us, hence the sampling.
-`cpu_baseline` times the oracle (CPU restatement of the reference path, kind "port") on a bounded
-sample of the same workload on the host cores.
+`cpu_baseline` times the oracle (CPU restatement of the reference path, kind "port") on the same
+workload at the full K on the host cores (at most 3 timed calls); the live reference itself, timed
+in the build container beside the port, is on record in profiles/r02_cpu_reference_vs_port.txt.
 """
 import argparse
 import json
@@ -120,14 +121,14 @@ def _time_oracle(wl, K, budget_s, max_calls, sync):
 
 
 def cpu_baseline(wl, budget_s=15.0):
-    """The oracle (oracle/mppi_oracle.py, a CPU restatement of the reference's command()) timed on a
-    bounded sample of the same workload: same T/nx/nu/model, fewer samples, incl. torch.randn.
+    """The oracle (oracle/mppi_oracle.py, a CPU restatement of the reference's command()) timed on
+    the same workload at the full K (same T/nx/nu/model, incl. torch.randn; 1 warm-up + <= 3 calls).
     Beside it, for orientation only: the same restatement with its tensors on cuda:0 at the FULL K
     -- i.e. the reference's own formulation (one ATen launch per tensor op, ~10 per time step) on
     this GPU, the comparator SURVEY.md 8(d) asks for next to the CPU number."""
     _, kind, nx, nu, Kfull, T = WORKLOADS[wl]
-    K = min(Kfull, 8192)
-    t, n = _time_oracle(wl, K, budget_s, 50, lambda: None)
+    K = Kfull
+    t, n = _time_oracle(wl, K, budget_s, 3, lambda: None)       # full K: 1 warm-up + at most 3 timed calls
     out = {"value": K / t, "unit": "rollouts/s", "cores": torch.get_num_threads(), "kind": "port",
            "host_cpus": os.cpu_count(),
            "sample": f"oracle command() incl. randn, K={K} of {Kfull}, T={T}, nx={nx}, nu={nu}, fp32, "
@@ -143,6 +144,42 @@ def cpu_baseline(wl, budget_s=15.0):
     except Exception as e:      # a comparator, never a reason to lose the bench line
         out["same_port_on_gpu"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return out
+
+
+def k1_hbm_cold(ctrl, n=32):
+    """K1 alone with its noise rows HBM-cold: the same launch (C-ABI mppi_rollout_cost on the last
+    command's problem block) cycled over NBUF row buffers of 4*K*T*nu bytes each, >= 1.5 GiB in total,
+    so that no launch finds its rows in the 256 MiB Infinity Cache (inside a command K1 runs right
+    after the generator wrote the 201 MB draw and part of its reads are cache hits: `frac` above is
+    that in-pipeline figure, this one is the pure-HBM one).  Device-clock span per launch, like `frac`."""
+    import ctypes as C
+    from pytorch_mppi_amd import _native as N
+    from pytorch_mppi_amd.mppi import _ptr
+    lib = N.lib()
+    p = ctrl._last
+    if p is None or int(p.noise_src) != N.NOISE_TNK4 or int(p.noise_coloured):
+        return None
+    n_el = N.noise_rows4(ctrl.T, ctrl.nu) * ctrl.K_local * 4
+    nbuf = max(4, -(-6 * (1 << 28) // (4 * n_el)))
+    bufs = [torch.randn(n_el, device=ctrl.d, dtype=ctrl.dtype) for _ in range(nbuf)]
+    st = ctrl._stream()
+    z_save = p.z
+    try:
+        for i in range(nbuf):                                   # warm-up: one pass over every buffer
+            p.z = _ptr(bufs[i])
+            N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
+        torch.cuda.synchronize()
+        lib.mppi_profile_enable(1 << 30)                        # device-clock stamps only
+        for i in range(n):
+            p.z = _ptr(bufs[i % nbuf])
+            N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
+        a, b, cn, ce = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_int64(0)
+        N.check(lib.mppi_profile_read2(C.byref(a), C.byref(b), C.byref(cn), C.byref(ce)), "mppi_profile_read2")
+        lib.mppi_profile_enable(0)
+    finally:
+        p.z = z_save
+    return {"avg_launch_us": b.value / max(1, cn.value) * 1e3, "launches": int(cn.value), "buffers": nbuf,
+            "bytes_cycled": 4 * n_el * nbuf}
 
 
 def main():
@@ -287,6 +324,7 @@ def main():
                     traffic = pmc[f"{args.workload}/{args.rng}"]["rollout_cost_kernel"]["traffic_bytes"]
             except Exception:
                 traffic = None
+            cold = k1_hbm_cold(ctrl) if not args.no_extras else None
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                         "kernel": "rollout_cost_kernel", "avg_launch_us": k1_ms * 1e3,
@@ -296,7 +334,16 @@ def main():
                                   f"{EVENT_EVERY}th of those launches are reported beside it and include the "
                                   "dispatch packets",
                         "algorithmic_bytes": alg_bytes,
-                        "frac_of_measured_copy_ceiling": ach / HBM_COPY_CEILING_GBS}
+                        "frac_of_measured_copy_ceiling": ach / HBM_COPY_CEILING_GBS,
+                        "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                          "passes of this command; a lookup, not measured in this run)" if traffic else None,
+                        "frac_note": "`frac` is K1 inside the command pipeline, where part of the 201 MB draw the "
+                                     "generator just wrote is still in the 256 MiB Infinity Cache; `frac_hbm_cold` is "
+                                     "the same launch with rows that are in HBM only"}
+            if cold:
+                ach_c = alg_bytes / (cold["avg_launch_us"] * 1e-6) / 1e9
+                roofline.update({"frac_hbm_cold": ach_c / HBM_PEAK_GBS, "achieved_hbm_cold": ach_c,
+                                 "avg_launch_us_hbm_cold": cold["avg_launch_us"], "hbm_cold_sample": cold})
 
     out = {
         "metric": "rollouts/sec (K x T state evals) per .command() call",

@@ -99,3 +99,33 @@ def make_mlp(W1, b1, W2, b2, res_scale=0.1):
         return (state ** 2).sum(dim=-1)
 
     return dynamics, cost
+
+
+# ---------------------------------------------------------------------------------------------
+# Deterministic stand-in for STOCHASTIC dynamics (rollout_samples M > 1, mppi.py:334-373): the M
+# rollouts of one action sequence differ by a fixed disturbance table w (M,T,nx) instead of by
+# draws made inside the callback, so the live reference, the oracle and the engine's callback path
+# see identical "randomness".  The callbacks get one batch of M*K rows, row = m*K + k (mppi.py:351);
+# any other batch size (get_rollouts, M = 1) is treated as m = 0.  Step-dependent signature
+# (state, u, t) -> construct the controller with step_dependent_dynamics=True.
+# ---------------------------------------------------------------------------------------------
+def make_linear_goal_multi(B, goal, w, K):
+    M = w.shape[0]
+
+    def dynamics(state, action, t):
+        rows = state.shape[0]
+        if rows == M * K:
+            m = torch.arange(rows, device=state.device) // K
+        else:
+            m = torch.zeros(rows, dtype=torch.long, device=state.device)
+        return state + action @ B.T + w[m, t]
+
+    def cost(state, action, t):
+        dx = goal - state
+        return (dx ** 2).sum(dim=-1)
+
+    def terminal(states, actions):
+        dx = goal - states[..., -1, :]
+        return (dx ** 2).sum(dim=-1)                    # (M,K) for (M,K,T,nx) states
+
+    return dynamics, cost, terminal

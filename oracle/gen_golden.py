@@ -47,6 +47,13 @@ def run_case(name, *, model, model_args, nx, nu, K, T, dtype, sigma, steps=2, st
         goal = torch.tensor(model_args["goal"], dtype=tdt)
         f, q, term = dyn.make_linear_goal(B, goal)
         extra["B"], extra["goal"] = _np(B), _np(goal)
+    elif model == "linear_multi":
+        # M > 1 rollouts (mppi.py:334-373): the M copies differ by a fixed disturbance table
+        B = torch.tensor(model_args["B"], dtype=tdt)
+        goal = torch.tensor(model_args["goal"], dtype=tdt)
+        w = torch.randn(ctor["rollout_samples"], T, nx, generator=g, dtype=tdt) * model_args["w_scale"]
+        f, q, term = dyn.make_linear_goal_multi(B, goal, w, K)
+        extra["B"], extra["goal"], extra["w"] = _np(B), _np(goal), _np(w)
     elif model == "mlp":
         W1, b1, W2, b2 = dyn.make_mlp_weights(nx, nu, model_args["hidden"], seed=2, dtype=tdt)
         f, q = dyn.make_mlp(W1, b1, W2, b2, model_args.get("res_scale", 0.1))
@@ -186,6 +193,14 @@ def main():
     run_case("smppi_quadtoy_f32", model="quadtoy", model_args={}, nx=6, nu=4, K=128, T=12, dtype="f32",
              sigma=[[1, 0.2, 0, 0], [0.2, 2, 0, 0], [0, 0, 0.5, 0], [0, 0, 0, 1.5]], steps=2, lambda_=25.0,
              smppi=dict(w_action_seq_cost=2.0, delta_t=1.0), sample_null_action=True, u_scale=0.5, seed=11)
+    # M = 3 rollouts per action sequence + discounted variance cost + terminal cost (mppi.py:334-373)
+    run_case("linear_multi_f64", model="linear_multi", model_args=dict(B=Bt, goal=[2.0, 2.0], w_scale=0.15), nx=2, nu=2,
+             K=100, T=10, dtype="f64", sigma=I2, state=[-3.0, -2.0], steps=3, lambda_=1.0, terminal=True,
+             rollout_samples=3, rollout_var_cost=0.1, rollout_var_discount=0.9, step_dependent_dynamics=True,
+             sample_null_action=True, u_max=[1.5, 1.0], seed=14)
+    run_case("linear_multi_f32", model="linear_multi", model_args=dict(B=Bt, goal=[1.0, -1.0], w_scale=0.3), nx=2, nu=2,
+             K=256, T=12, dtype="f32", sigma=[[1.0, 0.3], [0.3, 0.6]], steps=2, lambda_=6.0,
+             rollout_samples=4, rollout_var_cost=0.5, step_dependent_dynamics=True, per_sample_state=True, seed=15)
     run_batched_case("batched_linear_f64", N=3, K=100, T=10, dtype="f64", sigma=[[1.0, 0.0], [0.0, 1.0]], steps=3,
                      lambda_=1.0, u_max=[1.5, 1.0], seed=12)
     run_batched_case("batched_linear_full_f32", N=5, K=128, T=8, dtype="f32", sigma=[[1.0, 0.3], [0.3, 0.6]], steps=2,

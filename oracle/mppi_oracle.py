@@ -37,6 +37,9 @@ class Problem:
     step_dependent_dynamics: bool = False
     sample_null_action: bool = False
     noise_abs_cost: bool = False
+    rollout_samples: int = 1                  # M (mppi.py:76, :168)
+    rollout_var_cost: float = 0.0             # :77, :170
+    rollout_var_discount: float = 0.95        # :78, :171-175
     # resolved in __post_init__
     nu: int = field(init=False)
     dtype: torch.dtype = field(init=False)
@@ -148,6 +151,42 @@ def rollout_costs(p: Problem, state, perturbed_action):
     return cost, states, actions
 
 
+def rollout_costs_multi(p: Problem, state, perturbed_action):
+    """mppi.py:334-373 (M > 1): every action sequence is rolled out M times through the user's
+    (stochastic) callbacks as ONE batch of M*K rows, row = m*K + k; the cost is the mean over the M
+    rollouts plus `rollout_var_cost` x the discounted per-step variance over M (unbiased, torch
+    `.var(dim=0)`), discount `rollout_var_discount ** t` (:174-175, :364).  `states` / `actions` are
+    always stored, (M,K,T,.) (:349-350), and the terminal cost is called unconditionally (:369; the
+    default is `lambda states, actions: 0`)."""
+    K, T, nu = perturbed_action.shape
+    M = p.rollout_samples
+    cost_samples = torch.zeros(M, K, dtype=p.dtype)                    # :339-340
+    cost_var = torch.zeros(K, dtype=p.dtype)                           # :341
+    if state.shape == (K, p.nx):
+        s0 = state                                                     # :343-344
+    else:
+        s0 = state.view(1, -1).expand(K, -1)                           # :346
+    s0 = s0.repeat(M, 1, 1)                                            # :348
+    states = torch.empty(M, K, T, p.nx, dtype=p.dtype)
+    actions = torch.empty(M, K, T, nu, dtype=p.dtype)
+    disc = p.rollout_var_discount ** torch.arange(T, dtype=p.dtype)    # :174-175
+    x = s0.reshape(M * K, p.nx)
+    for t in range(T):
+        u = p.u_scale * perturbed_action[:, t].expand(M, -1, -1)       # :354
+        uf = u.reshape(M * K, nu)
+        x = p.dynamics(x, uf, t) if p.step_dependent_dynamics else p.dynamics(x, uf)          # :356
+        c = p.running_cost(x, uf, t) if p.step_dependent_dynamics else p.running_cost(x, uf)  # :361
+        c = c.reshape(M, K)
+        cost_samples = cost_samples + c                                # :362
+        cost_var = cost_var + c.var(dim=0) * disc[t]                   # :363-364
+        states[:, :, t] = x.reshape(M, K, -1)[:, :, :p.nx]             # :366
+        actions[:, :, t] = u
+    if p.terminal_state_cost is not None:
+        cost_samples = cost_samples + p.terminal_state_cost(states, actions)   # :369-370
+    cost = cost_samples.mean(dim=0) + cost_var * p.rollout_var_cost    # :371-372
+    return cost, states, actions
+
+
 def weights(cost_total, lambda_):
     """mppi.py:254-259 + :12-13 -- beta=min; w=exp(-(1/lambda)(c-beta)); omega = (1/eta) * w."""
     beta = torch.min(cost_total)
@@ -169,7 +208,10 @@ def command(p: Problem, U, state, z, shift_nominal_trajectory=True, sampler_acti
     perturbed = torch.clamp(perturbed, p.u_min, p.u_max)    # :383, :419-420
     noise = perturbed - U                                   # :385  (post-clamp noise)
     ac = action_cost(noise, p.fac, p.lambda_, p.noise_abs_cost)   # :409
-    rollout_cost, states, actions = rollout_costs(p, state, perturbed)   # :411
+    if p.rollout_samples > 1:                               # :292-295
+        rollout_cost, states, actions = rollout_costs_multi(p, state, perturbed)
+    else:
+        rollout_cost, states, actions = rollout_costs(p, state, perturbed)   # :411
     pert_cost = torch.sum(U * ac, dim=(1, 2))               # :415
     cost_total = rollout_cost + pert_cost                   # :416
     omega, w, beta, eta = weights(cost_total, p.lambda_)    # :267

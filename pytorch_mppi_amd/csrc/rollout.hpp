@@ -17,6 +17,8 @@
 // per wave.
 #pragma once
 #include <hip/hip_ext.h>
+#include <cstdlib>
+#include <type_traits>
 #include "actions.hpp"
 #include "dispatch.hpp"
 #include "models.hpp"
@@ -37,6 +39,7 @@ struct StepTables {
   const T* Um;
   const T* G;
   T* ktn_lds;      // MPPI_NOISE_KTN: wave-private transposition tiles (else unused)
+  int kwave0;      // raw index of the first sample of this wave's current chunk
 };
 
 // one timestep: actions from z, action cost, dynamics, running cost
@@ -186,6 +189,136 @@ __device__ __forceinline__ void ring_fetch(const KArgs<T>& a, int ss, int k, T (
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA ring (fp32, TNK4 / ACTIONS streams).  The register ring above keeps 9 rows (144 B per
+// lane) in flight because every row in flight costs 4 VGPRs; HBM-cold that is not enough for ONE
+// wave per SIMD to cover the memory latency (37.6 us = 5.36 TB/s at C3).  Here the rows travel
+// global -> LDS directly (`global_load_lds_dwordx4`: one wave instruction moves the 1 KiB row
+// [jb][k0..k0+63][4] -- contiguous in the sample-minor layout -- to LDS base + lane*16), so depth
+// costs LDS instead of registers: DMA_ROWS rows per wave (30 KiB) in flight, 120 KiB per CU.
+// hipcc does not count asm memory operations, so the waits are ours: the main loop keeps exactly
+// D slots (of P4 rows) outstanding and consumes the oldest behind `s_waitcnt vmcnt((D-1)*P4)`;
+// the compiler's own loads/stores only make those waits more conservative (vector memory retires
+// in order).  A slot is refilled right after it was read (`lgkmcnt(0)` first: the ds_reads have
+// returned before the DMA that overwrites them is issued).
+// ---------------------------------------------------------------------------------------------
+template <int NU, int ROWS_MAX>
+struct DmaRing {
+  static constexpr int P4 = Stream<NU>::P4;
+  static constexpr int D = (ROWS_MAX / P4) < 2 ? 2 : (ROWS_MAX / P4);   // slots (super-steps) in flight
+  static constexpr int ROWS = D * P4;
+  static constexpr int FLOATS_PER_WAVE = ROWS * 256;
+  static constexpr bool OK = ROWS <= 63;                                 // vmcnt is a 6-bit counter
+};
+
+// one row-of-4 for the 64 samples of this wave: global (uniform row base + per-lane byte offset) ->
+// LDS (uniform byte address + lane*16).  M0 carries the LDS address and is compiler-reserved: saved
+// and restored inside the statement.
+__device__ __forceinline__ void dma_row16(const float* row_base, unsigned lane_off_bytes, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_off_bytes), "s"(row_base), "s"(lds_byte_addr)
+      : "memory");
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <class Model, typename T, int NOISE, bool DIAG, int SLOW, int ROWS_MAX>
+__device__ __forceinline__ void rollout_stream_dma(const KArgs<T>& a, const ActionConsts<T, Model::NU>& ac,
+                                                   const Model& model, const StepTables<T>& tb, int k,
+                                                   bool active, int orow, float* ring_wave,
+                                                   T (&x)[Model::NX], T& rollout, T& pert) {
+  static_assert(sizeof(T) == 4 && (NOISE == MPPI_NOISE_TNK4 || NOISE == MPPI_NOISE_ACTIONS), "fp32 row streams only");
+  constexpr int NU = Model::NU;
+  constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
+  constexpr int D = DmaRing<NU, ROWS_MAX>::D;
+  const int nss = (a.Tn + TT - 1) / TT;
+  const int last = nss - 1;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const unsigned voff = (unsigned)k * 16u;                     // this lane's sample inside a row (bytes)
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)ring_wave);
+  const float* zbase = reinterpret_cast<const float*>(a.z);
+  const long long row_floats = (long long)a.K * 4;
+  const float* my = ring_wave + lane * 4;
+  T vprev[NU];
+#pragma unroll
+  for (int n = 0; n < NU; ++n) vprev[n] = T(0);
+
+  auto issue = [&](int ss_src, int slot) {
+#pragma unroll
+    for (int i = 0; i < P4; ++i)
+      dma_row16(zbase + ((long long)ss_src * P4 + i) * row_floats, voff, lds0 + (unsigned)((slot * P4 + i) * 1024));
+  };
+  // Every load the compiler knows about (per-control constants, initial state) is waited for HERE,
+  // with a wait the compiler sees: otherwise it defers those waits to the first use inside the
+  // loop, as vmcnt(0) -- which also drains the freshly issued ring (the asm loads are invisible to
+  // its bookkeeping, but vector memory retires in order).
+  __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0), expcnt/lgkmcnt untouched
+  // prologue: D slots in flight (short horizons re-read the last super-step; never consumed)
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(d < last ? d : last, d);
+
+  int slot = 0;
+  const int nmain = nss > D ? nss - D : 0;
+  for (int ss = 0; ss < nmain; ++ss) {
+    wait_vmcnt<(D - 1) * P4>();                               // the oldest slot has landed
+    T zt[P4 * 4];
+#pragma unroll
+    for (int i = 0; i < P4; ++i) {
+      const float4 v4 = *reinterpret_cast<const float4*>(my + (slot * P4 + i) * 256);
+      zt[4 * i] = v4.x; zt[4 * i + 1] = v4.y; zt[4 * i + 2] = v4.z; zt[4 * i + 3] = v4.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // slot read out: safe to overwrite
+    issue(ss + D, slot);                                      // ss + D <= last here
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+      rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, tb, k, active, orow, ss * TT + tt, &zt[tt * NU], x, vprev,
+                                                rollout, pert);
+    slot = slot + 1 == D ? 0 : slot + 1;
+  }
+  // tail: the ring holds super-steps nmain .. nmain+D-1 in issue order, nothing is refilled
+  static_for<0, D>([&](auto dc) {
+    constexpr int d = decltype(dc)::value;
+    const int ss = nmain + d;
+    if (ss < nss) {                                           // wave-uniform
+      wait_vmcnt<(D - 1 - d) * P4>();
+      T zt[P4 * 4];
+#pragma unroll
+      for (int i = 0; i < P4; ++i) {
+        const float4 v4 = *reinterpret_cast<const float4*>(my + (slot * P4 + i) * 256);
+        zt[4 * i] = v4.x; zt[4 * i + 1] = v4.y; zt[4 * i + 2] = v4.z; zt[4 * i + 3] = v4.w;
+      }
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const int t = ss * TT + tt;
+        if (t < a.Tn)
+          rollout_step<Model, T, NOISE, DIAG, SLOW>(a, ac, model, tb, k, active, orow, t, &zt[tt * NU], x, vprev,
+                                                    rollout, pert);
+      }
+      slot = slot + 1 == D ? 0 : slot + 1;
+    }
+  });
+  wait_vmcnt<0>();   // no DMA may still be in flight when the wave (and its LDS allocation) ends
+}
+
 template <class Model, typename T, int NOISE, bool DIAG, int SLOW>
 __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionConsts<T, Model::NU>& ac,
                                                const Model& model, const StepTables<T>& tb, int k,
@@ -203,9 +336,7 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
     if constexpr (Ktn<NU>::OK && sizeof(T) == 4) {
       constexpr int PL = Ktn<NU>::PL, MS = Ktn<NU>::MS;
       const int lane = threadIdx.x & (WAVE - 1);
-      const int kw0 = k - lane;                         // first sample of this wave (k is clamped: recompute below)
-      const int kwave0 = (blockIdx.x * K1_BLOCK + (int)threadIdx.x) - lane;
-      (void)kw0;
+      const int kwave0 = tb.kwave0;                     // first sample of this wave (raw, not clamped)
       float* ldsw = reinterpret_cast<float*>(tb.ktn_lds) + (threadIdx.x / WAVE) * Ktn<NU>::LDS_FLOATS_PER_WAVE;
       const int nmacro = (a.Tn + MS - 1) / MS;
       const int c = lane & 7, sl = lane >> 3;
@@ -325,8 +456,9 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
   }
 }
 
-// NOISE: MPPI_NOISE_TNK4 | _PHILOX | _ACTIONS (compile-time);  DIAG: diagonal Sigma
-template <class Model, typename T, int NOISE, bool DIAG>
+// NOISE: MPPI_NOISE_TNK4 | _PHILOX | _ACTIONS (compile-time);  DIAG: diagonal Sigma;
+// DMA_ROWS > 0: the rows travel through the LDS-DMA ring (fp32 row streams), 0: register ring
+template <class Model, typename T, int NOISE, bool DIAG, int DMA_ROWS = 0>
 __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a_in) {
   constexpr int NX = Model::NX, NU = Model::NU;
   const KArgs<T> a = env_view(a_in);        // MPPI_Batched: environment = blockIdx.z
@@ -338,11 +470,13 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
   T* red = G + a.J;                         // [BLOCK/WAVE]
   T* fac = red + BLOCK / WAVE;              // [2*NU*NU] full-Sigma factors (only if !DIAG)
 
-  const int kraw = blockIdx.x * K1_BLOCK + threadIdx.x;
-  const bool active = kraw < a.K;
-  const int k = active ? kraw : a.K - 1;   // tail lanes shadow the last sample, never store
-  const long long kg = a.k_offset + k;
-  const int orow = overwrite_row(a, kg);
+  // A workgroup handles the 256-sample chunks blockIdx.x, blockIdx.x + gridDim.x, ... (persistent
+  // form for K beyond one chunk per CU: every resident workgroup walks the rows in step with the
+  // others, chunk after chunk, instead of four desynchronised waves of workgroups)
+  int kraw = blockIdx.x * K1_BLOCK + threadIdx.x;
+  bool active = kraw < a.K;
+  int k = active ? kraw : a.K - 1;         // tail lanes shadow the last sample, never store
+  int orow = overwrite_row(a, a.k_offset + k);
 
   // Issue order matters (loads retire in order): first the few loads the set-up needs (nominal
   // sequence, initial state), then the ring prologue, so that the set-up's waits do not sit
@@ -371,11 +505,14 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
 
   constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT, D = Ring<NU, T>::D;
   T ring[D][P4 * 4];
-  if constexpr (NOISE != MPPI_NOISE_PHILOX && NOISE != MPPI_NOISE_KTN) {
-    const int last = (a.Tn + TT - 1) / TT - 1;
+  auto ring_prologue = [&]() {
+    if constexpr (NOISE != MPPI_NOISE_PHILOX && NOISE != MPPI_NOISE_KTN) {
+      const int last = (a.Tn + TT - 1) / TT - 1;
 #pragma unroll
-    for (int d = 0; d < D; ++d) ring_fetch<T, NOISE, NU>(a, d < last ? d : last, k, ring[d]);
-  }
+      for (int d = 0; d < D; ++d) ring_fetch<T, NOISE, NU>(a, d < last ? d : last, k, ring[d]);
+    }
+  };
+  if constexpr (DMA_ROWS == 0) ring_prologue();
 
 #pragma unroll
   for (int q = 0; q < UL; ++q) {
@@ -422,22 +559,37 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
     }
     __syncthreads();
   }
-  // KTN tiles start 16-B aligned behind the tables
-  T* ktn_lds = fac + (DIAG ? 0 : 2 * NU * NU);
+  // KTN tiles / DMA ring start 16-B aligned behind the tables and the factor block (present unless Sigma is diagonal)
+  T* ktn_lds = fac + ((DIAG && a.diag) ? 0 : 2 * NU * NU);
   ktn_lds += (4 - ((ktn_lds - Ue) & 3)) & 3;
-  const StepTables<T> tb{Ue, Um, G, ktn_lds};
+  StepTables<T> tb{Ue, Um, G, ktn_lds, kraw - (int)(threadIdx.x & (WAVE - 1))};
 
+  const int nchunks = (a.K + K1_BLOCK - 1) / K1_BLOCK;
+  for (int chunk = blockIdx.x;;) {
   T rollout = T(0), pert = T(0);
   // wave-uniform choice: does this wave own overwritten rows, or must it store the states?
   // (0 = neither; 1 = only the sample_null_action row: a select, no extra memory traffic; 2 = sampler
   // rows / states: conditional loads and stores, which cost the wave its exact vmcnt waits)
   const bool slow = __any(orow >= 0) || a.states != nullptr;
-  if (slow)
-    rollout_stream<Model, T, NOISE, DIAG, 2>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
-  else if (__any(orow == -1))
-    rollout_stream<Model, T, NOISE, DIAG, 1>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
-  else
-    rollout_stream<Model, T, NOISE, DIAG, 0>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
+  if constexpr (DMA_ROWS > 0) {
+    // wave-private ring behind the tables (1 KiB rows; the carve keeps it 16-B aligned)
+    float* ring_wave = reinterpret_cast<float*>(ktn_lds) + (threadIdx.x / WAVE) * DmaRing<NU, DMA_ROWS>::FLOATS_PER_WAVE;
+    // (launch_rollout sends problems with sampler rows or a `states` output to the register-ring
+    // kernel: their conditional vector-memory traffic is waited for with vmcnt(0) by the compiler,
+    // which would drain a DMA ring every step)
+    if (__any(orow == -1)) {
+      rollout_stream_dma<Model, T, NOISE, DIAG, 1, DMA_ROWS>(a, ac, model, tb, k, active, orow, ring_wave, x, rollout, pert);
+    } else {
+      rollout_stream_dma<Model, T, NOISE, DIAG, 0, DMA_ROWS>(a, ac, model, tb, k, active, orow, ring_wave, x, rollout, pert);
+    }
+  } else {
+    if (slow)
+      rollout_stream<Model, T, NOISE, DIAG, 2>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
+    else if (__any(orow == -1))
+      rollout_stream<Model, T, NOISE, DIAG, 1>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
+    else
+      rollout_stream<Model, T, NOISE, DIAG, 0>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
+  }
 
   if (a.use_terminal) rollout += model.terminal(x);                    // :324-328
   const T total = rollout + pert;                                      // :416
@@ -447,7 +599,55 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
   }
   const T bm = wave_min<T>(active ? total : inf_v<T>());      // one minimum per 64 samples
   if ((threadIdx.x & (WAVE - 1)) == 0 && kraw < a.K) a.block_min[kraw / WAVE] = bm;
-  if (a.tstamp != nullptr && threadIdx.x == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
+
+  // ---- next chunk of this workgroup (the LDS tables stay) ----
+  chunk += gridDim.x;
+  if (chunk >= nchunks) break;
+  kraw = chunk * K1_BLOCK + threadIdx.x;
+  active = kraw < a.K;
+  k = active ? kraw : a.K - 1;
+  orow = overwrite_row(a, a.k_offset + k);
+  tb.kwave0 = kraw - (int)(threadIdx.x & (WAVE - 1));
+  {
+    const T* __restrict__ s0 = a.state_per_sample ? a.state + (long long)k * NX : a.state;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = s0[i];
+  }
+  if constexpr (DMA_ROWS == 0) ring_prologue();
+  }
+  if (a.tstamp != nullptr) {
+    // exit stamp AFTER every wave of the workgroup is done (the stamp is the kernel's span on the
+    // device clock; without the barrier it missed the three other waves of the last workgroup)
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
+  }
+}
+
+// LDS-DMA ring depth (rows of 1 KiB per wave) for this launch, 0 = register ring.  One workgroup
+// per CU (<= 256 workgroups, the C3 case: one wave per SIMD) gets the deep ring (30 rows, 120 KiB
+// per workgroup); larger grids keep two workgroups per CU resident with 15 rows each, so that one
+// workgroup's prologue / epilogue overlaps the other's streaming.  MPPI_K1_DMA=0|15|30 overrides
+// (tools/ A/B runs), read once.
+template <class Model, typename T>
+static int dma_rows_for(const KArgs<T>& a, size_t smem_tables) {
+  if constexpr (sizeof(T) != 4) return 0;
+  constexpr int NU = Model::NU;
+  if (a.noise_src != MPPI_NOISE_TNK4 && a.noise_src != MPPI_NOISE_ACTIONS) return 0;
+  if (a.states != nullptr || a.n_sampler > 0) return 0;    // conditional VMEM per step: register-ring kernel
+#ifndef MPPI_K1_WITH_DMA
+  return 0;     // measured slower than the register ring: not instantiated in the product build
+#endif
+  static const int env = [] { const char* e = getenv("MPPI_K1_DMA"); return e ? atoi(e) : -1; }();
+  if (env == 0) return 0;
+  const long long nwg = (long long)((a.K + K1_BLOCK - 1) / K1_BLOCK) * a.n_env;
+  int rows = env > 0 ? env : (nwg <= 256 ? 30 : 15);
+  rows = rows >= 30 ? 30 : 15;
+  auto fits = [&](int r) {
+    return smem_tables + 16 + (size_t)(K1_BLOCK / WAVE) * (r == 30 ? DmaRing<NU, 30>::FLOATS_PER_WAVE : DmaRing<NU, 15>::FLOATS_PER_WAVE) * 4 <= 160 * 1024;
+  };
+  if (rows == 30 && !fits(30)) rows = 15;
+  if (rows == 15 && !fits(15)) rows = 0;
+  return rows;
 }
 
 template <class Model, typename T>
@@ -461,13 +661,33 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
     smem += (size_t)(4 + (K1_BLOCK / WAVE) * Ktn<NU>::LDS_FLOATS_PER_WAVE) * sizeof(T);
   }
   if (smem > 160 * 1024) return MPPI_E_UNSUPPORTED;   // T*nu beyond the LDS tables: not built
-  const dim3 grid((a.K + K1_BLOCK - 1) / K1_BLOCK, 1, a.n_env), block(K1_BLOCK);
+  const int dma = dma_rows_for<Model, T>(a, smem);
+  if (dma == 30) smem += 16 + (size_t)(K1_BLOCK / WAVE) * DmaRing<NU, 30>::FLOATS_PER_WAVE * 4;
+  else if (dma == 15) smem += 16 + (size_t)(K1_BLOCK / WAVE) * DmaRing<NU, 15>::FLOATS_PER_WAVE * 4;
+  // Persistent grid: at most one workgroup per CU and environment-slice (the kernel holds one wave
+  // per SIMD: 250+ registers), each walking its chunks blockIdx.x, +gridDim.x, ...  Launching all
+  // K/256 workgroups instead lets the later ones start whenever a CU frees up, out of step with the
+  // rest: measured 196 us against ~4 x 35 us at K = 262144.  MPPI_K1_PERSIST=0 restores the flat grid
+  // (A/B runs), =n allows n workgroups per CU.
+  const int nchunks = (a.K + K1_BLOCK - 1) / K1_BLOCK;
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  static const int persist = [] { const char* e = getenv("MPPI_K1_PERSIST"); return e ? atoi(e) : 1; }();
+  int gx = nchunks;
+  if (persist > 0) {
+    const int cap = (n_cu * persist) / (a.n_env > 1 ? a.n_env : 1);
+    if (gx > (cap > 1 ? cap : 1)) gx = cap > 1 ? cap : 1;
+  }
+  const dim3 grid(gx, 1, a.n_env), block(K1_BLOCK);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   profile_next_events(&ev0, &ev1, &a.tstamp);   // null events == plain launch
   // event-attached launch only while measuring; the plain launch is what hipGraph capture records
 #define MPPI_LAUNCH1(KERNEL)                                                                       \
   do {                                                                                             \
-    if (smem > 64 * 1024) /* long horizons: the LDS tables need the opt-in limit (160 KiB/CU) */   \
+    if (smem > 64 * 1024) /* long horizons / DMA ring: the opt-in limit (160 KiB/CU) */            \
       (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                 (int)smem);                                                        \
     if (ev0 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a);      \
@@ -478,11 +698,31 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
     if (diag) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, NOISE_, true>));                         \
     else MPPI_LAUNCH1((rollout_cost_kernel<Model, T, NOISE_, false>));                             \
   } while (0)
+#ifdef MPPI_K1_WITH_DMA
+#define MPPI_K1_DMA_OK(ROWS_) (sizeof(T) == 4 && DmaRing<NU, ROWS_>::OK)
+#else
+#define MPPI_K1_DMA_OK(ROWS_) false
+#endif
+#define MPPI_LAUNCH_DMA(NOISE_, ROWS_)                                                             \
+  do {                                                                                             \
+    if constexpr (MPPI_K1_DMA_OK(ROWS_)) {                                                         \
+      if (diag) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, NOISE_, true, ROWS_>));                \
+      else MPPI_LAUNCH1((rollout_cost_kernel<Model, T, NOISE_, false, ROWS_>));                    \
+    }                                                                                              \
+  } while (0)
   if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCH(MPPI_NOISE_PHILOX);
-  else if (a.noise_src == MPPI_NOISE_ACTIONS) MPPI_LAUNCH(MPPI_NOISE_ACTIONS);
-  else if (a.noise_src == MPPI_NOISE_KTN) {
+  else if (a.noise_src == MPPI_NOISE_ACTIONS) {
+    if (dma == 30) MPPI_LAUNCH_DMA(MPPI_NOISE_ACTIONS, 30);
+    else if (dma == 15) MPPI_LAUNCH_DMA(MPPI_NOISE_ACTIONS, 15);
+    else MPPI_LAUNCH(MPPI_NOISE_ACTIONS);
+  } else if (a.noise_src == MPPI_NOISE_KTN) {
     if constexpr (Ktn<NU>::OK && sizeof(T) == 4) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_KTN, true>));
-  } else MPPI_LAUNCH(MPPI_NOISE_TNK4);
+  } else {
+    if (dma == 30) MPPI_LAUNCH_DMA(MPPI_NOISE_TNK4, 30);
+    else if (dma == 15) MPPI_LAUNCH_DMA(MPPI_NOISE_TNK4, 15);
+    else MPPI_LAUNCH(MPPI_NOISE_TNK4);
+  }
+#undef MPPI_LAUNCH_DMA
 #undef MPPI_LAUNCH
 #undef MPPI_LAUNCH1
   return (int)hipGetLastError();

@@ -118,10 +118,21 @@ class MPPI:
         self.noise_mu = noise_mu.to(self.d)
         self.noise_sigma = noise_sigma.to(self.d)
         self._refresh_noise_factors()                                     # :130-139
+        # shard = (rank, world_size[, process_group]): this controller holds samples
+        # [k_offset, k_offset + K_local) of the K global ones (dist.py)
+        self._shard = None
+        self._shard_gen = None
+        self.k_offset = 0
+        self.K_local = self.K
+        if shard is not None:
+            from .dist import ShardPlan
+            self._shard = ShardPlan(self.K, *shard)
+            self.k_offset = self._shard.k_offset
+            self.K_local = self._shard.K_local
         self.U = U_init
         self.u_init = u_init.to(self.d)
         if self.U is None:
-            self.U = self._sample_noise((self.T,))                        # :144-145
+            self.U = self._replicated(self._sample_noise((self.T,)))      # :144-145
         else:
             self.U = self.U.to(device=self.d, dtype=self.dtype)
 
@@ -188,16 +199,13 @@ class MPPI:
             self._model = native_model_of(dynamics, running_cost, terminal_state_cost)
         if self._model is not None and (self._model.nx != self.nx or self._model.nu != self.nu):
             raise ValueError(f"native model dims ({self._model.nx},{self._model.nu}) != (nx,nu)=({self.nx},{self.nu})")
-        # shard = (rank, world_size[, process_group]): this controller holds samples
-        # [k_offset, k_offset + K_local) of the K global ones (dist.py)
-        self._shard = None
-        self.k_offset = 0
-        self.K_local = self.K
-        if shard is not None:
-            from .dist import ShardPlan
-            self._shard = ShardPlan(self.K, *shard)
-            self.k_offset = self._shard.k_offset
-            self.K_local = self._shard.K_local
+        if self._shard is not None and self._shard.world_size > 1 and rng != "philox":
+            # torch-generator modes: a shared U needs identically seeded ranks, which would make every
+            # shard draw the SAME perturbations (effective samples K / world).  Each shard therefore
+            # draws its rows from its own generator, keyed by (seed, rank); the default generator
+            # stays in lock-step across ranks (it only feeds the replicated U draws).
+            self._shard_gen = torch.Generator(device=self.d)
+            self._shard_gen.manual_seed((self.seed + 0x9E3779B97F4A7C15 * (self._shard.rank + 1)) & 0x7FFFFFFFFFFFFFFF)
         self._ws = None
         self._vec_cache = {}
         self._problem_cache = {}
@@ -274,7 +282,26 @@ class MPPI:
         self._problem_cache = {}
 
     def reset(self):
-        self.U = self._sample_noise((self.T,))
+        self.U = self._replicated(self._sample_noise((self.T,)))
+
+    def _replicated(self, t):
+        """Sharded controllers: a tensor every rank must hold identically (the randomly initialised
+        nominal sequence, mppi.py:144-145 / :290) is rank 0's draw, broadcast.  No process group (the
+        single-process shard emulation of the tests) or one shard: unchanged."""
+        sh = self._shard
+        if sh is None or sh.world_size <= 1:
+            return t
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return t
+        src = dist.get_global_rank(sh.group, 0) if sh.group is not None else 0
+        if t.is_cuda and dist.get_backend(sh.group) == "gloo":
+            h = t.detach().cpu().contiguous()           # test rigs (ranks sharing one GPU): via the host
+            dist.broadcast(h, src=src, group=sh.group)
+            return h.to(t.device)
+        t = t.contiguous()
+        dist.broadcast(t, src=src, group=sh.group)
+        return t
 
     # ------------------------------------------------------------------------------------------
     # noise plumbing
@@ -378,7 +405,8 @@ class MPPI:
         return C.c_void_p(torch._C._cuda_getCurrentRawStream(self._dev_index))
 
     def _randn(self, *shape):
-        return torch.randn(*shape, device=self.d, dtype=self.dtype)
+        # per-command sample draws; sharded torch modes draw from the shard's own generator
+        return torch.randn(*shape, device=self.d, dtype=self.dtype, generator=self._shard_gen)
 
     def _draw_noise(self, p, shape):
         """Bind this command's standard normals to the problem: injected / torch.randn (reference
@@ -489,6 +517,10 @@ class MPPI:
         (torch's generator advances correctly under graph replay; the Philox call counter is a
         launch argument and would be frozen); single shard; parameters (lambda_, bounds, ...) are
         frozen at capture -- capture again after changing them."""
+        if type(self) is not MPPI:
+            # SMPPI / KMPPI re-bind `action_sequence` / `theta` to fresh tensors every command; a captured
+            # graph would keep replaying the capture-time pointers
+            raise NotImplementedError(f"capture_command supports plain MPPI only, not {type(self).__name__}")
         if self.rng == "philox":
             raise ValueError("capture_command needs rng='torch' or 'torch-native' (see docstring)")
         if self._sharded():
@@ -498,7 +530,11 @@ class MPPI:
     def _to_state(self, state):
         if not torch.is_tensor(state):
             state = torch.tensor(state)
-        return state.to(dtype=self.dtype, device=self.d)                  # mppi.py:262-264
+        state = state.to(dtype=self.dtype, device=self.d)                 # mppi.py:262-264
+        if self.K_local != self.K and tuple(state.shape) == (self.K, self.nx):
+            # per-sample initial states (mppi.py:302) of the GLOBAL problem: this shard's rows
+            state = state[self.k_offset:self.k_offset + self.K_local]
+        return state
 
     def _sampler_rows(self, p):
         """mppi.py:393-399: rows [null, null+n) come from the sampler; global indices."""
@@ -583,7 +619,7 @@ class MPPI:
         self.cost_total = cost_total
 
         if not self._needs_generic():
-            s0 = self.state.contiguous() if per_sample else self.state.reshape(-1).contiguous()
+            s0 = self._fused_state(per_sample)
             p.state = _ptr(s0)
             p._keep["state"] = s0
             p.state_per_sample = int(per_sample)
@@ -604,6 +640,17 @@ class MPPI:
         N.check(lib.mppi_weights_partial(C.byref(p), st), "mppi_weights_partial")
         N.check(lib.mppi_finalize(C.byref(p), apply, st), "mppi_finalize")
         return p
+
+    def _fused_state(self, per_sample):
+        """Initial state as the fused kernels read it: (K_local,nx) rows or one (nx,) vector.  The
+        reference expands anything else to (K, numel) and lets the callbacks cope (mppi.py:305); a
+        compiled model has exactly nx state registers, so other sizes are refused."""
+        if per_sample:
+            return self.state.contiguous()
+        if self.state.numel() != self.nx:
+            raise ValueError(f"state has shape {tuple(self.state.shape)}; the fused path takes (nx,) = ({self.nx},) "
+                             f"or per-sample ({self.K}, {self.nx})")
+        return self.state.reshape(-1).contiguous()
 
     def _combine(self, p, records):
         """K5: identical rank-order combination of the all-gathered shard records on every rank."""
@@ -801,8 +848,11 @@ class MPPI:
 class GraphedCommand:
     """One captured `command()` (see `MPPI.capture_command`).  `g(state)` copies the state into the
     graph's static input, replays, and returns the graph's static action tensor (overwritten by the
-    next replay -- clone it to keep it).  `ctrl.U`, `cost_total`, `omega` and the lazy attributes
-    refer to the graph's static buffers and are current after every replay."""
+    next replay -- clone it to keep it).  `ctrl.U`, `cost_total` and `omega` refer to the graph's
+    static buffers and are current after every replay.  The lazily materialised attributes
+    (`noise`, `perturbed_action`, `states`, `actions`) are NOT available under replay (they read
+    None): they would have to be re-derived from the nominal sequence the command started from,
+    which the replay has already overwritten with the updated one."""
 
     def __init__(self, ctrl, state, shift, warmup):
         self.ctrl = ctrl
@@ -835,6 +885,9 @@ class GraphedCommand:
             state = torch.tensor(state)
         self.state.copy_(state.to(dtype=self.state.dtype).reshape(self.state.shape), non_blocking=True)
         self.graph.replay()
+        c = self.ctrl
+        c._last = None                       # see the class docstring: no lazy attributes under replay
+        c._noise = c._perturbed_action = c._states = c._actions = None
         return self.action
 
 
@@ -1215,7 +1268,7 @@ class KMPPI(MPPI):
         self._states = self._actions = self._noise = self._perturbed_action = None
         self._noise_theta = None
         if not self._needs_generic():
-            s0 = self.state.contiguous() if per_sample else self.state.reshape(-1).contiguous()
+            s0 = self._fused_state(per_sample)
             p.state = _ptr(s0)
             p._keep["state"] = s0
             p.state_per_sample = int(per_sample)

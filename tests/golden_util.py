@@ -14,9 +14,14 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TDT = {"f32": torch.float32, "f64": torch.float64}
 
 
-def golden_names(batched=False):
+def golden_names(batched=False, fused=None):
+    """Fixture names.  fused=True: only those with a native (fused-kernel) model; the M > 1 fixtures
+    (`*_multi_*`, deterministic stand-in for stochastic callbacks) exist on the callback path only."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if n.startswith("batched_") == batched]
+    names = [n for n in names if n.startswith("batched_") == batched]
+    if fused:
+        names = [n for n in names if "_multi_" not in n]
+    return names
 
 
 def oracle_run_batched(cfg, d, dtype=None):
@@ -61,6 +66,9 @@ def ctor_tensors(cfg, dtype):
 def torch_callables(cfg, d, dtype, device="cpu"):
     """(dynamics, running_cost, terminal) torch callables of the fixture's model."""
     m = cfg["model"]
+    if m == "linear_multi":
+        tt = lambda key: t(d, key, dtype).to(device)
+        return dyn.make_linear_goal_multi(tt("B"), tt("goal"), tt("w"), cfg["K"])
     if device != "cpu":
         tt = lambda key: t(d, key, dtype).to(device)
         if m == "linear_goal":

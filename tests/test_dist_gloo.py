@@ -72,3 +72,50 @@ def test_two_rank_exchange_and_combine_matches_unsharded():
     for rank, ok, same, shape in res:
         assert ok and same, (rank, ok, same)
         assert shape == (2, 2 + 10 * 2)
+
+
+def _worker_replicated_U(rank, world, port, out_q):
+    """under `shard=` the randomly initialised nominal sequence (mppi.py:144-145, :290)
+    must be ONE draw for all ranks, whatever the ranks' own generator states are."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pytorch_mppi_amd as pm
+        torch.manual_seed(100 + rank)                     # deliberately different per rank
+        m = pm.models.Integrator(6, 4)
+        c = pm.MPPI(m.dynamics, m.running_cost, 6, torch.eye(4), num_samples=64, horizon=7, device="cpu",
+                    shard=(rank, world), rng="torch")
+        outs = [c.U.clone()]
+        c.reset()
+        outs.append(c.U.clone())
+        same = []
+        for u in outs:
+            both = [torch.empty_like(u) for _ in range(world)]
+            dist.all_gather(both, u)
+            same.append(all(torch.equal(both[0], x) for x in both))
+        # the per-shard sample generators of the torch modes must differ between ranks
+        g = torch.tensor([c._shard_gen.initial_seed()], dtype=torch.int64)
+        gs = [torch.empty_like(g) for _ in range(world)]
+        dist.all_gather(gs, g)
+        distinct = len({int(x) for x in gs}) == world
+        out_q.put((rank, same, distinct, not torch.equal(outs[0], outs[1])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_controllers_share_one_initial_sequence_and_draw_distinct_samples():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_replicated_U, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, distinct, changed in res:
+        assert all(same), (rank, same)
+        assert distinct and changed

@@ -1,0 +1,137 @@
+"""GPU: edge semantics of the drop-in boundary that the main suites do not touch -- initial-state
+shapes on the fused path and under sharding, HIP-graph capture of the controller family, the
+sharded torch-generator modes."""
+import pytest
+import torch
+
+import pytorch_mppi_amd as pm
+
+pytestmark = pytest.mark.gpu
+
+
+def _lin():
+    return pm.models.LinearGoal(torch.tensor([[1.0, 0.0], [0.0, -1.0]]), torch.tensor([2.0, 2.0]))
+
+
+def test_capture_command_is_refused_for_smppi_and_kmppi():
+    """SMPPI / KMPPI re-bind `action_sequence` / `theta` per command; a captured graph would replay
+    stale pointers, so capture is plain-MPPI only."""
+    lin = _lin()
+    x = torch.tensor([-3.0, -2.0]).cuda()
+    for cls, extra in ((pm.SMPPI, dict(delta_t=0.5)), (pm.KMPPI, dict(num_support_pts=4))):
+        c = cls(lin.dynamics, lin.running_cost, 2, torch.eye(2), num_samples=256, horizon=8, device="cuda",
+                lambda_=5.0, rng="torch", **extra)
+        with pytest.raises(NotImplementedError):
+            c.capture_command(x)
+        c.command(x)           # the controller itself keeps working
+
+
+def test_graph_replay_hides_the_lazy_attributes():
+    m = pm.models.Integrator(6, 4)
+    c = pm.MPPI(m.dynamics, m.running_cost, 6, torch.eye(4), num_samples=2048, horizon=16, device="cuda",
+                lambda_=20.0, rng="torch")
+    x = torch.ones(6, device="cuda")
+    g = c.capture_command(x)
+    a = g(x).clone()
+    assert torch.isfinite(a).all() and c.cost_total is not None and abs(float(c.omega.sum()) - 1) < 1e-5
+    assert c.noise is None and c.perturbed_action is None      # not derivable after the replay overwrote U
+
+
+def test_fused_path_refuses_states_it_cannot_hold():
+    m = pm.models.Integrator(6, 4)
+    c = pm.MPPI(m.dynamics, m.running_cost, 6, torch.eye(4), num_samples=128, horizon=5, device="cuda", lambda_=5.0)
+    c.command(torch.ones(1, 6))                                 # (1,nx): the reference's view(1,-1) case
+    with pytest.raises(ValueError):
+        c.command(torch.ones(3, 6))                             # neither (nx,) nor (K,nx)
+
+
+def test_per_sample_states_of_the_global_problem_are_sliced_per_shard():
+    """mppi.py:302 under sharding: a (K_global, nx) state selects per-sample initial states; each
+    shard must take ITS rows (not row 0 for everybody)."""
+    K, T, nx, nu, world = 1024, 9, 6, 4, 4
+    g = torch.Generator().manual_seed(2)
+    m = pm.models.Integrator(nx, nu)
+    U0 = torch.randn(T, nu, generator=g) * 0.05
+    states = torch.randn(K, nx, generator=g).cuda()
+    z = torch.randn(K, T, nu, generator=g)
+    kw = dict(num_samples=K, horizon=T, device="cuda", lambda_=15.0, U_init=U0.clone(), rng="torch")
+    full = pm.MPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), **kw)
+    full.inject_noise(z)
+    a_full = full.command(states)
+    ctrls = [pm.MPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), shard=(r, world), **kw) for r in range(world)]
+    ps = []
+    for c in ctrls:
+        c.inject_noise(z)
+        ps.append(c._begin(states, True))
+        assert int(ps[-1].state_per_sample) == 1
+    records = torch.stack([p._keep["record"] for p in ps])
+    for c, p in zip(ctrls, ps):
+        c._combine(p, records)
+    acts = [c._end(p) for c, p in zip(ctrls, ps)]
+    for c, a in zip(ctrls, acts):
+        lo, hi = c._shard.bounds(c._shard.rank)
+        assert torch.allclose(c.cost_total, full.cost_total[lo:hi], rtol=1e-5, atol=1e-4)
+        assert torch.allclose(a, a_full, rtol=1e-5, atol=1e-6)
+
+
+def test_sharded_torch_modes_draw_rank_distinct_samples_without_a_process_group():
+    """rng='torch' under `shard=`: each shard's sample draws come from its own (seed, rank) generator
+    (identically seeded ranks must not duplicate the perturbations)."""
+    m = pm.models.Integrator(6, 4)
+    cs = [pm.MPPI(m.dynamics, m.running_cost, 6, torch.eye(4), num_samples=512, horizon=8, device="cuda", lambda_=10.0,
+                  U_init=torch.zeros(8, 4), rng="torch", seed=7, shard=(r, 2)) for r in range(2)]
+    x = torch.ones(6, device="cuda")
+    torch.manual_seed(0)
+    ps = [c._begin(x, True) for c in cs]
+    assert not torch.equal(ps[0]._keep["z_ktn"], ps[1]._keep["z_ktn"])
+    # and the draw is reproducible for a given (seed, rank)
+    c0 = pm.MPPI(m.dynamics, m.running_cost, 6, torch.eye(4), num_samples=512, horizon=8, device="cuda", lambda_=10.0,
+                 U_init=torch.zeros(8, 4), rng="torch", seed=7, shard=(0, 2))
+    p0 = c0._begin(x, True)
+    assert torch.equal(p0._keep["z_ktn"], ps[0]._keep["z_ktn"])
+
+
+@pytest.mark.parametrize("path", ["fused", "generic"])
+@pytest.mark.parametrize("rng", ["inject", "philox"])
+def test_set_noise_takes_effect_like_a_controller_built_with_the_new_noise(path, rng):
+    """SURVEY 8f-4 (reference autotune.py:140-189 rewrites noise_sigma / noise_mu between commands):
+    after `set_noise(Sigma2, mu2)` a command equals the fp64 oracle built with Sigma2 / mu2 -- sampler
+    factors, action-cost inverse and (Philox) generator-side colouring all refreshed -- diag -> full."""
+    import numpy as np
+    from oracle import mppi_oracle as orc, dynamics as dyn, philox as oph
+    K, T, nx, nu = 1200, 20, 8, 4
+    dt = torch.float64
+    g = torch.Generator().manual_seed(11)
+    m = pm.models.Integrator(nx, nu)
+    f, q = (m.dynamics, m.running_cost) if path == "fused" else ((lambda s, a: m.dynamics(s, a)), (lambda s, a: m.running_cost(s, a)))
+    f64, q64 = dyn.make_quadtoy(nx, nu)
+    sig1 = torch.diag(torch.tensor([1.0, 0.5, 2.0, 1.5], dtype=dt))
+    A = torch.randn(nu, nu, generator=g, dtype=dt) * 0.4
+    sig2 = A @ A.T + 0.3 * torch.eye(nu, dtype=dt)
+    mu2 = torch.tensor([0.1, -0.05, 0.0, 0.2], dtype=dt)
+    U0 = torch.randn(T, nu, generator=g, dtype=dt) * 0.05
+    x0 = torch.randn(nx, generator=g, dtype=dt)
+    umax = torch.full((nu,), 1.5, dtype=dt)
+    c = pm.MPPI(f, q, nx, sig1, num_samples=K, horizon=T, device="cuda", lambda_=8.0, U_init=U0.clone(), u_max=umax,
+                rng="philox" if rng == "philox" else "torch", seed=5)
+    assert (not c._needs_generic()) == (path == "fused")
+    U = U0
+    for call, (sig, mu) in enumerate(((sig1, torch.zeros(nu, dtype=dt)), (sig2, mu2), (sig1 * 0.5, mu2 * 0.0)), start=1):
+        if call > 1:
+            c.set_noise(sig, mu)
+        if rng == "philox":
+            z = torch.from_numpy(oph.normals_ktn(5, call, K, T, nu)).to(dt)
+        else:
+            z = torch.randn(K, T, nu, generator=g, dtype=dt)
+            c.inject_noise(z)
+        a = c.command(x0.cuda())
+        p = orc.Problem(dynamics=f64, running_cost=q64, nx=nx, noise_sigma=sig, K=K, T=T, lambda_=8.0, noise_mu=mu, u_max=umax)
+        r = orc.command(p, U, x0, z, True)
+        tol = 1e-9 if rng == "inject" else 1e-5               # Philox: hardware log/sin/cos vs numpy in Box-Muller
+        for got, key in ((a, "action"), (c.U, "U"), (c.cost_total, "cost_total"), (c.omega, "omega"),
+                         (c.perturbed_action, "perturbed_action")):
+            ref = r[key].numpy()
+            err = float(np.abs(got.cpu().numpy() - ref).max())
+            assert err <= tol * max(1.0, float(np.abs(ref).max())), (call, key, err)
+        U = r["U"]
+        c.U = U.cuda()                                        # same nominal sequence on both sides

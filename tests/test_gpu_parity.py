@@ -35,6 +35,7 @@ def _run_fixture(name, native):
     rtol = _tol(cfg)
     if cfg["model"] == "mlp" and cfg["dtype"] == "f32":
         rtol = 5e-5     # the reference's own fp32-vs-fp64 floor on this config is 2-3.5e-5
+    outs64 = gu.oracle_run(cfg, d, torch.float64) if (cfg["kmppi"] and cfg["dtype"] == "f32") else None
     for s in range(cfg["steps"]):
         ctrl.inject_noise(gu.t(d, f"z{s}", dtype))
         act = ctrl.command(state, shift_nominal_trajectory=bool(d[f"shift{s}"]))
@@ -46,17 +47,26 @@ def _run_fixture(name, native):
         if cfg.get("smppi"):
             got["action_sequence"] = ctrl.action_sequence
         for k, v in got.items():
-            kr = rtol
             if cfg["kmppi"] and cfg["dtype"] == "f32":
-                kr = 1e-4   # constant-W operator vs the reference's vmap(solve): SURVEY 3.3
-            _assert_close(v, d[f"{k}{s}"], kr, f"{name} step {s} {k} native={native}")
+                # the fp32 reference solves K (S,S) systems under vmap, the engine applies the constant
+                # operator W = K(Hs,Tk) Ktktk^-1: both are fp32 roundings of the SAME fp64
+                # quantity, so the yardstick is the fp64 oracle with the reference's own fp32 distance
+                # from it as the floor, not a blanket tolerance
+                ref64 = np.asarray(outs64[s][k].numpy(), dtype=np.float64)
+                ref32 = np.asarray(d[f"{k}{s}"], dtype=np.float64)
+                scale = max(1.0, float(np.abs(ref64).max()))
+                floor = float(np.abs(ref32 - ref64).max())
+                err = float(np.abs(v.detach().cpu().numpy().astype(np.float64) - ref64).max())
+                assert err <= max(1e-5 * scale, 2 * floor), (name, s, k, native, err, floor)
+                continue
+            _assert_close(v, d[f"{k}{s}"], rtol, f"{name} step {s} {k} native={native}")
         assert abs(float(ctrl.omega.sum()) - 1.0) < (1e-5 if cfg["dtype"] == "f32" else 1e-12)
         if cfg["sampler_rows"]:
             smp = ctrl.specific_action_sampler
             assert (smp.start_idx, smp.end_idx) == tuple(int(x) for x in d[f"slice{s}"])
 
 
-@pytest.mark.parametrize("name", gu.golden_names())
+@pytest.mark.parametrize("name", gu.golden_names(fused=True))
 def test_fused_path_matches_reference_fixture(name):
     _run_fixture(name, native=True)
 

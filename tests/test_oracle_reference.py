@@ -12,7 +12,8 @@ pytestmark = [pytest.mark.reference,
               pytest.mark.skipif(not ref_loader.reference_available(), reason="no /root/reference here")]
 
 
-@pytest.mark.parametrize("name", ["pendulum_c1_f64", "linear_full_f64", "linear_sampler_f64", "quadtoy_f32"])
+@pytest.mark.parametrize("name", ["pendulum_c1_f64", "linear_full_f64", "linear_sampler_f64", "quadtoy_f32",
+                                  "linear_multi_f64", "linear_multi_f32"])
 def test_oracle_bitwise_vs_live_reference(name):
     mod, proxy = ref_loader.load_reference()
     cfg, d = gu.load(name)
