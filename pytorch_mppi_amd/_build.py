@@ -17,7 +17,7 @@ SUFFIX = os.environ.get("MPPI_LIB_SUFFIX", "")
 LIB = os.path.join(HERE, f"libmppi_amd{SUFFIX}.so")
 OBJ_DIR = os.path.join(CSRC, "build" + SUFFIX)
 SOURCES = ["capi.hip", "update.hip", "rollout_pendulum.hip", "rollout_integrator.hip",
-           "rollout_linear_goal.hip", "rollout_mlp.hip", "rollout_mlp_mfma.hip"]
+           "rollout_linear_goal.hip", "rollout_mlp.hip", "rollout_mlp_mfma.hip", "rollout_mlp_split.hip"]
 # -ffp-contract=fast: mul+add pairs fuse into v_fma / v_pk_fma.  torch eager rounds twice where
 # the kernels round once, a <= 1 ulp difference per operation that the parity tests bound
 # (1e-5 relative fp32, 1e-9 fp64 on every public output of command()).
@@ -27,7 +27,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 
 # per-source extras: the Philox instantiations of K3 only stay scratch-free when their 16-row
 # tile loop is fully unrolled (static accumulator indices), which needs a higher pragma-unroll budget
-EXTRA = {"update.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
+EXTRA = {"update.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
+         # MFMA results straight into VGPRs: every hidden activation is read by the VALU (tanh), and an
+         # AGPR accumulator costs a v_accvgpr_read per value in a VALU-bound kernel
+         "rollout_mlp_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc():

@@ -19,4 +19,7 @@ MPPI_DECL_MODEL(mlp)
 // fp32 MFMA formulation of the MLP rollout (rollout_mlp_mfma.hip)
 bool mlp_mfma_supported(int nx, int nu, int hidden);
 int rollout_mlp_mfma(const KArgs<float>& a, hipStream_t st);
+// bf16 matrix cores with three-piece operand splitting, fp32-level accuracy (rollout_mlp_split.hip)
+bool mlp_split_supported(int nx, int nu, int hidden);
+int rollout_mlp_split(const KArgs<float>& a, hipStream_t st);
 }  // namespace mppi

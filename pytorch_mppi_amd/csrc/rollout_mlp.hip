@@ -20,14 +20,19 @@ template <typename T> static int go(const KArgs<T>& a, hipStream_t st) {
   return MPPI_E_UNSUPPORTED;
 }
 int rollout_mlp(const KArgs<float>& a, hipStream_t st) {
-  // fp32 + (nx,nu)=(16,4) + hidden in {64,128,256}: matrix-core kernel; MPPI_MLP_VALU=1 forces the
-  // per-lane form (A/B measurements, tools/)
+  // fp32 + (nx,nu)=(16,4): matrix-core kernels.  hidden = 256: 16-bit MFMAs on split operands (bf16 x 3
+  // for layer 1, fp16 x 2 for layer 2; fp32-level accuracy, rollout_mlp_split.hip); hidden in {64,128,256} with MPPI_MLP_EXACT=1
+  // (or where the split kernel has no instantiation): the exact-fp32 MFMA kernel, bit-for-bit an fmaf
+  // chain -- the checker of the former.  MPPI_MLP_VALU=1 forces the per-lane form (A/B measurements).
   const char* fv = getenv("MPPI_MLP_VALU");
   const bool force_valu = fv != nullptr && fv[0] == '1';
+  const char* fe = getenv("MPPI_MLP_EXACT");
+  const bool force_exact = fe != nullptr && fe[0] == '1';
   if (!force_valu && a.states == nullptr && a.B == nullptr && a.smooth_w == 0.f &&
       mlp_mfma_supported(a.nx, a.nu, a.hidden)) {
-    // the matrix-core kernel reads the engine's own layout: ask the caller to convert a (K,T,nu) draw
+    // the matrix-core kernels read the engine's own layout: ask the caller to convert a (K,T,nu) draw
     if (a.noise_src == MPPI_NOISE_KTN) return MPPI_E_UNSUPPORTED;
+    if (!force_exact && mlp_split_supported(a.nx, a.nu, a.hidden)) return rollout_mlp_split(a, st);
     return rollout_mlp_mfma(a, st);
   }
   return go(a, st);

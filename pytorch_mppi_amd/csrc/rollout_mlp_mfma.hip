@@ -47,6 +47,16 @@ constexpr int MLP_NX = 16, MLP_NU = 4, MLP_NI = 20;
 constexpr int MLP_NT = MPPI_MLP_NT;
 constexpr int MLP_THREADS = 256 / (16 * MLP_NT) * WAVE;
 
+// component g (lane-dependent) of a row held in registers, as two levels of v_cndmask.  The operands
+// are pinned in VGPRs: left alone, hipcc turns the select into a dynamically indexed load of the
+// array, which forces the row through scratch memory every timestep.
+__device__ __forceinline__ float pick4(const float (&z)[4], int g) {
+  float a0 = z[0], a1 = z[1], a2 = z[2], a3 = z[3];
+  asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+  const float lo = (g & 1) ? a1 : a0, hi = (g & 1) ? a3 : a2;
+  return (g & 2) ? hi : lo;
+}
+
 template <int HT /* hidden / 16 */, int NOISE, bool DIAG>
 __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KArgs<float> a_in) {
   constexpr int NU = MLP_NU, NX = MLP_NX, NT = MLP_NT, H = HT * 16;
@@ -145,18 +155,26 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
     ppart[i] = 0.f;
   }
 
+  // nu = 4: one row-of-4 per (timestep, sample).  Lane (g,s) needs only component g of it unless the
+  // row must be coloured by a full Sigma (or is generated here): a 4-byte load of that component --
+  // picking it out of a loaded float4 with a lane-dependent select makes hipcc index the row
+  // dynamically, i.e. through scratch memory
+  constexpr bool ROW1 = NOISE != MPPI_NOISE_PHILOX && (DIAG || NOISE == MPPI_NOISE_ACTIONS);
   float zc[NT][4], zn[NT][4];
   auto fetch = [&](int t, float (&dst)[NT][4]) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) noise4<float, NOISE == MPPI_NOISE_ACTIONS ? MPPI_NOISE_TNK4 : NOISE>(a, t, kk[i], dst[i]);
+    for (int i = 0; i < NT; ++i) {
+      if constexpr (ROW1) dst[i][0] = a.z[((long long)t * a.K + kk[i]) * 4 + g];
+      else noise4<float, NOISE == MPPI_NOISE_ACTIONS ? MPPI_NOISE_TNK4 : NOISE>(a, t, kk[i], dst[i]);
+    }
   };
-  fetch(0, zn);   // nu = 4: one row-of-4 per (timestep, sample)
+  fetch(0, zn);
 
   for (int t = 0; t < a.Tn; ++t) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) zc[i][c] = zn[i][c];
+      for (int c = 0; c < (ROW1 ? 1 : 4); ++c) zc[i][c] = zn[i][c];
     }
     if constexpr (NOISE == MPPI_NOISE_PHILOX) {
       if (a.z != nullptr && g == 0) {
@@ -173,9 +191,9 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
     for (int i = 0; i < NT; ++i) {
       float v;
       if constexpr (NOISE == MPPI_NOISE_ACTIONS) {
-        v = g == 0 ? zc[i][0] : (g == 1 ? zc[i][1] : (g == 2 ? zc[i][2] : zc[i][3]));
+        v = zc[i][0];                                   // ROW1: component g was loaded
       } else if constexpr (DIAG) {
-        const float zg = g == 0 ? zc[i][0] : (g == 1 ? zc[i][1] : (g == 2 ? zc[i][2] : zc[i][3]));
+        const float zg = ROW1 ? zc[i][0] : pick4(zc[i], g);
         v = fmaf(zg, sd_g, Umt);
       } else {
         float acc = Umt;

@@ -1,0 +1,504 @@
+// K1 for the 2-layer MLP residual model on the 16-bit matrix cores with fp32-level accuracy:
+// every fp32 operand is split into 16-bit pieces and the significant piece products are accumulated
+// in fp32 -- BASELINE.json configs[3..4]: nx=16, nu=4, hidden=256.
+//
+//   x' = x + s * (W2 tanh(W1 [x;u] + b1) + b2),   cost = sum x^2
+//
+// Why: v_mfma_f32_16x16x4_f32 (rollout_mlp_mfma.hip, the exact-fp32 kernel that stays as the
+// checker, MPPI_MLP_EXACT=1) runs at the fp32 VECTOR rate, 32 cycles per instruction, and shares
+// the SIMD's issue with the tanh VALU work: 144 MFMAs x 32 + tanh = ~7000 cycles per (16 samples x
+// 1 timestep), 790 us at C4.  The 16-bit MFMAs (v_mfma_f32_16x16x32_{bf16,f16}) do 8x the MACs in
+// 16 cycles, asynchronously to the VALU.
+//   layer 1 (K = 20 inputs; its B operand is the UNBOUNDED state, so the pieces must keep fp32's
+//     exponent range): bf16 x 3 by truncation, v = hi + mid + lo exactly (8 + 8 + 8 significant bits,
+//     hi = v & 0xFFFF0000, mid = (v - hi) & 0xFFFF0000, lo = v - hi - mid), six of the nine products
+//         a.b ~= lo.hi + hi.lo + mid.mid + mid.hi + hi.mid + hi.hi      (smallest first)
+//     dropping mid.lo, lo.mid, lo.lo <= 2^-23 relative;
+//   layer 2 (K = 256 hidden; its B operand is r = 1/(2^h + 1) in (0,1), 256 activations per sample
+//     and timestep: splitting them is the VALU cost that decides the kernel's speed): fp16 x 2, see
+//     PlanesH below -- three products, 2.5 VALU ops per activation.
+// Measured at C4 (profiles/r02_c4_*): 577 us per launch against 792 us for the exact-fp32 kernel, the
+// same 3.6e-7 relative error on cost_total against the fp64 oracle.  The kernel is bound by VALU
+// ISSUE of its one wave per SIMD (v_exp + v_rcp = 32 of ~48 VALU cycles per activation); the matrix
+// pipe's 16 x 120 = 1920 cycles per (16 samples x timestep) hide behind it.
+//
+// Transposed chain, samples on the MFMA column axis, NO lane permutes or LDS round trips between
+// layers or timesteps.  Lane l = (g = l >> 4, s = l & 15); 16x16x32 operand layout (checked by
+// tools/micro/mfma_bf16_layout.hip): A[i][k] and B[k][j] hold k = 8g + e (e = 0..7) at i = j = s,
+// D[i][j] holds i = 4g + r (r = 0..3) at j = s.
+//   layer 1   H^T (16 hidden x 16 samples) = A1[m] (16 x 32) . B1 (32 x 16)    per hidden tile m
+//       k-slot (g, e):  e < 4 -> state x[4g+e]   e = 4 -> control u[g]   e = 5, g = 0 -> constant 1
+//       (the bias b1 rides in that column of A1)   e = 6, 7 -> 0
+//       => B1 is built from what lane (g,s) already holds: the layer-2 output rows 4g+r and its own
+//          control dimension g.
+//   layer 2   O^T (16 states x 16 samples) = sum_j A2[j] (16 x 32) . B2[j] (32 x 16),  j = 0..H/32-1
+//       k-slot (g, e) of step j = hidden unit 16 (2j + (e >> 2)) + 4g + (e & 3)
+//       => B2[j] is exactly the lane's accumulator registers of hidden tiles 2j and 2j+1.
+// All weights live in registers for the whole launch: H/16 * 3 * 4 (bf16 planes of W1) + H/32 * 2 * 4
+// (fp16 planes of W2) = 256 registers at H = 256 -- one wave per SIMD (512-register budget), two
+// sample tiles per wave.  tanh = 1 - 2r, r = 1 / (2^x + 1): the affine parts are folded into the
+// weights exactly as in the fp32 kernel, only v_exp + v_add + v_rcp run per hidden unit.
+#include <hip/hip_ext.h>
+#include <type_traits>
+#include "actions.hpp"
+#include "dispatch.hpp"
+
+namespace mppi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr float B3_EXP2_SCALE = 2.8853900817779268f;   // 2 * log2(e)
+constexpr int B3_NX = 16, B3_NU = 4, B3_NI = 20;
+constexpr int B3_NT = 2;                                // sample tiles (of 16) per wave
+constexpr int B3_THREADS = 256;                         // 4 waves = one per SIMD
+constexpr int B3_SAMPLES = (B3_THREADS / WAVE) * B3_NT * 16;   // samples per workgroup chunk (128)
+
+// one fp32 value -> its three bf16 pieces, each still an fp32 whose low 16 bits are zero
+struct Split3 { float h, m, l; };
+__device__ __forceinline__ Split3 split3(float v) {
+  Split3 r;
+  r.h = __uint_as_float(__float_as_uint(v) & 0xFFFF0000u);
+  const float r1 = v - r.h;                              // exact
+  r.m = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+  r.l = r1 - r.m;                                        // exact, <= 8 significant bits
+  return r;
+}
+// bf16 pair (lo half = a, hi half = b) out of two fp32 whose bf16 truncation is wanted
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+// eight fp32 -> three bf16x8 planes
+struct Planes { u32x4 h, m, l; };
+__device__ __forceinline__ Planes split_pack8(const float (&v)[8]) {
+  Split3 s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = split3(v[e]);
+  Planes p;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    p.h[q] = pack_bf16(v[2 * q], v[2 * q + 1]);          // truncation = the upper halves as they are
+    p.m[q] = pack_bf16(s[2 * q].m, s[2 * q + 1].m);
+    p.l[q] = pack_bf16(s[2 * q].l, s[2 * q + 1].l);
+  }
+  return p;
+}
+__device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+// acc += a . b with the six significant piece products, smallest first
+__device__ __forceinline__ f32x4 mma6(const Planes& a, const Planes& b, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.l), as_bf(b.h), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.h), as_bf(b.l), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.m), as_bf(b.m), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.m), as_bf(b.h), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.h), as_bf(b.m), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.h), as_bf(b.h), acc, 0, 0, 0);
+  return acc;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void b3_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    b3_static_for<I + 1, N>(f);
+  }
+}
+
+// product pr of the six: 0 l.h | 1 h.l | 2 m.m | 3 m.h | 4 h.m | 5 h.h   (a = weights, b = inputs).
+// `pr` is a constant after unrolling: the selects fold.
+__device__ __forceinline__ f32x4 mfma_p(const Planes& a, const Planes& b, int pr, f32x4 acc) {
+  const u32x4& pa = (pr == 0) ? a.l : ((pr == 2 || pr == 3) ? a.m : a.h);
+  const u32x4& pb = (pr == 1) ? b.l : ((pr == 2 || pr == 4) ? b.m : b.h);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(pa), as_bf(pb), acc, 0, 0, 0);
+}
+
+// Layer 2 (K = hidden = 256 per output, its B operand = the 256 activations r per sample and
+// timestep: the VALU-bound part of the kernel) runs on v_mfma_f32_16x16x32_f16 with TWO-piece fp16
+// operands: 11 + 11 significant bits per operand against 8 + 8 + 8 for bf16, so three MFMAs per
+// k-step instead of six and 2.5 VALU ops per activation for the split instead of 5.5
+// (v_cvt_pk_f16_f32 packs a pair, round to nearest; the residual is one v_pk_add_f32):
+//   r  in (0,1)   = rh + rm,        rm = fp16(r - rh) unscaled: |r - rh - rm| <= 2^-25 absolute
+//   W' = -2 W2    = Wh + 2^-11 Wm,  Wm = fp16((W' - Wh) * 2^11): relative error <= 2^-22
+//   W'.r ~= Wh.rh + Wh.rm  (one accumulator pair)  +  2^-11 * Wm.rh  (its own accumulator)
+// dropping Wm.rm <= 2^-22 relative: ~3e-7 rms per term, unbiased, ~2e-8 relative after the 256-term
+// sum -- below the fp32 rounding of the activations themselves.  fp16's range is no issue here: r is
+// in (0,1) and the weights are bounded by the model (|W2| < 3e4 is checked on the host,
+// models.MLPResidual); layer 1, whose B operand is the unbounded state, keeps bf16 x 3.
+struct PlanesH { u32x4 h, m; };
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+constexpr float B3_MID_SCALE = 2048.0f, B3_MID_UNSCALE = 1.0f / 2048.0f;
+__device__ __forceinline__ unsigned cvt_pk_f16(f32x2 v) {       // v_cvt_pk_f16_f32, round to nearest even
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ f32x2 f16pair_to_f32(unsigned p) {   // v_cvt_f32_f16 (+ SDWA for the high half)
+  return __builtin_convertvector(__builtin_bit_cast(f16x2_t, p), f32x2);
+}
+__device__ __forceinline__ f32x4 mfma_h(const u32x4& a, const u32x4& b, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+// eight fp32 weights -> {fp16 hi, fp16 of the 2^11-scaled residual}
+__device__ __forceinline__ PlanesH split_pack8_h(const float (&v)[8]) {
+  PlanesH p;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 w = {v[2 * q], v[2 * q + 1]};
+    const unsigned hp = cvt_pk_f16(w);
+    p.h[q] = hp;
+    p.m[q] = cvt_pk_f16((w - f16pair_to_f32(hp)) * f32x2{B3_MID_SCALE, B3_MID_SCALE});
+  }
+  return p;
+}
+
+// r = 1 / (2^x + 1)  (tanh = 1 - 2r with the affine parts folded into the weights)
+__device__ __forceinline__ float sigm2(float x_exp2_units) {
+  return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x_exp2_units) + 1.0f);
+}
+
+}  // namespace
+
+// component g (lane-dependent) of a row held in registers, as two levels of v_cndmask.  The operands
+// are pinned in VGPRs: left alone, hipcc turns the select into a dynamically indexed load of the
+// array, which forces the row through scratch memory every timestep.
+__device__ __forceinline__ float pick4(const float (&z)[4], int g) {
+  float a0 = z[0], a1 = z[1], a2 = z[2], a3 = z[3];
+  asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+  const float lo = (g & 1) ? a1 : a0, hi = (g & 1) ? a3 : a2;
+  return (g & 2) ? hi : lo;
+}
+
+template <int HT /* hidden / 16 */, int NOISE, bool DIAG>
+__global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const KArgs<float> a_in) {
+  static_assert(HT % 2 == 0, "layer 2 consumes hidden tiles in pairs");
+  constexpr int NU = B3_NU, NX = B3_NX, NT = B3_NT, H = HT * 16, HP = HT / 2;
+  const KArgs<float> a = env_view(a_in);
+  if (a.tstamp != nullptr && threadIdx.x == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* Ue = reinterpret_cast<float*>(smem_raw);   // [J]
+  float* Um = Ue + a.J;                             // [J]
+  float* G = Um + a.J;                              // [J]
+  float* fac = G + a.J;                             // [2*NU*NU]
+
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int g = lane >> 4, s = lane & 15;
+
+  // ---- parameters: blob = W1 (H,20) | b1 (H) | W2 (16,H) | b2 (16) | res_scale ----
+  const float* __restrict__ W1 = a.mp;
+  const float* __restrict__ b1 = W1 + H * B3_NI;
+  const float* __restrict__ W2 = b1 + H;
+  const float* __restrict__ b2 = W2 + NX * H;
+  const float rs = b2[NX];
+
+  // A fragments, three bf16 planes each, resident for the whole launch
+  Planes A1[HT];
+  PlanesH A2[HP];
+#pragma unroll
+  for (int m = 0; m < HT; ++m) {
+    const float* __restrict__ row = W1 + (16 * m + s) * B3_NI;     // hidden unit 16m + s
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = B3_EXP2_SCALE * row[4 * g + e];
+    v[4] = B3_EXP2_SCALE * row[NX + g];
+    v[5] = g == 0 ? B3_EXP2_SCALE * b1[16 * m + s] : 0.f;          // bias column (B1 holds 1 there)
+    v[6] = 0.f; v[7] = 0.f;
+    A1[m] = split_pack8(v);
+  }
+  float rowsum = 0.f;                                              // of row s of W2, this lane's quarter
+#pragma unroll
+  for (int j = 0; j < HP; ++j) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float w = W2[s * H + 16 * (2 * j + (e >> 2)) + 4 * g + (e & 3)];   // state row s, hidden h(j,g,e)
+      rowsum += w;
+      v[e] = -2.0f * w;
+    }
+    A2[j] = split_pack8_h(v);
+  }
+  rowsum += __shfl_xor(rowsum, 16, WAVE);
+  rowsum += __shfl_xor(rowsum, 32, WAVE);
+  float b2r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b2r[r] = b2[4 * g + r] + __shfl(rowsum, 4 * g + r, WAVE);   // D rows are 4g+r
+
+  ActionConsts<float, NU> ac;
+  ac.load(a, DIAG ? nullptr : fac);
+  for (int j = threadIdx.x; j < a.J; j += B3_THREADS) Ue[j] = u_eff(a, j);
+  __syncthreads();
+  for (int j = threadIdx.x; j < a.J; j += B3_THREADS) {
+    const int n = j % NU, t0 = j - n;
+    const float uj = Ue[j];
+    Um[j] = a.coloured ? uj : uj + a.mu[n];
+    float gg;
+    if constexpr (DIAG) {
+      if (a.coloured && !a.diag) {          // generator-coloured full Sigma: whole-row G from global
+        gg = 0.f;
+        for (int m = 0; m < NU; ++m) gg = fmaf(a.sinv[n * NU + m], Ue[t0 + m], gg);
+      } else {
+        gg = uj * a.sinv[n * NU + n];
+      }
+    } else {
+      gg = 0.f;
+      for (int m = 0; m < NU; ++m) gg = fmaf(ac.Sm[n * NU + m], Ue[t0 + m], gg);
+    }
+    G[j] = a.lambda_ * gg;
+  }
+  __syncthreads();
+  const float sd_g = a.coloured ? 1.f : a.L[g * NU + g], lo_g = a.umin[g], hi_g = a.umax[g];
+  float Lrow[NU];
+  if constexpr (!DIAG) {
+#pragma unroll
+    for (int m = 0; m < NU; ++m) Lrow[m] = ac.Lm[g * NU + m];
+  }
+
+  // ---- persistent over 128-sample chunks: the 288 weight registers are loaded once per workgroup ----
+  const int nchunks = (a.K + B3_SAMPLES - 1) / B3_SAMPLES;
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int kbase = chunk * B3_SAMPLES + wv * (NT * 16);
+    int kk[NT], orow[NT];
+    bool act[NT];
+    float x[NT][4], cpart[NT], ppart[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int kraw = kbase + 16 * i + s;
+      act[i] = kraw < a.K;
+      kk[i] = act[i] ? kraw : a.K - 1;
+      orow[i] = overwrite_row(a, a.k_offset + kk[i]);
+      const float* __restrict__ s0 = a.state_per_sample ? a.state + (long long)kk[i] * NX : a.state;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[i][r] = s0[4 * g + r];
+      cpart[i] = 0.f;
+      ppart[i] = 0.f;
+    }
+
+    // nu = 4: one row-of-4 per (timestep, sample).  Lane (g,s) needs only component g of it unless the
+    // row must be coloured by a full Sigma (or is generated here): a 4-byte load of that component --
+    // picking it out of a loaded float4 with a lane-dependent select makes hipcc index the row
+    // dynamically, i.e. through scratch memory
+    constexpr bool ROW1 = NOISE != MPPI_NOISE_PHILOX && (DIAG || NOISE == MPPI_NOISE_ACTIONS);
+    float zc[NT][4], zn[NT][4];
+    auto fetch = [&](int t, float (&dst)[NT][4]) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        if constexpr (ROW1) dst[i][0] = a.z[((long long)t * a.K + kk[i]) * 4 + g];
+        else noise4<float, NOISE == MPPI_NOISE_ACTIONS ? MPPI_NOISE_TNK4 : NOISE>(a, t, kk[i], dst[i]);
+      }
+    };
+    fetch(0, zn);
+
+    for (int t = 0; t < a.Tn; ++t) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int c = 0; c < (ROW1 ? 1 : 4); ++c) zc[i][c] = zn[i][c];
+      }
+      if constexpr (NOISE == MPPI_NOISE_PHILOX) {
+        if (a.z != nullptr && g == 0) {
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+            if (act[i]) store4<float>(const_cast<float*>(a.z), a.K, t, kk[i], zc[i]);
+        }
+      }
+      fetch(t + 1 < a.Tn ? t + 1 : t, zn);   // prefetch the next step's rows (compute >> latency here)
+
+      // ---- actions (identical to the fp32 matrix-core kernel): lane (g,s) owns control dimension g ----
+      const float Ut = Ue[t * NU + g], Umt = Um[t * NU + g], Gt = G[t * NU + g];
+      Planes B1[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        float v;
+        if constexpr (NOISE == MPPI_NOISE_ACTIONS) {
+          v = zc[i][0];                                   // ROW1: component g was loaded
+        } else if constexpr (DIAG) {
+          const float zg = ROW1 ? zc[i][0] : pick4(zc[i], g);
+          v = fmaf(zg, sd_g, Umt);
+        } else {
+          float acc = Umt;
+#pragma unroll
+          for (int m = 0; m < NU; ++m) acc = fmaf(zc[i][m], Lrow[m], acc);
+          v = acc;
+        }
+        if (orow[i] == -1) v = 0.f;
+        else if (orow[i] >= 0) v = a.sampler[((long long)orow[i] * a.Tn + t) * NU + g];
+        v = clampT(v, lo_g, hi_g);
+        const float e = v - Ut;
+        ppart[i] = fmaf(Gt, ac.abs_cost ? fabsf(e) : e, ppart[i]);
+        const float in[8] = {x[i][0], x[i][1], x[i][2], x[i][3], a.u_scale * v, g == 0 ? 1.0f : 0.0f, 0.f, 0.f};
+        B1[i] = split_pack8(in);
+      }
+
+      // ---- the two layers as an explicit software pipeline --------------------------------------
+      // Cycle budget per (16 samples x 1 timestep) on one SIMD (wave64 VALU op = 4 cycles, v_exp /
+      // v_rcp = 16, MFMA 16x16x32 = 16 with a 4-cycle issue): 144 MFMAs = 2304 cycles of matrix pipe,
+      // and per hidden activation exp + add + rcp (36) + split / pack (~22) = ~58 VALU cycles x 64
+      // activations per lane = ~3700-4200: the kernel is VALU-bound, and an in-order wave only overlaps
+      // the matrix pipe with VALU work that sits BETWEEN its MFMAs.  Two further rules:
+      //  * a dependent MFMA (same accumulator) cannot issue until its predecessor has drained, so the
+      //    six piece products never go back to back into one register quad: layer 1 round-robins
+      //    the 2 hidden tiles x NT sample tiles of a pair (same accumulator every 4th layer-1 slot);
+      //    layer 2 keeps three accumulators per sample tile, one per magnitude class of the products
+      //    (small: l.h h.l m.m | middle: m.h h.m | big: h.h), summed once per timestep;
+      //  * pair j's activation work B(j) runs between the MFMAs of layer 1 of pair j+1, A(j+1), and of
+      //    layer 2 of pair j-1, C(j-1) (both independent of it; Hc and B2 are double-buffered).
+      // sched_barrier(0) after every slot keeps hipcc's scheduler from re-clustering the slots.
+      f32x4 Os[NT], Om[NT], Ob[NT];
+      f32x4 Hc[2][2][NT];                      // [buffer][hidden tile of the pair][sample tile]
+      float rr[NT][8];                         // r = 1/(2^h+1) of the pair's 8 hidden units per lane
+      PlanesH B2[2][NT];                       // [buffer][sample tile]: fp16 hi | fp16 residual
+      const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      static_assert(NT == 2, "slot decoding assumes two sample tiles per wave");
+      auto layer1_slot = [&](auto jn_c, auto slot_c) {             // slot 0..23 of pair jn: A(jn)
+        constexpr int jn = decltype(jn_c)::value, slot = decltype(slot_c)::value;
+        constexpr int pr = slot >> 2, q = (slot >> 1) & 1, i = slot & 1, buf = jn & 1;
+        Hc[buf][q][i] = mfma_p(A1[2 * jn + q], B1[i], pr, pr == 0 ? zero4 : Hc[buf][q][i]);
+      };
+      auto layer2_slot = [&](auto jc_c, auto slot_c) {             // slot 0..5 of k-step jc: C(jc)
+        constexpr int jc = decltype(jc_c)::value, slot = decltype(slot_c)::value;
+        // Wh.rh -> Ob | Wh.rm -> Om | Wm.rh -> Os (2^11-scaled), each for both sample tiles: every
+        // accumulator is touched once per k-step, i.e. dependent MFMAs are a whole iteration apart
+        constexpr int pr = slot >> 1, i = slot & 1, buf = jc & 1;
+        if constexpr (pr == 0) Ob[i] = mfma_h(A2[jc].h, B2[buf][i].h, jc == 0 ? zero4 : Ob[i]);
+        else if constexpr (pr == 1) Om[i] = mfma_h(A2[jc].h, B2[buf][i].m, jc == 0 ? zero4 : Om[i]);
+        else Os[i] = mfma_h(A2[jc].m, B2[buf][i].h, jc == 0 ? zero4 : Os[i]);
+      };
+      auto valu_unit = [&](auto j_c, auto unit_c) {                // unit 0..15 of B(j): 8 value pairs x 2 phases
+        constexpr int j = decltype(j_c)::value, unit = decltype(unit_c)::value;
+        constexpr int pair = unit >> 1, phase = unit & 1, buf = j & 1;
+        constexpr int i = pair >> 2, q = pair & 3, e0 = 2 * q;
+        // plain scalar fp32 adds on purpose: v_pk_add_f32 is no faster than two v_add_f32 on gfx950
+        // (and measurably slower next to MFMAs), and hipcc pads the trans -> VALU forwarding hazard
+        // only for instructions it emits itself
+        if constexpr (phase == 0) {
+          rr[i][e0] = sigm2(Hc[buf][e0 >> 2][i][e0 & 3]);
+          rr[i][e0 + 1] = sigm2(Hc[buf][(e0 + 1) >> 2][i][(e0 + 1) & 3]);
+        } else {
+          const unsigned hp = cvt_pk_f16(f32x2{rr[i][e0], rr[i][e0 + 1]});   // round-to-nearest fp16 hi pieces
+          const f32x2 hf = f16pair_to_f32(hp);
+          const float r1a = rr[i][e0] - hf.x, r1b = rr[i][e0 + 1] - hf.y;     // exact
+          B2[buf][i].h[q] = hp;
+          B2[buf][i].m[q] = cvt_pk_f16(f32x2{r1a, r1b});                      // |r - hi - mid| <= 2^-25
+        }
+      };
+      // A(0): layer 1 of the first pair, nothing to overlap it with
+      b3_static_for<0, 24>([&](auto sc) {
+        layer1_slot(std::integral_constant<int, 0>{}, sc);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      b3_static_for<0, HP>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr bool hasA = j + 1 < HP, hasC = j >= 1;
+        constexpr int nA = hasA ? 24 : 0, nC = hasC ? 6 : 0, N = nA + nC;   // MFMA slots of this iteration
+        b3_static_for<0, N>([&](auto sc) {
+          constexpr int sl = decltype(sc)::value;
+          // the nC layer-2 slots spread evenly among the nA layer-1 slots
+          constexpr int c_before = (sl * nC) / N, c_after = ((sl + 1) * nC) / N;
+          if constexpr (c_after > c_before) layer2_slot(std::integral_constant<int, (j >= 1 ? j - 1 : 0)>{},
+                                                        std::integral_constant<int, c_before>{});
+          else layer1_slot(std::integral_constant<int, (hasA ? j + 1 : 0)>{}, std::integral_constant<int, sl - c_before>{});
+          // B(j)'s 16 VALU units spread evenly over the N slots
+          b3_static_for<(sl * 16) / N, ((sl + 1) * 16) / N>([&](auto uc) { valu_unit(jc, uc); });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      // C(HP-1): the last k-step of layer 2
+      b3_static_for<0, 6>([&](auto sc) {
+        layer2_slot(std::integral_constant<int, HP - 1>{}, sc);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      f32x4 O[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) O[i] = (Ob[i] + Om[i]) + B3_MID_UNSCALE * Os[i];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          x[i][r] = fmaf(rs, O[i][r] + b2r[r], x[i][r]);
+          cpart[i] = fmaf(x[i][r], x[i][r], cpart[i]);
+        }
+      }
+    }
+
+    // ---- per-sample totals: sum the 4 lane groups (dims 4g..4g+3 / control dim g) ----
+    float bm = inf_v<float>();
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      float c = cpart[i], p = ppart[i];
+      c += __shfl_xor(c, 16, WAVE); c += __shfl_xor(c, 32, WAVE);
+      p += __shfl_xor(p, 16, WAVE); p += __shfl_xor(p, 32, WAVE);
+      const float total = c + p;
+      if (act[i] && g == 0) {
+        a.cost[kk[i]] = total;
+        if (a.pert != nullptr) a.pert[kk[i]] = p;
+      }
+      if (act[i]) bm = fminf(bm, total);
+    }
+    // minima are kept per 64 consecutive samples: this wave's 32 samples are half of slot kbase/64;
+    // the two waves sharing a slot combine through LDS
+    bm = wave_min(bm);
+    __shared__ float red[B3_THREADS / WAVE];
+    __syncthreads();
+    if (lane == 0) red[wv] = bm;
+    __syncthreads();
+    if (lane == 0 && (wv & 1) == 0) {
+      const int slot = kbase / WAVE;
+      if (slot < a.nb1) a.block_min[slot] = fminf(red[wv], red[wv + 1]);
+    }
+  }
+  if (a.tstamp != nullptr) {
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
+  }
+}
+
+template <int HT>
+static int launch_b3(const KArgs<float>& a_in, hipStream_t st) {
+  KArgs<float> a = a_in;
+  const bool diag = a.diag != 0 || a.coloured != 0;
+  const size_t smem = (size_t)(3 * a.J + 2 * B3_NU * B3_NU) * sizeof(float);
+  if (smem > 60 * 1024) return MPPI_E_UNSUPPORTED;
+  const int nchunks = (a.K + B3_SAMPLES - 1) / B3_SAMPLES;
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  int gx = nchunks;
+  const int cap = n_cu / (a.n_env > 1 ? a.n_env : 1);
+  if (gx > (cap > 1 ? cap : 1)) gx = cap > 1 ? cap : 1;       // one workgroup per CU, persistent over its chunks
+  const dim3 grid(gx, 1, a.n_env), block(B3_THREADS);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  profile_next_events(&ev0, &ev1, &a.tstamp);
+#define MPPI_LAUNCH1(KERNEL)                                                                         \
+  do {                                                                                               \
+    if (ev0 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a);        \
+    else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, a);                                       \
+  } while (0)
+#define MPPI_LAUNCH(NOISE_)                                                                          \
+  do {                                                                                               \
+    if (diag) MPPI_LAUNCH1((rollout_mlp_split_kernel<HT, NOISE_, true>));                           \
+    else MPPI_LAUNCH1((rollout_mlp_split_kernel<HT, NOISE_, false>));                               \
+  } while (0)
+  if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCH(MPPI_NOISE_PHILOX);
+  else if (a.noise_src == MPPI_NOISE_ACTIONS) MPPI_LAUNCH(MPPI_NOISE_ACTIONS);
+  else MPPI_LAUNCH(MPPI_NOISE_TNK4);
+#undef MPPI_LAUNCH
+#undef MPPI_LAUNCH1
+  return (int)hipGetLastError();
+}
+
+bool mlp_split_supported(int nx, int nu, int hidden) {
+  return nx == B3_NX && nu == B3_NU && hidden == 256;
+}
+
+int rollout_mlp_split(const KArgs<float>& a, hipStream_t st) {
+  if (a.mp == nullptr) return MPPI_E_BADARG;
+  if (!mlp_split_supported(a.nx, a.nu, a.hidden) || a.states != nullptr) return MPPI_E_UNSUPPORTED;
+  return launch_b3<16>(a, st);
+}
+
+}  // namespace mppi

@@ -144,6 +144,10 @@ class MLPResidual(NativeModel):
         self.hidden = int(self.W1.shape[0])
         self.res_scale = float(res_scale)
         assert self.W1.shape == (self.hidden, self.nx + self.nu) and self.W2.shape == (self.nx, self.hidden)
+        # the matrix-core kernel runs layer 2 on two-piece fp16 operands (csrc/rollout_mlp_split.hip):
+        # its weights (-2 W2) must stay inside fp16's range
+        if float(self.W2.abs().max()) >= 3.0e4:
+            raise ValueError("MLPResidual: |W2| >= 3e4 is outside the fused matrix-core kernel's operand range")
 
     @classmethod
     def random(cls, nx, nu, hidden, seed=2, dtype=torch.float32, res_scale=0.1):

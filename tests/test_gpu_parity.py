@@ -220,11 +220,14 @@ def test_size_independent_properties_at_full_size():
 
 
 @pytest.mark.parametrize("H,K,full_sigma,per_sample,rng", [(256, 1000, False, False, "torch"), (128, 257, True, True, "torch"),
-                                                            (64, 4096, False, False, "philox")])
-def test_mlp_mfma_kernel_matches_valu_kernel_and_fp64_oracle(H, K, full_sigma, per_sample, rng, monkeypatch):
-    """fp32 MFMA formulation of the MLP rollout (csrc/rollout_mlp_mfma.hip) against (a) the per-lane
-    VALU kernel of the same model and (b) the fp64 oracle; ragged K (tail tiles), full Sigma,
-    per-sample initial states, null-action row, Philox generate-once."""
+                                                            (64, 4096, False, False, "philox"), (256, 300, True, True, "philox"),
+                                                            (256, 2500, False, False, "philox")])
+def test_mlp_matrix_core_kernels_match_valu_kernel_and_fp64_oracle(H, K, full_sigma, per_sample, rng, monkeypatch):
+    """The MLP rollout on the matrix cores -- 16-bit MFMAs on split operands, bf16 x 3 / fp16 x 2
+    (csrc/rollout_mlp_split.hip, the default at hidden = 256) and the exact-fp32 MFMA kernel
+    (csrc/rollout_mlp_mfma.hip, MPPI_MLP_EXACT=1, every hidden width) -- against (a) the per-lane VALU
+    kernel of the same model and (b) the fp64 oracle; ragged K (tail tiles / partial chunks), full
+    Sigma, per-sample initial states, null-action row, Philox generate-once."""
     import pytorch_mppi_amd as pm
     from oracle import mppi_oracle as orc, dynamics as dyn, philox as oph
     T, nx, nu = 12, 16, 4
@@ -235,8 +238,9 @@ def test_mlp_mfma_kernel_matches_valu_kernel_and_fp64_oracle(H, K, full_sigma, p
     sig = torch.tensor([[1.0, 0.3, 0, 0], [0.3, 0.8, 0, 0], [0, 0, 0.5, 0.1], [0, 0, 0.1, 1.2]]) if full_sigma else torch.eye(nu)
     umax = torch.tensor([1.5] * nu)
 
-    def run(force_valu):
-        monkeypatch.setenv("MPPI_MLP_VALU", "1" if force_valu else "0")
+    def run(kernel):
+        monkeypatch.setenv("MPPI_MLP_VALU", "1" if kernel == "valu" else "0")
+        monkeypatch.setenv("MPPI_MLP_EXACT", "1" if kernel == "exact" else "0")
         c = pm.MPPI(model.dynamics, model.running_cost, nx, sig, num_samples=K, horizon=T, device="cuda", lambda_=5.0,
                     U_init=U0.clone(), u_min=-umax, u_max=umax, sample_null_action=True, rng=rng, seed=77)
         if rng == "torch":
@@ -245,19 +249,22 @@ def test_mlp_mfma_kernel_matches_valu_kernel_and_fp64_oracle(H, K, full_sigma, p
         return c, a
 
     z = torch.randn(K, T, nu, generator=g) if rng == "torch" else torch.from_numpy(oph.normals_ktn(77, 1, K, T, nu))
-    c_m, a_m = run(False)
-    c_v, a_v = run(True)
+    c_b, a_b = run("split")            # hidden != 256: falls to the exact kernel
+    c_m, a_m = run("exact")
+    c_v, a_v = run("valu")
     f, q = dyn.make_mlp(*[t.double() for t in (model.W1, model.b1, model.W2, model.b2)])
     p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=sig.double(), K=K, T=T, lambda_=5.0,
                     u_min=-umax.double(), u_max=umax.double(), sample_null_action=True)
     r = orc.command(p, U0.double(), x0.double(), z.double(), True)
     tol = 1e-5 if rng == "torch" else 5e-5       # Philox: hardware log/sin/cos in Box-Muller vs numpy
-    for c, a, name in ((c_m, a_m, "mfma"), (c_v, a_v, "valu")):
+    for c, a, name in ((c_b, a_b, "split-16bit"), (c_m, a_m, "mfma-fp32"), (c_v, a_v, "valu")):
         _assert_close(c.cost_total, r["cost_total"].numpy(), tol, f"{name} cost_total")
         _assert_close(a, r["action"].numpy(), tol, f"{name} action")
         _assert_close(c.U, r["U"].numpy(), tol, f"{name} U")
     assert torch.allclose(c_m.cost_total, c_v.cost_total, rtol=2e-6, atol=0)
+    assert torch.allclose(c_b.cost_total, c_m.cost_total, rtol=5e-6, atol=0)     # split products: ~2 ulp per term
     assert torch.equal(c_m.perturbed_action, c_v.perturbed_action)
+    assert torch.equal(c_b.perturbed_action, c_v.perturbed_action)
 
 
 @pytest.mark.parametrize("name", gu.golden_names(batched=True))

@@ -53,8 +53,9 @@ def timeit(fn, n=40, rotate=True, hook=False):
 k1 = lambda: N.check(lib.mppi_rollout_cost(C.byref(p), st), "k1")
 k3 = lambda: N.check(lib.mppi_weights_partial(C.byref(p), st), "k3")
 tag = f"K={K} NBUF={NBUF} MPPI_K1_DMA={os.environ.get('MPPI_K1_DMA', 'auto')} MPPI_K3_DMA={os.environ.get('MPPI_K3_DMA', 'auto')}"
-for name, fn, hook in (("K1 rollout_cost", k1, True), ("K3 weights_partial", k3, False)):
-    for rot in (True, False):
+only_cold = os.environ.get("ONLY_COLD") == "1"       # K1, rotating buffers only (clean rocprofv3 trace)
+for name, fn, hook in ((("K1 rollout_cost", k1, True),) if only_cold else (("K1 rollout_cost", k1, True), ("K3 weights_partial", k3, False))):
+    for rot in ((True,) if only_cold else (True, False)):
         med, mn, dev = timeit(fn, rotate=rot, hook=hook)
         d = f"device-clock avg {dev:7.1f} us -> {alg / dev / 1e3:7.1f} GB/s ({alg / dev / 1e3 / 8000 * 100:4.1f}% of 8 TB/s)" if dev else ""
         print(f"[{tag}] {name:20s} {'HBM-cold (rotating)' if rot else 'cache-warm (1 buf)':20s} "

@@ -1,4 +1,4 @@
-// Standalone check (GPU) of the operand layout assumed by csrc/rollout_mlp_bf16x3.hip for
+// Standalone check (GPU) of the operand layout assumed by csrc/rollout_mlp_split.hip for
 // v_mfma_f32_16x16x32_bf16:  A[i][k]: lane l holds i = l & 15, k = 8*(l >> 4) + e (e = 0..7, two per VGPR,
 // low half first);  B[k][j]: lane l holds j = l & 15, k = 8*(l >> 4) + e;  D[i][j]: lane l holds
 // j = l & 15, i = 4*(l >> 4) + r.  A = asymmetric random bf16-exact integers, B likewise; compares with
