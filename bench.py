@@ -296,11 +296,21 @@ def main():
         # C4/C5: the rollout is a chain of two dense layers per state evaluation -> fp32 MFMA bound
         flops = 2.0 * ((nx + nu) * 256 + 256 * nx) * Klocal * T
         ach = flops / (k1_ms * 1e-3) / 1e12
+        exact = os.environ.get("MPPI_MLP_EXACT") == "1"
+        # what the matrix pipe actually executes in the split kernel: per (16 samples x timestep) 96 bf16
+        # + 24 fp16 MFMAs of 16x16x32 (2*16*16*32 flop each); the exact kernel executes the algorithmic flops
+        executed = flops if exact else 120 * 2.0 * 16 * 16 * 32 * (Klocal / 16) * T
         roofline = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                    "kernel": "rollout_mlp_mfma_kernel", "avg_launch_us": k1_ms * 1e3,
+                    "kernel": "rollout_mlp_mfma_kernel (fp32 MFMA)" if exact else "rollout_mlp_split_kernel (bf16x3 / fp16x2 MFMA)",
+                    "avg_launch_us": k1_ms * 1e3,
                     "avg_launch_us_hip_events": k1_ms_events * 1e3,
-                    "algorithmic_flops": flops}
+                    "algorithmic_flops": flops,
+                    "peak_note": "peak = dense fp32 MFMA (157.3 TFLOP/s): the path computes in fp32 (dtype f32, results at fp32 "
+                                 "accuracy); `achieved` = algorithmic fp32 flops / launch time",
+                    "executed_mfma_tflops": executed / (k1_ms * 1e-3) / 1e12,
+                    "executed_frac_of_bf16_dense_peak": None if exact else executed / (k1_ms * 1e-3) / 1e12 / 2500.0,
+                    "limiter": "VALU issue of one wave per SIMD (v_exp + v_rcp per hidden activation), not the matrix pipe"}
     elif k1:
         if ctrl.last_draw == "philox-k1":
             # no-HBM mode: the normals never exist in memory; report the time against the

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 12
+#define MPPI_ABI_VERSION 13
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -63,7 +63,8 @@ enum {
 enum {
   MPPI_E_BADARG = -1,      /* null pointer / inconsistent sizes                            */
   MPPI_E_UNSUPPORTED = -2, /* no kernel instantiated for this (model, nx, nu, dtype, ...)  */
-  MPPI_E_WORKSPACE = -3    /* workspace too small                                          */
+  MPPI_E_WORKSPACE = -3,   /* workspace too small                                          */
+  MPPI_E_DIST = -4         /* RCCL reported an error (message in mppi_last_error)          */
 };
 
 /* One command()'s worth of inputs/outputs.  Pointers marked [opt] may be NULL. */
@@ -205,6 +206,22 @@ int mppi_command(const MppiProblem* p, int apply, void* stream);
  * on every rank: beta = min beta_g; s_g = exp(-(beta_g-beta)/lambda); eta = sum s_g eta_g;
  * U_out = shift(U) + sum s_g P_g / eta; rescales this shard's omega. */
 int mppi_combine(const MppiProblem* p, const void* records, int32_t n_shards, void* stream);
+
+/* Multi-GPU exchange (the reference has none): K is sharded over one process per GPU,
+ * the only data-path collective of a command is ONE all-gather of the (2 + T*nu)-element shard
+ * record, issued through RCCL's C API on the CALLER'S stream (RCCL is bound at run time with
+ * dlsym/dlopen; mppi_dist_available() says whether it was found).  Bootstrap: rank 0 obtains an id
+ * with mppi_dist_unique_id (128 bytes), ships it to the other ranks by any means (e.g. a
+ * torch.distributed broadcast at start-up), every rank calls mppi_dist_init.
+ *   mppi_exchange_combine  ncclAllGather(p->record -> records[world_size][2+J]) then mppi_combine (K5)
+ *   mppi_command_sharded   mppi_command(apply = 0) + mppi_exchange_combine: one sharded command of
+ *                          the fused path as ONE call, five launches on one stream, no host hop    */
+int mppi_dist_available(void);
+int mppi_dist_unique_id(void* id128);
+int mppi_dist_init(const void* id128, int32_t rank, int32_t world_size, void** comm_out);
+int mppi_dist_destroy(void* comm);
+int mppi_exchange_combine(const MppiProblem* p, void* comm, void* records, int32_t world_size, void* stream);
+int mppi_command_sharded(const MppiProblem* p, void* comm, void* records, int32_t world_size, void* stream);
 
 /* User models.  The reference's plugin API is "any Python callable" (mppi.py:63-64); the fused
  * equivalent is a device functor {step, cost, terminal} that pytorch_mppi_amd/jit.py wraps around

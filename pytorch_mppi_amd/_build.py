@@ -16,7 +16,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SUFFIX = os.environ.get("MPPI_LIB_SUFFIX", "")
 LIB = os.path.join(HERE, f"libmppi_amd{SUFFIX}.so")
 OBJ_DIR = os.path.join(CSRC, "build" + SUFFIX)
-SOURCES = ["capi.hip", "update.hip", "rollout_pendulum.hip", "rollout_integrator.hip",
+SOURCES = ["capi.hip", "dist.hip", "update.hip", "rollout_pendulum.hip", "rollout_integrator.hip",
            "rollout_linear_goal.hip", "rollout_mlp.hip", "rollout_mlp_mfma.hip", "rollout_mlp_split.hip"]
 # -ffp-contract=fast: mul+add pairs fuse into v_fma / v_pk_fma.  torch eager rounds twice where
 # the kernels round once, a <= 1 ulp difference per operation that the parity tests bound
@@ -76,7 +76,7 @@ def build(force=False, verbose=True):
 
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(one, srcs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -9,11 +9,12 @@ import os
 
 from . import _build
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
 E_UNSUPPORTED = -2
+E_DIST = -4
 MODEL_NONE, MODEL_PENDULUM, MODEL_INTEGRATOR, MODEL_LINEAR_GOAL, MODEL_MLP = 0, 1, 2, 3, 4
 MODEL_CUSTOM_BASE = 100
 
@@ -66,6 +67,12 @@ SYMBOLS = {
     "mppi_command": (C.c_int, [_PP, C.c_int, _vp]),
     "mppi_combine": (C.c_int, [_PP, _vp, C.c_int32, _vp]),
     "mppi_register_model": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    "mppi_dist_available": (C.c_int, []),
+    "mppi_dist_unique_id": (C.c_int, [_vp]),
+    "mppi_dist_init": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "mppi_dist_destroy": (C.c_int, [_vp]),
+    "mppi_exchange_combine": (C.c_int, [_PP, _vp, _vp, C.c_int32, _vp]),
+    "mppi_command_sharded": (C.c_int, [_PP, _vp, _vp, C.c_int32, _vp]),
     "mppi_profile_enable": (C.c_int, [C.c_int]),
     "mppi_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mppi_profile_read2": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

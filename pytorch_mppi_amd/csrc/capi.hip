@@ -16,6 +16,8 @@ static int fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
   return code;
 }
+// message hook for the other translation units of the C-ABI (dist.hip)
+int mppi_fail_message(int code, const char* msg) { return fail(code, msg); }
 static int hipfail(int code, const char* where) {
   if (code > 0)
     snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString((hipError_t)code));

@@ -11,8 +11,47 @@ then combines the records in rank order (mppi_combine, K5), which yields bit-ide
 all ranks:   beta = min beta_g,  s_g = exp(-(beta_g-beta)/lambda),
              eta = sum_g s_g eta_g,  U += sum_g s_g P_g / eta.
 """
+import ctypes as C
+import os
+
 import torch
 import torch.distributed as dist
+
+
+class NativeComm:
+    """An RCCL communicator owned by the C-ABI (include/mppi_amd.h, csrc/dist.hip): the record
+    all-gather of a sharded command is then issued by the engine itself on the caller's stream --
+    no torch.distributed call, no pool stream, no cross-stream wait on the per-command path.
+    torch.distributed (any backend) is only used ONCE, to ship rank 0's 128-byte RCCL id."""
+
+    def __init__(self, rank, world_size, device, group=None):
+        from . import _native as N
+        lib = N.lib()
+        if not lib.mppi_dist_available():
+            raise RuntimeError("RCCL not found by the engine library: " + lib.mppi_last_error().decode(errors="replace"))
+        idbuf = (C.c_char * 128)()
+        if world_size > 1:
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("NativeComm with world_size > 1 needs an initialised torch.distributed group for the id hand-out")
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            on_dev = dist.get_backend(group) == "nccl"
+            t = torch.zeros(128, dtype=torch.uint8, device=device if on_dev else "cpu")
+            if rank == 0:
+                N.check(lib.mppi_dist_unique_id(idbuf), "mppi_dist_unique_id")
+                t.copy_(torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8))
+            dist.broadcast(t, src=src, group=group)
+            idbuf.raw = bytes(t.cpu().numpy().tobytes())
+        else:
+            N.check(lib.mppi_dist_unique_id(idbuf), "mppi_dist_unique_id")
+        comm = C.c_void_p()
+        with torch.cuda.device(device):
+            N.check(lib.mppi_dist_init(idbuf, int(rank), int(world_size), C.byref(comm)), "mppi_dist_init")
+        self._lib, self.handle, self.world_size = lib, comm, int(world_size)
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            self._lib.mppi_dist_destroy(self.handle)
+            self.handle = None
 
 
 class ShardPlan:
@@ -25,6 +64,23 @@ class ShardPlan:
         base, rem = divmod(self.K, self.world_size)
         self.K_local = base + (1 if rank < rem else 0)
         self.k_offset = rank * base + min(rank, rem)
+        self._native = None            # NativeComm | False (tried, unavailable) | None (not tried)
+
+    def native_comm(self, device):
+        """The engine-owned RCCL communicator for this plan, or None: when the process group is
+        RCCL-backed (backend "nccl": one rank per GPU), or at world_size 1 (measurement / test rig).
+        MPPI_NATIVE_RCCL=0 keeps the exchange on torch.distributed."""
+        if self._native is None:
+            self._native = False
+            if os.environ.get("MPPI_NATIVE_RCCL", "1") != "0" and torch.device(device).type == "cuda":
+                ok = self.world_size == 1 or (dist.is_available() and dist.is_initialized()
+                                              and dist.get_backend(self.group) == "nccl")
+                if ok:
+                    try:
+                        self._native = NativeComm(self.rank, self.world_size, device, self.group)
+                    except RuntimeError:
+                        self._native = False
+        return self._native or None
 
     def bounds(self, rank):
         base, rem = divmod(self.K, self.world_size)

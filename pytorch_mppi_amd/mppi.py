@@ -560,7 +560,12 @@ class MPPI:
 
     def _command(self, state, shift):
         p = self._begin(state, shift)
-        if self._sharded():
+        if self._sharded() and not getattr(p, "_combined", False):
+            comm = None if self.overlap_collective else self._shard.native_comm(self.d)
+            if comm is not None:
+                # generic path: the engine issues the record all-gather itself (RCCL C API on this stream) + K5
+                self._exchange_native(p, comm)
+                return self._end(p)
             if self.overlap_collective and self.last_draw == "philox-fill" and not self._injected:
                 records, work = self._shard.all_gather_start(p._keep["record"])
                 self._prefetch_philox_rows(p)   # queued behind K4, runs while the collective is in flight
@@ -570,6 +575,12 @@ class MPPI:
                 records = self._shard.all_gather(p._keep["record"])
             self._combine(p, records)
         return self._end(p)
+
+    def _exchange_native(self, p, comm):
+        records = torch.empty(comm.world_size, 2 + p.T * p.nu, device=self.d, dtype=self.dtype)
+        p._keep["records"] = records
+        N.check(N.lib().mppi_exchange_combine(C.byref(p), comm.handle, _ptr(records), comm.world_size, self._stream()),
+                "mppi_exchange_combine")
 
     def _prefetch_philox_rows(self, p):
         """Sharded commands: the Philox rows of the NEXT command are a pure function of
@@ -624,11 +635,24 @@ class MPPI:
             p._keep["state"] = s0
             p.state_per_sample = int(per_sample)
             p.use_terminal = int(self.terminal_state_cost is not None)
-            rc = lib.mppi_command(C.byref(p), apply, st)                  # K1 + K3 + K4, one call
+            comm = None
+            if apply == 0 and not self.overlap_collective:
+                comm = self._shard.native_comm(self.d)
+
+            def launch():
+                if comm is None:
+                    return lib.mppi_command(C.byref(p), apply, st)            # K1 + K3 + K4, one call
+                # sharded: K1 + K3 + K4 + ncclAllGather + K5 on this stream, one call
+                records = torch.empty(comm.world_size, 2 + p.T * p.nu, device=self.d, dtype=self.dtype)
+                p._keep["records"] = records
+                p._combined = True
+                return lib.mppi_command_sharded(C.byref(p), comm.handle, _ptr(records), comm.world_size, st)
+
+            rc = launch()
             if rc == N.E_UNSUPPORTED and p.noise_src == N.NOISE_KTN:
                 self.ktn_direct = False            # no in-place instantiation for this model: convert from now on
                 self._convert_noise(p)
-                rc = lib.mppi_command(C.byref(p), apply, st)
+                rc = launch()
             N.check(rc, "mppi_command")
             if p.noise_src == N.NOISE_PHILOX and p.z:
                 p.noise_src = N.NOISE_TNK4        # the rows K1 generated are in p.z now (lazy attributes)
@@ -1046,7 +1070,23 @@ class MPPI_Batched:
                  u_per_command=1,
                  step_dependent_dynamics=False,
                  noise_abs_cost=False,
-                 *, rng="torch", seed=None):
+                 *, rng="torch", seed=None, shard=None):
+        # shard = (rank, world_size[, group]): the ENVIRONMENT axis is split contiguously over the ranks
+        # ("the better fit for filling 8 GPUs"); every environment is a complete,
+        # independent controller, so a sharded command needs no collective at all -- only the ONE noise
+        # draw all environments share (mppi.py:838) must be the same on every rank, which the engine's
+        # Philox stream is by construction (a pure function of seed and command number)
+        self.N_global = int(num_envs)
+        self.env_offset = 0
+        self._env_shard = None
+        if shard is not None:
+            from .dist import ShardPlan
+            self._env_shard = ShardPlan(num_envs, *shard)
+            if self._env_shard.world_size > 1 and rng != "philox":
+                raise ValueError("MPPI_Batched(shard=...) needs rng='philox': the shared noise draw must be identical on "
+                                 "every rank (or inject it with inject_noise)")
+            num_envs = self._env_shard.K_local
+            self.env_offset = self._env_shard.k_offset
         # parameter resolution is MPPI's (identical rules, mppi.py:730-790); the inner controller is
         # never commanded itself -- it is the parameter block + launch plumbing for all N envs
         self._c = MPPI(dynamics, running_cost, nx, noise_sigma, num_samples=num_samples, horizon=horizon,
@@ -1059,8 +1099,22 @@ class MPPI_Batched:
         self.d, self.dtype = c.d, c.dtype
         self.N, self.K, self.T, self.nx, self.nu = num_envs, c.K, c.T, c.nx, c.nu
         self.u_per_command = u_per_command
-        self.U = self._sample_noise((self.N, self.T))                     # :796-797
+        self.U = self._initial_U()                                        # :796-797
         self.cost_total = self.omega = None
+
+    def _initial_U(self):
+        """(N,T,nu) random nominal sequences (mppi.py:796-797).  Sharded: rank 0's draw for all N_global
+        environments, broadcast, of which this rank keeps its slice -- the same U an unsharded
+        controller seeded like rank 0 would hold."""
+        if self._env_shard is None or self._env_shard.world_size <= 1:
+            return self._sample_noise((self.N, self.T))
+        c = self._c
+        c._shard = self._env_shard                     # borrow MPPI._replicated's broadcast
+        try:
+            U = c._replicated(self._sample_noise((self.N_global, self.T)))
+        finally:
+            c._shard = None
+        return U[self.env_offset:self.env_offset + self.N].contiguous()
 
     # attribute surface shared with the inner parameter block
     lambda_ = property(lambda self: self._c.lambda_, lambda self, v: setattr(self._c, "lambda_", v))
@@ -1079,7 +1133,7 @@ class MPPI_Batched:
         self._c.compile(**kwargs)
 
     def reset(self):
-        self.U = self._sample_noise((self.N, self.T))
+        self.U = self._initial_U()
 
     def inject_noise(self, z):
         self._c.inject_noise(z)
@@ -1090,7 +1144,10 @@ class MPPI_Batched:
         c = self._c
         if not torch.is_tensor(states):
             states = torch.tensor(states)
-        states = states.to(dtype=self.dtype, device=self.d).reshape(self.N, self.nx).contiguous()
+        states = states.to(dtype=self.dtype, device=self.d)
+        if self.N != self.N_global and states.numel() == self.N_global * self.nx:
+            states = states.reshape(self.N_global, self.nx)[self.env_offset:self.env_offset + self.N]   # this rank's environments
+        states = states.reshape(self.N, self.nx).contiguous()
         Nn, K, T, nu = self.N, self.K, self.T, self.nu
         p = c._problem(U=self.U.reshape(Nn * T, nu))
         p.num_envs = Nn
@@ -1290,7 +1347,11 @@ class KMPPI(MPPI):
             N.check(lib.mppi_finalize(C.byref(pt), 1, st), "mppi_finalize")
         else:
             N.check(lib.mppi_finalize(C.byref(pt), 0, st), "mppi_finalize")
-            self._combine(pt, self._shard.all_gather(record))
+            comm = self._shard.native_comm(self.d)
+            if comm is not None:
+                self._exchange_native(pt, comm)
+            else:
+                self._combine(pt, self._shard.all_gather(record))
         self.omega, self.cost_total_non_zero = omega, wnz
         self._record = record
         self._last, self._last_theta = p, pt

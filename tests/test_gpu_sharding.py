@@ -144,6 +144,69 @@ def test_sharded_philox_generates_next_rows_behind_the_collective():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("kind", ["mppi-fused", "mppi-generic", "kmppi"])
+def test_engine_owned_rccl_exchange_world_size_one(kind):
+    """The exchange inside the C-ABI (csrc/dist.hip): mppi_dist_unique_id / mppi_dist_init create an RCCL
+    communicator bound at run time, mppi_command_sharded = K1 + K3 + K4 + ncclAllGather + K5 on the
+    caller's stream in ONE call (fused path), mppi_exchange_combine for the callback path and KMPPI.
+    One GPU here: world_size 1, the collective has no peer -- what is checked is the whole code path
+    and that the result is the unsharded command.  No torch.distributed involved at all."""
+    from pytorch_mppi_amd import MPPI, KMPPI, models
+    from pytorch_mppi_amd.dist import NativeComm
+    m = models.Integrator(8, 4)
+    f, q = (m.dynamics, m.running_cost) if kind != "mppi-generic" else ((lambda s, a: m.dynamics(s, a)), (lambda s, a: m.running_cost(s, a)))
+    cls, extra = (KMPPI, dict(num_support_pts=6)) if kind == "kmppi" else (MPPI, {})
+    mk = lambda shard: cls(f, q, 8, 0.5 * torch.eye(4), num_samples=3000, horizon=20, device="cuda", lambda_=4.0,
+                           u_max=torch.ones(4), U_init=torch.zeros(20, 4), rng="philox", seed=5, shard=shard, **extra)
+    a, b = mk(None), mk((0, 1))
+    b._force_collective = True
+    x = torch.linspace(-1, 1, 8, device="cuda")
+    for i in range(4):
+        ua, ub = a.command(x), b.command(x)
+        torch.testing.assert_close(ua, ub, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(a.U, b.U, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(a.cost_total, b.cost_total, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(a.omega, b.omega, rtol=1e-4, atol=1e-8)
+    assert isinstance(b._shard._native, NativeComm), "the sharded command must have gone through the engine's own RCCL communicator"
+    if kind == "mppi-fused":
+        assert b._last._combined and b._last._keep["records"].shape == (1, 2 + 20 * 4)
+        assert torch.equal(b._last._keep["records"][0], b._last._keep["record"])     # the all-gather of one rank is its record
+    b._shard._native.close()
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_env_sharded_mppi_batched_needs_no_collective(native):
+    """MPPI_Batched(shard=(rank, world)): the environment axis split over the ranks (3 shards of 7
+    environments, emulated back to back).  Every environment is an independent controller and the one
+    shared noise draw is the same Philox stream on every rank, so each shard reproduces exactly its
+    slice of the unsharded controller -- without any exchange."""
+    N_env, K, T, world = 7, 512, 9, 3
+    lin = pm.models.LinearGoal(torch.tensor([[1.0, 0.0], [0.0, -1.0]]), torch.tensor([2.0, 2.0]))
+    f, q = (lin.dynamics, lin.running_cost) if native else ((lambda s, a: lin.dynamics(s, a)), (lambda s, a: lin.running_cost(s, a)))
+    g = torch.Generator().manual_seed(4)
+    U0 = torch.randn(N_env, T, 2, generator=g) * 0.2
+    states = torch.randn(N_env, 2, generator=g) * 2
+    kw = dict(num_samples=K, horizon=T, device="cuda", lambda_=3.0, u_max=torch.tensor([1.5, 1.0]), rng="philox", seed=21)
+    full = pm.MPPI_Batched(f, q, 2, torch.eye(2), N_env, **kw)
+    full.U = U0.cuda().clone()
+    shards = [pm.MPPI_Batched(f, q, 2, torch.eye(2), N_env, shard=(r, world), **kw) for r in range(world)]
+    lo = 0
+    for c in shards:
+        assert c.N_global == N_env and c.env_offset == lo
+        c.U = U0[lo:lo + c.N].cuda().clone()
+        lo += c.N
+    assert lo == N_env
+    for step in range(3):
+        a_full = full.command(states)
+        for c in shards:
+            a = c.command(states)                          # the GLOBAL state array: the shard takes its rows
+            sl = slice(c.env_offset, c.env_offset + c.N)
+            assert torch.equal(a, a_full[sl]) and torch.equal(c.U, full.U[sl])
+            assert torch.equal(c.cost_total, full.cost_total[sl]) and torch.equal(c.omega, full.omega[sl])
+    with pytest.raises(ValueError):
+        pm.MPPI_Batched(f, q, 2, torch.eye(2), N_env, shard=(0, 2), num_samples=K, horizon=T, device="cuda", rng="torch")
+
+
 def _torchrun(args, env_extra=None, timeout=300):
     import subprocess
     import sys

@@ -16,8 +16,10 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 Kper = bench.WORKLOADS[wl][4]
-for name, shard, overlap in (("single", None, False), ("sharded(world=1,nccl)", (0, 1), False),
-                             ("sharded + next rows behind the collective", (0, 1), True)):
+for name, shard, overlap, native in (("single", None, False, "1"), ("sharded(world=1), engine-owned RCCL comm", (0, 1), False, "1"),
+                                     ("sharded(world=1), torch.distributed nccl", (0, 1), False, "0"),
+                                     ("sharded + next rows behind the collective (torch.distributed)", (0, 1), True, "0")):
+    os.environ["MPPI_NATIVE_RCCL"] = native
     ctrl, x0, _ = bench.make_controller(pm, wl, dev, rng, shard, Kper)
     ctrl.lambda_ = 50.0
     ctrl._force_collective = shard is not None
@@ -30,12 +32,12 @@ for name, shard, overlap in (("single", None, False), ("sharded(world=1,nccl)", 
     for _ in range(n):
         ctrl.command(x0)
     torch.cuda.synchronize()
-    print(f"{name:24s} {1e3 * (time.perf_counter() - t0) / n:.4f} ms/command", flush=True)
+    print(f"{name:64s} {1e3 * (time.perf_counter() - t0) / n:.4f} ms/command", flush=True)
     # host-only cost: how long the python call itself takes (the GPU runs behind)
     t0 = time.perf_counter()
     for _ in range(n):
         ctrl.command(x0)
     th = time.perf_counter() - t0
     torch.cuda.synchronize()
-    print(f"{'':24s} {1e3 * th / n:.4f} ms host time per command", flush=True)
+    print(f"{'':64s} {1e3 * th / n:.4f} ms host time per command", flush=True)
 dist.destroy_process_group()
