@@ -159,7 +159,7 @@ def k1_hbm_cold(ctrl, n=32):
     p = ctrl._last
     if p is None or int(p.noise_src) != N.NOISE_TNK4 or int(p.noise_coloured):
         return None
-    n_el = N.noise_rows4(ctrl.T, ctrl.nu) * ctrl.K_local * 4
+    n_el = ctrl._zelems(ctrl.T)
     nbuf = max(4, -(-6 * (1 << 28) // (4 * n_el)))
     bufs = [torch.randn(n_el, device=ctrl.d, dtype=ctrl.dtype) for _ in range(nbuf)]
     st = ctrl._stream()

@@ -15,7 +15,8 @@
  *
  * Noise layouts
  *   MPPI_NOISE_TNK4   engine-native, sample-minor: z4[jb][k][c] with j = 4*jb + c the flat
- *                     (t*nu + n) index, jb < J4 = mppi_noise_rows4(T, nu).  One wave reads
+ *                     (t*nu + n) index, jb < J4 = mppi_noise_rows4(T, nu), k < K <= noise_pitch
+ *                     (the row pitch: J4 * noise_pitch * 4 elements in all).  One wave reads
  *                     1 KiB contiguous per instruction (16 B per lane).
  *   MPPI_NOISE_PHILOX no array: the float4 at [jb][k] is generated in-kernel from
  *                     Philox4x32-10(counter = (k_global, jb, call_lo, call_hi), key = seed)
@@ -40,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 13
+#define MPPI_ABI_VERSION 14
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -98,6 +99,8 @@ typedef struct MppiProblem {
   double lambda_;             /* mppi.py:96, read live                                     */
   double u_scale;             /* mppi.py:313                                               */
   uint64_t seed, call;        /* Philox key / per-command counter word                     */
+  int64_t noise_pitch;        /* TNK4 row pitch in samples: row jb starts at element jb*noise_pitch*4;
+                                 0 = K (dense).  mppi_noise_pitch(K, dtype) is the engine's choice   */
   /* SMPPI (mppi.py:451-570), lifted control: v = clamp(A + (U+eps)*dt), noise = (v-A)/dt - U.
    * The host passes base_seq = A + U*dt, noise_L/noise_mu pre-multiplied by dt and the ACTION
    * bounds in u_min/u_max; the kernels then only need 1/dt and the smoothness weight.         */
@@ -144,6 +147,10 @@ const char* mppi_last_error(void);
 /* rows of 4 in the TNK4 layout for a (T,nu) sequence: ceil(T*nu/4), padded so that whole
  * super-steps of lcm(4,nu) elements can be read without a tail test. */
 int64_t mppi_noise_rows4(int32_t T, int32_t nu);
+
+/* recommended row pitch (samples) of a TNK4 array for K samples: K, or K + 1 MiB worth of samples
+ * when a dense row would be a multiple of 2 MiB (HBM bank aliasing between the rows K1 streams) */
+int64_t mppi_noise_pitch(int32_t K, int32_t dtype);
 
 /* elements of dtype the workspace must hold for this problem */
 int64_t mppi_workspace_elems(const MppiProblem* p);

@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
@@ -33,7 +33,7 @@ class MppiProblem(C.Structure):
         ("noise_src", C.c_int32), ("u_per_command", C.c_int32), ("step_offset", C.c_int32),
         ("hidden", C.c_int32), ("num_envs", C.c_int32), ("noise_coloured", C.c_int32),
         ("lambda_", C.c_double), ("u_scale", C.c_double),
-        ("seed", C.c_uint64), ("call", C.c_uint64),
+        ("seed", C.c_uint64), ("call", C.c_uint64), ("noise_pitch", C.c_int64),
         ("noise_rescale", C.c_double), ("smooth_weight", C.c_double),
         ("state", _vp), ("U", _vp), ("u_init", _vp), ("noise_mu", _vp), ("noise_L", _vp),
         ("sigma_inv", _vp), ("u_min", _vp), ("u_max", _vp), ("model_params", _vp), ("z", _vp),
@@ -53,6 +53,7 @@ SYMBOLS = {
     "mppi_problem_size": (C.c_int64, []),
     "mppi_last_error": (C.c_char_p, []),
     "mppi_noise_rows4": (C.c_int64, [C.c_int32, C.c_int32]),
+    "mppi_noise_pitch": (C.c_int64, [C.c_int32, C.c_int32]),
     "mppi_workspace_elems": (C.c_int64, [_PP]),
     "mppi_model_supported": (C.c_int, [C.c_int32] * 5),
     "mppi_noise_fill_philox": (C.c_int, [_PP, _vp, _vp]),
@@ -129,6 +130,11 @@ def check(code, what):
 
 def noise_rows4(T, nu):
     return int(lib().mppi_noise_rows4(int(T), int(nu)))
+
+
+def noise_pitch(K, dtype_code):
+    """Row pitch (samples) of a TNK4 noise array for K samples (include/mppi_amd.h)."""
+    return int(lib().mppi_noise_pitch(int(K), int(dtype_code)))
 
 
 def model_supported(model_id, nx, nu, dtype_code, hidden=0):

@@ -36,6 +36,19 @@ extern "C" int64_t mppi_noise_rows4(int32_t T, int32_t nu) {
   return (int64_t)((T + tt - 1) / tt) * p4;
 }
 
+// Row pitch (in samples) the engine recommends for a TNK4 array of K samples.  A row is K*4 elements;
+// when that is a multiple of 2 MiB, consecutive rows land on the same HBM banks and the row-streaming
+// K1 (9 rows in flight per lane, all workgroups at the same offset of their rows) loses a quarter of
+// its bandwidth: measured 53 % of 8 TB/s at K = 262144 (4 MiB rows) against 71 % at K = 327680
+// (5 MiB) -- profiles/r02_k1_row_stride.txt.  Such rows are padded by 1 MiB.
+extern "C" int64_t mppi_noise_pitch(int32_t K, int32_t dtype) {
+  if (K <= 0) return 0;
+  const int64_t bps = dtype == MPPI_F64 ? 32 : 16;               // bytes of one row-of-4 per sample
+  const int64_t row = (int64_t)K * bps;
+  if (row >= (2 << 20) && row % (2 << 20) == 0) return K + (1 << 20) / bps;
+  return K;
+}
+
 namespace {
 // run-time registered (JIT-compiled) models: see mppi_register_model
 typedef int (*custom_rollout_fn)(const void* kargs, void* stream);
@@ -81,6 +94,8 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.K = p->K; a.Tn = p->T; a.nx = p->nx; a.nu = p->nu; a.J = p->T * p->nu;
   a.J4 = (int)mppi_noise_rows4(p->T, p->nu);
   a.k_offset = p->k_offset;
+  a.zp = p->noise_pitch > 0 ? p->noise_pitch : p->K;
+  if (a.zp < p->K) return fail(MPPI_E_BADARG, "noise_pitch < K");
   a.model_id = p->model_id; a.diag = p->sigma_diagonal; a.abs_cost = p->noise_abs_cost;
   a.null_action = p->sample_null_action; a.n_sampler = p->n_sampler_rows;
   a.state_per_sample = p->state_per_sample; a.shift = p->shift; a.use_terminal = p->use_terminal;

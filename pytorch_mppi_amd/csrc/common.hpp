@@ -17,6 +17,7 @@ template <typename T>
 struct KArgs {
   int K, Tn, nx, nu, J, J4;
   long long k_offset;
+  long long zp;   // row pitch of the TNK4 noise array in samples (>= K; mppi_noise_pitch)
   int model_id, diag, abs_cost, null_action, n_sampler, state_per_sample, shift, use_terminal,
       noise_src, u_per_command, hidden,
       coloured;   // z holds eps = L z + mu already (generator-side colouring): add U, bound, done
@@ -187,7 +188,7 @@ __device__ __forceinline__ void noise4(const KArgs<T>& a, long long jb, int k, T
   if constexpr (NOISE == MPPI_NOISE_PHILOX) {
     philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, out);
   } else {
-    load4<T>(a.z, a.K, jb, k, out);
+    load4<T>(a.z, a.zp, jb, k, out);
   }
 }
 // K3's form: same rows, read for the last time
@@ -196,7 +197,7 @@ __device__ __forceinline__ void noise4_last(const KArgs<T>& a, long long jb, int
   if constexpr (NOISE == MPPI_NOISE_PHILOX) {
     philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, out);
   } else {
-    load4_last<T>(a.z, a.K, jb, k, out);
+    load4_last<T>(a.z, a.zp, jb, k, out);
   }
 }
 

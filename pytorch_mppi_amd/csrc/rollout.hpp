@@ -256,7 +256,7 @@ __device__ __forceinline__ void rollout_stream_dma(const KArgs<T>& a, const Acti
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)ring_wave);
   const float* zbase = reinterpret_cast<const float*>(a.z);
-  const long long row_floats = (long long)a.K * 4;
+  const long long row_floats = a.zp * 4;
   const float* my = ring_wave + lane * 4;
   T vprev[NU];
 #pragma unroll
@@ -390,7 +390,7 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
           const long long jb = (long long)(ss0 + b) * P4 + i;
           noise4<T, NOISE>(a, jb, k, r);   // rows past the horizon: unused
           // "generate once": keep the stream for K3 to re-read instead of regenerating it
-          if (a.z != nullptr && active && jb < a.J4) store4<T>(const_cast<T*>(a.z), a.K, jb, k, r);
+          if (a.z != nullptr && active && jb < a.J4) store4<T>(const_cast<T*>(a.z), a.zp, jb, k, r);
           zb[b][4 * i + 0] = r[0]; zb[b][4 * i + 1] = r[1]; zb[b][4 * i + 2] = r[2]; zb[b][4 * i + 3] = r[3];
         }
       }

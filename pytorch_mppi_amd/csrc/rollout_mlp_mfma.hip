@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
   auto fetch = [&](int t, float (&dst)[NT][4]) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      if constexpr (ROW1) dst[i][0] = a.z[((long long)t * a.K + kk[i]) * 4 + g];
+      if constexpr (ROW1) dst[i][0] = a.z[((long long)t * a.zp + kk[i]) * 4 + g];
       else noise4<float, NOISE == MPPI_NOISE_ACTIONS ? MPPI_NOISE_TNK4 : NOISE>(a, t, kk[i], dst[i]);
     }
   };
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
       if (a.z != nullptr && g == 0) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
-          if (act[i]) store4<float>(const_cast<float*>(a.z), a.K, t, kk[i], zc[i]);
+          if (act[i]) store4<float>(const_cast<float*>(a.z), a.zp, t, kk[i], zc[i]);
       }
     }
     fetch(t + 1 < a.Tn ? t + 1 : t, zn);   // prefetch the next step's rows (compute >> latency here)

@@ -9,6 +9,7 @@
 // launch and on every rank.
 #include "actions.hpp"
 #include "update.hpp"
+#include "weights.hpp"
 
 namespace mppi {
 
@@ -22,7 +23,7 @@ __global__ void __launch_bounds__(BLOCK) noise_fill_philox_kernel(const KArgs<T>
   for (int jb = blockIdx.y; jb < a.J4; jb += gridDim.y) {
     T r[4];
     philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, r);
-    T* o = out + ((long long)jb * a.K + k) * 4;
+    T* o = out + ((long long)jb * a.zp + k) * 4;
     o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
   }
 }
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(BLOCK) noise_fill_philox_coloured_kernel(const
 #pragma unroll
     for (int i = 0; i < P4; ++i) {
       const T r[4] = {ec[4 * i], ec[4 * i + 1], ec[4 * i + 2], ec[4 * i + 3]};
-      store4<T>(out, a.K, (long long)ss * P4 + i, k, r);
+      store4<T>(out, a.zp, (long long)ss * P4 + i, k, r);
     }
   }
 }
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(BLOCK) noise_from_ktn_kernel(const KArgs<T> a,
     const int k = k0 + kl, jb = (j0 >> 2) + jbl;
     if (k < a.K && jb < a.J4) {
       const T v[4] = {tile[kl][4 * jbl + 0], tile[kl][4 * jbl + 1], tile[kl][4 * jbl + 2], tile[kl][4 * jbl + 3]};
-      store4<T>(out, a.K, jb, k, v);
+      store4<T>(out, a.zp, jb, k, v);
     }
   }
 }
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(64) kmppi_interp_kernel(const KArgs<T> a, cons
       ob[c++] = acc[n];
       if (c == 4) {
         if (active) {
-          T* o = out + (jb * a.K + k) * 4;
+          T* o = out + (jb * a.zp + k) * 4;
           o[0] = ob[0]; o[1] = ob[1]; o[2] = ob[2]; o[3] = ob[3];
         }
         ++jb; c = 0;
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(64) kmppi_interp_kernel(const KArgs<T> a, cons
   while (jb < J4out) {
     for (; c < 4; ++c) ob[c] = T(0);
     if (active) {
-      T* o = out + (jb * a.K + k) * 4;
+      T* o = out + (jb * a.zp + k) * 4;
       o[0] = ob[0]; o[1] = ob[1]; o[2] = ob[2]; o[3] = ob[3];
     }
     ++jb; c = 0;
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(BLOCK) kmppi_interp_mfma_kernel(const KArgs<fl
       const int t = t0 + 4 * g + r;
       if (active && t < Thor) {
         const float v[4] = {D[0][r], D[1][r], D[2][r], D[3][r]};
-        store4<float>(out, a.K, (long long)t * P4 + q, k, v);
+        store4<float>(out, a.zp, (long long)t * P4 + q, k, v);
       }
     }
   }
@@ -354,7 +355,7 @@ __global__ void __launch_bounds__(BLOCK) prepare_kernel(const KArgs<T> a_in) {
       T r[4];
       noise4<T, NOISE>(a, (long long)ss * P4 + i, k, r);
       if constexpr (NOISE == MPPI_NOISE_PHILOX) {
-        if (a.z != nullptr) store4<T>(const_cast<T*>(a.z), a.K, (long long)ss * P4 + i, k, r);
+        if (a.z != nullptr) store4<T>(const_cast<T*>(a.z), a.zp, (long long)ss * P4 + i, k, r);
       }
       zc[4 * i] = r[0]; zc[4 * i + 1] = r[1]; zc[4 * i + 2] = r[2]; zc[4 * i + 3] = r[3];
     }
@@ -401,80 +402,6 @@ __global__ void __launch_bounds__(BLOCK) cost_block_min_kernel(const KArgs<T> a_
 //   NU == 0 : diagonal Sigma, any nu (element-wise in j; per-column constants in LDS)
 //   NU  > 0 : full Sigma (colouring needs whole timesteps; tile = whole super-steps)
 // =============================================================================================
-template <typename T>
-__device__ __forceinline__ T shard_beta(const KArgs<T>& a, T* red) {
-  T m = inf_v<T>();
-  for (int i = threadIdx.x; i < a.nb1; i += BLOCK) {
-    const T v = a.block_min[i];
-    m = v < m ? v : m;
-  }
-  return block_min<T>(m, red);
-}
-
-// mppi.py:12-13 / :256: exp(-(1/lambda) * (cost - beta))
-template <typename T>
-__device__ __forceinline__ T weight_of(T cost, T beta, T inv_lambda) {
-  return m_exp(-inv_lambda * (cost - beta));
-}
-
-// Overwritten rows (sample_null_action / sampler rows, mppi.py:387-400) are masked out of the
-// streaming loop (weight 0) and added back afterwards, one lane per column: their "noise" is
-// clamp(0 | sampler action) - U, independent of z.  Returns the correction for column j.
-template <typename T>
-__device__ __forceinline__ T overwrite_correction(const KArgs<T>& a, int kbeg, int kend, int j,
-                                                  T uj, T lo, T hi, T beta, T inv_lambda) {
-  // rows are global indices [0, n_over); this block covers local samples [kbeg, kend)
-  const long long n_over = (a.null_action ? 1 : 0) + (long long)a.n_sampler;
-  T corr = T(0);
-  for (int k = kbeg; k < kend; ++k) {
-    const long long kg = a.k_offset + k;
-    if (kg >= n_over) break;
-    const int orow = overwrite_row(a, kg);
-    T v = T(0);
-    if (orow >= 0) v = a.sampler[(long long)orow * a.J + j];
-    v = clampT(v, lo, hi);
-    corr += weight_of<T>(a.cost[k], beta, inv_lambda) * (v - uj);
-  }
-  return corr;
-}
-
-// the streaming loop of the diagonal K3 over one 64-column tile; SPARSE: 64-sample groups whose
-// weights are all exactly zero (live[r] == false, wave-uniform) are skipped -- no load, no RNG
-template <typename T, int NOISE, int R, bool SPARSE>
-__device__ __forceinline__ void k3_tile_loop(const KArgs<T>& a, int jt, int nrows, const int (&kk)[R],
-                                             const T (&w)[R], const bool (&live)[R], const T* cU,
-                                             const T* cS, const T* cM, const T* cLo, const T* cHi,
-                                             T (&acc)[UPD_TJ]) {
-#pragma unroll
-  for (int jbl = 0; jbl < UPD_TJ / 4; ++jbl) {
-    if (jbl < nrows) {
-      const long long jb = (long long)jt * (UPD_TJ / 4) + jbl;
-      T zz[R][4];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (!SPARSE || live[r]) noise4_last<T, NOISE>(a, jb, kk[r], zz[r]);
-      }
-      T u4[4], s4[4], m4[4], lo4[4], hi4[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        u4[c] = cU[4 * jbl + c]; s4[c] = cS[4 * jbl + c]; m4[c] = cM[4 * jbl + c];
-        lo4[c] = cLo[4 * jbl + c]; hi4[c] = cHi[4 * jbl + c];
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (!SPARSE || live[r]) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            T v = u4[c] + (zz[r][c] * s4[c] + m4[c]);
-            v = clampT(v, lo4[c], hi4[c]);
-            acc[4 * jbl + c] += w[r] * (v - u4[c]);
-          }
-        }
-      }
-    }
-  }
-}
-
 template <typename T, int NOISE, int R>
 __global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs<T> a_in) {
   const KArgs<T> a = env_view(a_in);

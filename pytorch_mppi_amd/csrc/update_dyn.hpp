@@ -27,7 +27,7 @@ struct RowCursor {
       row = jb;
       noise4<T, NOISE>(a, jb, k, r);
       if constexpr (NOISE == MPPI_NOISE_PHILOX) {
-        if (store_generated && a.z != nullptr) store4<T>(const_cast<T*>(a.z), a.K, jb, k, r);
+        if (store_generated && a.z != nullptr) store4<T>(const_cast<T*>(a.z), a.zp, jb, k, r);
       }
     }
     const int c = (int)(j & 3);
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(DYN_BLOCK) kmppi_interp_dyn_kernel(const KArgs
       const int t = (int)(j / nu), n = (int)(j - (long long)t * nu);
       for (int s = 0; s < S; ++s) acc += W[t * S + s] * ctrl[(s * nu + n) * DYN_BLOCK + tid];   // :665
     }
-    out[((j >> 2) * a.K + k) * 4 + (j & 3)] = acc;        // padded tail = 0
+    out[((j >> 2) * a.zp + k) * 4 + (j & 3)] = acc;        // padded tail = 0
   }
 }
 

@@ -354,6 +354,7 @@ class MPPI:
         if hit is None or hit[0] != key:
             p = N.MppiProblem()
             p.K, p.T, p.nx, p.nu = self.K_local, Tn, self.nx, self.nu
+            p.noise_pitch = self._zpitch()
             p.S = 0
             p.dtype = _DT[self.dtype]
             p.k_offset = self.k_offset
@@ -389,6 +390,17 @@ class MPPI:
         p.U = Ut.data_ptr()
         p._keep = keep      # keep the tensors alive as long as the struct
         return p
+
+    def _zpitch(self):
+        """Row pitch (samples) of this controller's TNK4 noise arrays (engine's choice, mppi_noise_pitch)."""
+        key = (self.K_local, self.dtype)
+        if getattr(self, "_zpitch_cache", (None, 0))[0] != key:
+            self._zpitch_cache = (key, N.noise_pitch(self.K_local, _DT[self.dtype]))
+        return self._zpitch_cache[1]
+
+    def _zelems(self, Tn):
+        """Elements of a TNK4 array for a (Tn, nu) sequence over this controller's samples."""
+        return N.noise_rows4(Tn, self.nu) * self._zpitch() * 4
 
     def _attach_workspace(self, p):
         key = (p.K, p.T, p.nu, p.num_envs)
@@ -427,8 +439,7 @@ class MPPI:
         elif self.rng == "torch-native":
             # same generator, drawn straight into the engine's sample-minor layout: no conversion
             # pass; which (k,t,n) gets which draw differs from the reference-layout draw
-            rows4 = N.noise_rows4(Tn, nu)
-            zn = self._randn(rows4 * K * 4)
+            zn = self._randn(self._zelems(Tn))
             p.noise_src = N.NOISE_TNK4
             p.z = _ptr(zn)
             p._keep["z"] = zn
@@ -442,7 +453,7 @@ class MPPI:
                 # generate once, keep the rows for K3 to re-read: Philox + Box-Muller costs more per
                 # element than an HBM read
                 rows4 = N.noise_rows4(Tn, nu)
-                n = rows4 * K * 4
+                n = self._zelems(Tn)
                 # inside K1 every lane generates its own rows one after the other (~0.35 us per
                 # row-of-4, however small K is); the generator launch spreads them over the whole chip
                 # and costs one launch (~4 us): it wins from ~16 rows per sample on (tools/k_sweep.py)
@@ -493,8 +504,7 @@ class MPPI:
         """(K,T,nu) draw kept in p._keep['z_ktn'] -> the engine's sample-minor rows-of-4."""
         z = p._keep["z_ktn"]
         K, Tn, nu = z.shape
-        rows4 = N.noise_rows4(Tn, nu)
-        zn = torch.empty(rows4 * K * 4, device=self.d, dtype=self.dtype)
+        zn = torch.empty(self._zelems(Tn), device=self.d, dtype=self.dtype)
         N.check(N.lib().mppi_noise_from_ktn(C.byref(p), _ptr(z), _ptr(zn), self._stream()), "mppi_noise_from_ktn")
         p.noise_src = N.NOISE_TNK4
         p.z = _ptr(zn)
@@ -594,7 +604,7 @@ class MPPI:
         q = N.MppiProblem.from_buffer_copy(p)
         q.call = self._call + 1
         q.noise_src = N.NOISE_PHILOX
-        n = N.noise_rows4(q.T, q.nu) * q.K * 4
+        n = self._zelems(q.T)
         zn = torch.empty(n, device=self.d, dtype=self.dtype)
         N.check(N.lib().mppi_noise_fill_philox(C.byref(q), _ptr(zn), self._stream()), "mppi_noise_fill_philox")
         self._pf_rows = ((q.K, q.T, q.nu, int(q.k_offset), int(q.seed), int(q.call)), zn)
@@ -1159,7 +1169,7 @@ class MPPI_Batched:
             # ONE draw serves all N environments: generate the rows once, every environment's K1 / K3
             # block then reads them (in-kernel generation would repeat the Philox work N times)
             if not p.z:
-                zn = torch.empty(N.noise_rows4(T, nu) * K * 4, device=self.d, dtype=self.dtype)
+                zn = torch.empty(c._zelems(T), device=self.d, dtype=self.dtype)
                 p.z = _ptr(zn)
                 p._keep["z"] = zn
             N.check(lib.mppi_noise_fill_philox(C.byref(p), p.z, st), "mppi_noise_fill_philox")
@@ -1313,8 +1323,7 @@ class KMPPI(MPPI):
         p.noise_src, p.z, p.call = pt.noise_src, pt.z, pt.call
         self._attach_workspace(p)
         pt.workspace, pt.workspace_elems = p.workspace, p.workspace_elems
-        rows4 = N.noise_rows4(self.T, self.nu)
-        v_raw = torch.empty(rows4 * K * 4, device=self.d, dtype=self.dtype)
+        v_raw = torch.empty(self._zelems(self.T), device=self.d, dtype=self.dtype)
         N.check(lib.mppi_kmppi_interp(C.byref(p), _ptr(v_raw), st), "mppi_kmppi_interp")
         p.noise_src, p.z = N.NOISE_ACTIONS, _ptr(v_raw)
         p._keep["v_raw"] = v_raw

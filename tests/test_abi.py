@@ -54,6 +54,14 @@ def test_noise_rows4(T, nu, rows):
     assert rows * 4 >= T * nu
 
 
+@pytest.mark.parametrize("K,dtype,pitch", [(65536, N.F32, 65536), (131072, N.F32, 131072 + 65536), (262144, N.F32, 262144 + 65536),
+                                           (100000, N.F32, 100000), (8192, N.F64, 8192), (65536, N.F64, 65536 + 32768),
+                                           (393216, N.F32, 393216 + 65536)])
+def test_noise_row_pitch(K, dtype, pitch):
+    """rows that would be a multiple of 2 MiB are padded by 1 MiB (HBM bank aliasing between streamed rows)"""
+    assert N.noise_pitch(K, dtype) == pitch
+
+
 def test_model_support_table():
     assert N.model_supported(N.MODEL_PENDULUM, 2, 1, N.F32)
     assert N.model_supported(N.MODEL_PENDULUM, 2, 1, N.F64)

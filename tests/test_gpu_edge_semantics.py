@@ -135,3 +135,46 @@ def test_set_noise_takes_effect_like_a_controller_built_with_the_new_noise(path,
             assert err <= tol * max(1.0, float(np.abs(ref).max())), (call, key, err)
         U = r["U"]
         c.U = U.cuda()                                        # same nominal sequence on both sides
+
+
+@pytest.mark.parametrize("rng", ["philox", "torch-native", "inject"])
+@pytest.mark.parametrize("cls", ["mppi", "kmppi"])
+def test_padded_noise_row_pitch_changes_nothing(rng, cls):
+    """K = 131072 fp32: a dense row-of-4 array would have 2 MiB rows, so the engine pads the row pitch
+    by 1 MiB (mppi_noise_pitch).  Same commands as with the dense layout forced, through every producer
+    and consumer of the rows (generator / torch draw / layout conversion, K1, K3, KMPPI interpolation,
+    lazy noise materialisation)."""
+    from pytorch_mppi_amd import _native as N
+    K, T, nx, nu = 131072, 6, 6, 4
+    assert N.noise_pitch(K, N.F32) == K + 65536
+    m = pm.models.Integrator(nx, nu)
+    g = torch.Generator().manual_seed(3)
+    U0 = torch.randn(T, nu, generator=g) * 0.1
+    x = torch.randn(nx, generator=g).cuda()
+    S = 4
+    zs = [torch.randn(K, S if cls == "kmppi" else T, nu, generator=g) for _ in range(2)]
+    outs = []
+    for dense in (False, True):
+        torch.manual_seed(11)
+        kw = dict(num_samples=K, horizon=T, device="cuda", lambda_=8.0, U_init=U0.clone(), u_max=torch.ones(nu),
+                  rng="torch" if rng == "inject" else rng, seed=9)
+        c = pm.KMPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), num_support_pts=S, **kw) if cls == "kmppi" else \
+            pm.MPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), **kw)
+        if rng == "inject":
+            c.ktn_direct = False                     # force the (K,T,nu) -> rows conversion pass
+        if dense:
+            c._zpitch_cache = ((c.K_local, c.dtype), K)
+        res = []
+        for z in zs:
+            if rng == "inject":
+                c.inject_noise(z)
+            a = c.command(x)
+            assert int(c._last.noise_pitch) == (K if dense else K + 65536)
+            res.append((a.clone(), c.cost_total.clone(), c.omega.clone(), c.noise.clone()))
+        outs.append(res)
+    for r_pad, r_dense in zip(*outs):
+        for u, v in zip(r_pad, r_dense):
+            if rng == "torch-native":                # the draw fills the padded array: other samples get other normals
+                assert u.shape == v.shape and torch.isfinite(u).all()
+            else:
+                assert torch.equal(u, v)

@@ -70,7 +70,8 @@ def _consumed_normals(ctrl, p=None):
     if "z_ktn" in p._keep and int(p.noise_src) == N.NOISE_KTN:
         return p._keep["z_ktn"].cpu()
     assert not int(p.noise_coloured)
-    rows = p._keep["z"].view(-1, K, 4)                       # [J4][K][4]
+    pitch = int(p.noise_pitch) or K
+    rows = p._keep["z"].view(-1, pitch, 4)[:, :K]            # [J4][pitch][4]: the first K samples of every row
     return rows.permute(1, 0, 2).reshape(K, -1)[:, :T * nu].reshape(K, T, nu).cpu()
 
 

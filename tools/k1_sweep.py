@@ -23,8 +23,10 @@ x0 = torch.randn(nx, device="cuda")
 c.command(x0)
 lib = N.lib()
 p = c._last
-rows4 = N.noise_rows4(T, nu)
-zs = [torch.randn(rows4 * K * 4, device="cuda") for _ in range(NBUF)]
+if os.environ.get("DENSE_PITCH") == "1":         # A/B: the dense layout (row pitch = K) against the engine's padded pitch
+    p.noise_pitch = K
+    c._zpitch_cache = ((c.K_local, c.dtype), K)
+zs = [torch.randn(c._zelems(T), device="cuda") for _ in range(NBUF)]
 st = c._stream()
 
 
