@@ -206,8 +206,17 @@ int mppi_finalize(const MppiProblem* p, int apply, void* stream);
 
 /* K1 + K3 + K4 in one call (the fused path of one MPPI._command, mppi.py:261-275): exactly
  * mppi_rollout_cost, then mppi_weights_partial on the rows K1 read or generated, then
- * mppi_finalize(apply).  Nothing is launched when K1 refuses the problem (negative status). */
+ * mppi_finalize(apply).  Nothing is launched when K1 refuses the problem (negative status).
+ * Small problems (K <= 16384, T*nu <= 256, diagonal Sigma or a coloured stream, no sampler rows, rows
+ * in memory: p->z set) are run as ONE launch -- every workgroup appends its part of K3 to its rollout
+ * and the last one to finish combines the partial records and applies K4 -- IF the caller passes
+ * omega == NULL and cost_total_non_zero == NULL; both are functions of the outputs that ARE written:
+ *   cost_total_non_zero = exp(-(cost_total - record[0]) / lambda),  omega = cost_total_non_zero / record[1].
+ * The WORKSPACE MUST BE ZERO-FILLED ONCE before its first use (the arrival ticket lives in its last
+ * 4 elements; every command leaves it at zero). */
 int mppi_command(const MppiProblem* p, int apply, void* stream);
+/* process-wide count of mppi_command calls that ran in the single-launch form (tests, bench) */
+int64_t mppi_stat_single_launch_commands(void);
 
 /* K5 -- multi-GPU: combine `n_shards` records (all-gathered, rank order) exactly the same way
  * on every rank: beta = min beta_g; s_g = exp(-(beta_g-beta)/lambda); eta = sum s_g eta_g;

@@ -66,6 +66,7 @@ SYMBOLS = {
     "mppi_weights_partial": (C.c_int, [_PP, _vp]),
     "mppi_finalize": (C.c_int, [_PP, C.c_int, _vp]),
     "mppi_command": (C.c_int, [_PP, C.c_int, _vp]),
+    "mppi_stat_single_launch_commands": (C.c_int64, []),
     "mppi_combine": (C.c_int, [_PP, _vp, C.c_int32, _vp]),
     "mppi_register_model": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "mppi_dist_available": (C.c_int, []),

@@ -77,7 +77,7 @@ Carve carve(const MppiProblem* p) {
   const int64_t ne = p->num_envs > 1 ? p->num_envs : 1;
   // sized for the finest chunking (R = 1) so one workspace serves every noise_src of the same problem
   const int64_t nkc_max = (p->K + BLOCK - 1) / BLOCK;
-  c.total = ne * ((int64_t)c.nb1 + nkc_max + nkc_max * c.Jpad);
+  c.total = ne * ((int64_t)c.nb1 + nkc_max + nkc_max * c.Jpad) + 4;     // + the arrival ticket of the single-launch command
   return c;
 }
 
@@ -114,6 +114,8 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.record = (T*)p->record;
   T* ws = (T*)p->workspace;
   a.tstamp = nullptr;
+  a.fuse = -1;
+  a.ticket = reinterpret_cast<unsigned*>(ws + (c.total - 4));
   a.n_env = p->num_envs > 1 ? p->num_envs : 1;
   if (a.n_env > 1 && (p->state_per_sample || p->n_sampler_rows > 0 || p->states != nullptr || p->base_seq != nullptr ||
                       p->S > 0 || p->noise_src == MPPI_NOISE_ACTIONS))
@@ -138,11 +140,12 @@ int need_noise(const KArgs<T>& a) {
 }
 
 template <typename T>
-int do_rollout(const MppiProblem* p, hipStream_t st) {
+int do_rollout(const MppiProblem* p, hipStream_t st, int fuse = -1) {
   KArgs<T> a;
   if (int e = make_args<T>(p, a)) return e;
   if (int e = need_noise(a)) return e;
   if (!a.state || !a.cost) return fail(MPPI_E_BADARG, "rollout needs state and cost_total");
+  a.fuse = fuse;
   int r;
   switch (p->model_id) {
     case MPPI_MODEL_PENDULUM: r = rollout_pendulum(a, st); break;
@@ -159,6 +162,7 @@ int do_rollout(const MppiProblem* p, hipStream_t st) {
       r = fn((const void*)&a, (void*)st);
     }
   }
+  if (r == MPPI_OK_FUSED) return r;
   return hipfail(r, "mppi_rollout_cost");
 }
 }  // namespace
@@ -389,8 +393,16 @@ extern "C" int mppi_finalize(const MppiProblem* p, int apply, void* stream) {
                   do_finalize<double>(p, apply, (hipStream_t)stream));
 }
 
+static long long g_single_launch_commands = 0;
+extern "C" int64_t mppi_stat_single_launch_commands(void) { return g_single_launch_commands; }
+
 extern "C" int mppi_command(const MppiProblem* p, int apply, void* stream) {
-  if (int e = mppi_rollout_cost(p, stream)) return e;
+  // small problems: K1's launch carries K3 and K4 as well when the caller left omega and
+  // cost_total_non_zero NULL (they are functions of cost_total and the record: see the header)
+  const int e1 = BY_DTYPE(p, do_rollout<float>(p, (hipStream_t)stream, apply ? 1 : 0),
+                          do_rollout<double>(p, (hipStream_t)stream, apply ? 1 : 0));
+  if (e1 == MPPI_OK_FUSED) { ++g_single_launch_commands; return 0; }
+  if (e1) return e1;
   MppiProblem q = *p;
   // "generate once": K1 stored the Philox rows it generated, K3 re-reads them
   if (q.noise_src == MPPI_NOISE_PHILOX && q.z != nullptr) q.noise_src = MPPI_NOISE_TNK4;

@@ -7,6 +7,9 @@
 
 namespace mppi {
 
+// internal status of a K1 launcher: the launch carried the whole command (K3 + K4 included)
+constexpr int MPPI_OK_FUSED = -100;
+
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;            // threads per workgroup of the per-sample kernels
 constexpr int UPD_TJ = 64;            // j-columns per K3 tile (= one value per lane after the
@@ -32,6 +35,8 @@ struct KArgs {
   int nb1, nkc, Jpad, R;
   int n_env;      // MPPI_Batched: environments on grid.z (1 = single controller)
   unsigned long long* tstamp;   // measurement hook: {min entry, max exit} on wall_clock64, or null
+  int fuse;                     // -1: K1 only | 0 / 1: whole command in K1's launch if eligible (value = K4's `apply`)
+  unsigned* ticket;             // arrival counter of the single-launch command (workspace tail, kept at 0)
 };
 
 // MPPI_Batched: the view of the argument block for environment blockIdx.z.  The noise (z), all
@@ -72,6 +77,36 @@ __device__ __forceinline__ float m_tanh(float x) { return tanhf(x); }
 __device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
 __device__ __forceinline__ float m_fmod(float a, float b) { return fmodf(a, b); }
 __device__ __forceinline__ double m_fmod(double a, double b) { return fmod(a, b); }
+// Python / torch floor-mod `a % b` for b > 0 and |a / b| < 2^22: k = floor(a / b), r = a - k b.  fmod's
+// result is exactly representable, so the single rounding of the fma is exact once k is right; the
+// two fix-ups repair a k that the rounded quotient put off by one.  Same bits as fmodf + sign
+// fix-up (the ocml fmod is an exact-remainder LOOP, ~100 instructions per call).
+__device__ __forceinline__ float m_floormod(float a, float b) {
+  const float k = floorf(a * (1.0f / b));
+  float r = fmaf(-k, b, a);
+  r = r < 0.0f ? r + b : r;
+  r = r >= b ? r - b : r;
+  return r;
+}
+__device__ __forceinline__ double m_floormod(double a, double b) {
+  const double k = floor(a * (1.0 / b));
+  double r = fma(-k, b, a);
+  r = r < 0.0 ? r + b : r;
+  r = r >= b ? r - b : r;
+  return r;
+}
+// sinf for arguments of moderate size: ocml's sinf, with its Payne-Hanek path for huge arguments
+// (|x| >= 2^17: 64-bit multiply chains, ~1000 instructions, the registers to match) pruned from the hot
+// path by telling the compiler the range; a state that really gets that large takes the out-of-line
+// full version.  Same bits as sinf either way.
+__device__ __attribute__((noinline)) static float m_sin_huge(float x) { return sinf(x); }
+__device__ __forceinline__ float m_sin_moderate(float x) {
+  const float ax = __builtin_fabsf(x);
+  if (__builtin_expect(!(ax < 8192.0f), 0)) return m_sin_huge(x);
+  __builtin_assume(ax < 8192.0f);
+  return sinf(x);
+}
+__device__ __forceinline__ double m_sin_moderate(double x) { return sin(x); }
 __device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
 __device__ __forceinline__ float m_fma(float a, float b, float c) { return fmaf(a, b, c); }

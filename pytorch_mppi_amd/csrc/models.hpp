@@ -21,7 +21,7 @@ struct PendulumModel {
   __device__ explicit PendulumModel(const KArgs<T>&) {}
   __device__ __forceinline__ void step(T (&x)[NX], const T (&u)[NU], int) const {
     const T uc = clampT(u[0], T(-2), T(2));                         // pendulum.py:41-42
-    T nthd = x[1] + (T(15) * m_sin(x[0]) + T(3) * uc) * T(0.05);       // :44  3g/(2l)=15, 3/(ml^2)=3
+    T nthd = x[1] + (T(15) * m_sin_moderate(x[0]) + T(3) * uc) * T(0.05);   // :44  3g/(2l)=15, 3/(ml^2)=3
     nthd = clampT(nthd, T(-8), T(8));                               // :45
     x[0] = x[0] + nthd * T(0.05);                                      // :46
     x[1] = nthd;
@@ -29,9 +29,7 @@ struct PendulumModel {
   __device__ __forceinline__ T cost(const T (&x)[NX], const T (&)[NU], int) const {
     // angle_normalize (pendulum.py:52-53) with torch's floor-mod `%`
     const T pi = T(3.141592653589793), two_pi = T(6.283185307179586);
-    T r = m_fmod(x[0] + pi, two_pi);
-    if (r != T(0) && r < T(0)) r += two_pi;
-    const T an = r - pi;
+    const T an = m_floormod(x[0] + pi, two_pi) - pi;
     return an * an + T(0.1) * (x[1] * x[1]);                           // :56-61
   }
   __device__ __forceinline__ T terminal(const T (&)[NX]) const { return T(0); }

@@ -22,6 +22,7 @@
 #include "actions.hpp"
 #include "dispatch.hpp"
 #include "models.hpp"
+#include "weights.hpp"
 
 namespace mppi {
 
@@ -458,7 +459,8 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
 
 // NOISE: MPPI_NOISE_TNK4 | _PHILOX | _ACTIONS (compile-time);  DIAG: diagonal Sigma;
 // DMA_ROWS > 0: the rows travel through the LDS-DMA ring (fp32 row streams), 0: register ring
-template <class Model, typename T, int NOISE, bool DIAG, int DMA_ROWS = 0>
+// FUSE: the whole command of a small problem in this ONE launch (see the block behind the chunk loop)
+template <class Model, typename T, int NOISE, bool DIAG, int DMA_ROWS = 0, bool FUSE = false>
 __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a_in) {
   constexpr int NX = Model::NX, NU = Model::NU;
   const KArgs<T> a = env_view(a_in);        // MPPI_Batched: environment = blockIdx.z
@@ -565,6 +567,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
   StepTables<T> tb{Ue, Um, G, ktn_lds, kraw - (int)(threadIdx.x & (WAVE - 1))};
 
   const int nchunks = (a.K + K1_BLOCK - 1) / K1_BLOCK;
+  T fuse_total = T(0);
   for (int chunk = blockIdx.x;;) {
   T rollout = T(0), pert = T(0);
   // wave-uniform choice: does this wave own overwritten rows, or must it store the states?
@@ -599,6 +602,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
   }
   const T bm = wave_min<T>(active ? total : inf_v<T>());      // one minimum per 64 samples
   if ((threadIdx.x & (WAVE - 1)) == 0 && kraw < a.K) a.block_min[kraw / WAVE] = bm;
+  if constexpr (FUSE) { fuse_total = total; break; }          // fused launches have one chunk per workgroup
 
   // ---- next chunk of this workgroup (the LDS tables stay) ----
   chunk += gridDim.x;
@@ -614,6 +618,176 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
     for (int i = 0; i < NX; ++i) x[i] = s0[i];
   }
   if constexpr (DMA_ROWS == 0) ring_prologue();
+  }
+
+  if constexpr (FUSE) {
+    // ------------------------------------------------------------------------------------------
+    // Single-launch command for small problems (K <= 64 workgroups, T*nu <= 256): a command of
+    // 8192 x 32 is 1 MB of traffic and was three launches bound by their boundaries and by the host
+    // (12.6 + 5 + 5 us of kernels inside a 31 us command).  Here the workgroup goes on, behind its
+    // rollout, with
+    //   B  its own part of K3 -- weights relative to the WORKGROUP's minimum beta_b, eta_b, and
+    //      P_b[j] = sum_k w_k eps'_k[j] over its 256 samples (the rows it has just read or generated are
+    //      re-read out of L1/L2) -- published as a partial record {beta_b, eta_b, P_b};
+    //   C  (the LAST workgroup to finish, elected by an arrival ticket) the rank-order style combine
+    //      of all partial records in workgroup order -- beta = min beta_b, s_b = exp(-(beta_b-beta)/lambda),
+    //      eta = sum s_b eta_b, P = sum s_b P_b -- and K4's update U_out = shift(U) + P/eta, the action
+    //      and the shard record.
+    // No grid barrier and no spinning: nobody waits for anybody.  Partial records cross CUs / XCDs
+    // through agent-scope (sc1, write-through / L1-bypassing) stores and loads on BOTH sides -- per-XCD
+    // L2s are not coherent, and plain stores would need an agent release fence that also writes back
+    // the freshly generated rows (~6 us).  omega and
+    // cost_total_non_zero are NOT written (the caller opted in by passing NULL for both): they are
+    // exp(-(cost_total - record[0]) / lambda) [/ record[1]].  The ticket lives in the workspace and
+    // is left at 0 again.
+    // ------------------------------------------------------------------------------------------
+    __shared__ __attribute__((aligned(16))) T f_cU[UPD_TJ], f_cS[UPD_TJ], f_cM[UPD_TJ], f_cLo[UPD_TJ], f_cHi[UPD_TJ];
+    __shared__ T f_red[K1_BLOCK / WAVE];
+    __shared__ T f_wsum[K1_BLOCK / WAVE][UPD_TJ];
+    __shared__ T f_s[64];
+    __shared__ int f_last;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    const int b = blockIdx.x, nb = gridDim.x;
+    const T inv_lambda = T(1) / a.lambda_;
+    const T beta_b = block_min<T>(active ? fuse_total : inf_v<T>(), f_red);
+    const T wk = active ? weight_of<T>(fuse_total, beta_b, inv_lambda) : T(0);
+    const T eta_b = block_sum<T>(wk, f_red);
+    const bool over = a.null_action && (a.k_offset + kraw) == 0;          // the sample_null_action row (no sampler rows here)
+    const T w1[1] = {over ? T(0) : wk};
+    const bool live1[1] = {__ballot(w1[0] != T(0)) != 0ull};
+    const int njt = a.Jpad / UPD_TJ;
+    for (int jt = 0; jt < njt; ++jt) {
+      const int j0 = jt * UPD_TJ;
+      __syncthreads();                       // the previous tile's constants and sums are consumed
+      if (threadIdx.x < UPD_TJ) {
+        const int j = j0 + threadIdx.x;
+        const bool ok = j < a.J;
+        const int n = ok ? j % NU : 0;
+        f_cU[threadIdx.x] = ok ? u_base(a, j) : T(0);
+        f_cS[threadIdx.x] = ok ? (a.coloured ? T(1) : a.L[n * NU + n]) : T(0);
+        f_cM[threadIdx.x] = (ok && !a.coloured) ? a.mu[n] : T(0);
+        f_cLo[threadIdx.x] = ok ? a.umin[n] : T(0);
+        f_cHi[threadIdx.x] = ok ? a.umax[n] : T(0);
+      }
+      __syncthreads();
+      T acc[UPD_TJ];
+#pragma unroll
+      for (int i = 0; i < UPD_TJ; ++i) acc[i] = T(0);
+      const int nrows = a.J4 - jt * (UPD_TJ / 4);
+      if (live1[0]) {
+        // One wave per SIMD here (a small problem fills a fraction of the chip): the 16 row reads of the
+        // tile are all issued before the first is used -- row by row, each would expose an L2 round trip
+        T zz[UPD_TJ / 4][4];
+#pragma unroll
+        for (int jbl = 0; jbl < UPD_TJ / 4; ++jbl) {
+          const int jr = jbl < nrows ? jbl : nrows - 1;                  // clamped: no branch between the loads
+          load4<T>(a.z, a.zp, (long long)jt * (UPD_TJ / 4) + jr, k, zz[jbl]);
+        }
+#pragma unroll
+        for (int jbl = 0; jbl < UPD_TJ / 4; ++jbl) {
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) {
+            const int cc = 4 * jbl + c4;
+            T v = f_cU[cc] + (zz[jbl][c4] * f_cS[cc] + f_cM[cc]);
+            v = clampT(v, f_cLo[cc], f_cHi[cc]);
+            acc[cc] = jbl < nrows ? w1[0] * (v - f_cU[cc]) : T(0);
+          }
+        }
+      }
+      f_wsum[wv][lane] = live1[0] ? wave_reduce_transpose64<T>(acc) : T(0);
+      __syncthreads();
+      if (threadIdx.x < UPD_TJ) {
+        T sum = f_wsum[0][threadIdx.x];
+#pragma unroll
+        for (int i = 1; i < K1_BLOCK / WAVE; ++i) sum += f_wsum[i][threadIdx.x];
+        const int j = j0 + threadIdx.x;
+        if (a.null_action && a.k_offset == 0 && b == 0 && j < a.J) {
+          // the overwritten row 0 (masked above): its noise is clamp(0) - U, weight from its own cost
+          const T w0 = __shfl(wk, 0, WAVE);                              // wave 0 == threads < 64 here
+          sum += w0 * (clampT(T(0), f_cLo[threadIdx.x], f_cHi[threadIdx.x]) - f_cU[threadIdx.x]);
+        }
+        if (j < a.Jpad)
+          __hip_atomic_store(&a.P_part[(long long)b * a.Jpad + j], sum * a.e_scale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&a.eta_part[b], eta_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.block_min[(long long)b * (K1_BLOCK / WAVE)], beta_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // every partial store of this workgroup has left the CU before its ticket is drawn
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      f_last = old == (unsigned)(nb - 1);
+    }
+    __syncthreads();
+    if (f_last) {
+      // ---- C: combine, in workgroup order whoever is last ----
+      // All loads of the first pass are issued before anything waits for one of them: an agent-scope
+      // load is a round trip to the memory side (~1-2 us), and beta -> s_b -> eta -> P as dependent
+      // round trips was most of this phase's time.
+      constexpr int SL = K1_BLOCK / UPD_TJ, MAXI = 64 / SL;              // 4 slices of the workgroup index, <= 16 each
+      const int c = threadIdx.x & (UPD_TJ - 1), sl = threadIdx.x / UPD_TJ;
+      T bmin = inf_v<T>(), etab = T(0);
+      if (threadIdx.x < nb) {
+        bmin = __hip_atomic_load(&a.block_min[(long long)threadIdx.x * (K1_BLOCK / WAVE)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        etab = __hip_atomic_load(&a.eta_part[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      T pp[MAXI];
+      auto load_tile = [&](int j) {
+#pragma unroll
+        for (int q = 0; q < MAXI; ++q) {
+          const int i = sl + SL * q;
+          pp[q] = (i < nb && j < a.J)
+                      ? __hip_atomic_load(&a.P_part[(long long)i * a.Jpad + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                      : T(0);
+        }
+      };
+      load_tile(c);
+      const T my_beta = bmin;
+      const T beta = block_min<T>(bmin, f_red);
+      if (threadIdx.x < nb) {
+        const T sb = m_exp(-inv_lambda * (my_beta - beta));
+        f_s[threadIdx.x] = sb;
+        f_cU[threadIdx.x] = sb * etab;
+      }
+      __syncthreads();
+      T eta = T(0);
+      for (int i = 0; i < nb; ++i) eta += f_cU[i];                        // fixed order
+      const T inv_eta = T(1) / eta;
+      // P[j] = sum_b s_b P_b[j]: 64 columns x 4 interleaved slices of the workgroup index per pass,
+      // slices combined in fixed order
+      for (int j0 = 0; j0 < a.J; j0 += UPD_TJ) {
+        const int j = j0 + c;
+        if (j0 > 0) load_tile(j);
+        T part = T(0);
+#pragma unroll
+        for (int q = 0; q < MAXI; ++q) {
+          const int i = sl + SL * q;
+          part += (i < nb ? f_s[i] : T(0)) * pp[q];
+        }
+        f_wsum[sl][c] = part;
+        __syncthreads();
+        if (threadIdx.x < UPD_TJ && j < a.J) {
+          T P = f_wsum[0][c];
+#pragma unroll
+          for (int q = 1; q < SL; ++q) P += f_wsum[q][c];
+          a.record[2 + j] = P;
+          if (a.fuse) {                                                  // apply: mppi.py:268-275
+            const T un = u_eff(a, j) + P * inv_eta;
+            a.U_out[j] = un;
+            if (a.action_out != nullptr && j < a.u_per_command * a.nu) a.action_out[j] = un;
+          }
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        a.record[0] = beta;
+        a.record[1] = eta;
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next command
+      }
+    }
   }
   if (a.tstamp != nullptr) {
     // exit stamp AFTER every wave of the workgroup is done (the stamp is the kernel's span on the
@@ -681,6 +855,14 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
     const int cap = (n_cu * persist) / (a.n_env > 1 ? a.n_env : 1);
     if (gx > (cap > 1 ? cap : 1)) gx = cap > 1 ? cap : 1;
   }
+  // Whole command in this one launch?  (the caller asked for it -- a.fuse >= 0 -- and left omega /
+  // cost_total_non_zero NULL; small diagonal-form problem, rows in memory after K1, no sampler rows)
+  const bool fuse = a.fuse >= 0 && a.ticket != nullptr && dma == 0 && diag && a.n_env == 1 && a.n_sampler == 0 &&
+                    a.states == nullptr && a.omega == nullptr && a.wnz == nullptr && a.record != nullptr &&
+                    (a.fuse == 0 || a.U_out != nullptr) && nchunks <= 64 && a.R == 1 && a.nkc == nchunks &&
+                    a.Jpad <= 4 * UPD_TJ && a.z != nullptr &&
+                    (a.noise_src == MPPI_NOISE_TNK4 || a.noise_src == MPPI_NOISE_PHILOX);
+  if (fuse) gx = nchunks;
   const dim3 grid(gx, 1, a.n_env), block(K1_BLOCK);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   profile_next_events(&ev0, &ev1, &a.tstamp);   // null events == plain launch
@@ -710,6 +892,12 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
       else MPPI_LAUNCH1((rollout_cost_kernel<Model, T, NOISE_, false, ROWS_>));                    \
     }                                                                                              \
   } while (0)
+  if (fuse) {
+    if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_PHILOX, true, 0, true>));
+    else MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_TNK4, true, 0, true>));
+    const int e = (int)hipGetLastError();
+    return e != 0 ? e : MPPI_OK_FUSED;
+  }
   if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCH(MPPI_NOISE_PHILOX);
   else if (a.noise_src == MPPI_NOISE_ACTIONS) {
     if (dma == 30) MPPI_LAUNCH_DMA(MPPI_NOISE_ACTIONS, 30);

@@ -55,7 +55,8 @@ class SpecificActionSampler:
 
 
 def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    # a plain int is what a ctypes c_void_p field wants; no wrapper object per pointer per command
+    return None if t is None else t.data_ptr()
 
 
 class MPPI:
@@ -165,8 +166,9 @@ class MPPI:
 
         # results of the last command (mppi.py:180-184)
         self.cost_total = None
-        self.cost_total_non_zero = None
-        self.omega = None
+        self._omega = None
+        self._wnz = None
+        self._lazy_w = None        # (lambda used, record) when omega / cost_total_non_zero are derived on first read
         self._states = None
         self._actions = None
         self._noise = None
@@ -207,6 +209,8 @@ class MPPI:
             self._shard_gen = torch.Generator(device=self.d)
             self._shard_gen.manual_seed((self.seed + 0x9E3779B97F4A7C15 * (self._shard.rank + 1)) & 0x7FFFFFFFFFFFFFFF)
         self._ws = None
+        self._zbuf = {}
+        self._rec_buf = None
         self._vec_cache = {}
         self._problem_cache = {}
         self._ws_need = {}
@@ -402,13 +406,25 @@ class MPPI:
         """Elements of a TNK4 array for a (Tn, nu) sequence over this controller's samples."""
         return N.noise_rows4(Tn, self.nu) * self._zpitch() * 4
 
+    def _row_buffer(self, n):
+        """The TNK4 row array a command generates or converts its normals into.  ONE buffer per size,
+        reused by every command (stream order makes that safe; the lazily materialised attributes only
+        ever refer to the LAST command's rows): an allocation less per command."""
+        buf = self._zbuf.get(n)
+        if buf is None or buf.dtype != self.dtype:
+            if len(self._zbuf) > 4:
+                self._zbuf.clear()
+            buf = self._zbuf[n] = torch.empty(n, device=self.d, dtype=self.dtype)
+        return buf
+
     def _attach_workspace(self, p):
         key = (p.K, p.T, p.nu, p.num_envs)
         need = self._ws_need.get(key)
         if need is None:
             need = self._ws_need[key] = int(N.lib().mppi_workspace_elems(C.byref(p)))
         if self._ws is None or self._ws.numel() < need or self._ws.dtype != self.dtype:
-            self._ws = torch.empty(max(need, 1), device=self.d, dtype=self.dtype)
+            # zero-filled: the single-launch command keeps its arrival ticket in the last elements
+            self._ws = torch.zeros(max(need, 1), device=self.d, dtype=self.dtype)
         p.workspace = self._ws.data_ptr()
         p.workspace_elems = self._ws.numel()
 
@@ -467,7 +483,7 @@ class MPPI:
                     p._keep["z"] = zn
                     p.noise_src = N.NOISE_TNK4
                     return
-                zn = torch.empty(n, device=self.d, dtype=self.dtype)
+                zn = self._row_buffer(n)
                 p.z = _ptr(zn)
                 p._keep["z"] = zn
                 if fill:
@@ -504,7 +520,7 @@ class MPPI:
         """(K,T,nu) draw kept in p._keep['z_ktn'] -> the engine's sample-minor rows-of-4."""
         z = p._keep["z_ktn"]
         K, Tn, nu = z.shape
-        zn = torch.empty(self._zelems(Tn), device=self.d, dtype=self.dtype)
+        zn = self._row_buffer(self._zelems(Tn))
         N.check(N.lib().mppi_noise_from_ktn(C.byref(p), _ptr(z), _ptr(zn), self._stream()), "mppi_noise_from_ktn")
         p.noise_src = N.NOISE_TNK4
         p.z = _ptr(zn)
@@ -630,13 +646,26 @@ class MPPI:
         per_sample = tuple(self.state.shape) == (K, self.nx)              # mppi.py:302
         self._states = self._actions = self._noise = self._perturbed_action = None
 
-        omega = torch.empty(K, device=self.d, dtype=self.dtype)
-        wnz = torch.empty(K, device=self.d, dtype=self.dtype)
+        apply = 0 if self._sharded() else 1
+        # omega = (1/eta) exp(-(c - beta)/lambda) and cost_total_non_zero (mppi.py:256-258) are functions of
+        # cost_total and the record {beta, eta, ...}: a single-shard command leaves them to their first
+        # read (two allocations and a pass over K less per command, and what lets a small problem run
+        # as ONE launch); a sharded one has K5 rescale them, so there they are written
+        lazy = apply == 1
+        omega = None if lazy else torch.empty(K, device=self.d, dtype=self.dtype)
+        wnz = None if lazy else torch.empty(K, device=self.d, dtype=self.dtype)
         U_new = torch.empty(self.T, self.nu, device=self.d, dtype=self.dtype)
-        record = torch.empty(2 + self.T * self.nu, device=self.d, dtype=self.dtype)
+        if lazy:
+            # single shard: the record {beta, eta, P} is only read back by the lazily derived weights of
+            # THIS command -> one buffer for all commands
+            record = self._rec_buf
+            if record is None or record.numel() != 2 + self.T * self.nu or record.dtype != self.dtype:
+                record = self._rec_buf = torch.empty(2 + self.T * self.nu, device=self.d, dtype=self.dtype)
+        else:
+            record = torch.empty(2 + self.T * self.nu, device=self.d, dtype=self.dtype)
         p.omega, p.cost_total_non_zero, p.U_out, p.record = _ptr(omega), _ptr(wnz), _ptr(U_new), _ptr(record)
         p._keep.update(omega=omega, wnz=wnz, U_new=U_new, record=record)
-        apply = 0 if self._sharded() else 1
+        self._lazy_w = (float(self.lambda_), record) if lazy else None
         self.cost_total = cost_total
 
         if not self._needs_generic():
@@ -693,15 +722,14 @@ class MPPI:
                 "mppi_combine")
 
     def _end(self, p):
-        self.omega = p._keep["omega"]
-        self.cost_total_non_zero = p._keep["wnz"]
+        self._omega = p._keep["omega"]
+        self._wnz = p._keep["wnz"]
         self._record = p._keep["record"]
         self._last = p                # keeps z / U / sampler tensors alive for the lazy attributes
         self.U = p._keep["U_new"]                                         # mppi.py:270 (new tensor)
-        action = self.U[:self.u_per_command]
         if self.u_per_command == 1:
-            action = action[0]                                            # :271-275
-        return action
+            return self.U[0]                                              # :271-275 (one view instead of two)
+        return self.U[:self.u_per_command]
 
     # ------------------------------------------------------------------------------------------
     # generic (callback) path: mppi.py:297-332 around the engine's prepare kernel
@@ -802,6 +830,33 @@ class MPPI:
         N.check(lib.mppi_prepare(C.byref(p), self._stream()), "mppi_prepare")
         p.perturbed_action = p.noise = None
         self._perturbed_action, self._noise = pa, noise
+
+    def _derive_weights(self):
+        lam, record = self._lazy_w
+        w = torch.exp((-1.0 / lam) * (self.cost_total - record[0]))     # mppi.py:12-13, :256 (beta = record[0])
+        self._wnz = w
+        self._omega = (1.0 / record[1]) * w                             # :257-258 (eta = record[1])
+
+    @property
+    def omega(self):
+        if self._omega is None and self._lazy_w is not None and self.cost_total is not None:
+            self._derive_weights()
+        return self._omega
+
+    @omega.setter
+    def omega(self, v):
+        self._omega = v
+        self._lazy_w = None if v is None else self._lazy_w
+
+    @property
+    def cost_total_non_zero(self):
+        if self._wnz is None and self._lazy_w is not None and self.cost_total is not None:
+            self._derive_weights()
+        return self._wnz
+
+    @cost_total_non_zero.setter
+    def cost_total_non_zero(self, v):
+        self._wnz = v
 
     @property
     def noise(self):
@@ -922,6 +977,7 @@ class GraphedCommand:
         c = self.ctrl
         c._last = None                       # see the class docstring: no lazy attributes under replay
         c._noise = c._perturbed_action = c._states = c._actions = None
+        c._omega = c._wnz = None             # derived again, on demand, from this replay's cost_total / record
         return self.action
 
 

@@ -14,11 +14,10 @@ def pendulum_user():
     return builtin, jit.compile_model(
         "pendulum_user", 2, 1, dynamics=builtin.dynamics, running_cost=builtin.running_cost,
         step="const T uc = clampT(u[0], T(-2), T(2));"
-             "T nthd = x[1] + (T(15) * m_sin(x[0]) + T(3) * uc) * T(0.05);"
+             "T nthd = x[1] + (T(15) * m_sin_moderate(x[0]) + T(3) * uc) * T(0.05);"
              "nthd = clampT(nthd, T(-8), T(8)); x[0] = x[0] + nthd * T(0.05); x[1] = nthd;",
         cost="const T pi = T(3.141592653589793), two_pi = T(6.283185307179586);"
-             "T r = m_fmod(x[0] + pi, two_pi); if (r != T(0) && r < T(0)) r += two_pi;"
-             "const T an = r - pi; return an * an + T(0.1) * (x[1] * x[1]);")
+             "const T an = m_floormod(x[0] + pi, two_pi) - pi; return an * an + T(0.1) * (x[1] * x[1]);")
 
 
 def unicycle_callables():

@@ -178,3 +178,70 @@ def test_padded_noise_row_pitch_changes_nothing(rng, cls):
                 assert u.shape == v.shape and torch.isfinite(u).all()
             else:
                 assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("case", ["pendulum-philox", "pendulum-inject", "integrator-null-bounds", "smppi", "sharded", "f64"])
+def test_single_launch_command_for_small_problems(case):
+    """Small problems (K <= 16384, T*nu <= 256, diagonal Sigma) run the whole command -- rollout, weights,
+    weighted sums, combine over workgroups by the last one to arrive, update -- as ONE launch.  Checked:
+    the single-launch form is what ran, several consecutive commands (the arrival ticket must be back at
+    zero each time) agree with the fp64 oracle, omega / cost_total_non_zero (derived on first read) too,
+    and a problem just outside the envelope still takes the three-launch path with the same results."""
+    import numpy as np
+    from pytorch_mppi_amd import _native as N
+    from oracle import mppi_oracle as orc, dynamics as dyn, philox as oph
+    lib = N.lib()
+    g = torch.Generator().manual_seed(13)
+    dt = torch.float64 if case == "f64" else torch.float32
+    if case.startswith("pendulum"):
+        m, nx, nu, K, T = pm.models.Pendulum(), 2, 1, 8192, 32
+        sigma = torch.tensor(10.0, dtype=dt)
+        kw = dict(u_min=torch.tensor(-2.0, dtype=dt), u_max=torch.tensor(2.0, dtype=dt), lambda_=1.0)
+        f64, q64 = dyn.pendulum_dynamics, dyn.pendulum_cost
+        x0 = torch.tensor([3.141592653589793, 1.0], dtype=dt)
+    else:
+        nx, nu, K, T = 6, 4, 3000, 20                      # ragged K: the last workgroup is partly empty
+        m = pm.models.Integrator(nx, nu)
+        sigma = torch.diag(torch.tensor([1.0, 0.5, 2.0, 1.5], dtype=dt))
+        kw = dict(lambda_=12.0, sample_null_action=True, u_max=torch.full((nu,), 1.2, dtype=dt), noise_mu=torch.tensor([0.1, 0.0, -0.1, 0.0], dtype=dt))
+        f64, q64 = dyn.make_quadtoy(nx, nu)
+        x0 = torch.randn(nx, generator=g, dtype=dt)
+    U0 = torch.randn(T, nu, generator=g, dtype=dt) * 0.1
+    rng = "torch" if case == "pendulum-inject" else "philox"
+    cls, extra = (pm.SMPPI, dict(w_action_seq_cost=0.5, delta_t=0.5)) if case == "smppi" else (pm.MPPI, {})
+    shard = (0, 1) if case == "sharded" else None
+    c = cls(m.dynamics, m.running_cost, nx, sigma, num_samples=K, horizon=T, device="cuda", U_init=U0.clone(), rng=rng, seed=3,
+            shard=shard, **kw, **extra)
+    if case == "pendulum-inject":
+        c.ktn_direct = False                               # rows through the layout conversion -> TNK4 in memory
+    if case == "sharded":
+        c._force_collective = True
+    p64 = orc.Problem(dynamics=f64, running_cost=q64, nx=nx, noise_sigma=sigma.double(), K=K, T=T,
+                      **{k: (v.double() if torch.is_tensor(v) else v) for k, v in kw.items()})
+    n0 = lib.mppi_stat_single_launch_commands()
+    U = U0.double()
+    A = U0.double().clone()
+    Ud = torch.zeros_like(U)
+    for call in (1, 2, 3):
+        z = torch.from_numpy(oph.normals_ktn(3, call, K, T, nu)).double() if rng == "philox" else torch.randn(K, T, nu, generator=g, dtype=torch.float64)
+        if rng != "philox":
+            c.inject_noise(z.to(dt))
+        a = c.command(x0.cuda())
+        if case == "smppi":
+            r = orc.smppi_command(p64, Ud, A, x0.double(), z, torch.tensor(float("-inf")), torch.tensor(float("inf")), 0.5, 0.5, True)
+            Ud, A = r["U"], r["action_sequence"]
+        else:
+            r = orc.command(p64, U, x0.double(), z, True)
+            U = r["U"]
+        tol = (1e-9 if dt == torch.float64 else 1e-5) if rng != "philox" else 5e-5
+        for got, key in ((a, "action"), (c.cost_total, "cost_total"), (c.omega, "omega")):
+            ref = r[key].numpy()
+            err = float(np.abs(got.cpu().numpy().astype(np.float64) - ref).max())
+            assert err <= tol * max(1.0, float(np.abs(ref).max())), (case, call, key, err)
+        assert abs(float(c.omega.double().sum()) - 1.0) < 1e-5
+        if case != "smppi":
+            c.U = U.to(dt).cuda()
+        else:
+            c.U, c.action_sequence = Ud.to(dt).cuda(), A.to(dt).cuda()
+    ran_single = lib.mppi_stat_single_launch_commands() - n0
+    assert ran_single == (0 if case == "sharded" else 3), ran_single       # sharded commands keep omega eager -> 3 launches

@@ -33,9 +33,13 @@ def _run_fixture(name, native):
         assert not ctrl._needs_generic(), "fused kernel missing for a golden fixture"
     state = gu.t(d, "state", dtype).cuda()
     rtol = _tol(cfg)
-    if cfg["model"] == "mlp" and cfg["dtype"] == "f32":
-        rtol = 5e-5     # the reference's own fp32-vs-fp64 floor on this config is 2-3.5e-5
-    outs64 = gu.oracle_run(cfg, d, torch.float64) if (cfg["kmppi"] and cfg["dtype"] == "f32") else None
+    # fp32 fixtures: the live reference's fp32 results and the engine's are two roundings of the same
+    # fp64 quantity, and a peaked softmax amplifies last-bit differences of the costs (pendulum_f32 step 1:
+    # the REFERENCE's own fp32 U is 8.5e-5 away from its fp64 U).  The yardstick is therefore the fp64
+    # oracle, with the reference's fp32 distance from it as the floor:
+    #     err(engine_fp32 vs ref_fp64) <= max(1e-5 * scale, 2 * err(ref_fp32 vs ref_fp64)).
+    # fp64 fixtures are compared with the reference's fp64 results directly at 1e-9.
+    outs64 = gu.oracle_run(cfg, d, torch.float64) if cfg["dtype"] == "f32" else None
     for s in range(cfg["steps"]):
         ctrl.inject_noise(gu.t(d, f"z{s}", dtype))
         act = ctrl.command(state, shift_nominal_trajectory=bool(d[f"shift{s}"]))
@@ -47,11 +51,7 @@ def _run_fixture(name, native):
         if cfg.get("smppi"):
             got["action_sequence"] = ctrl.action_sequence
         for k, v in got.items():
-            if cfg["kmppi"] and cfg["dtype"] == "f32":
-                # the fp32 reference solves K (S,S) systems under vmap, the engine applies the constant
-                # operator W = K(Hs,Tk) Ktktk^-1: both are fp32 roundings of the SAME fp64
-                # quantity, so the yardstick is the fp64 oracle with the reference's own fp32 distance
-                # from it as the floor, not a blanket tolerance
+            if outs64 is not None:
                 ref64 = np.asarray(outs64[s][k].numpy(), dtype=np.float64)
                 ref32 = np.asarray(d[f"{k}{s}"], dtype=np.float64)
                 scale = max(1.0, float(np.abs(ref64).max()))
