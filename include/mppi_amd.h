@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 14
+#define MPPI_ABI_VERSION 15
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -87,7 +87,7 @@ typedef struct MppiProblem {
   int32_t use_terminal;       /* add the model's terminal cost (mppi.py:324-328)           */
   int32_t noise_src;          /* MPPI_NOISE_*                                              */
   int32_t u_per_command;      /* mppi.py:271                                               */
-  int32_t step_offset;        /* reserved (0)                                              */
+  int32_t rollout_samples;    /* M (mppi.py:76, :334-373): state rollouts per action sequence (fused: <= 4); 0/1 = one */
   int32_t hidden;             /* MLP hidden width                                          */
   int32_t num_envs;           /* MPPI_Batched (mppi.py:691-873): N independent controllers that
                                  share ONE noise draw; 0/1 = single.  state (N,nx), U / U_out
@@ -106,6 +106,8 @@ typedef struct MppiProblem {
    * bounds in u_min/u_max; the kernels then only need 1/dt and the smoothness weight.         */
   double noise_rescale;       /* 1/dt (SMPPI) -- multiplies the bounded noise; 1 for MPPI   */
   double smooth_weight;       /* w_action_seq_cost * u_scale^2 (mppi.py:559-562); 0 = off   */
+  double rollout_var_cost;    /* M > 1: weight of the discounted cost variance over the M rollouts (mppi.py:77, :372) */
+  double rollout_var_discount;/* M > 1: its per-step discount (mppi.py:78, :174-175, :364)  */
   /* ---- inputs (device) ---- */
   const void* state;          /* (nx) or (K,nx)                                            */
   const void* U;              /* (T,nu) nominal sequence BEFORE this command's shift       */
@@ -122,6 +124,10 @@ typedef struct MppiProblem {
   const void* theta;          /* KMPPI (S,nu) control points (after shift)           [opt] */
   const void* base_seq;       /* (T,nu) sequence the noise is added to and measured from;
                                  NULL = the (shifted) nominal U itself (MPPI/KMPPI)    [opt] */
+  const void* process_noise_sd;/* (nx) std of the Gaussian disturbance a native model adds to every
+                                 post-dynamics state -- what makes its dynamics stochastic, each of the
+                                 M rollouts drawing its own (engine Philox stream, key = seed ^ tag);
+                                 NULL = deterministic dynamics                         [opt] */
   /* ---- outputs (device) ---- */
   void* cost_total;           /* (K)                                                       */
   void* omega;                /* (K) normalised weights (mppi.py:258)                [opt] */

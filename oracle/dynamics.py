@@ -129,3 +129,19 @@ def make_linear_goal_multi(B, goal, w, K):
         return (dx ** 2).sum(dim=-1)                    # (M,K) for (M,K,T,nx) states
 
     return dynamics, cost, terminal
+
+
+# ---------------------------------------------------------------------------------------------
+# Process noise with INJECTED draws: x' = f(x, u) + sd * w[m, k, t].  The callbacks of an M > 1
+# command see one batch of M*K rows, row = m*K + k (mppi.py:351); w (M,K,T,nx) holds the draws the
+# engine's fused kernel makes itself (oracle/philox.process_normals), so the oracle and the kernel
+# see identical disturbances.  Step-dependent signature -> step_dependent_dynamics=True.
+# ---------------------------------------------------------------------------------------------
+def with_injected_process_noise(dynamics, w, sd):
+    M, K = w.shape[0], w.shape[1]
+
+    def noisy(state, action, t):
+        assert state.shape[0] == M * K
+        return dynamics(state, action) + sd * w[:, :, t].reshape(M * K, -1)
+
+    return noisy

@@ -63,3 +63,28 @@ def normals_ktn(seed, call, K, T, nu, k_offset=0):
     z4 = normals_tnk4(seed, call, K, T, nu, k_offset)          # (J4,K,4)
     flat = z4.transpose(1, 0, 2).reshape(K, -1)                # (K, J4*4)
     return np.ascontiguousarray(flat[:, :T * nu].reshape(K, T, nu))
+
+
+PROCESS_NOISE_KEY_TAG = 0x5A5A5A5AA5A5A5A5
+
+
+def process_normals(seed, call, K, T, M, nx, MM=4, k_offset=0):
+    """(M, K, T, nx) float32 -- the process-noise draws of the fused multi-rollout kernel
+    (pytorch_mppi_amd/csrc/rollout.hpp, rollout_stream_multi): Philox key = seed ^ PROCESS_NOISE_KEY_TAG,
+    counter = (k_global, (t * MM + m) * ceil(nx/4) + block, call), four normals per call."""
+    nxb = -(-nx // 4)
+    key = (seed ^ PROCESS_NOISE_KEY_TAG) & 0xFFFFFFFFFFFFFFFF
+    out = np.zeros((M, K, T, 4 * nxb), dtype=np.float32)
+    kg = np.arange(K, dtype=np.uint64) + np.uint64(k_offset)
+    c0 = kg.astype(np.uint32)
+    c2 = np.full(K, call & 0xFFFFFFFF, dtype=np.uint32)
+    c3 = np.uint32((call >> 32) & 0xFFFFFFFF) ^ (kg >> np.uint64(32)).astype(np.uint32)
+    for m in range(M):
+        for t in range(T):
+            for q in range(nxb):
+                jb = np.full(K, (t * MM + m) * nxb + q, dtype=np.uint32)
+                r0, r1, r2, r3 = philox4x32_10(c0, jb, c2, c3, key & 0xFFFFFFFF, (key >> 32) & 0xFFFFFFFF)
+                a, b = box_muller(r0, r1)
+                c, d = box_muller(r2, r3)
+                out[m, :, t, 4 * q:4 * q + 4] = np.stack([a, b, c, d], axis=-1)
+    return out[..., :nx]

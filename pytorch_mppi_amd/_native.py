@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
@@ -30,14 +30,15 @@ class MppiProblem(C.Structure):
         ("model_id", C.c_int32), ("sigma_diagonal", C.c_int32), ("noise_abs_cost", C.c_int32),
         ("sample_null_action", C.c_int32), ("n_sampler_rows", C.c_int32),
         ("state_per_sample", C.c_int32), ("shift", C.c_int32), ("use_terminal", C.c_int32),
-        ("noise_src", C.c_int32), ("u_per_command", C.c_int32), ("step_offset", C.c_int32),
+        ("noise_src", C.c_int32), ("u_per_command", C.c_int32), ("rollout_samples", C.c_int32),
         ("hidden", C.c_int32), ("num_envs", C.c_int32), ("noise_coloured", C.c_int32),
         ("lambda_", C.c_double), ("u_scale", C.c_double),
         ("seed", C.c_uint64), ("call", C.c_uint64), ("noise_pitch", C.c_int64),
         ("noise_rescale", C.c_double), ("smooth_weight", C.c_double),
+        ("rollout_var_cost", C.c_double), ("rollout_var_discount", C.c_double),
         ("state", _vp), ("U", _vp), ("u_init", _vp), ("noise_mu", _vp), ("noise_L", _vp),
         ("sigma_inv", _vp), ("u_min", _vp), ("u_max", _vp), ("model_params", _vp), ("z", _vp),
-        ("sampler_actions", _vp), ("W", _vp), ("theta", _vp), ("base_seq", _vp),
+        ("sampler_actions", _vp), ("W", _vp), ("theta", _vp), ("base_seq", _vp), ("process_noise_sd", _vp),
         ("cost_total", _vp), ("omega", _vp), ("cost_total_non_zero", _vp), ("U_out", _vp),
         ("action_out", _vp), ("perturbed_action", _vp), ("noise", _vp), ("pert_cost", _vp),
         ("states", _vp), ("record", _vp),

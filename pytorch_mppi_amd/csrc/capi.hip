@@ -114,6 +114,9 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.record = (T*)p->record;
   T* ws = (T*)p->workspace;
   a.tstamp = nullptr;
+  a.M = p->rollout_samples > 1 ? p->rollout_samples : 1;
+  a.var_cost = (T)p->rollout_var_cost; a.var_disc = (T)p->rollout_var_discount;
+  a.proc_sd = (const T*)p->process_noise_sd;
   a.fuse = -1;
   a.ticket = reinterpret_cast<unsigned*>(ws + (c.total - 4));
   a.n_env = p->num_envs > 1 ? p->num_envs : 1;

@@ -35,6 +35,9 @@ struct KArgs {
   int nb1, nkc, Jpad, R;
   int n_env;      // MPPI_Batched: environments on grid.z (1 = single controller)
   unsigned long long* tstamp;   // measurement hook: {min entry, max exit} on wall_clock64, or null
+  int M;                        // state rollouts per action sequence (mppi.py:334-373); 1 = the common case
+  T var_cost, var_disc;         // M > 1: weight / per-step discount of the cost variance over the M rollouts
+  const T* proc_sd;             // (nx) std of the native model's process noise, or null
   int fuse;                     // -1: K1 only | 0 / 1: whole command in K1's launch if eligible (value = K4's `apply`)
   unsigned* ticket;             // arrival counter of the single-launch command (workspace tail, kept at 0)
 };

@@ -123,6 +123,105 @@ __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionCons
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// M > 1 state rollouts per action sequence (mppi.py:334-373): the lane keeps M copies of the state,
+// feeds every copy the same bounded action, lets the model's process noise tell them apart and
+// accumulates   cost_samples[m] += c_m,   cost_var += var_m(c_m) * discount^t   (unbiased variance,
+// torch's .var(dim=0));   total = mean_m(cost_samples[m] + terminal_m) + rollout_var_cost * cost_var.
+// The action rows are read ONCE per sample whatever M is (the reference expands them M-fold), so the
+// memory side is that of M = 1 and the extra work is arithmetic -- plain row reads, no register ring.
+// Process noise: x[i] += sd[i] * n,  n ~ N(0,1) from the engine's Philox with its own key (seed ^ tag)
+// and counter (sample, (t * MM + m) * ceil(NX/4) + block, command) -- oracle/philox.py restates it.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned long long PROCESS_NOISE_KEY_TAG = 0x5A5A5A5AA5A5A5A5ull;
+
+template <class Model, typename T, int NOISE, bool DIAG, int MM>
+__device__ __forceinline__ void rollout_stream_multi(const KArgs<T>& a, const ActionConsts<T, Model::NU>& ac,
+                                                     const Model& model, const StepTables<T>& tb, int k, bool active,
+                                                     int orow, const T (&x0)[Model::NX], T& rollout, T& pert) {
+  constexpr int NX = Model::NX, NU = Model::NU;
+  constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT, NXB = (NX + 3) / 4;
+  const int M = a.M;
+  T xm[MM][NX], cs[MM];
+#pragma unroll
+  for (int m = 0; m < MM; ++m) {
+    cs[m] = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xm[m][i] = x0[i];
+  }
+  T cvar = T(0), dpow = T(1);
+  const T inv_M = T(1) / (T)M, inv_Mm1 = T(1) / (T)(M - 1);
+  const int nss = (a.Tn + TT - 1) / TT;
+  for (int ss = 0; ss < nss; ++ss) {
+    T zc[P4 * 4];
+#pragma unroll
+    for (int i = 0; i < P4; ++i) {
+      T r[4];
+      noise4<T, NOISE>(a, (long long)ss * P4 + i, k, r);
+      zc[4 * i] = r[0]; zc[4 * i + 1] = r[1]; zc[4 * i + 2] = r[2]; zc[4 * i + 3] = r[3];
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int t = ss * TT + tt;
+      if (t >= a.Tn) break;
+      // ---- the action of this step: as rollout_step ----
+      T z[NU], v[NU], e[NU], u[NU];
+#pragma unroll
+      for (int n = 0; n < NU; ++n) z[n] = zc[tt * NU + n];
+      const T* __restrict__ srow = orow >= 0 ? a.sampler + ((long long)orow * a.Tn + t) * NU : nullptr;
+      if (a.noise_src == MPPI_NOISE_ACTIONS) make_action<T, NU, true, true>(ac, tb.Ue + t * NU, srow, z, orow, v, e);
+      else make_action<T, NU, DIAG, false>(ac, tb.Ue + t * NU, srow, z, orow, v, e);
+      const T* __restrict__ Gt = tb.G + t * NU;
+#pragma unroll
+      for (int n = 0; n < NU; ++n) {
+        pert = m_fma(Gt[n], ac.abs_cost ? m_abs(e[n]) : e[n], pert);              // mppi.py:409, :415
+        u[n] = a.u_scale * v[n];                                                  // :354
+      }
+      // ---- M copies of the state ----
+      T c[MM], mean = T(0);
+#pragma unroll
+      for (int m = 0; m < MM; ++m) {
+        c[m] = T(0);
+        if (m < M) {
+          model.step(xm[m], u, t);                                                // :356
+          if (a.proc_sd != nullptr) {
+#pragma unroll
+            for (int q = 0; q < NXB; ++q) {
+              T w[4];
+              philox_normal4<T>(a.seed ^ PROCESS_NOISE_KEY_TAG, a.call, a.k_offset + k, ((long long)t * MM + m) * NXB + q, w);
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (4 * q + i < NX) xm[m][4 * q + i] = m_fma(a.proc_sd[4 * q + i], w[i], xm[m][4 * q + i]);
+            }
+          }
+          c[m] = model.cost(xm[m], u, t);                                         // :361
+          cs[m] += c[m];                                                          // :362
+          mean += c[m];
+          if (a.states != nullptr && active) {                                    // :366, layout (M,K,T,nx)
+            T* __restrict__ so = a.states + (((long long)m * a.K + k) * a.Tn + t) * NX;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) so[i] = xm[m][i];
+          }
+        }
+      }
+      mean *= inv_M;
+      T var = T(0);
+#pragma unroll
+      for (int m = 0; m < MM; ++m) {
+        const T d = c[m] - mean;
+        if (m < M) var = m_fma(d, d, var);
+      }
+      cvar = m_fma(var * inv_Mm1, dpow, cvar);                                    // :363-364
+      dpow *= a.var_disc;
+    }
+  }
+  T tot = T(0);
+#pragma unroll
+  for (int m = 0; m < MM; ++m)
+    if (m < M) tot += cs[m] + (a.use_terminal ? model.terminal(xm[m]) : T(0));    // :369-370
+  rollout = tot * inv_M + a.var_cost * cvar;                                      // :371-372
+}
+
 #ifndef MPPI_K1_BLOCK
 #define MPPI_K1_BLOCK 256   // threads per K1 workgroup (multiple of 64)
 #endif
@@ -460,7 +559,8 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
 // NOISE: MPPI_NOISE_TNK4 | _PHILOX | _ACTIONS (compile-time);  DIAG: diagonal Sigma;
 // DMA_ROWS > 0: the rows travel through the LDS-DMA ring (fp32 row streams), 0: register ring
 // FUSE: the whole command of a small problem in this ONE launch (see the block behind the chunk loop)
-template <class Model, typename T, int NOISE, bool DIAG, int DMA_ROWS = 0, bool FUSE = false>
+// MM > 1: up to MM state rollouts per action sequence (rollout_stream_multi)
+template <class Model, typename T, int NOISE, bool DIAG, int DMA_ROWS = 0, bool FUSE = false, int MM = 1>
 __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a_in) {
   constexpr int NX = Model::NX, NU = Model::NU;
   const KArgs<T> a = env_view(a_in);        // MPPI_Batched: environment = blockIdx.z
@@ -514,7 +614,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
       for (int d = 0; d < D; ++d) ring_fetch<T, NOISE, NU>(a, d < last ? d : last, k, ring[d]);
     }
   };
-  if constexpr (DMA_ROWS == 0) ring_prologue();
+  if constexpr (DMA_ROWS == 0 && MM == 1) ring_prologue();
 
 #pragma unroll
   for (int q = 0; q < UL; ++q) {
@@ -574,7 +674,9 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
   // (0 = neither; 1 = only the sample_null_action row: a select, no extra memory traffic; 2 = sampler
   // rows / states: conditional loads and stores, which cost the wave its exact vmcnt waits)
   const bool slow = __any(orow >= 0) || a.states != nullptr;
-  if constexpr (DMA_ROWS > 0) {
+  if constexpr (MM > 1) {
+    rollout_stream_multi<Model, T, NOISE, DIAG, MM>(a, ac, model, tb, k, active, orow, x, rollout, pert);
+  } else if constexpr (DMA_ROWS > 0) {
     // wave-private ring behind the tables (1 KiB rows; the carve keeps it 16-B aligned)
     float* ring_wave = reinterpret_cast<float*>(ktn_lds) + (threadIdx.x / WAVE) * DmaRing<NU, DMA_ROWS>::FLOATS_PER_WAVE;
     // (launch_rollout sends problems with sampler rows or a `states` output to the register-ring
@@ -594,7 +696,9 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
       rollout_stream<Model, T, NOISE, DIAG, 0>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
   }
 
-  if (a.use_terminal) rollout += model.terminal(x);                    // :324-328
+  if constexpr (MM == 1) {
+    if (a.use_terminal) rollout += model.terminal(x);                  // :324-328
+  }
   const T total = rollout + pert;                                      // :416
   if (active) {
     a.cost[k] = total;
@@ -617,7 +721,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = s0[i];
   }
-  if constexpr (DMA_ROWS == 0) ring_prologue();
+  if constexpr (DMA_ROWS == 0 && MM == 1) ring_prologue();
   }
 
   if constexpr (FUSE) {
@@ -857,7 +961,7 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
   }
   // Whole command in this one launch?  (the caller asked for it -- a.fuse >= 0 -- and left omega /
   // cost_total_non_zero NULL; small diagonal-form problem, rows in memory after K1, no sampler rows)
-  const bool fuse = a.fuse >= 0 && a.ticket != nullptr && dma == 0 && diag && a.n_env == 1 && a.n_sampler == 0 &&
+  const bool fuse = a.fuse >= 0 && a.M == 1 && a.ticket != nullptr && dma == 0 && diag && a.n_env == 1 && a.n_sampler == 0 &&
                     a.states == nullptr && a.omega == nullptr && a.wnz == nullptr && a.record != nullptr &&
                     (a.fuse == 0 || a.U_out != nullptr) && nchunks <= 64 && a.R == 1 && a.nkc == nchunks &&
                     a.Jpad <= 4 * UPD_TJ && a.z != nullptr &&
@@ -892,6 +996,13 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
       else MPPI_LAUNCH1((rollout_cost_kernel<Model, T, NOISE_, false, ROWS_>));                    \
     }                                                                                              \
   } while (0)
+  if (a.M > 1) {
+    // several state rollouts per action sequence: rows in memory (the caller fills / converts them), plain MPPI
+    if (a.M > 4 || (a.noise_src != MPPI_NOISE_TNK4) || a.B != nullptr || a.smooth_w != T(0)) return MPPI_E_UNSUPPORTED;
+    if (diag) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_TNK4, true, 0, false, 4>));
+    else MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_TNK4, false, 0, false, 4>));
+    return (int)hipGetLastError();
+  }
   if (fuse) {
     if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_PHILOX, true, 0, true>));
     else MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_TNK4, true, 0, true>));

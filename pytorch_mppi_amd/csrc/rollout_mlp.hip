@@ -28,7 +28,7 @@ int rollout_mlp(const KArgs<float>& a, hipStream_t st) {
   const bool force_valu = fv != nullptr && fv[0] == '1';
   const char* fe = getenv("MPPI_MLP_EXACT");
   const bool force_exact = fe != nullptr && fe[0] == '1';
-  if (!force_valu && a.states == nullptr && a.B == nullptr && a.smooth_w == 0.f &&
+  if (!force_valu && a.M == 1 && a.states == nullptr && a.B == nullptr && a.smooth_w == 0.f &&
       mlp_mfma_supported(a.nx, a.nu, a.hidden)) {
     // the matrix-core kernels read the engine's own layout: ask the caller to convert a (K,T,nu) draw
     if (a.noise_src == MPPI_NOISE_KTN) return MPPI_E_UNSUPPORTED;

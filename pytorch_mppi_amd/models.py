@@ -31,6 +31,25 @@ class NativeModel:
     def __init__(self):
         self._blob_cache = {}
         self._param_version = 0
+        self.process_noise = None      # (nx,) std of the Gaussian disturbance added to every post-dynamics state
+
+    def with_process_noise(self, std):
+        """Make the dynamics stochastic: x' = f(x, u) + std * n, n ~ N(0, I) -- what `rollout_samples > 1`
+        (mppi.py:334-373) is for.  The torch callable draws n with torch.randn_like; the fused kernel draws
+        it from the engine's Philox stream (one independent draw per sample, timestep and rollout copy)."""
+        std = torch.as_tensor(std, dtype=torch.float64).reshape(-1)
+        if std.numel() == 1:
+            std = std.expand(self.nx).clone()
+        if std.numel() != self.nx:
+            raise ValueError(f"process noise std must have nx = {self.nx} entries")
+        self.process_noise = std
+        self._param_version += 1
+        return self
+
+    def _noisy(self, nxt):
+        if self.process_noise is None:
+            return nxt
+        return nxt + self.process_noise.to(device=nxt.device, dtype=nxt.dtype) * torch.randn_like(nxt)
 
     # -- torch callables in the reference's plugin convention ----------------------------------
     def dynamics(self, state, action):
@@ -76,7 +95,7 @@ class Pendulum(NativeModel):
         newthdot = thdot + (15.0 * torch.sin(th) + 3.0 * u) * 0.05       # :44
         newthdot = torch.clamp(newthdot, -8, 8)                          # :45
         newth = th + newthdot * 0.05                                     # :46
-        return torch.cat((newth, newthdot), dim=1)
+        return self._noisy(torch.cat((newth, newthdot), dim=1))
 
     def running_cost(self, state, action):
         an = ((state[:, 0] + math.pi) % (2 * math.pi)) - math.pi         # :52-53
@@ -95,7 +114,7 @@ class Integrator(NativeModel):
     def dynamics(self, state, action):
         nxt = state.clone()
         nxt[..., :self.nu] = nxt[..., :self.nu] + action
-        return nxt
+        return self._noisy(nxt)
 
     def running_cost(self, state, action):
         return (state ** 2).sum(dim=-1)
@@ -121,7 +140,7 @@ class LinearGoal(NativeModel):
 
     def dynamics(self, state, action):
         B, _ = self._on(state)
-        return state + action @ B.T
+        return self._noisy(state + action @ B.T)
 
     def running_cost(self, state, action):
         _, goal = self._on(state)
@@ -168,7 +187,7 @@ class MLPResidual(NativeModel):
     def dynamics(self, state, action):
         W1, b1, W2, b2 = (t.to(state.device, state.dtype) for t in (self.W1, self.b1, self.W2, self.b2))
         h = torch.tanh(torch.cat((state, action), dim=1) @ W1.T + b1)
-        return state + self.res_scale * (h @ W2.T + b2)
+        return self._noisy(state + self.res_scale * (h @ W2.T + b2))
 
     def running_cost(self, state, action):
         return (state ** 2).sum(dim=-1)

@@ -197,7 +197,7 @@ class MPPI:
         self._call = 0
         self._injected = []
         self._model = None
-        if not step_dependent_dynamics and self.M == 1:
+        if not step_dependent_dynamics:
             self._model = native_model_of(dynamics, running_cost, terminal_state_cost)
         if self._model is not None and (self._model.nx != self.nx or self._model.nu != self.nu):
             raise ValueError(f"native model dims ({self._model.nx},{self._model.nu}) != (nx,nu)=({self.nx},{self.nu})")
@@ -343,7 +343,8 @@ class MPPI:
         m = self._model
         return (Tn, self.K_local, self.nx, self.nu, self.k_offset, id(m), m.hidden if m is not None else 0,
                 bool(self.noise_abs_cost), bool(self.sample_null_action), int(self.u_per_command),
-                float(self.lambda_), float(self.u_scale), self.seed, tv(self.u_init), tv(self.noise_mu),
+                float(self.lambda_), float(self.u_scale), int(self.M), float(self.rollout_var_cost),
+                float(self.rollout_var_discount), self.seed, tv(self.u_init), tv(self.noise_mu),
                 tv(self._sigma_inv_kernel), tv(self._noise_L), tv(self.u_min), tv(self.u_max),
                 m._param_version if m is not None else 0)
 
@@ -370,6 +371,9 @@ class MPPI:
             p.u_per_command = int(self.u_per_command)
             p.lambda_ = float(self.lambda_)
             p.u_scale = float(self.u_scale)
+            p.rollout_samples = int(self.M)
+            p.rollout_var_cost = float(self.rollout_var_cost)
+            p.rollout_var_discount = float(self.rollout_var_discount)
             p.seed = self.seed
             keep = dict(
                 u_init=self._vec(self.u_init), mu=self._vec(self.noise_mu),
@@ -382,6 +386,9 @@ class MPPI:
             if self._model is not None:
                 keep["mp"] = self._model.param_blob(self.d, self.dtype)
                 p.model_params = _ptr(keep["mp"])
+                if self._model.process_noise is not None:
+                    keep["psd"] = self._model.process_noise.to(device=self.d, dtype=self.dtype).contiguous()
+                    p.process_noise_sd = _ptr(keep["psd"])
             hit = (key, p, keep)
             self._problem_cache[Tn] = hit
         # a fresh struct per command (the previous one stays valid for the lazy attributes)
@@ -442,6 +449,10 @@ class MPPI:
         lib = N.lib()
         K, Tn, nu = shape
         self.last_draw = None
+        if self.M > 1 and (self._injected or self.rng != "philox"):
+            # the fused multi-rollout kernel keys its process-noise stream with the command number too
+            self._call += 1
+            p.call = self._call
         if self._injected:
             z = self._injected.pop(0)
             z = torch.as_tensor(z).to(device=self.d, dtype=self.dtype)
@@ -474,6 +485,8 @@ class MPPI:
                 # row-of-4, however small K is); the generator launch spreads them over the whole chip
                 # and costs one launch (~4 us): it wins from ~16 rows per sample on (tools/k_sweep.py)
                 fill = self.philox_fill if self.philox_fill is not None else rows4 >= 16
+                if self.M > 1 and not self._needs_generic():
+                    fill = True            # the multi-rollout K1 reads its rows from memory
                 self.last_draw = "philox-fill" if fill else "philox-k1"
                 pf, self._pf_rows = self._pf_rows, None
                 if fill and pf is not None and pf[0] == (K, Tn, nu, int(p.k_offset), int(p.seed), int(p.call)):
@@ -512,7 +525,7 @@ class MPPI:
         self._convert_noise(p)
 
     def _ktn_direct_ok(self, p, Tn, nu, z):
-        return (self.ktn_direct and self.dtype == torch.float32 and self._diagonal_sigma and (Tn * nu) % 4 == 0
+        return (self.ktn_direct and self.M == 1 and self.dtype == torch.float32 and self._diagonal_sigma and (Tn * nu) % 4 == 0
                 and nu in (4, 8, 12, 16) and z.data_ptr() % 16 == 0 and p.num_envs <= 1 and Tn == self.T
                 and not self._needs_generic())
 
@@ -576,13 +589,20 @@ class MPPI:
         p._keep["sampler"] = actions
 
     def _needs_generic(self):
-        if self._model is None or self.M != 1:
+        if self._model is None:
+            return True
+        if self.M != 1 and not self._fused_multi_ok():
             return True
         s = self.specific_action_sampler
         if s is not None and type(s).specific_dynamics is not SpecificActionSampler.specific_dynamics:
             return True      # arbitrary Python post-processing of the dynamics (mppi.py:315-317)
         p_ok = N.model_supported(self._model.model_id, self.nx, self.nu, _DT[self.dtype], self._model.hidden)
         return not p_ok
+
+    def _fused_multi_ok(self):
+        """M > 1 rollouts per action sequence inside K1 (csrc/rollout.hpp rollout_stream_multi): plain MPPI,
+        at most 4 copies of the state per lane; anything else runs the reference's callback loop."""
+        return type(self) is MPPI and 1 < self.M <= 4 and self.specific_action_sampler is None
 
     def _command(self, state, shift):
         p = self._begin(state, shift)
@@ -880,16 +900,17 @@ class MPPI:
 
     @property
     def states(self):
-        """(1,K,T,nx) visited states; like the reference only kept when a terminal cost is set
-        (mppi.py:307-310, :329-331)."""
-        if self._states is None and self._last is not None and self.terminal_state_cost is not None \
-                and not self._needs_generic():
+        """Visited states: (1,K,T,nx), like the reference only kept when a terminal cost is set
+        (mppi.py:307-310, :329-331) -- or (M,K,T,nx) for M > 1 rollouts, where the reference always
+        stores them (:349-350, :366)."""
+        want = self.terminal_state_cost is not None or self.M > 1
+        if self._states is None and self._last is not None and want and not self._needs_generic():
             lib = N.lib()
             p = self._last
             if p.noise_src == N.NOISE_KTN:
                 self._convert_noise(p)
             K = self.K_local
-            states = torch.empty(1, K, self.T, self.nx, device=self.d, dtype=self.dtype)
+            states = torch.empty(max(1, self.M), K, self.T, self.nx, device=self.d, dtype=self.dtype)
             scratch = torch.empty(K, device=self.d, dtype=self.dtype)
             old = p.cost_total
             p.states, p.cost_total = _ptr(states), _ptr(scratch)
@@ -905,9 +926,10 @@ class MPPI:
 
     @property
     def actions(self):
-        if self._actions is None and self._last is not None and self.terminal_state_cost is not None \
-                and not self._needs_generic():
-            self._actions = self.perturbed_action.unsqueeze(0)   # = (u_scale*v)/u_scale, mppi.py:412
+        want = self.terminal_state_cost is not None or self.M > 1
+        if self._actions is None and self._last is not None and want and not self._needs_generic():
+            # = (u_scale*v)/u_scale, mppi.py:412; M > 1: the same actions for every rollout copy (:354)
+            self._actions = self.perturbed_action.unsqueeze(0).expand(max(1, self.M), -1, -1, -1)
         return self._actions
 
     @actions.setter

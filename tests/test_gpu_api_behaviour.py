@@ -35,8 +35,7 @@ def make(path, cls=MPPI, dtype=DT, terminal=False, **kw):
         args["terminal_state_cost"] = term
     args.update(kw)
     c = cls(**args)
-    assert (c._model is not None) == (path == "fused" and not args.get("step_dependent_dynamics", False)
-                                      and args.get("rollout_samples", 1) == 1)
+    assert (c._model is not None) == (path == "fused" and not args.get("step_dependent_dynamics", False))
     return c
 
 

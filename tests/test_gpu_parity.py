@@ -398,3 +398,61 @@ def test_generator_coloured_full_sigma_matches_oracle(model_kind, nu, dtype):
             c.U = r["U"].to(dtype).cuda()                # same nominal sequence on both sides for the next call
         for x, y in zip(*outs):                          # the two engine variants against each other
             torch.testing.assert_close(x, y, rtol=2e-5 if dtype == torch.float32 else 1e-10, atol=2e-5 if dtype == torch.float32 else 1e-10)
+
+
+@pytest.mark.parametrize("case", ["integrator-f32-M3", "integrator-f64-M4-fullsigma", "lineargoal-f64-M2-terminal", "integrator-f32-M3-deterministic"])
+def test_fused_multi_rollout_matches_oracle(case):
+    """rollout_samples M > 1 inside K1 (csrc/rollout.hpp rollout_stream_multi; reference mppi.py:334-373): M
+    copies of the state per lane, the native model's process noise drawn in-kernel, mean cost + discounted
+    cost variance.  Against the fp64 oracle (`rollout_costs_multi`, pinned bit-for-bit against the live
+    reference) fed the SAME action draws and the SAME process-noise draws (oracle/philox.py restates
+    both streams); the (M,K,T,nx) `states` the reference always keeps for M > 1 included."""
+    import pytorch_mppi_amd as pm
+    from oracle import mppi_oracle as orc, dynamics as dyn, philox as oph
+    dt = torch.float64 if "f64" in case else torch.float32
+    M = int(case.split("-M")[1][0])
+    g = torch.Generator().manual_seed(len(case))
+    K, T = 1500, 14
+    if case.startswith("lineargoal"):
+        nx, nu = 2, 2
+        m = pm.models.LinearGoal(torch.tensor([[1.0, 0.0], [0.0, -1.0]]), torch.tensor([2.0, 2.0]))
+        base, q2, term = dyn.make_linear_goal(m.B.double(), m.goal.double())
+        terminal = True
+    else:
+        nx, nu = 6, 4
+        m = pm.models.Integrator(nx, nu)
+        base, q2 = dyn.make_quadtoy(nx, nu)
+        term, terminal = None, False
+    sd = torch.linspace(0.05, 0.2, nx, dtype=torch.float64)
+    if "deterministic" not in case:
+        m.with_process_noise(sd)
+    A = torch.randn(nu, nu, generator=g, dtype=torch.float64) * 0.3
+    sigma = (A @ A.T + 0.5 * torch.eye(nu, dtype=torch.float64)) if "fullsigma" in case else torch.diag(torch.linspace(0.5, 1.5, nu, dtype=torch.float64))
+    U0 = torch.randn(T, nu, generator=g, dtype=torch.float64) * 0.1
+    x0 = torch.randn(nx, generator=g, dtype=torch.float64)
+    kw = dict(lambda_=9.0, sample_null_action=True, u_max=torch.full((nu,), 1.3, dtype=torch.float64),
+              rollout_samples=M, rollout_var_cost=0.3, rollout_var_discount=0.9)
+    cast = lambda v: v.to(dt) if torch.is_tensor(v) else v
+    c = pm.MPPI(m.dynamics, m.running_cost, nx, sigma.to(dt), num_samples=K, horizon=T, device="cuda", U_init=U0.to(dt),
+                rng="philox", seed=41, terminal_state_cost=(m.terminal_state_cost if terminal else None),
+                **{k: cast(v) for k, v in kw.items()})
+    assert c._model is not None and not c._needs_generic(), "M > 1 with a native model must take the fused kernel"
+    U = U0
+    for call in (1, 2):
+        z = torch.from_numpy(oph.normals_ktn(41, call, K, T, nu)).double()
+        w = torch.from_numpy(oph.process_normals(41, call, K, T, M, nx)).double()
+        if "deterministic" in case:
+            w = torch.zeros_like(w)
+        f64 = dyn.with_injected_process_noise(base, w, sd)
+        p = orc.Problem(dynamics=f64, running_cost=lambda s_, a_, t_: q2(s_, a_), nx=nx, noise_sigma=sigma, K=K, T=T,
+                        step_dependent_dynamics=True, terminal_state_cost=term if terminal else None, **kw)
+        r = orc.command(p, U, x0, z, True)
+        a = c.command(x0.to(dt).cuda())
+        tol = 5e-5                                           # Philox: hardware log/sin/cos vs numpy in Box-Muller
+        _assert_close(c.cost_total, r["cost_total"].numpy(), tol, f"{case} call {call} cost_total")
+        _assert_close(a, r["action"].numpy(), tol, f"{case} call {call} action")
+        _assert_close(c.U, r["U"].numpy(), tol, f"{case} call {call} U")
+        assert c.states.shape == (M, K, T, nx) and c.actions.shape == (M, K, T, nu)
+        _assert_close(c.states, r["states"].numpy(), tol, f"{case} call {call} states")
+        U = r["U"]
+        c.U = U.to(dt).cuda()

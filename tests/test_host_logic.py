@@ -119,7 +119,9 @@ def test_cpu_device_has_no_compute_path():
 def test_unbuilt_features_fail_loudly():
     m = _lin()
     c = pm.MPPI(m.dynamics, m.running_cost, 2, torch.eye(2, dtype=torch.double), rollout_samples=3, device="cpu")
-    assert c._model is None and c._needs_generic()      # M > 1 always takes the callback path
+    assert c._model is not None and c._fused_multi_ok()  # M <= 4 copies of the state run inside K1
+    c9 = pm.MPPI(m.dynamics, m.running_cost, 2, torch.eye(2, dtype=torch.double), rollout_samples=9, device="cpu")
+    assert c9._needs_generic()                           # more than that: the reference's callback loop
     with pytest.raises(RuntimeError):
         c.command(torch.zeros(2, dtype=torch.double))
     with pytest.raises(ValueError):
