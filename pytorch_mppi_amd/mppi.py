@@ -197,8 +197,11 @@ class MPPI:
         self._call = 0
         self._injected = []
         self._model = None
-        if not step_dependent_dynamics:
-            self._model = native_model_of(dynamics, running_cost, terminal_state_cost)
+        m = native_model_of(dynamics, running_cost, terminal_state_cost)
+        # step-dependent callbacks (mppi.py:147-154): fused when the native model's callables take t too
+        # (jit.compile_model(..., step_dependent=True); the device functor always sees the timestep)
+        if m is not None and bool(step_dependent_dynamics) == bool(getattr(m, "step_dependent", False)):
+            self._model = m
         if self._model is not None and (self._model.nx != self.nx or self._model.nu != self.nu):
             raise ValueError(f"native model dims ({self._model.nx},{self._model.nu}) != (nx,nu)=({self.nx},{self.nu})")
         if self._shard is not None and self._shard.world_size > 1 and rng != "philox":

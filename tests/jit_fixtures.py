@@ -42,3 +42,23 @@ def unicycle():
         step="const T c = m_cos(x[2]), s = m_sin(x[2]); x[0] += p[0] * u[0] * c; x[1] += p[0] * u[0] * s; x[2] += p[0] * u[1];",
         cost="const T dx = x[0] - p[1], dy = x[1] - p[2]; return dx * dx + dy * dy + T(0.01) * (u[0] * u[0] + u[1] * u[1]);",
         terminal="const T dx = x[0] - p[1], dy = x[1] - p[2]; return p[3] * (dx * dx + dy * dy);")
+
+
+def drifting_callables(dtype=torch.float64):
+    """time-VARYING dynamics and cost (step_dependent_dynamics=True, mppi.py:147-154): the control authority
+    grows with the timestep, the goal moves"""
+    def f(s, a, t):
+        return s + DT_ * (1.0 + 0.05 * t) * a
+
+    def q(s, a, t):
+        return (s[:, 0] - 0.1 * t) ** 2 + (s[:, 1] + 0.05 * t) ** 2 + 0.01 * (a ** 2).sum(-1)
+
+    return f, q
+
+
+def drifting():
+    f, q = drifting_callables()
+    return jit.compile_model(
+        "drifting", 2, 2, dynamics=f, running_cost=q, params=[DT_], step_dependent=True,
+        step="const T g = p[0] * (T(1) + T(0.05) * T(t)); x[0] += g * u[0]; x[1] += g * u[1];",
+        cost="const T dx = x[0] - T(0.1) * T(t), dy = x[1] + T(0.05) * T(t); return dx * dx + dy * dy + T(0.01) * (u[0] * u[0] + u[1] * u[1]);")

@@ -53,3 +53,36 @@ def test_jit_unicycle_fused_equals_callback_path_and_oracle(dtype):
             np.testing.assert_allclose(got.cpu().double().numpy(), ref, rtol=tol, atol=tol * max(1.0, np.abs(ref).max()), err_msg=name)
     assert fused.states.shape == (1, K, T, 3)
     assert torch.allclose(fused.states, generic.states, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_step_dependent_dynamics_run_fused(dtype):
+    """step_dependent_dynamics=True (mppi.py:147-154) with a native model whose callables take t: the fused
+    kernel (the device functor always sees the timestep), not the callback loop; against the callback path
+    on the same callables and the fp64 oracle."""
+    from oracle import mppi_oracle as orc
+    f, q = jf.drifting_callables()
+    model = jf.drifting()
+    K, T = 900, 18
+    g = torch.Generator().manual_seed(8)
+    U0 = torch.randn(T, 2, generator=g, dtype=torch.float64) * 0.1
+    x0 = torch.tensor([0.3, -0.2], dtype=torch.float64)
+    sigma = torch.diag(torch.tensor([0.7, 1.2], dtype=torch.float64))
+    z = torch.randn(K, T, 2, generator=g, dtype=torch.float64)
+    kw = dict(num_samples=K, horizon=T, device="cuda", lambda_=0.8, U_init=U0.to(dtype), step_dependent_dynamics=True)
+    fused = pm.MPPI(model.dynamics, model.running_cost, 2, sigma.to(dtype), **kw)
+    generic = pm.MPPI(f, q, 2, sigma.to(dtype), **kw)
+    assert fused._model is model and not fused._needs_generic() and generic._needs_generic()
+    p = orc.Problem(dynamics=f, running_cost=q, nx=2, noise_sigma=sigma, K=K, T=T, lambda_=0.8, step_dependent_dynamics=True)
+    r = orc.command(p, U0, x0, z, True)
+    tol = 1e-9 if dtype == torch.float64 else 2e-5
+    for c in (fused, generic):
+        c.inject_noise(z.to(dtype))
+        a = c.command(x0.to(dtype).cuda())
+        for name, got in (("action", a), ("U", c.U), ("cost_total", c.cost_total)):
+            ref = r[name].numpy()
+            np.testing.assert_allclose(got.cpu().double().numpy(), ref, rtol=tol, atol=tol * max(1.0, np.abs(ref).max()), err_msg=name)
+    # a time-independent native model keeps refusing the flag's mismatch: callback path
+    m2 = pm.models.Integrator(2, 2)
+    c2 = pm.MPPI(lambda s, a, t: m2.dynamics(s, a), lambda s, a, t: m2.running_cost(s, a), 2, sigma.to(dtype), **kw)
+    assert c2._needs_generic()
