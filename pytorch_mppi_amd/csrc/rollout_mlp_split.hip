@@ -56,6 +56,10 @@ namespace {
 constexpr float B3_EXP2_SCALE = 2.8853900817779268f;   // 2 * log2(e)
 constexpr int B3_NX = 16, B3_NU = 4, B3_NI = 20;
 constexpr int B3_NT = 2;                                // sample tiles (of 16) per wave
+#ifndef MPPI_SPLIT_VPU
+#define MPPI_SPLIT_VPU 2
+#endif
+constexpr int B3_VPU = MPPI_SPLIT_VPU;                  // hidden activations per VALU unit of the software pipeline (2 | 4 | 8)
 constexpr int B3_THREADS = 256;                         // 4 waves = one per SIMD
 constexpr int B3_SAMPLES = (B3_THREADS / WAVE) * B3_NT * 16;   // samples per workgroup chunk (128)
 
@@ -366,22 +370,33 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
         else if constexpr (pr == 1) Om[i] = mfma_h(A2[jc].h, B2[buf][i].m, jc == 0 ? zero4 : Om[i]);
         else Os[i] = mfma_h(A2[jc].m, B2[buf][i].h, jc == 0 ? zero4 : Os[i]);
       };
-      auto valu_unit = [&](auto j_c, auto unit_c) {                // unit 0..15 of B(j): 8 value pairs x 2 phases
+      // B(j) = activation work of the pair's 16 hidden values per lane, in units of VPU values x 2 phases
+      // (phase 0: r = 1/(2^h + 1); phase 1: fp16 split + pack).  VPU independent exp -> add -> rcp chains per
+      // unit: the transcendental results are needed a few instructions after their issue.
+      constexpr int VPU = B3_VPU, NUNIT = 2 * (16 / VPU);
+      auto valu_unit = [&](auto j_c, auto unit_c) {
         constexpr int j = decltype(j_c)::value, unit = decltype(unit_c)::value;
-        constexpr int pair = unit >> 1, phase = unit & 1, buf = j & 1;
-        constexpr int i = pair >> 2, q = pair & 3, e0 = 2 * q;
+        constexpr int grp = unit >> 1, phase = unit & 1, buf = j & 1;
+        constexpr int v0 = grp * VPU;                              // first of the unit's values: v = 8 i + e
         // plain scalar fp32 adds on purpose: v_pk_add_f32 is no faster than two v_add_f32 on gfx950
         // (and measurably slower next to MFMAs), and hipcc pads the trans -> VALU forwarding hazard
         // only for instructions it emits itself
         if constexpr (phase == 0) {
-          rr[i][e0] = sigm2(Hc[buf][e0 >> 2][i][e0 & 3]);
-          rr[i][e0 + 1] = sigm2(Hc[buf][(e0 + 1) >> 2][i][(e0 + 1) & 3]);
+#pragma unroll
+          for (int v = v0; v < v0 + VPU; ++v) {
+            const int i = v >> 3, e = v & 7;
+            rr[i][e] = sigm2(Hc[buf][e >> 2][i][e & 3]);
+          }
         } else {
-          const unsigned hp = cvt_pk_f16(f32x2{rr[i][e0], rr[i][e0 + 1]});   // round-to-nearest fp16 hi pieces
-          const f32x2 hf = f16pair_to_f32(hp);
-          const float r1a = rr[i][e0] - hf.x, r1b = rr[i][e0 + 1] - hf.y;     // exact
-          B2[buf][i].h[q] = hp;
-          B2[buf][i].m[q] = cvt_pk_f16(f32x2{r1a, r1b});                      // |r - hi - mid| <= 2^-25
+#pragma unroll
+          for (int v = v0; v < v0 + VPU; v += 2) {
+            const int i = v >> 3, e0 = v & 7, q = e0 >> 1;
+            const unsigned hp = cvt_pk_f16(f32x2{rr[i][e0], rr[i][e0 + 1]});   // round-to-nearest fp16 hi pieces
+            const f32x2 hf = f16pair_to_f32(hp);
+            const float r1a = rr[i][e0] - hf.x, r1b = rr[i][e0 + 1] - hf.y;     // exact
+            B2[buf][i].h[q] = hp;
+            B2[buf][i].m[q] = cvt_pk_f16(f32x2{r1a, r1b});                      // |r - hi - mid| <= 2^-25
+          }
         }
       };
       // A(0): layer 1 of the first pair, nothing to overlap it with
@@ -400,8 +415,8 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
           if constexpr (c_after > c_before) layer2_slot(std::integral_constant<int, (j >= 1 ? j - 1 : 0)>{},
                                                         std::integral_constant<int, c_before>{});
           else layer1_slot(std::integral_constant<int, (hasA ? j + 1 : 0)>{}, std::integral_constant<int, sl - c_before>{});
-          // B(j)'s 16 VALU units spread evenly over the N slots
-          b3_static_for<(sl * 16) / N, ((sl + 1) * 16) / N>([&](auto uc) { valu_unit(jc, uc); });
+          // B(j)'s VALU units spread evenly over the N slots
+          b3_static_for<(sl * NUNIT) / N, ((sl + 1) * NUNIT) / N>([&](auto uc) { valu_unit(jc, uc); });
           __builtin_amdgcn_sched_barrier(0);
         });
       });

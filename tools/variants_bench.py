@@ -39,6 +39,9 @@ timeit("MPPI peaked softmax (lambda=0.05)", pm.MPPI(m.dynamics, m.running_cost, 
                                                     **{**kw, "lambda_": 0.05}), x0)
 timeit("MPPI + u bounds + null action", pm.MPPI(m.dynamics, m.running_cost, nx, sig, rng=rng, u_min=-torch.ones(nu),
                                                u_max=torch.ones(nu), sample_null_action=True, **kw), x0)
+mn = pm.models.Integrator(nx, nu).with_process_noise(0.05)
+timeit("MPPI M=3 rollouts, process noise", pm.MPPI(mn.dynamics, mn.running_cost, nx, sig, rng=rng, rollout_samples=3,
+                                                   rollout_var_cost=0.1, **kw), x0)
 full = torch.eye(nu) + 0.1 * torch.ones(nu, nu)
 timeit("MPPI full Sigma (Cholesky)", pm.MPPI(m.dynamics, m.running_cost, nx, full, rng=rng, **kw), x0)
 timeit("KMPPI S=32", pm.KMPPI(m.dynamics, m.running_cost, nx, sig, num_support_pts=32,
