@@ -15,6 +15,7 @@ prof() { # name, command...
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_$name -o $name -- "$@" > $REPO/gpurun_out/r02${T}_prof_$name.log 2>&1)
   local DB=$(find gpurun_out/prof_$name -name "*.db" | head -1)
   [ -n "$DB" ] && python tools/prof_summary.py $DB gpurun_out/r02${T}_trace_$name.txt > /dev/null
+  rm -rf gpurun_out/prof_$name          # the .db files are tens of MB each: only the summaries travel back
 }
 prof c3 python $REPO/bench.py --no-extras --no-cpu-baseline
 prof c4 python $REPO/bench.py --workload c4 --no-extras --no-cpu-baseline
@@ -26,6 +27,7 @@ pmc() { # name, counters, command...
   (cd /tmp && timeout 600 rocprofv3 --pmc $ctr -d $REPO/gpurun_out/pmc_$name -o $name -- "$@" > $REPO/gpurun_out/r02${T}_pmc_$name.log 2>&1)
   local DB=$(find gpurun_out/pmc_$name -name "*.db" | head -1)
   [ -n "$DB" ] && python tools/pmc_summary.py $DB gpurun_out/r02${T}_pmc_$name.txt > /dev/null
+  rm -rf gpurun_out/pmc_$name
 }
 pmc c3_fetch FETCH_SIZE python $REPO/bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline
 pmc c3_write WRITE_SIZE python $REPO/bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline
