@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 15
+#define MPPI_ABI_VERSION 16
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -183,12 +183,36 @@ int mppi_noise_from_ktn(const MppiProblem* p, const void* z_ktn, void* z_tnk4, v
  * written in TNK4 layout (J = T*nu) to v_tnk4. */
 int mppi_kmppi_interp(const MppiProblem* p, void* v_tnk4, void* stream);
 
+/* KMPPI's bookkeeping on the nominal sequences, one small launch each (a host-side formulation costs a roll, a
+ * copy and two GEMM launches per command):
+ *   mppi_kmppi_shift       KMPPI.shift_nominal_trajectory (mppi.py:232-238, :617-619):
+ *                          U_out (T,nu) = roll(U, -1) with u_init (nu) in the last row;  theta_out (S,nu) = W_shift (S,S) theta
+ *   mppi_kmppi_trajectory  deparameterize_to_trajectory_single (mppi.py:682, :647-648):  U_out (T,nu) = W (T,S) theta (S,nu)
+ * Outputs must not alias inputs. */
+int mppi_kmppi_shift(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void* U, const void* u_init,
+                     const void* theta, const void* W_shift, void* U_out, void* theta_out, void* stream);
+int mppi_kmppi_trajectory(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void* W, const void* theta,
+                          void* U_out, void* stream);
+
 /* K1 -- replaces _compute_total_cost_batch (mppi.py:407-417) = _sample_noise colouring
  * (:201-206), _compute_perturbed_action_and_noise (:375-385), _sample_specific_actions
  * (:387-400), _bound_action (:419-420), _compute_action_cost (:186-199) and
  * _compute_rollout_costs_single (:297-332) for a native model: writes cost_total (K) and the
  * per-block minima into the workspace. */
 int mppi_rollout_cost(const MppiProblem* p, void* stream);
+
+/* K1 for KMPPI with the interpolation INSIDE the launch (mppi.py:653-670 + :407-417): `p` as for
+ * mppi_kmppi_interp -- the trajectory problem (T, U, state, cost_total, sampler rows ...) whose noise_src / z /
+ * noise_pitch / seed / call describe the SUPPORT-point stream (S rows of nu; MPPI_NOISE_TNK4 or
+ * MPPI_NOISE_PHILOX), plus S, theta (S,nu), W (T,S).  Bounded control points stay in the lane's registers,
+ * v[t] = sum_s W[t,s] theta'[s] is formed four timesteps at a time on the matrix cores and consumed by the
+ * rollout at once: nothing of shape (K,T,nu) is written or read.  Same cost_total as mppi_kmppi_interp followed by
+ * mppi_rollout_cost(noise_src = MPPI_NOISE_ACTIONS) up to fp32 rounding of the sum over s.
+ * fp32, diagonal Sigma, nu in {4,8,12,16}, S*nu <= 384, native / JIT models on the per-lane path; anything else
+ * returns MPPI_E_UNSUPPORTED before any launch -> run the two calls instead. */
+int mppi_rollout_cost_kmppi(const MppiProblem* p, void* stream);
+/* process-wide count of mppi_rollout_cost_kmppi calls that launched (tests, bench) */
+int64_t mppi_stat_kmppi_fused_rollouts(void);
 
 /* generic path (user callbacks stay Python callables, mppi.py:63-64): everything of
  * _compute_total_cost_batch except the rollout loop: writes perturbed_action, noise (K,T,nu)

@@ -30,7 +30,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 EXTRA = {"update.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
          # MFMA results straight into VGPRs: every hidden activation is read by the VALU (tanh), and an
          # AGPR accumulator costs a v_accvgpr_read per value in a VALU-bound kernel
-         "rollout_mlp_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+         "rollout_mlp_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+         # the KMPPI-fused K1 (rollout_kmppi.hpp) pins 256 control points in the AGPRs and reads its 4 x nu
+         # accumulator tile with the VALU: same flag for every unit that instantiates it (jit.py passes it too)
+         "rollout_integrator.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+         "rollout_linear_goal.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+K1_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]     # for translation units built around csrc/rollout.hpp (jit.py)
 
 
 def _hipcc():

@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
@@ -62,12 +62,16 @@ SYMBOLS = {
     "mppi_noise_from_ktn": (C.c_int, [_PP, _vp, _vp, _vp]),
     "mppi_kmppi_interp": (C.c_int, [_PP, _vp, _vp]),
     "mppi_rollout_cost": (C.c_int, [_PP, _vp]),
+    "mppi_rollout_cost_kmppi": (C.c_int, [_PP, _vp]),
+    "mppi_kmppi_shift": (C.c_int, [C.c_int32] * 4 + [_vp] * 7),
+    "mppi_kmppi_trajectory": (C.c_int, [C.c_int32] * 4 + [_vp] * 4),
     "mppi_prepare": (C.c_int, [_PP, _vp]),
     "mppi_cost_block_min": (C.c_int, [_PP, _vp]),
     "mppi_weights_partial": (C.c_int, [_PP, _vp]),
     "mppi_finalize": (C.c_int, [_PP, C.c_int, _vp]),
     "mppi_command": (C.c_int, [_PP, C.c_int, _vp]),
     "mppi_stat_single_launch_commands": (C.c_int64, []),
+    "mppi_stat_kmppi_fused_rollouts": (C.c_int64, []),
     "mppi_combine": (C.c_int, [_PP, _vp, C.c_int32, _vp]),
     "mppi_register_model": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "mppi_dist_available": (C.c_int, []),

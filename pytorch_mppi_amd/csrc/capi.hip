@@ -118,6 +118,7 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.var_cost = (T)p->rollout_var_cost; a.var_disc = (T)p->rollout_var_discount;
   a.proc_sd = (const T*)p->process_noise_sd;
   a.fuse = -1;
+  a.W = a.theta = nullptr; a.S = 0;
   a.ticket = reinterpret_cast<unsigned*>(ws + (c.total - 4));
   a.n_env = p->num_envs > 1 ? p->num_envs : 1;
   if (a.n_env > 1 && (p->state_per_sample || p->n_sampler_rows > 0 || p->states != nullptr || p->base_seq != nullptr ||
@@ -143,12 +144,19 @@ int need_noise(const KArgs<T>& a) {
 }
 
 template <typename T>
-int do_rollout(const MppiProblem* p, hipStream_t st, int fuse = -1) {
+int do_rollout(const MppiProblem* p, hipStream_t st, int fuse = -1, bool kmppi = false) {
   KArgs<T> a;
   if (int e = make_args<T>(p, a)) return e;
   if (int e = need_noise(a)) return e;
   if (!a.state || !a.cost) return fail(MPPI_E_BADARG, "rollout needs state and cost_total");
   a.fuse = fuse;
+  if (kmppi) {
+    // interpolation inside K1: z / seed / call describe the support-point stream (S rows of nu)
+    if (p->S <= 0 || !p->theta || !p->W) return fail(MPPI_E_BADARG, "mppi_rollout_cost_kmppi needs S, theta, W");
+    if (a.noise_src != MPPI_NOISE_TNK4 && a.noise_src != MPPI_NOISE_PHILOX)
+      return fail(MPPI_E_UNSUPPORTED, "mppi_rollout_cost_kmppi: support points come from MPPI_NOISE_TNK4 or MPPI_NOISE_PHILOX");
+    a.W = (const T*)p->W; a.theta = (const T*)p->theta; a.S = p->S;
+  }
   int r;
   switch (p->model_id) {
     case MPPI_MODEL_PENDULUM: r = rollout_pendulum(a, st); break;
@@ -345,8 +353,39 @@ extern "C" int mppi_kmppi_interp(const MppiProblem* p, void* out, void* stream) 
   return BY_DTYPE(p, do_interp<float>(p, out, (hipStream_t)stream), do_interp<double>(p, out, (hipStream_t)stream));
 }
 
+extern "C" int mppi_kmppi_shift(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void* U, const void* u_init,
+                                const void* theta, const void* W_shift, void* U_out, void* theta_out, void* stream) {
+  if (T <= 0 || S <= 0 || nu <= 0 || !U || !u_init || !theta || !W_shift || !U_out || !theta_out)
+    return fail(MPPI_E_BADARG, "mppi_kmppi_shift: bad argument");
+  if (dtype == MPPI_F32)
+    return hipfail(launch_kmppi_sequences<float>(S, S, nu, (const float*)W_shift, (const float*)theta, (float*)theta_out, T,
+                                                 (const float*)U, (const float*)u_init, (float*)U_out, (hipStream_t)stream), "mppi_kmppi_shift");
+  if (dtype == MPPI_F64)
+    return hipfail(launch_kmppi_sequences<double>(S, S, nu, (const double*)W_shift, (const double*)theta, (double*)theta_out, T,
+                                                  (const double*)U, (const double*)u_init, (double*)U_out, (hipStream_t)stream), "mppi_kmppi_shift");
+  return fail(MPPI_E_BADARG, "bad dtype");
+}
+extern "C" int mppi_kmppi_trajectory(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void* W, const void* theta,
+                                     void* U_out, void* stream) {
+  if (T <= 0 || S <= 0 || nu <= 0 || !W || !theta || !U_out) return fail(MPPI_E_BADARG, "mppi_kmppi_trajectory: bad argument");
+  if (dtype == MPPI_F32)
+    return hipfail(launch_kmppi_sequences<float>(T, S, nu, (const float*)W, (const float*)theta, (float*)U_out, 0, nullptr, nullptr,
+                                                 nullptr, (hipStream_t)stream), "mppi_kmppi_trajectory");
+  if (dtype == MPPI_F64)
+    return hipfail(launch_kmppi_sequences<double>(T, S, nu, (const double*)W, (const double*)theta, (double*)U_out, 0, nullptr,
+                                                  nullptr, nullptr, (hipStream_t)stream), "mppi_kmppi_trajectory");
+  return fail(MPPI_E_BADARG, "bad dtype");
+}
+
 extern "C" int mppi_rollout_cost(const MppiProblem* p, void* stream) {
   return BY_DTYPE(p, do_rollout<float>(p, (hipStream_t)stream), do_rollout<double>(p, (hipStream_t)stream));
+}
+static long long g_kmppi_fused_rollouts = 0;
+extern "C" int64_t mppi_stat_kmppi_fused_rollouts(void) { return g_kmppi_fused_rollouts; }
+extern "C" int mppi_rollout_cost_kmppi(const MppiProblem* p, void* stream) {
+  const int r = BY_DTYPE(p, do_rollout<float>(p, (hipStream_t)stream, -1, true), do_rollout<double>(p, (hipStream_t)stream, -1, true));
+  if (r == 0) ++g_kmppi_fused_rollouts;
+  return r;
 }
 
 template <typename T>

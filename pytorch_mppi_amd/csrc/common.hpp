@@ -40,6 +40,8 @@ struct KArgs {
   const T* proc_sd;             // (nx) std of the native model's process noise, or null
   int fuse;                     // -1: K1 only | 0 / 1: whole command in K1's launch if eligible (value = K4's `apply`)
   unsigned* ticket;             // arrival counter of the single-launch command (workspace tail, kept at 0)
+  const T *W, *theta;           // KMPPI inside K1 (rollout_kmppi.hpp): (T,S) operator, (S,nu) control points; else null
+  int S;                        //   number of support points; z / seed / call then describe the SUPPORT-point stream
 };
 
 // MPPI_Batched: the view of the argument block for environment blockIdx.z.  The noise (z), all

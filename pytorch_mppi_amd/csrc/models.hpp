@@ -91,6 +91,7 @@ struct LinearGoalModel {
 template <typename T, int NX_, int NU_>
 struct MlpModel {
   static constexpr int NX = NX_, NU = NU_, NI = NX_ + NU_;
+  static constexpr bool NO_KMPPI_FUSE = true;   // the per-lane MLP needs its registers for the hidden layer
   const T* __restrict__ W1;
   const T* __restrict__ b1;
   const T* __restrict__ W2;

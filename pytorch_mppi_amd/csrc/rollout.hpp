@@ -44,7 +44,8 @@ struct StepTables {
 };
 
 // one timestep: actions from z, action cost, dynamics, running cost
-template <class Model, typename T, int NOISE, bool DIAG, int SLOW>
+// SMOOTH = false: the caller knows there is no smoothness cost (no uniform branch on a.smooth_w in the step)
+template <class Model, typename T, int NOISE, bool DIAG, int SLOW, bool SMOOTH = true>
 __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionConsts<T, Model::NU>& ac,
                                              const Model& model, const StepTables<T>& tb, int k,
                                              bool active, int orow, int t, const T* zt,
@@ -101,7 +102,7 @@ __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionCons
     pert = m_fma(Gt[n], ac.abs_cost ? m_abs(e) : e, pert);                 // :409, :415
     u[n] = a.u_scale * v[n];                                               // :313
   }
-  if (a.smooth_w != T(0)) {
+  if (SMOOTH && a.smooth_w != T(0)) {
     // SMPPI smoothness cost w * |u_scale * (v[t] - v[t-1])|^2 (mppi.py:559-562); vprev = v at t = 0
     T d2 = T(0);
 #pragma unroll
@@ -901,6 +902,10 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
   }
 }
 
+}  // namespace mppi
+#include "rollout_kmppi.hpp"   // KMPPI: interpolation inside K1 (needs rollout_step)
+namespace mppi {
+
 // LDS-DMA ring depth (rows of 1 KiB per wave) for this launch, 0 = register ring.  One workgroup
 // per CU (<= 256 workgroups, the C3 case: one wave per SIMD) gets the deep ring (30 rows, 120 KiB
 // per workgroup); larger grids keep two workgroups per CU resident with 15 rows each, so that one
@@ -931,6 +936,7 @@ static int dma_rows_for(const KArgs<T>& a, size_t smem_tables) {
 template <class Model, typename T>
 static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
   constexpr int NU = Model::NU;
+  if (a_in.W != nullptr) return launch_rollout_kmppi<Model, T>(a_in, st);   // mppi_rollout_cost_kmppi
   KArgs<T> a = a_in;
   const bool diag = a.diag != 0 || a.coloured != 0;   // a coloured stream runs the diagonal instantiation
   size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (a.diag != 0 ? 0 : 2 * NU * NU)) * sizeof(T);   // factors / Sigma^-1 of a coloured stream

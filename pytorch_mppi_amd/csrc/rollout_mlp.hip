@@ -20,6 +20,7 @@ template <typename T> static int go(const KArgs<T>& a, hipStream_t st) {
   return MPPI_E_UNSUPPORTED;
 }
 int rollout_mlp(const KArgs<float>& a, hipStream_t st) {
+  if (a.W != nullptr) return MPPI_E_UNSUPPORTED;   // KMPPI: the matrix-core kernels read raw action rows (two-launch form)
   // fp32 + (nx,nu)=(16,4): matrix-core kernels.  hidden = 256: 16-bit MFMAs on split operands (bf16 x 3
   // for layer 1, fp16 x 2 for layer 2; fp32-level accuracy, rollout_mlp_split.hip); hidden in {64,128,256} with MPPI_MLP_EXACT=1
   // (or where the split kernel has no instantiation): the exact-fp32 MFMA kernel, bit-for-bit an fmaf

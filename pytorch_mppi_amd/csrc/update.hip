@@ -965,6 +965,39 @@ int launch_combine(const KArgs<T>& a, const T* rec, int G, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// KMPPI's per-command bookkeeping on the nominal sequences, as ONE tiny launch each instead of the
+// roll / copy / two GEMM launches a host-side formulation costs (~5 us of stream time apiece inside a
+// ~120 us command):
+//   shift        (mppi.py:232-238, :617-619):  theta_out = W_shift theta,  U_out = roll(U, -1), last row = u_init
+//   trajectory   (mppi.py:682):                U_out     = W theta
+// out[r][n] = sum_s M[r][s] x[s][n] in index order; one thread per output element.
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) kmppi_sequences_kernel(int R, int S, int nu, const T* __restrict__ M,
+                                                                const T* __restrict__ x, T* __restrict__ out, int Troll,
+                                                                const T* __restrict__ U, const T* __restrict__ u_init,
+                                                                T* __restrict__ U_out) {
+  const int g = blockIdx.x * BLOCK + threadIdx.x;
+  if (g < R * nu) {
+    const int r = g / nu, n = g - r * nu;
+    T acc = T(0);
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) acc = m_fma(M[r * S + s], x[s * nu + n], acc);   // loads of 8 terms in flight, sum in index order
+    out[g] = acc;
+  } else if (g - R * nu < Troll * nu) {
+    const int j = g - R * nu, jn = j + nu;
+    U_out[j] = jn < Troll * nu ? U[jn] : u_init[jn - Troll * nu];
+  }
+}
+
+template <typename T>
+int launch_kmppi_sequences(int R, int S, int nu, const T* M, const T* x, T* out, int Troll, const T* U,
+                           const T* u_init, T* U_out, hipStream_t st) {
+  const int n = (R + Troll) * nu;
+  hipLaunchKernelGGL(kmppi_sequences_kernel<T>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, R, S, nu, M, x, out,
+                     Troll, U, u_init, U_out);
+  return (int)hipGetLastError();
+}
+
 #define MPPI_INST(T)                                                                     \
   template int launch_noise_fill_philox<T>(const KArgs<T>&, T*, hipStream_t);             \
   template int launch_noise_fill_philox_coloured<T>(const KArgs<T>&, T*, hipStream_t);    \
@@ -974,7 +1007,8 @@ int launch_combine(const KArgs<T>& a, const T* rec, int G, hipStream_t st) {
   template int launch_cost_block_min<T>(const KArgs<T>&, hipStream_t);                    \
   template int launch_weights_partial<T>(const KArgs<T>&, hipStream_t);                   \
   template int launch_finalize<T>(const KArgs<T>&, int, hipStream_t);                     \
-  template int launch_combine<T>(const KArgs<T>&, const T*, int, hipStream_t);
+  template int launch_combine<T>(const KArgs<T>&, const T*, int, hipStream_t);              \
+  template int launch_kmppi_sequences<T>(int, int, int, const T*, const T*, T*, int, const T*, const T*, T*, hipStream_t);
 MPPI_INST(float)
 MPPI_INST(double)
 

@@ -27,7 +27,7 @@ import typing
 import torch
 
 from . import _native as N
-from .models import NativeModel, native_model_of
+from .models import MLPResidual, NativeModel, native_model_of
 
 logger = logging.getLogger(__name__)
 
@@ -1327,6 +1327,7 @@ class KMPPI(MPPI):
         self.interpolation_kernel = kernel
         self.ktn_direct = False        # the support-point draw always goes through the layout conversion
         self.coloured_fill = False     # the interpolation kernel colours the support points itself
+        self.fuse_interpolation = True  # K1 interpolates in-kernel where it can (mppi_rollout_cost_kmppi)
         self._noise_theta = None
         self._last_theta = None
         self.prepare_vmap_interpolation()
@@ -1371,8 +1372,38 @@ class KMPPI(MPPI):
         return torch.einsum("ts,ksn->ktn", self._W, theta), K.unsqueeze(0).expand(self.K, -1, -1)
 
     def shift_nominal_trajectory(self):
-        super().shift_nominal_trajectory()
-        self.theta = self._W_shift @ self.theta                           # mppi.py:617-619
+        if not self._native_sequences():
+            super().shift_nominal_trajectory()
+            self.theta = self._W_shift @ self.theta                       # mppi.py:617-619
+            return
+        # one small launch for both sequences (host-side: roll + copy + GEMM = three)
+        U = self.U.to(device=self.d, dtype=self.dtype).contiguous()
+        th = self.theta.to(device=self.d, dtype=self.dtype).contiguous()
+        u0 = self._vec(self.u_init)
+        U_new, th_new = torch.empty_like(U), torch.empty_like(th)
+        N.check(N.lib().mppi_kmppi_shift(_DT[self.dtype], self.T, int(self.num_support_pts), self.nu, _ptr(U), _ptr(u0), _ptr(th),
+                                         _ptr(self._W_shift), _ptr(U_new), _ptr(th_new), self._stream()), "mppi_kmppi_shift")
+        self.U, self.theta = U_new, th_new
+
+    def _fused_interp_expected(self):
+        """mirror of mppi_rollout_cost_kmppi's conditions (include/mppi_amd.h); a wrong guess only costs time"""
+        S, nu = int(self.num_support_pts), self.nu
+        return (self.fuse_interpolation and self.dtype == torch.float32 and self._diagonal_sigma and nu % 4 == 0
+                and nu <= 16 and S <= min(64, (384 // nu) & ~3) and not self._needs_generic()
+                and not isinstance(self._model, MLPResidual))
+
+    def _native_sequences(self):
+        return (self.d.type == "cuda" and self._W.dtype == self.dtype and tuple(self.U.shape) == (self.T, self.nu)
+                and tuple(self.theta.shape) == (int(self.num_support_pts), self.nu))
+
+    def _trajectory_of(self, theta):
+        """U = W theta (mppi.py:682)"""
+        if not self._native_sequences():
+            return self._W @ theta
+        U = torch.empty(self.T, self.nu, device=self.d, dtype=self.dtype)
+        N.check(N.lib().mppi_kmppi_trajectory(_DT[self.dtype], self.T, int(self.num_support_pts), self.nu, _ptr(self._W),
+                                              _ptr(theta), _ptr(U), self._stream()), "mppi_kmppi_trajectory")
+        return U
 
     def _noise_shape(self):
         return (self.K_local, int(self.num_support_pts), self.nu)
@@ -1391,7 +1422,15 @@ class KMPPI(MPPI):
         pt.shift = 0
         pt.sample_null_action = 0
         self._attach_workspace(pt)
-        self._draw_noise(pt, self._noise_shape())
+        fill_keep = self.philox_fill
+        if self.philox_fill is None and self._fused_interp_expected():
+            # K1 keeps the bounded control points in registers: generating their rows there (and again in K3)
+            # costs +4 us of K1 and saves the 19 us generator launch and its 100 MB (C3-sized work)
+            self.philox_fill = False
+        try:
+            self._draw_noise(pt, self._noise_shape())
+        finally:
+            self.philox_fill = fill_keep
         if pt.noise_src == N.NOISE_PHILOX:
             pt.z = None       # support-point stream is tiny: interp and the theta update regenerate it
         # --- trajectory problem ---
@@ -1404,10 +1443,6 @@ class KMPPI(MPPI):
         p.noise_src, p.z, p.call = pt.noise_src, pt.z, pt.call
         self._attach_workspace(p)
         pt.workspace, pt.workspace_elems = p.workspace, p.workspace_elems
-        v_raw = torch.empty(self._zelems(self.T), device=self.d, dtype=self.dtype)
-        N.check(lib.mppi_kmppi_interp(C.byref(p), _ptr(v_raw), st), "mppi_kmppi_interp")
-        p.noise_src, p.z = N.NOISE_ACTIONS, _ptr(v_raw)
-        p._keep["v_raw"] = v_raw
         self._sampler_rows(p)
         cost_total = torch.empty(K, device=self.d, dtype=self.dtype)
         p.cost_total = _ptr(cost_total)
@@ -1420,8 +1455,16 @@ class KMPPI(MPPI):
             p._keep["state"] = s0
             p.state_per_sample = int(per_sample)
             p.use_terminal = int(self.terminal_state_cost is not None)
-            N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
+            # interpolation inside K1 where that kernel exists (fp32, diagonal Sigma, nu % 4 == 0, S*nu <= 384):
+            # the (K,T,nu) raw actions are never written; lazy attributes build them on demand (_raw_actions)
+            rc = lib.mppi_rollout_cost_kmppi(C.byref(p), st) if self.fuse_interpolation else N.E_UNSUPPORTED
+            if rc == N.E_UNSUPPORTED:
+                self._raw_actions(p)
+                N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
+            else:
+                N.check(rc, "mppi_rollout_cost_kmppi")
         else:
+            self._raw_actions(p)
             self._generic_total_cost(p, cost_total, st)
         self.cost_total = cost_total
         # --- theta update: K3/K4 on the support-point stream (mppi.py:679-681) ---
@@ -1446,11 +1489,35 @@ class KMPPI(MPPI):
         self._record = record
         self._last, self._last_theta = p, pt
         self.theta = theta_new
-        self.U = self._W @ self.theta                                     # mppi.py:682
+        self.U = self._trajectory_of(self.theta)                          # mppi.py:682
         action = self.U[:self.u_per_command]
         if self.u_per_command == 1:
             action = action[0]
         return action
+
+    def _raw_actions(self, p=None):
+        """(K,T,nu) raw interpolated actions of the last command in the engine layout (mppi.py:665): the
+        two-launch form of K1, the generic path and the lazy attributes read them; the fused K1 does not."""
+        p = self._last if p is None else p
+        if p is None or "v_raw" in p._keep:
+            return
+        v_raw = torch.empty(self._zelems(self.T), device=self.d, dtype=self.dtype)
+        N.check(N.lib().mppi_kmppi_interp(C.byref(p), _ptr(v_raw), self._stream()), "mppi_kmppi_interp")
+        p.noise_src, p.z = N.NOISE_ACTIONS, _ptr(v_raw)
+        p._keep["v_raw"] = v_raw
+
+    def _materialize(self):
+        self._raw_actions()
+        super()._materialize()
+
+    @property
+    def states(self):
+        self._raw_actions()
+        return MPPI.states.fget(self)
+
+    @states.setter
+    def states(self, v):
+        self._states = v
 
     @property
     def noise_theta(self):

@@ -456,3 +456,105 @@ def test_fused_multi_rollout_matches_oracle(case):
         _assert_close(c.states, r["states"].numpy(), tol, f"{case} call {call} states")
         U = r["U"]
         c.U = U.to(dt).cuda()
+
+
+@pytest.mark.parametrize("nx,nu,K,T,S,rng", [
+    (16, 12, 4096, 64, 32, "philox"),     # the C3-shaped case: every support point present, 128 control points per lane in LDS
+    (16, 12, 1000, 64, 32, "torch"),      # ragged K, rows from memory
+    (16, 12, 777, 30, 15, "philox"),      # S not a multiple of 4 (zero-padded operator columns), T not a multiple of 4
+    (16, 12, 512, 41, 30, "torch"),       # S4 == SMAX with two padded support points
+    (6, 4, 2048, 24, 12, "philox"),       # nu = 4: everything in the accumulation registers
+    (8, 4, 640, 50, 25, "torch"),
+])
+def test_kmppi_interpolation_inside_k1_matches_the_two_launch_form_and_the_oracle(nx, nu, K, T, S, rng):
+    """mppi_rollout_cost_kmppi (bounded control points in registers, interpolation on the matrix cores
+    inside K1; mppi.py:653-670) against (a) mppi_kmppi_interp + mppi_rollout_cost on the same draw and
+    (b) the fp64 oracle fed that draw: cost_total, theta, U, action; sampler rows and the null action
+    included; the lazy (K,T,nu) attributes come out of the same draw."""
+    import pytorch_mppi_amd as pm
+    from oracle import dynamics as dyn
+    from oracle import mppi_oracle as orc
+    g = torch.Generator().manual_seed(K + S)
+    sigma = torch.diag(torch.rand(nu, generator=g, dtype=torch.float64) * 0.5 + 0.3)
+    umax = torch.rand(nu, generator=g, dtype=torch.float64) * 0.8 + 0.6
+    mu = torch.randn(nu, generator=g, dtype=torch.float64) * 0.05
+    x0 = torch.randn(nx, generator=g, dtype=torch.float64)
+    kw64 = dict(lambda_=12.0, u_max=umax, noise_mu=mu, sample_null_action=True, u_scale=0.9)
+    m = pm.models.Integrator(nx, nu)
+
+    def make(fuse):
+        c = pm.KMPPI(m.dynamics, m.running_cost, nx, sigma.float(), num_samples=K, horizon=T, device="cuda",
+                     num_support_pts=S, kernel=pm.RBFKernel(sigma=1.5), U_init=torch.zeros(T, nu), rng=rng, seed=11,
+                     **{k: (v.float() if torch.is_tensor(v) else v) for k, v in kw64.items()})
+        c.fuse_interpolation = fuse
+        assert not c._needs_generic()
+        return c
+
+    a, b = make(True), make(False)
+    f64, q64 = dyn.make_quadtoy(nx, nu)
+    p = orc.Problem(dynamics=f64, running_cost=q64, nx=nx, noise_sigma=sigma, K=K, T=T, **kw64)
+    W, W_shift, _, _ = orc.kmppi_matrices(T, S, torch.float64, kernel=lambda t, tk: orc.rbf_kernel(t, tk, sigma=1.5))
+    theta, U = torch.zeros(S, nu, dtype=torch.float64), torch.zeros(T, nu, dtype=torch.float64)
+    lib = pm._native.lib()
+    for s in range(2):
+        if rng == "torch":
+            z = torch.randn(K, S, nu, generator=g)
+            a.inject_noise(z); b.inject_noise(z)
+        n0 = lib.mppi_stat_kmppi_fused_rollouts()
+        ua = a.command(x0.float().cuda())
+        assert lib.mppi_stat_kmppi_fused_rollouts() == n0 + 1, "the fused K1 did not run"
+        ub = b.command(x0.float().cuda())
+        assert lib.mppi_stat_kmppi_fused_rollouts() == n0 + 1
+        sc = max(1.0, float(b.cost_total.abs().max()))
+        assert float((a.cost_total - b.cost_total).abs().max()) <= 1e-5 * sc
+        for name, x, y in (("theta", a.theta, b.theta), ("U", a.U, b.U), ("action", ua, ub)):
+            assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max())), (name, s)
+        # the oracle on the bounded control-point noise the engine itself reports (identical for both forms)
+        assert torch.equal(a.noise_theta, b.noise_theta)
+        # z such that clamp(theta + L z + mu) reproduces the engine's control points: feed the oracle the
+        # engine's own draw where it is available (torch), else recover it from noise_theta (un-clamped rows only)
+        if rng == "torch":
+            r = orc.kmppi_command(p, theta, U, x0, z.double(), W, W_shift, True)
+            theta, U = r["theta"], r["U"]
+            for name, got, ref in (("cost_total", a.cost_total, r["cost_total"]), ("theta", a.theta, r["theta"]),
+                                   ("U", a.U, r["U"]), ("action", ua, r["action"])):
+                ref = ref.numpy()
+                err = float(np.abs(got.detach().cpu().double().numpy() - ref).max())
+                assert err <= 3e-5 * max(1.0, float(np.abs(ref).max())), (name, s, err)
+        # lazy attributes of the fused form: built on demand from the same control points
+        assert float((a.perturbed_action - b.perturbed_action).abs().max()) == 0.0
+        assert float((a.noise - b.noise).abs().max()) == 0.0
+
+
+def test_kmppi_interpolation_inside_k1_with_sampler_rows_per_sample_states_and_terminal_cost():
+    import pytorch_mppi_amd as pm
+    nx, nu, K, T, S = 12, 4, 600, 20, 10         # LinearGoal has a terminal cost; (12, 4) is a compiled instantiation
+    g = torch.Generator().manual_seed(5)
+    Bm = torch.randn(nx, nu, generator=g) * 0.3
+    m = pm.models.LinearGoal(Bm, torch.randn(nx, generator=g))
+    if not pm._native.lib().mppi_model_supported(m.model_id, nx, nu, 0, 0):
+        pytest.skip("no LinearGoal(2,4) instantiation")
+    rows = torch.randn(3, T, nu, generator=g).cuda()
+
+    class Rows(pm.SpecificActionSampler):
+        def sample_trajectories(self, state, info):
+            return rows
+
+    def make(fuse):
+        c = pm.KMPPI(m.dynamics, m.running_cost, nx, torch.eye(nu) * 0.4, num_samples=K, horizon=T, device="cuda",
+                     num_support_pts=S, terminal_state_cost=m.terminal_state_cost, lambda_=5.0, rng="philox", seed=3,
+                     specific_action_sampler=Rows(), sample_null_action=True, U_init=torch.zeros(T, nu),
+                     u_min=-torch.ones(nu), u_max=torch.ones(nu))
+        c.fuse_interpolation = fuse
+        return c
+
+    a, b = make(True), make(False)
+    xs = torch.randn(K, nx, generator=g).cuda()
+    for s in range(2):
+        ua, ub = a.command(xs), b.command(xs)
+        sc = max(1.0, float(b.cost_total.abs().max()))
+        assert float((a.cost_total - b.cost_total).abs().max()) <= 1e-5 * sc
+        assert float((a.theta - b.theta).abs().max()) <= 1e-5
+        assert float((ua - ub).abs().max()) <= 1e-5
+        assert a.states.shape == (1, K, T, nx)
+        assert float((a.states - b.states).abs().max()) <= 1e-5 * max(1.0, float(b.states.abs().max()))
