@@ -194,6 +194,12 @@ int mppi_kmppi_shift(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void
 int mppi_kmppi_trajectory(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void* W, const void* theta,
                           void* U_out, void* stream);
 
+/* SMPPI.shift_nominal_trajectory (mppi.py:488-492) plus the base sequence of the next command (:540), one launch:
+ * U_out = roll(U, -1) with u_init in the last row; A_out = roll(action_sequence, -1) with the last row repeated;
+ * B_out = A_out + U_out * dt (what MppiProblem.base_seq points at).  Outputs must not alias inputs. */
+int mppi_smppi_shift(int32_t dtype, int32_t T, int32_t nu, const void* U, const void* u_init, const void* A, double dt,
+                     void* U_out, void* A_out, void* B_out, void* stream);
+
 /* K1 -- replaces _compute_total_cost_batch (mppi.py:407-417) = _sample_noise colouring
  * (:201-206), _compute_perturbed_action_and_noise (:375-385), _sample_specific_actions
  * (:387-400), _bound_action (:419-420), _compute_action_cost (:186-199) and

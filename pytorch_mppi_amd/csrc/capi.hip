@@ -365,6 +365,17 @@ extern "C" int mppi_kmppi_shift(int32_t dtype, int32_t T, int32_t S, int32_t nu,
                                                   (const double*)U, (const double*)u_init, (double*)U_out, (hipStream_t)stream), "mppi_kmppi_shift");
   return fail(MPPI_E_BADARG, "bad dtype");
 }
+extern "C" int mppi_smppi_shift(int32_t dtype, int32_t T, int32_t nu, const void* U, const void* u_init, const void* A, double dt,
+                                void* U_out, void* A_out, void* B_out, void* stream) {
+  if (T <= 0 || nu <= 0 || !U || !u_init || !A || !U_out || !A_out || !B_out) return fail(MPPI_E_BADARG, "mppi_smppi_shift: bad argument");
+  if (dtype == MPPI_F32)
+    return hipfail(launch_smppi_shift<float>(T, nu, (const float*)U, (const float*)u_init, (const float*)A, (float)dt, (float*)U_out,
+                                             (float*)A_out, (float*)B_out, (hipStream_t)stream), "mppi_smppi_shift");
+  if (dtype == MPPI_F64)
+    return hipfail(launch_smppi_shift<double>(T, nu, (const double*)U, (const double*)u_init, (const double*)A, dt, (double*)U_out,
+                                              (double*)A_out, (double*)B_out, (hipStream_t)stream), "mppi_smppi_shift");
+  return fail(MPPI_E_BADARG, "bad dtype");
+}
 extern "C" int mppi_kmppi_trajectory(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void* W, const void* theta,
                                      void* U_out, void* stream) {
   if (T <= 0 || S <= 0 || nu <= 0 || !W || !theta || !U_out) return fail(MPPI_E_BADARG, "mppi_kmppi_trajectory: bad argument");

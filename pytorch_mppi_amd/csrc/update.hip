@@ -998,6 +998,29 @@ int launch_kmppi_sequences(int R, int S, int nu, const T* M, const T* x, T* out,
   return (int)hipGetLastError();
 }
 
+// SMPPI.shift_nominal_trajectory (mppi.py:488-492) and the base sequence of the next command (:540) in one
+// launch (host-side: two concatenations and an add):
+//   U_out = roll(U, -1), last row = u_init;   A_out = roll(A, -1), last row repeats;   B_out = A_out + U_out * dt
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) smppi_shift_kernel(int J, int nu, const T* __restrict__ U, const T* __restrict__ u_init,
+                                                            const T* __restrict__ A, T dt, T* __restrict__ U_out,
+                                                            T* __restrict__ A_out, T* __restrict__ B_out) {
+  const int j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= J) return;
+  const int jn = j + nu;
+  const T u = jn < J ? U[jn] : u_init[jn - J];
+  const T av = jn < J ? A[jn] : A[j];
+  U_out[j] = u;
+  A_out[j] = av;
+  B_out[j] = av + dt * u;
+}
+template <typename T>
+int launch_smppi_shift(int Tn, int nu, const T* U, const T* u_init, const T* A, T dt, T* U_out, T* A_out, T* B_out, hipStream_t st) {
+  const int J = Tn * nu;
+  hipLaunchKernelGGL(smppi_shift_kernel<T>, dim3((J + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, J, nu, U, u_init, A, dt, U_out, A_out, B_out);
+  return (int)hipGetLastError();
+}
+
 #define MPPI_INST(T)                                                                     \
   template int launch_noise_fill_philox<T>(const KArgs<T>&, T*, hipStream_t);             \
   template int launch_noise_fill_philox_coloured<T>(const KArgs<T>&, T*, hipStream_t);    \
@@ -1008,7 +1031,8 @@ int launch_kmppi_sequences(int R, int S, int nu, const T* M, const T* x, T* out,
   template int launch_weights_partial<T>(const KArgs<T>&, hipStream_t);                   \
   template int launch_finalize<T>(const KArgs<T>&, int, hipStream_t);                     \
   template int launch_combine<T>(const KArgs<T>&, const T*, int, hipStream_t);              \
-  template int launch_kmppi_sequences<T>(int, int, int, const T*, const T*, T*, int, const T*, const T*, T*, hipStream_t);
+  template int launch_kmppi_sequences<T>(int, int, int, const T*, const T*, T*, int, const T*, const T*, T*, hipStream_t); \
+  template int launch_smppi_shift<T>(int, int, const T*, const T*, const T*, T, T*, T*, T*, hipStream_t);
 MPPI_INST(float)
 MPPI_INST(double)
 

@@ -1052,6 +1052,16 @@ class SMPPI(MPPI):
     def shift_nominal_trajectory(self):
         # roll(-1) + overwrite of the last row (mppi.py:488-492) as ONE concatenation each: these are
         # host-launched tiny kernels and a command is only ~100 us long
+        if self.d.type == "cuda" and tuple(self.U.shape) == (self.T, self.nu) == tuple(self.action_sequence.shape):
+            # both shifts and the base sequence A + U*dt of the command that follows in ONE small launch
+            U = self.U.to(device=self.d, dtype=self.dtype).contiguous()
+            A = self.action_sequence.to(device=self.d, dtype=self.dtype).contiguous()
+            U_new, A_new, B = torch.empty_like(U), torch.empty_like(U), torch.empty_like(U)
+            N.check(N.lib().mppi_smppi_shift(_DT[self.dtype], self.T, self.nu, _ptr(U), _ptr(self._vec(self.u_init)), _ptr(A),
+                                             float(self.delta_t), _ptr(U_new), _ptr(A_new), _ptr(B), self._stream()), "mppi_smppi_shift")
+            self.U, self.action_sequence = U_new, A_new
+            self._base_ready = (U_new, A_new, float(self.delta_t), B)
+            return
         u_last = torch.as_tensor(self.u_init, device=self.U.device, dtype=self.U.dtype).reshape(1, -1).expand(1, self.nu)
         self.U = torch.cat((self.U[1:], u_last), dim=0)
         A = self.action_sequence
@@ -1086,7 +1096,11 @@ class SMPPI(MPPI):
         dt = float(self.delta_t)
         keep = p._keep
         A = self.action_sequence.to(device=self.d, dtype=self.dtype)
-        keep["B"] = torch.add(A, keep["U"], alpha=dt).contiguous()        # base of :540, one kernel
+        br = getattr(self, "_base_ready", None)
+        if br is not None and br[0] is self.U and br[1] is self.action_sequence and br[2] == dt and keep["U"] is self.U:
+            keep["B"] = br[3]                                             # came out of the shift launch
+        else:
+            keep["B"] = torch.add(A, keep["U"], alpha=dt).contiguous()    # base of :540, one kernel
         # colouring factors x dt: constant between parameter changes -> cached on the parameter tensors
         ck = (id(keep["L"]), keep["L"]._version, id(keep["mu"]), keep["mu"]._version, dt)
         if self._dt_cache is None or self._dt_cache[0] != ck:

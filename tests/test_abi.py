@@ -90,3 +90,35 @@ def test_bad_calls_refused_on_host():
     assert b"dtype" in lib.mppi_last_error()
     with pytest.raises(RuntimeError, match="code -1"):
         N.check(-1, "x")
+
+
+def test_plain_c_client_links_and_agrees_on_the_struct(tmp_path):
+    """The boundary is a C ABI: the header compiles as strict C99 (no C++, no torch types), a C program links
+    against the shared library, sees the same ABI version and sizeof(MppiProblem), and a compute entry point
+    refuses an empty problem on the host (no GPU needed)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "client.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "mppi_amd.h"\n'
+        "int main(void) {\n"
+        "  MppiProblem p; memset(&p, 0, sizeof p);\n"
+        '  printf("%d %lld %lld %d %d\\n", mppi_abi_version(), (long long)mppi_problem_size(), (long long)sizeof p,\n'
+        "         mppi_rollout_cost(&p, NULL), mppi_rollout_cost_kmppi(&p, NULL));\n"
+        "  return 0;\n}\n")
+    exe = tmp_path / "client"
+    from pytorch_mppi_amd import _build
+    N.lib()                                    # builds the library if it is not there yet
+    libdir = os.path.dirname(_build.LIB)
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                        "-o", str(exe), "-L", libdir, "-l:" + os.path.basename(_build.LIB), "-Wl,-rpath," + libdir,
+                        "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    ver, size_lib, size_c, rc1, rc2 = (int(x) for x in out.stdout.split())
+    assert ver == N.ABI_VERSION and size_lib == size_c == C.sizeof(N.MppiProblem)
+    assert rc1 == -1 and rc2 == -1             # MPPI_E_BADARG
