@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<flo
   const int SPW = S4 + 4;                   // padded operator row: the four rows of a tile fall on different banks
   float* Ue = reinterpret_cast<float*>(smem_raw);       // [J] nominal sequence (what the noise is measured from)
   float* G = Ue + ((a.J + 3) & ~3);                     // [J] lambda * U / sigma^2
-  float* thl = G + ((a.J + 3) & ~3);                    // [S*NU] control points theta
+  float* thl = G + ((a.J + 3) & ~3);                    // [S*NU] control points theta + noise mean
   float* Wl = thl + ((S * NU + 3) & ~3);                // [T4][SPW], zero outside (T, S)
   float* thx = Wl + T4 * SPW;                           // [NL/4][K1_BLOCK][4] bounded control points beyond the AGPRs
   for (int j = threadIdx.x; j < a.J; j += K1_BLOCK) {
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<flo
     Ue[j] = u_base(a, j);
     G[j] = a.lambda_ * (u_eff(a, j) * a.sinv[n * NU + n]);
   }
-  for (int i = threadIdx.x; i < S * NU; i += K1_BLOCK) thl[i] = a.theta[i];
+  for (int i = threadIdx.x; i < S * NU; i += K1_BLOCK) thl[i] = a.theta[i] + (a.coloured ? 0.f : a.mu[i % NU]);   // theta + mu
   for (int i = threadIdx.x; i < T4 * SPW; i += K1_BLOCK) {
     const int t = i / SPW, s = i - t * SPW;
     Wl[i] = (t < Thor && s < S) ? a.W[(long long)t * S + s] : 0.f;
@@ -136,12 +136,13 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<flo
         z4 = ring[row % RD];
         if constexpr (row + RD < ROWS) ring[row % RD] = fetch(row + RD);
       }
+      // theta' = clamp(theta + mu + sd z): one fma, max, min per value.  A support point beyond S gets some
+      // finite value (row and theta index are clamped) that only ever meets the zero columns of the operator
       kf32x4_t v4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int n = 4 * q + i;
-        const float v = clampT(thl[(s < S ? s : 0) * NU + n] + (z4[i] * ac.sd[n] + ac.mu[n]), ac.lo[n], ac.hi[n]);
-        v4[i] = s < S ? v : 0.f;                        // wave-uniform select
+        v4[i] = clampT(m_fma(z4[i], ac.sd[n], thl[(s < S ? s : 0) * NU + n]), ac.lo[n], ac.hi[n]);
       }
       if constexpr (i0 < NA) {
 #pragma unroll

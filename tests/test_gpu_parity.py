@@ -61,6 +61,15 @@ def _run_fixture(name, native):
                 continue
             _assert_close(v, d[f"{k}{s}"], rtol, f"{name} step {s} {k} native={native}")
         assert abs(float(ctrl.omega.sum()) - 1.0) < (1e-5 if cfg["dtype"] == "f32" else 1e-12)
+        # cost_total_non_zero = exp(-(cost_total - min) / lambda) (mppi.py:12-13, :256) is a public result as well; the
+        # fixtures do not store it, so it is re-derived in fp64 from the reference's cost_total.  Its sensitivity to
+        # the costs is w / lambda per unit of cost: the bound is the cost tolerance scaled by that.
+        lam = float(cfg["ctor"].get("lambda_", 1.0))
+        ct_ref = np.asarray(d[f"cost_total{s}"], dtype=np.float64)
+        w_ref = np.exp(-(ct_ref - ct_ref.min()) / lam)
+        w = ctrl.cost_total_non_zero.detach().cpu().numpy().astype(np.float64)
+        ct_tol = (1e-9 if cfg["dtype"] == "f64" else 1e-4) * max(1.0, float(np.abs(ct_ref).max()))
+        assert float(np.abs(w - w_ref).max()) <= ct_tol / lam + (1e-12 if cfg["dtype"] == "f64" else 1e-6), (name, s, "cost_total_non_zero")
         if cfg["sampler_rows"]:
             smp = ctrl.specific_action_sampler
             assert (smp.start_idx, smp.end_idx) == tuple(int(x) for x in d[f"slice{s}"])
