@@ -117,8 +117,10 @@ __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
 __device__ __forceinline__ float m_fma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double m_fma(double a, double b, double c) { return fma(a, b, c); }
 
-// torch.clamp(x, lo, hi) = min(max(x, lo), hi)  (v_max_f32 / v_min_f32)
-__device__ __forceinline__ float clampT(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// torch.clamp(x, lo, hi) = min(max(x, lo), hi) for lo <= hi: the median of the three, ONE v_med3_f32 (fminf(fmaxf())
+// is three instructions: the compiler canonicalises x first).  Infinite bounds pass x through; a NaN x comes out
+// as lo in both forms (fmaxf and v_med3 both return the non-NaN operand).
+__device__ __forceinline__ float clampT(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 __device__ __forceinline__ double clampT(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
 template <typename T> __device__ __forceinline__ T inf_v();

@@ -169,8 +169,8 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<flo
           for (int n = 0; n < NU; ++n) rollout += zt[n];
           continue;
 #endif
-          rollout_step<Model, float, MPPI_NOISE_ACTIONS, true, 2>(a, ac, model, tb, k, active, orow, t, zt, x, vprev,
-                                                                 rollout, pert);
+          rollout_step<Model, float, MPPI_NOISE_ACTIONS, true, 2, false>(a, ac, model, tb, k, active, orow, t, zt, x, vprev,
+                                                                        rollout, pert);   // KMPPI has no smoothness cost
         }
       }
     };
