@@ -44,7 +44,8 @@ struct StepTables {
 };
 
 // one timestep: actions from z, action cost, dynamics, running cost
-// SMOOTH = false: the caller knows there is no smoothness cost (no uniform branch on a.smooth_w in the step)
+// SMOOTH = false: the caller knows this is not an SMPPI problem -- no smoothness cost (no uniform branch on
+// a.smooth_w in the step) and e_scale == 1 (no rescaling multiply)
 template <class Model, typename T, int NOISE, bool DIAG, int SLOW, bool SMOOTH = true>
 __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionConsts<T, Model::NU>& ac,
                                              const Model& model, const StepTables<T>& tb, int k,
@@ -98,7 +99,7 @@ __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionCons
 #pragma unroll
   for (int n = 0; n < NU; ++n) {
     v[n] = clampT(v[n], ac.lo[n], ac.hi[n]);                               // :383
-    const T e = (v[n] - Ut[n]) * ac.e_scale;                               // :385 (SMPPI :544)
+    const T e = SMOOTH ? (v[n] - Ut[n]) * ac.e_scale : v[n] - Ut[n];       // :385 (SMPPI :544)
     pert = m_fma(Gt[n], ac.abs_cost ? m_abs(e) : e, pert);                 // :409, :415
     u[n] = a.u_scale * v[n];                                               // :313
   }

@@ -3,19 +3,19 @@
 //   v[t]      = sum_s W[t,s] theta'[s]                    W = K(Hs,Tk) Ktktk^-1, (T,S)     :665, :621-628
 //   v[t]      = sampler row | 0, clamp, e = v - U[t], action cost, dynamics, running cost  :666-670, :297-332
 // The two-launch form (mppi_kmppi_interp, then K1 on raw actions) writes and re-reads a (K,T,nu)
-// array: 62 + 35 us at K = 65536, T = 64, nu = 12, S = 32.  Here a lane keeps the S*nu bounded control
-// points of ITS sample in registers for the whole horizon (384 of the 512 a wave owns at one wave per
-// SIMD, most of them in the accumulation-register half of the file, which the matrix instruction
-// reads directly) and produces four timesteps at a time with v_mfma_f32_4x4x1_16b_f32 -- sixteen
-// independent 4x4 outer products, one per group of four lanes:
+// array: 62 + 35 us at K = 65536, T = 64, nu = 12, S = 32 (fused: 73-76 us).  Here a lane keeps the S*nu
+// bounded control points of ITS sample resident for the whole horizon (up to 256 in the accumulation-register
+// half of the file, which the matrix instruction reads directly, the rest in LDS) and produces four timesteps
+// at a time with v_mfma_f32_4x4x1_16b_f32 -- sixteen independent 4x4 outer products, one per group of four lanes:
 //     D[i] of lane l  +=  A(lane 4*(l/4) + i) * B(lane l)
 // A = W[t0 + (l & 3)][s]   (the lane's row of the operator tile, read from LDS)
 // B = theta'[s][n] of the lane's own sample
-// so D[i] is v[t0 + i][n] of the lane's own sample: no exchange between lanes, nothing staged, and the
-// rollout consumes the four timesteps straight out of the accumulators.  The instruction is an exact
-// fp32 multiply-add (K = 1), the sum over s runs in index order.
-// Bound: K*T*S*nu fp32 MACs on the matrix pipe (32 MAC / cycle / SIMD: 20 us at C3-sized work) next
-// to the K*S*nu support-point rows read once (100 MB); the rollout arithmetic issues underneath.
+// so D[i] is v[t0 + i][n] of the lane's own sample: no exchange between lanes, nothing staged, and the rollout
+// consumes the four timesteps straight out of the accumulators.  The instruction is an exact fp32 multiply-add
+// (K = 1), the sum over s runs in index order.
+// Cost at C3-sized work (tools/micro/kmppi_k1_parts.hip): the K*T*S*nu fp32 MACs take 22 us on the matrix pipe
+// (8 cycles per instruction, 32 MAC / cycle / SIMD), the support-point rows 17 us to read (or ~20 us to generate in
+// the prologue), the rollout arithmetic 13-18 us; the phases of a wave run one after the other (one wave per SIMD).
 // fp32, diagonal Sigma, nu in {4, 8, 12, 16}, S*nu <= 384; anything else keeps the two-launch form.
 #pragma once
 
@@ -55,6 +55,31 @@ __device__ __forceinline__ float to_agpr(float v) {
   return r;
 }
 
+// the four timesteps of one accumulator tile (D[n][i] = raw action n of timestep t0 + i)
+template <class Model, int MODE>
+__device__ __forceinline__ void kmppi_steps4(const KArgs<float>& a, const ActionConsts<float, Model::NU>& ac, const Model& model,
+                                             const StepTables<float>& tb, int k, bool active, int orow, int t0,
+                                             const kf32x4_t (&D)[Model::NU], float (&x)[Model::NX], float (&vprev)[Model::NU],
+                                             float& rollout, float& pert) {
+  constexpr int NU = Model::NU;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + i;
+    if (t < a.Tn) {
+      float zt[NU];
+#pragma unroll
+      for (int n = 0; n < NU; ++n) zt[n] = D[n][i];
+#if defined(MPPI_KMPPI_EXP) && (MPPI_KMPPI_EXP & 4)   // experiment (tools/micro/kmppi_k1_parts.hip): no rollout arithmetic
+#pragma unroll
+      for (int n = 0; n < NU; ++n) rollout += zt[n];
+      continue;
+#endif
+      rollout_step<Model, float, MPPI_NOISE_ACTIONS, true, MODE, false>(a, ac, model, tb, k, active, orow, t, zt, x, vprev,
+                                                                        rollout, pert);   // KMPPI: no SMPPI terms
+    }
+  }
+}
+
 template <class Model, int NOISE>
 __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<float> a) {
   constexpr int NX = Model::NX, NU = Model::NU, P4 = NU / 4, SMAX = KmppiFuse<NU>::SMAX;
@@ -62,7 +87,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<flo
   if (a.tstamp != nullptr && threadIdx.x == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int S = a.S, Thor = a.Tn;
-  const int T4 = (Thor + 3) & ~3, S4 = (S + 3) & ~3;        // support points beyond S: theta' = 0 and W = 0
+  const int T4 = (Thor + 3) & ~3, S4 = (S + 3) & ~3;        // support points beyond S only ever meet zero columns of W
   const int SPW = S4 + 4;                   // padded operator row: the four rows of a tile fall on different banks
   float* Ue = reinterpret_cast<float*>(smem_raw);       // [J] nominal sequence (what the noise is measured from)
   float* G = Ue + ((a.J + 3) & ~3);                     // [J] lambda * U / sigma^2
@@ -156,30 +181,14 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<flo
     float vprev[NU];
 #pragma unroll
     for (int n = 0; n < NU; ++n) vprev[n] = 0.f;
-    auto steps4 = [&](const kf32x4_t (&D)[NU], int t0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int t = t0 + i;
-        if (t < Thor) {
-          float zt[NU];
-#pragma unroll
-          for (int n = 0; n < NU; ++n) zt[n] = D[n][i];
-#if defined(MPPI_KMPPI_EXP) && (MPPI_KMPPI_EXP & 4)   // experiment: no rollout arithmetic
-#pragma unroll
-          for (int n = 0; n < NU; ++n) rollout += zt[n];
-          continue;
-#endif
-          rollout_step<Model, float, MPPI_NOISE_ACTIONS, true, 2, false>(a, ac, model, tb, k, active, orow, t, zt, x, vprev,
-                                                                        rollout, pert);   // KMPPI has no smoothness cost
-        }
-      }
-    };
+    // wave-uniform choice, as in K1: 0 = no overwritten rows in this wave; 1 = only the sample_null_action row (a
+    // select); 2 = sampler rows / `states` output (conditional loads and stores per step)
+    const int step_mode = (__any(orow >= 0) || a.states != nullptr) ? 2 : (__any(orow == -1) ? 1 : 0);
     // the nu MFMAs of support point s (B straight from the AGPRs, or from the four-vectors `b` read out of LDS)
     auto mac_s = [&](auto sc, float w, const kf32x4_t (&b)[P4], kf32x4_t (&D)[NU]) {
       constexpr int s = decltype(sc)::value;
 #pragma unroll
       for (int q = 0; q < P4; ++q) {
-        constexpr int dummy = 0; (void)dummy;
         const int i0 = s * NU + 4 * q;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -224,35 +233,42 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<flo
         if constexpr (s % 4 == 3) w = wn;
       });
     };
-    if (S4 == SMAX) {
-      for (int t0 = 0; t0 < Thor; t0 += 4) {
-        kf32x4_t D[NU];
-        macs_full(t0, D);
-        steps4(D, t0);
+    // the whole horizon, for one wave-uniform step mode (decided once: no branch between a tile's MFMAs and its steps)
+    auto horizon = [&](auto mode_c) {
+      constexpr int MODE = decltype(mode_c)::value;
+      if (S4 == SMAX) {
+        for (int t0 = 0; t0 < Thor; t0 += 4) {
+          kf32x4_t D[NU];
+          macs_full(t0, D);
+          kmppi_steps4<Model, MODE>(a, ac, model, tb, k, active, orow, t0, D, x, vprev, rollout, pert);
+        }
+      } else {
+        for (int t0 = 0; t0 < Thor; t0 += 4) {
+          kf32x4_t D[NU];
+  #pragma unroll
+          for (int n = 0; n < NU; ++n) D[n] = kf32x4_t{0.f, 0.f, 0.f, 0.f};
+          const kf32x4_t* Wr = reinterpret_cast<const kf32x4_t*>(Wl + (t0 + (lane & 3)) * SPW);
+          static_for<0, SMAX / 4>([&](auto gc) {
+            constexpr int s4 = decltype(gc)::value;
+            if (4 * s4 < S) {                             // wave-uniform; beyond S: theta' = 0, W = 0
+              const kf32x4_t w = Wr[s4];
+              static_for<0, 4>([&](auto jc) {
+                constexpr int s = 4 * s4 + decltype(jc)::value;
+                kf32x4_t b[P4];
+  #pragma unroll
+                for (int q = 0; q < P4; ++q) b[q] = kf32x4_t{0.f, 0.f, 0.f, 0.f};
+                lds_s(std::integral_constant<int, s>{}, b);
+                mac_s(std::integral_constant<int, s>{}, w[s % 4], b, D);
+              });
+            }
+          });
+          kmppi_steps4<Model, MODE>(a, ac, model, tb, k, active, orow, t0, D, x, vprev, rollout, pert);
+        }
       }
-    } else {
-      for (int t0 = 0; t0 < Thor; t0 += 4) {
-        kf32x4_t D[NU];
-#pragma unroll
-        for (int n = 0; n < NU; ++n) D[n] = kf32x4_t{0.f, 0.f, 0.f, 0.f};
-        const kf32x4_t* Wr = reinterpret_cast<const kf32x4_t*>(Wl + (t0 + (lane & 3)) * SPW);
-        static_for<0, SMAX / 4>([&](auto gc) {
-          constexpr int s4 = decltype(gc)::value;
-          if (4 * s4 < S) {                             // wave-uniform; beyond S: theta' = 0, W = 0
-            const kf32x4_t w = Wr[s4];
-            static_for<0, 4>([&](auto jc) {
-              constexpr int s = 4 * s4 + decltype(jc)::value;
-              kf32x4_t b[P4];
-#pragma unroll
-              for (int q = 0; q < P4; ++q) b[q] = kf32x4_t{0.f, 0.f, 0.f, 0.f};
-              lds_s(std::integral_constant<int, s>{}, b);
-              mac_s(std::integral_constant<int, s>{}, w[s % 4], b, D);
-            });
-          }
-        });
-        steps4(D, t0);
-      }
-    }
+    };
+    if (step_mode == 0) horizon(std::integral_constant<int, 0>{});
+    else if (step_mode == 1) horizon(std::integral_constant<int, 1>{});
+    else horizon(std::integral_constant<int, 2>{});
     if (a.use_terminal) rollout += model.terminal(x);                    // :324-328
     const float total = rollout + pert;                                  // :416
     if (active) {
