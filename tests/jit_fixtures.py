@@ -62,3 +62,30 @@ def drifting():
         "drifting", 2, 2, dynamics=f, running_cost=q, params=[DT_], step_dependent=True,
         step="const T g = p[0] * (T(1) + T(0.05) * T(t)); x[0] += g * u[0]; x[1] += g * u[1];",
         cost="const T dx = x[0] - T(0.1) * T(t), dy = x[1] + T(0.05) * T(t); return dx * dx + dy * dy + T(0.01) * (u[0] * u[0] + u[1] * u[1]);")
+
+
+def cart4_callables():
+    """4 controls, 6 states: damped double integrator in three axes with a coupled yaw control -- a user model
+    with nu % 4 == 0, i.e. one the KMPPI-fused K1 (interpolation inside the kernel) is instantiated for"""
+    def f(s, a):
+        v = 0.9 * s[:, 3:6] + DT_ * a[:, 0:3] + 0.02 * a[:, 3:4] * s[:, [1, 2, 0]]
+        return torch.cat((s[:, 0:3] + DT_ * v, v), dim=1)
+
+    def q(s, a):
+        return ((s[:, 0] - GX) ** 2 + (s[:, 1] - GY) ** 2 + s[:, 2] ** 2 + 0.1 * (s[:, 3:6] ** 2).sum(-1)
+                + 0.01 * (a ** 2).sum(-1))
+
+    return f, q
+
+
+def cart4():
+    f, q = cart4_callables()
+    return jit.compile_model(
+        "cart4", 6, 4, dynamics=f, running_cost=q, params=[DT_, GX, GY],
+        step="const T v0 = T(0.9) * x[3] + p[0] * u[0] + T(0.02) * u[3] * x[1];"
+             "const T v1 = T(0.9) * x[4] + p[0] * u[1] + T(0.02) * u[3] * x[2];"
+             "const T v2 = T(0.9) * x[5] + p[0] * u[2] + T(0.02) * u[3] * x[0];"
+             "x[0] += p[0] * v0; x[1] += p[0] * v1; x[2] += p[0] * v2; x[3] = v0; x[4] = v1; x[5] = v2;",
+        cost="const T dx = x[0] - p[1], dy = x[1] - p[2];"
+             "return dx * dx + dy * dy + x[2] * x[2] + T(0.1) * (x[3] * x[3] + x[4] * x[4] + x[5] * x[5])"
+             " + T(0.01) * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]);")

@@ -86,3 +86,39 @@ def test_step_dependent_dynamics_run_fused(dtype):
     m2 = pm.models.Integrator(2, 2)
     c2 = pm.MPPI(lambda s, a, t: m2.dynamics(s, a), lambda s, a, t: m2.running_cost(s, a), 2, sigma.to(dtype), **kw)
     assert c2._needs_generic()
+
+
+def test_jit_model_under_kmppi_interpolates_inside_k1():
+    """A user model with four controls under KMPPI: its own shared object carries the KMPPI-fused K1
+    (csrc/rollout_kmppi.hpp, reached through mppi_register_model's launcher); checked against the generic
+    callback path and the fp64 oracle on the same draw."""
+    from oracle import mppi_oracle as orc
+    f, q = jf.cart4_callables()
+    model = jf.cart4()
+    K, T, S, nu, nx = 1500, 28, 14, 4, 6
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(nx, generator=g, dtype=torch.float64) * 0.3
+    sigma = torch.diag(torch.rand(nu, generator=g, dtype=torch.float64) + 0.4)
+    umax = torch.full((nu,), 1.5, dtype=torch.float64)
+    kw = dict(num_samples=K, horizon=T, device="cuda", lambda_=2.0, u_max=umax.float(), num_support_pts=S,
+              U_init=torch.zeros(T, nu))
+    fused = pm.KMPPI(model.dynamics, model.running_cost, nx, sigma.float(), **kw)
+    generic = pm.KMPPI(f, q, nx, sigma.float(), **kw)
+    assert not fused._needs_generic() and generic._needs_generic() and fused._fused_interp_expected()
+    p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=sigma, K=K, T=T, lambda_=2.0, u_max=umax)
+    W, W_shift, _, _ = orc.kmppi_matrices(T, S, torch.float64)
+    theta, U = torch.zeros(S, nu, dtype=torch.float64), torch.zeros(T, nu, dtype=torch.float64)
+    lib = pm._native.lib()
+    for s in range(2):
+        z = torch.randn(K, S, nu, generator=g, dtype=torch.float64)
+        r = orc.kmppi_command(p, theta, U, x0, z, W, W_shift, True)
+        theta, U = r["theta"], r["U"]
+        n0 = lib.mppi_stat_kmppi_fused_rollouts()
+        for c in (fused, generic):
+            c.inject_noise(z.float())
+            a = c.command(x0.float().cuda())
+            for name, got in (("action", a), ("U", c.U), ("theta", c.theta), ("cost_total", c.cost_total)):
+                ref = r[name].numpy()
+                np.testing.assert_allclose(got.cpu().double().numpy(), ref, rtol=3e-5, atol=3e-5 * max(1.0, np.abs(ref).max()),
+                                           err_msg=f"{name} step {s}")
+        assert lib.mppi_stat_kmppi_fused_rollouts() == n0 + 1       # the fused controller took the in-kernel interpolation

@@ -1,0 +1,4 @@
+#!/bin/bash
+mkdir -p gpurun_out && cd /root/repo
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee gpurun_out/all_tests.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
