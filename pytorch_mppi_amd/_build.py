@@ -18,6 +18,22 @@ LIB = os.path.join(HERE, f"libmppi_amd{SUFFIX}.so")
 OBJ_DIR = os.path.join(CSRC, "build" + SUFFIX)
 SOURCES = ["capi.hip", "dist.hip", "update.hip", "rollout_pendulum.hip", "rollout_integrator.hip",
            "rollout_linear_goal.hip", "rollout_mlp.hip", "rollout_mlp_mfma.hip", "rollout_mlp_split.hip"]
+# translation units: (source, object name, extra flags).  The two heaviest sources are compiled as two units each
+# (groups of model dimensions selected with a define) so that the parallel build is not one long compile
+_GROUPS = {"rollout_integrator.hip": "MPPI_INTEGRATOR_GROUP", "rollout_linear_goal.hip": "MPPI_LINEAR_GROUP"}
+
+
+def _units():
+    units = []
+    for src in SOURCES:
+        if src in _GROUPS:
+            for g in (0, 1):
+                units.append((src, src.replace(".hip", f"_g{g}.o"), [f"-D{_GROUPS[src]}={g}"]))
+        else:
+            units.append((src, src.replace(".hip", ".o"), []))
+    # longest first: the pool starts the big ones before the small ones
+    heavy = {"rollout_integrator.hip": 0, "rollout_linear_goal.hip": 1, "update.hip": 2, "rollout_mlp.hip": 3}
+    return sorted(units, key=lambda u: heavy.get(u[0], 9))
 # -ffp-contract=fast: mul+add pairs fuse into v_fma / v_pk_fma.  torch eager rounds twice where
 # the kernels round once, a <= 1 ulp difference per operation that the parity tests bound
 # (1e-5 relative fp32, 1e-9 fp64 on every public output of command()).
@@ -55,6 +71,7 @@ def _deps_hash():
     h.update(open(os.path.join(INCLUDE, "mppi_amd.h"), "rb").read())
     h.update(" ".join(FLAGS).encode())
     h.update(repr(sorted(EXTRA.items())).encode())
+    h.update(repr(_units()).encode())
     return h.hexdigest()
 
 
@@ -69,17 +86,18 @@ def build(force=False, verbose=True):
         return LIB
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    srcs = [u for u in _units() if os.path.exists(os.path.join(CSRC, u[0]))]
 
-    def one(src):
-        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+    def one(unit):
+        src, objname, defs = unit
+        obj = os.path.join(OBJ_DIR, objname)
+        cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), *defs, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
         return obj
 
-    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 8, len(srcs))) as ex:
         objs = list(ex.map(one, srcs))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -181,9 +181,10 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<flo
     float vprev[NU];
 #pragma unroll
     for (int n = 0; n < NU; ++n) vprev[n] = 0.f;
-    // wave-uniform choice, as in K1: 0 = no overwritten rows in this wave; 1 = only the sample_null_action row (a
-    // select); 2 = sampler rows / `states` output (conditional loads and stores per step)
-    const int step_mode = (__any(orow >= 0) || a.states != nullptr) ? 2 : (__any(orow == -1) ? 1 : 0);
+    // wave-uniform choice, as in K1: 0 = no overwritten row in this wave (no select, no conditional memory traffic
+    // in the steps); 2 = null-action / sampler rows or a `states` output.  (K1's select-only mode 1 is not
+    // instantiated here: one more copy of the horizon loop per model for the one wave that owns row 0.)
+    const int step_mode = (__any(orow != -2) || a.states != nullptr) ? 2 : 0;
     // the nu MFMAs of support point s (B straight from the AGPRs, or from the four-vectors `b` read out of LDS)
     auto mac_s = [&](auto sc, float w, const kf32x4_t (&b)[P4], kf32x4_t (&D)[NU]) {
       constexpr int s = decltype(sc)::value;
@@ -267,7 +268,6 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<flo
       }
     };
     if (step_mode == 0) horizon(std::integral_constant<int, 0>{});
-    else if (step_mode == 1) horizon(std::integral_constant<int, 1>{});
     else horizon(std::integral_constant<int, 2>{});
     if (a.use_terminal) rollout += model.terminal(x);                    // :324-328
     const float total = rollout + pert;                                  // :416
