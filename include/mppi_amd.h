@@ -194,6 +194,11 @@ int mppi_kmppi_shift(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void
 int mppi_kmppi_trajectory(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void* W, const void* theta,
                           void* U_out, void* stream);
 
+/* Host -> device hand-over of a SMALL buffer (the state of a closed loop: mppi.py:262-264) inside the launch packet of
+ * a one-wave kernel: 4..2048 bytes, a multiple of 4, from ordinary (pageable) host memory, which is consumed before
+ * the call returns; ordered on `stream` like any kernel.  ~5 us of host time against ~20 us for a pageable hipMemcpy. */
+int mppi_upload_small(const void* src_host, int64_t nbytes, void* dst_device, void* stream);
+
 /* SMPPI.shift_nominal_trajectory (mppi.py:488-492) plus the base sequence of the next command (:540), one launch:
  * U_out = roll(U, -1) with u_init in the last row; A_out = roll(action_sequence, -1) with the last row repeated;
  * B_out = A_out + U_out * dt (what MppiProblem.base_seq points at).  Outputs must not alias inputs. */

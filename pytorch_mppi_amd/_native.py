@@ -65,6 +65,7 @@ SYMBOLS = {
     "mppi_rollout_cost_kmppi": (C.c_int, [_PP, _vp]),
     "mppi_kmppi_shift": (C.c_int, [C.c_int32] * 4 + [_vp] * 7),
     "mppi_kmppi_trajectory": (C.c_int, [C.c_int32] * 4 + [_vp] * 4),
+    "mppi_upload_small": (C.c_int, [_vp, C.c_int64, _vp, _vp]),
     "mppi_smppi_shift": (C.c_int, [C.c_int32] * 3 + [_vp] * 3 + [C.c_double] + [_vp] * 4),
     "mppi_prepare": (C.c_int, [_PP, _vp]),
     "mppi_cost_block_min": (C.c_int, [_PP, _vp]),

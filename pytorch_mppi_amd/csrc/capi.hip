@@ -365,6 +365,32 @@ extern "C" int mppi_kmppi_shift(int32_t dtype, int32_t T, int32_t S, int32_t nu,
                                                   (const double*)U, (const double*)u_init, (double*)U_out, (hipStream_t)stream), "mppi_kmppi_shift");
   return fail(MPPI_E_BADARG, "bad dtype");
 }
+// ---- small host -> device upload through the kernel arguments -----------------------------------------
+// The state of a closed loop arrives from the host every step (nx values).  A pageable hipMemcpy costs the host
+// ~20 us, pinned staging needs an event per slot; here the bytes travel INSIDE the launch packet (kernarg) of a
+// one-wave kernel that writes them to `dst`: the host buffer is consumed before the call returns, nothing to
+// keep alive, nothing to wait for.
+namespace {
+template <int WORDS> struct UploadBlob { unsigned w[WORDS]; };
+template <int WORDS>
+__global__ void __launch_bounds__(64) upload_small_kernel(const UploadBlob<WORDS> b, unsigned* __restrict__ dst, int nwords) {
+  for (int i = threadIdx.x; i < nwords; i += 64) dst[i] = b.w[i];
+}
+template <int WORDS>
+int upload_small(const void* src, int64_t nbytes, void* dst, hipStream_t st) {
+  UploadBlob<WORDS> b;
+  memcpy(b.w, src, (size_t)nbytes);
+  hipLaunchKernelGGL(upload_small_kernel<WORDS>, dim3(1), dim3(64), 0, st, b, (unsigned*)dst, (int)(nbytes / 4));
+  return (int)hipGetLastError();
+}
+}  // namespace
+extern "C" int mppi_upload_small(const void* src_host, int64_t nbytes, void* dst_device, void* stream) {
+  if (src_host == nullptr || dst_device == nullptr || nbytes <= 0 || nbytes % 4 != 0 || nbytes > 2048)
+    return fail(MPPI_E_BADARG, "mppi_upload_small: 4..2048 bytes, a multiple of 4");
+  if (nbytes <= 128) return hipfail(upload_small<32>(src_host, nbytes, dst_device, (hipStream_t)stream), "mppi_upload_small");
+  return hipfail(upload_small<512>(src_host, nbytes, dst_device, (hipStream_t)stream), "mppi_upload_small");
+}
+
 extern "C" int mppi_smppi_shift(int32_t dtype, int32_t T, int32_t nu, const void* U, const void* u_init, const void* A, double dt,
                                 void* U_out, void* A_out, void* B_out, void* stream) {
   if (T <= 0 || nu <= 0 || !U || !u_init || !A || !U_out || !A_out || !B_out) return fail(MPPI_E_BADARG, "mppi_smppi_shift: bad argument");

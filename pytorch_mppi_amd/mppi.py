@@ -569,10 +569,23 @@ class MPPI:
             raise ValueError("capture_command is single-shard")
         return GraphedCommand(self, state, bool(shift_nominal_trajectory), warmup)
 
+    def _host_state_to_device(self, state):
+        """A small host-resident state (what a simulator hands back every step) travels inside the launch packet
+        of a one-wave kernel (`mppi_upload_small`): ~5 us of host time, no staging buffer to keep alive.  The
+        pageable `.to(device)` stalls the host for ~20 us per command -- the whole budget of a small problem."""
+        src = state.detach().to(dtype=self.dtype).contiguous()            # host-side cast (a no-op for matching dtypes)
+        out = torch.empty(src.shape, dtype=self.dtype, device=self.d)
+        N.check(N.lib().mppi_upload_small(src.data_ptr(), src.numel() * src.element_size(), _ptr(out), self._stream()),
+                "mppi_upload_small")
+        return out
+
     def _to_state(self, state):
         if not torch.is_tensor(state):
-            state = torch.tensor(state)
-        state = state.to(dtype=self.dtype, device=self.d)                 # mppi.py:262-264
+            state = torch.as_tensor(state)
+        if state.device.type == "cpu" and self.d.type == "cuda" and 0 < state.numel() * (8 if self.dtype == torch.float64 else 4) <= 2048:
+            state = self._host_state_to_device(state)
+        else:
+            state = state.to(dtype=self.dtype, device=self.d)             # mppi.py:262-264
         if self.K_local != self.K and tuple(state.shape) == (self.K, self.nx):
             # per-sample initial states (mppi.py:302) of the GLOBAL problem: this shard's rows
             state = state[self.k_offset:self.k_offset + self.K_local]

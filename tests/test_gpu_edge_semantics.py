@@ -245,3 +245,27 @@ def test_single_launch_command_for_small_problems(case):
             c.U, c.action_sequence = Ud.to(dt).cuda(), A.to(dt).cuda()
     ran_single = lib.mppi_stat_single_launch_commands() - n0
     assert ran_single == (0 if case == "sharded" else 3), ran_single       # sharded commands keep omega eager -> 3 launches
+
+
+def test_host_resident_states_take_the_kernarg_upload_and_match_device_states():
+    """numpy / CPU-tensor / list states (what a simulator returns, mppi.py:262-264) travel inside a launch packet
+    (mppi_upload_small); same results as the device-tensor state, a different state every command; larger host
+    states (per-sample) keep the ordinary copy."""
+    g = torch.Generator().manual_seed(2)
+    nx, nu, K, T = 6, 4, 512, 12
+    m = pm.models.Integrator(nx, nu)
+    mk = lambda: pm.MPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), num_samples=K, horizon=T, device="cuda",
+                         rng="philox", seed=4, U_init=torch.zeros(T, nu))
+    a, b, c = mk(), mk(), mk()
+    for i in range(11):
+        x = torch.randn(nx, generator=g)
+        ua = a.command(x.cuda())
+        ub = b.command(x.numpy() if i % 2 else x)           # numpy array / CPU tensor
+        uc = c.command([float(v) for v in x])               # python list
+        assert torch.equal(ua, ub) and torch.equal(ua, uc), i
+        assert b.state.is_cuda and torch.equal(b.state.cpu(), x)
+    # per-sample initial states from the host as well
+    xs = torch.randn(K, nx, generator=g)
+    assert torch.equal(a.command(xs.cuda()), b.command(xs.numpy()))
+    x64 = torch.randn(nx, generator=g, dtype=torch.float64)          # a dtype the controller has to cast
+    assert torch.equal(a.command(x64.float().cuda()), b.command(x64.numpy()))

@@ -20,4 +20,11 @@ for wl in ("c3", "c2"):
         for _ in range(n):
             ctrl.command(s)
         torch.cuda.synchronize()
-        print(f"{wl} state as {name:14s}: {1e3 * (time.perf_counter() - t0) / n:.4f} ms/command", flush=True)
+        t_open = (time.perf_counter() - t0) / n
+        # closed loop as a simulator sees it: the action goes back to the host every step (a device sync per step)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            a = ctrl.command(s).cpu()
+        t_closed = (time.perf_counter() - t0) / n
+        print(f"{wl} state as {name:14s}: {1e3 * t_open:.4f} ms/command back to back, {1e3 * t_closed:.4f} ms/step with the action "
+              f"read back each step", flush=True)
