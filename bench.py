@@ -423,6 +423,32 @@ def main():
             others[wl] = rec
             del cw
         out["other_workloads"] = others
+        # the rest of the controller family on the headline shape, same lambda recipe
+        if args.workload == "c3":
+            fam = {}
+            d_, kind_, nx_, nu_, K_, T_ = WORKLOADS["c3"]
+            m_ = pm.models.Integrator(nx_, nu_)
+            sig_ = torch.eye(nu_, device=device)
+            kwf = dict(num_samples=K_, horizon=T_, device=device, rng=args.rng, lambda_=float(ctrl.lambda_))
+            cands = {
+                "kmppi_S32": lambda: pm.KMPPI(m_.dynamics, m_.running_cost, nx_, sig_, num_support_pts=T_ // 2,
+                                              kernel=pm.RBFKernel(sigma=2.0), **kwf),
+                "smppi": lambda: pm.SMPPI(m_.dynamics, m_.running_cost, nx_, sig_, action_min=-torch.ones(nu_), action_max=torch.ones(nu_),
+                                          w_action_seq_cost=1.0, delta_t=0.1, **kwf)}
+            for name, mk in cands.items():
+                cf_ = mk()
+                for _ in range(5):
+                    cf_.command(x0)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(30):
+                    cf_.command(x0)
+                torch.cuda.synchronize()
+                dw = time.perf_counter() - t1
+                fam[name] = {"ms_per_step": dw / 30 * 1e3, "rollouts_per_s": K_ * 30 / dw}
+                del cf_
+            fam["kmppi_interpolation_inside_k1_launches"] = int(lib.mppi_stat_kmppi_fused_rollouts())
+            out["controller_family_on_c3_shape"] = fam
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:

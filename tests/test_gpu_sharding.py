@@ -243,3 +243,28 @@ def test_bench_two_ranks_prints_one_valid_json_line():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["K_global"] == 2 * d["config"]["K_per_gpu"]
     assert d["config"]["ranks_hold_identical_U"] is True and d["value"] > 0 and "cpu_baseline" not in d
 
+
+
+def test_sharded_kmppi_with_the_interpolation_inside_k1_rolls_out_its_own_global_rows():
+    """KMPPI under `shard=` on the fused-interpolation path with in-kernel Philox: every shard must draw the rows of
+    ITS global samples (counter = global k) and see the null-action row on shard 0 only -- its cost_total is the slice
+    of the unsharded controller's.  (The exchange itself is stubbed: the costs are final before it.)"""
+    nx, nu, K, T, S = 6, 4, 3000, 20, 10
+    m = pm.models.Integrator(nx, nu)
+    x0 = torch.linspace(-1, 1, nx).cuda()
+    kw = dict(num_samples=K, horizon=T, device="cuda", lambda_=5.0, num_support_pts=S, rng="philox", seed=21,
+              sample_null_action=True, U_init=torch.zeros(T, nu), u_max=torch.ones(nu))
+    full = pm.KMPPI(m.dynamics, m.running_cost, nx, torch.eye(nu) * 0.6, **kw)
+    lib = pm._native.lib()
+    n0 = lib.mppi_stat_kmppi_fused_rollouts()
+    full.command(x0)
+    world = 3
+    for r in range(world):
+        c = pm.KMPPI(m.dynamics, m.running_cost, nx, torch.eye(nu) * 0.6, shard=(r, world), **kw)
+        c._shard.native_comm = lambda device: None
+        c._shard.all_gather = lambda rec: torch.stack([rec] * world)          # stub: not what is under test
+        c.command(x0)
+        lo, hi = c._shard.bounds(r)
+        ref = full.cost_total[lo:hi]
+        assert float((c.cost_total - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max())), r
+    assert lib.mppi_stat_kmppi_fused_rollouts() == n0 + 1 + world
