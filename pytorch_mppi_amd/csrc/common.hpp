@@ -100,16 +100,22 @@ __device__ __forceinline__ double m_floormod(double a, double b) {
   r = r >= b ? r - b : r;
   return r;
 }
-// sinf for arguments of moderate size: ocml's sinf, with its Payne-Hanek path for huge arguments
-// (|x| >= 2^17: 64-bit multiply chains, ~1000 instructions, the registers to match) pruned from the hot
-// path by telling the compiler the range; a state that really gets that large takes the out-of-line
-// full version.  Same bits as sinf either way.
-__device__ __attribute__((noinline)) static float m_sin_huge(float x) { return sinf(x); }
+// sinf for arguments of moderate size: ocml's sinf, with its Payne-Hanek path for huge arguments (|x| >= 2^17:
+// 64-bit multiply chains, ~1000 instructions, the registers to match) pruned from the hot path by telling the
+// compiler the range.  An argument that really is that large (no physical angle is) is first reduced modulo 2 pi in
+// fp64 -- a handful of instructions, no call, no stack -- which keeps fp32-level accuracy up to |x| ~ 2^40; same bits
+// as sinf below 8192, NaN for NaN / inf like sinf.
 __device__ __forceinline__ float m_sin_moderate(float x) {
-  const float ax = __builtin_fabsf(x);
-  if (__builtin_expect(!(ax < 8192.0f), 0)) return m_sin_huge(x);
+  float xr = x;
+  if (__builtin_expect(!(__builtin_fabsf(x) < 8192.0f), 0)) {
+    const double t = (double)x;
+    const double k = __builtin_rint(t * 0.15915494309189535);            // 1 / (2 pi)
+    xr = (float)__builtin_fma(-k, 6.283185307179586, t);                 // |xr| <= pi  (NaN for NaN / inf)
+  }
+  const float ax = __builtin_fabsf(xr);
+  if (__builtin_expect(!(ax < 8192.0f), 0)) return xr - xr;              // NaN
   __builtin_assume(ax < 8192.0f);
-  return sinf(x);
+  return sinf(xr);
 }
 __device__ __forceinline__ double m_sin_moderate(double x) { return sin(x); }
 __device__ __forceinline__ float m_abs(float x) { return fabsf(x); }

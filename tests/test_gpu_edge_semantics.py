@@ -269,3 +269,27 @@ def test_host_resident_states_take_the_kernarg_upload_and_match_device_states():
     assert torch.equal(a.command(xs.cuda()), b.command(xs.numpy()))
     x64 = torch.randn(nx, generator=g, dtype=torch.float64)          # a dtype the controller has to cast
     assert torch.equal(a.command(x64.float().cuda()), b.command(x64.numpy()))
+
+
+def test_pendulum_with_an_angle_far_outside_the_usual_range():
+    """The fused pendulum prunes sinf's huge-argument path from its hot loop and reduces such angles modulo 2 pi in
+    fp64 instead (csrc/common.hpp m_sin_moderate); an initial angle of tens of thousands of radians must still roll
+    out like the torch callables do (same fp32 states, sin to fp32 rounding)."""
+    m = pm.models.Pendulum()
+    K, T = 512, 20
+    z = torch.randn(K, T, 1, generator=torch.Generator().manual_seed(4))
+    kw = dict(num_samples=K, horizon=T, device="cuda", lambda_=1.0, u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0),
+              U_init=torch.zeros(T, 1))
+    for th0 in (9000.0, 3.0e5, -2.5e6):
+        x0 = torch.tensor([th0, 0.5]).cuda()
+        fused = pm.MPPI(m.dynamics, m.running_cost, 2, torch.tensor(4.0), **kw)
+        generic = pm.MPPI(lambda s, a: m.dynamics(s, a), lambda s, a: m.running_cost(s, a), 2, torch.tensor(4.0), **kw)
+        assert not fused._needs_generic() and generic._needs_generic()
+        outs = []
+        for c in (fused, generic):
+            c.inject_noise(z)
+            c.command(x0)
+            outs.append(c.cost_total)
+        scale = float(outs[1].abs().max())
+        assert torch.isfinite(outs[0]).all()
+        assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale, th0
