@@ -567,3 +567,46 @@ def test_kmppi_interpolation_inside_k1_with_sampler_rows_per_sample_states_and_t
         assert float((ua - ub).abs().max()) <= 1e-5
         assert a.states.shape == (1, K, T, nx)
         assert float((a.states - b.states).abs().max()) <= 1e-5 * max(1.0, float(b.states.abs().max()))
+
+
+def test_kmppi_interpolation_inside_k1_through_the_api_surface():
+    """reset / change_horizon / u_per_command > 1 / shift off / bounds change between commands: the in-kernel
+    interpolation follows the controller's state exactly like the two-launch form (same Philox draw)."""
+    import pytorch_mppi_amd as pm
+    nx, nu, K, T, S = 8, 4, 1024, 18, 9
+    m = pm.models.Integrator(nx, nu)
+
+    def make(fuse):
+        c = pm.KMPPI(m.dynamics, m.running_cost, nx, torch.eye(nu) * 0.5, num_samples=K, horizon=T, device="cuda",
+                     num_support_pts=S, lambda_=3.0, rng="philox", seed=77, u_per_command=3, U_init=torch.zeros(T, nu),
+                     u_max=torch.full((nu,), 2.0))
+        c.fuse_interpolation = fuse
+        return c
+
+    a, b = make(True), make(False)
+    x = torch.linspace(-1.0, 1.0, nx).cuda()
+
+    def step(**kw):
+        ua, ub = a.command(x, **kw), b.command(x, **kw)
+        assert ua.shape == ub.shape == (3, nu)
+        for name, p, q in (("action", ua, ub), ("theta", a.theta, b.theta), ("U", a.U, b.U), ("cost", a.cost_total, b.cost_total)):
+            assert float((p - q).abs().max()) <= 1e-5 * max(1.0, float(q.abs().max())), name
+
+    step()
+    step(shift_nominal_trajectory=False)
+    for c in (a, b):
+        c.u_max = torch.full((nu,), 0.7, device="cuda")
+        c.u_min = -c.u_max
+    step()
+    for c in (a, b):
+        c.change_horizon(T + 6)                 # rebuilds the interpolation operators (T x S changes)
+    step()
+    for c in (a, b):
+        c.change_horizon(T - 4)
+        c.theta.zero_()
+        c.U = torch.zeros(T - 4, nu, device="cuda")
+    step()
+    lib = pm._native.lib()
+    n0 = lib.mppi_stat_kmppi_fused_rollouts()
+    a.command(x)
+    assert lib.mppi_stat_kmppi_fused_rollouts() == n0 + 1
