@@ -2,6 +2,8 @@
 driven with the same callables and the same injected noise -- breadth over (K, T, nu, diagonal/full
 Sigma, mu, bounds, u_scale, abs cost, null action, shift, fp32/fp64), i.e. over the kernel
 instantiations that the golden fixtures do not reach (prepare / K3 for nu = 1..8, full-Sigma K3, ragged K)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -10,6 +12,8 @@ import pytorch_mppi_amd as pm
 from oracle import mppi_oracle as orc
 
 pytestmark = pytest.mark.gpu
+# MPPI_EXTRA_SEEDS=n: n further seeds for each of the two randomised sweeps (long runs on the GPU box; 0 by default)
+_EXTRA = int(os.environ.get("MPPI_EXTRA_SEEDS", "0"))
 
 
 def _case(seed, nu=None):
@@ -49,7 +53,7 @@ def _case(seed, nu=None):
     return dict(nx=nx, nu=nu, K=K, T=T, dtype=dtype, sigma=sigma, kw=kw, B=Bm, goal=goal, U0=U0, x0=x0, z=z)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", list(range(24)) + [1000 + i for i in range(_EXTRA)])
 def test_generic_path_random_config_vs_fp64_oracle(seed):
     _generic_vs_oracle(seed, _case(seed))
 
@@ -107,7 +111,7 @@ def _generic_vs_oracle(seed, c):
                                        err_msg=f"seed {seed} step {s} {name} {c['K']}x{c['T']}x{c['nu']}")
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", list(range(12)) + [2000 + i for i in range(_EXTRA)])
 def test_fused_integrator_random_config_vs_fp64_oracle(seed):
     """same sweep on the fused kernel (Integrator instantiations: (2,2) (4,2) (6,4) (8,4) (12,6) (16,12))"""
     from oracle import dynamics as dyn
