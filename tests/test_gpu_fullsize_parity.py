@@ -209,3 +209,55 @@ def test_c3_two_shards_equal_oracle_on_global_draw():
                omega=torch.cat([c.omega for c in ctrls]))
     _check("c3/2 shards", got, r64, r32)
     assert 50 <= _n_eff(r64["omega"]) <= 5000
+
+
+@pytest.mark.parametrize("rng,regime", [("torch", "healthy"), ("torch", "peaked"), ("philox", "healthy")])
+def test_c3_shape_kmppi_65536x64_s32_interpolation_inside_k1(rng, regime):
+    """KMPPI at the headline shape -- K = 65536, T = 64, nx = 16, nu = 12, S = 32 support points -- on the path
+    the bench's family block times: bounded control points in registers, interpolation on the matrix cores inside K1,
+    theta update by K3 / K4 on the support-point stream.  Against `oracle.kmppi_command` (mppi.py:653-688) in fp64 and fp32
+    on the draw the kernels consumed (the torch draw, or the engine's Philox stream restated in numpy), same criterion as
+    above for action, U, theta, cost_total, omega."""
+    import pytorch_mppi_amd as pm
+    from oracle import mppi_oracle as orc, philox as oph
+    cfg = C3
+    model, mk, sigma, kw, x0, _ = _setup(cfg)
+    K, T, nu, S = cfg["K"], cfg["T"], cfg["nu"], 32
+    kernel_sigma = 2.0
+
+    def make(lam):
+        return pm.KMPPI(model.dynamics, model.running_cost, cfg["nx"], sigma, num_samples=K, horizon=T, device="cuda",
+                        lambda_=lam, num_support_pts=S, kernel=pm.RBFKernel(sigma=kernel_sigma), rng=rng, seed=4321,
+                        U_init=torch.zeros(T, nu), u_max=torch.full((nu,), 1.5))
+    lam = 1.0
+    for _ in range(2):
+        probe = make(lam)
+        probe.command(x0.cuda())
+        lam = _lambda_for(probe.cost_total, 1000.0 if regime == "healthy" else 3.0)
+        del probe
+    ctrl = make(lam)
+    lib = pm._native.lib()
+    n0 = lib.mppi_stat_kmppi_fused_rollouts()
+    act = ctrl.command(x0.cuda())
+    assert lib.mppi_stat_kmppi_fused_rollouts() == n0 + 1, "the interpolation did not run inside K1"
+    if rng == "torch":
+        z = ctrl._last_theta._keep["z_ktn"].cpu()
+    else:
+        z = torch.from_numpy(oph.normals_ktn(4321, int(ctrl._last.call), K, S, nu))
+    outs = []
+    for dt in (torch.float64, torch.float32):
+        f, q = mk(dt)
+        p = orc.Problem(dynamics=f, running_cost=q, nx=cfg["nx"], noise_sigma=sigma.to(dt), K=K, T=T, lambda_=lam,
+                        u_max=torch.full((nu,), 1.5, dtype=dt))
+        W, W_shift, _, _ = orc.kmppi_matrices(T, S, dt, kernel=lambda t, tk: orc.rbf_kernel(t, tk, sigma=kernel_sigma))
+        outs.append(orc.kmppi_command(p, torch.zeros(S, nu, dtype=dt), torch.zeros(T, nu, dtype=dt), x0.to(dt), z.to(dt), W, W_shift, True))
+    r64, r32 = outs
+    got = dict(action=act, U=ctrl.U, theta=ctrl.theta, cost_total=ctrl.cost_total, omega=ctrl.omega)
+    for k in ("action", "U", "theta", "cost_total", "omega"):
+        ref = r64[k].numpy().astype(np.float64)
+        scale = float(np.abs(ref).max())
+        err = float(np.abs(got[k].detach().cpu().numpy().astype(np.float64) - ref).max())
+        floor = float(np.abs(r32[k].numpy().astype(np.float64) - ref).max())
+        assert err <= max(1e-5 * scale, 2 * floor), (rng, regime, k, "err/scale", err / scale, "ref32 floor/scale", floor / scale)
+    n_eff = _n_eff(r64["omega"])
+    assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff
