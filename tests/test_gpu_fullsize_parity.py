@@ -261,3 +261,47 @@ def test_c3_shape_kmppi_65536x64_s32_interpolation_inside_k1(rng, regime):
         assert err <= max(1e-5 * scale, 2 * floor), (rng, regime, k, "err/scale", err / scale, "ref32 floor/scale", floor / scale)
     n_eff = _n_eff(r64["omega"])
     assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff
+
+
+@pytest.mark.parametrize("regime", ["healthy", "peaked"])
+def test_c3_shape_smppi_65536x64_lifted_controls(regime):
+    """SMPPI (mppi.py:451-570) at the headline shape on the engine's Philox rows: shift of both sequences and
+    the base sequence in one launch, K1 with the smoothness cost, K3 / K4 with the 1/dt rescaling; against
+    `oracle.smppi_command` in fp64 / fp32 on the consumed draw (action = integrated action sequence)."""
+    import pytorch_mppi_amd as pm
+    from oracle import mppi_oracle as orc
+    cfg = C3
+    model, mk, sigma, kw, x0, U0 = _setup(cfg)
+    K, T, nu = cfg["K"], cfg["T"], cfg["nu"]
+    dt_, w_ = 0.1, 0.7
+    amax = torch.full((nu,), 1.2)
+
+    def make(lam):
+        return pm.SMPPI(model.dynamics, model.running_cost, cfg["nx"], sigma, num_samples=K, horizon=T, device="cuda", lambda_=lam,
+                        rng="philox", seed=4321, U_init=U0.clone(), action_max=amax, w_action_seq_cost=w_, delta_t=dt_)
+    lam = 1.0
+    for _ in range(2):
+        probe = make(lam)
+        probe.command(x0.cuda())
+        lam = _lambda_for(probe.cost_total, 1000.0 if regime == "healthy" else 3.0)
+        del probe
+    ctrl = make(lam)
+    A0 = ctrl.action_sequence.detach().cpu().clone()     # = U_init (mppi.py:479-483); the lifted control starts at zero
+    Ud0 = ctrl.U.detach().cpu().clone()
+    act = ctrl.command(x0.cuda())
+    z = _consumed_normals(ctrl)
+    outs = []
+    for dt in (torch.float64, torch.float32):
+        f, q = mk(dt)
+        p = orc.Problem(dynamics=f, running_cost=q, nx=cfg["nx"], noise_sigma=sigma.to(dt), K=K, T=T, lambda_=lam)
+        outs.append(orc.smppi_command(p, Ud0.to(dt), A0.to(dt), x0.to(dt), z.to(dt), -amax.to(dt), amax.to(dt), w_, dt_, True))
+    r64, r32 = outs
+    got = dict(action=act, U=ctrl.U, action_sequence=ctrl.action_sequence, cost_total=ctrl.cost_total, omega=ctrl.omega)
+    for k in got:
+        ref = r64[k].numpy().astype(np.float64)
+        scale = float(np.abs(ref).max())
+        err = float(np.abs(got[k].detach().cpu().numpy().astype(np.float64) - ref).max())
+        floor = float(np.abs(r32[k].numpy().astype(np.float64) - ref).max())
+        assert err <= max(1e-5 * scale, 2 * floor), (regime, k, "err/scale", err / scale, "ref32 floor/scale", floor / scale)
+    n_eff = _n_eff(r64["omega"])
+    assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff
