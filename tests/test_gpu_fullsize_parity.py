@@ -305,3 +305,45 @@ def test_c3_shape_smppi_65536x64_lifted_controls(regime):
         assert err <= max(1e-5 * scale, 2 * floor), (regime, k, "err/scale", err / scale, "ref32 floor/scale", floor / scale)
     n_eff = _n_eff(r64["omega"])
     assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff
+
+
+def test_c3_shape_mppi_batched_8_envs_x_8192_shared_draw():
+    """MPPI_Batched (mppi.py:691-873) at C3's T, nx, nu with 8 environments x 8192 samples: ONE draw shared by
+    all environments, environment = grid z of every launch, per-environment beta / eta / omega / U.  Each environment
+    against `oracle.command` (N independent MPPI commands on the same z, :838-869) in fp64 / fp32."""
+    import pytorch_mppi_amd as pm
+    from oracle import mppi_oracle as orc
+    cfg = C3
+    model, mk, sigma, kw, _, _ = _setup(cfg)
+    Nn, K, T, nu, nx = 8, 8192, cfg["T"], cfg["nu"], cfg["nx"]
+    g = torch.Generator().manual_seed(11)
+    xs = torch.randn(Nn, nx, generator=g)
+    U0 = torch.randn(Nn, T, nu, generator=g) * 0.02
+
+    def make(lam):
+        c = pm.MPPI_Batched(model.dynamics, model.running_cost, nx, sigma, Nn, num_samples=K, horizon=T, device="cuda",
+                            lambda_=lam, rng="philox", seed=4321)
+        c.U = U0.clone().cuda()
+        return c
+    lam = 1.0
+    for _ in range(2):
+        probe = make(lam)
+        probe.command(xs.cuda())
+        lam = _lambda_for(probe.cost_total[0], 500.0)
+        del probe
+    ctrl = make(lam)
+    act = ctrl.command(xs.cuda())
+    p = ctrl._last
+    pitch = int(p.noise_pitch) or K
+    rows = p._keep["z"].view(-1, pitch, 4)[:, :K]
+    z = rows.permute(1, 0, 2).reshape(K, -1)[:, :T * nu].reshape(K, T, nu).cpu()
+    for e in range(Nn):
+        outs = []
+        for dt in (torch.float64, torch.float32):
+            f, q = mk(dt)
+            pr = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=sigma.to(dt), K=K, T=T, lambda_=lam)
+            outs.append(orc.command(pr, U0[e].to(dt), xs[e].to(dt), z.to(dt), True))
+        r64, r32 = outs
+        got = dict(action=act[e], U=ctrl.U[e], cost_total=ctrl.cost_total[e], omega=ctrl.omega[e])
+        _check(f"batched env {e}", got, r64, r32)
+        assert abs(float(ctrl.omega[e].double().sum()) - 1.0) < 1e-5
