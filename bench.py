@@ -13,12 +13,21 @@ nx=16, nu=12, fp32) -- the configuration the north_star's roofline target is quo
 per GPU (weak scaling: the sample axis is sharded, K_global = N*65536).
 Prints ONE JSON line (rank 0).  `roofline` is for K1 = rollout_cost_kernel (HBM-bound: it streams
 the K*T*nu standard normals once): algorithmic bytes 4*K*T*nu + 4*K per launch
-divided by its average duration over the K1 launches of the timed region, measured two ways through
-the C-ABI hook (mppi_profile_enable / mppi_profile_read2): the kernel's own span on the device wall
-clock on EVERY launch (min workgroup entry .. max exit: what rocprofv3 --kernel-trace reports, free
-of charge) and HIP events attached to the launch itself (hipExtLaunchKernelGGL start/stop events, on
-the stream the engine launches on = torch's current stream) on every 4th launch -- they additionally
-contain the two dispatch packets (~2-3 us) and each costs the stream ~5 us, hence the sampling.
+divided by its average DISPATCH duration over the K1 launches of the timed region.  The clock: every K1
+launch stamps the device wall clock at workgroup entry and exit (C-ABI hook mppi_profile_enable /
+mppi_profile_read_launches; min entry .. max exit = the kernel's own span, no extra packets in the timed
+region), plus DISPATCH_OFFSET_US, the constant part of a dispatch that span cannot see (ramp in front
+of the first wave, drain behind the last) -- calibrated against `rocprofv3 --kernel-trace` on the SAME
+launches (profiles/r03_k1_clock_calibration.txt), so that `avg_launch_us` is the figure rocprofv3
+reports; `frac_device_span` is the span alone.  HIP events attached to a launch are NOT a neutral clock
+on this stack (an event-carrying dispatch reads ~3 us longer on every clock, rocprofv3 included:
+profiles/r03_event_clock.txt): they are sampled in a short pass of their own behind the timed region and
+reported as `avg_launch_us_hip_events`.
+`latency_ms_synced` is the reference's own protocol (tests/benchmark_mppi.py:84-113: reset, sync, one
+command, sync; 3 warm-ups, 20 iterations, 10 % trimmed mean) beside the pipelined `ms_per_step`.
+N > 1: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run on 127.0.0.1) when it is not
+already one of them; on a box with fewer than N GPUs the ranks share the devices and the record exchange is
+staged through gloo (a test rig for the code path, labelled as such in `config.backend`).
 `cpu_baseline` times the oracle (CPU restatement of the reference path, kind "port") on the same
 workload at the full K on the host cores (at most 3 timed calls); the live reference itself, timed
 in the build container beside the port, is on record in profiles/r02_cpu_reference_vs_port.txt.
@@ -44,7 +53,10 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
-EVENT_EVERY = 4            # HIP events on every 4th K1 launch (device-clock stamps on all of them)
+# What `rocprofv3 --kernel-trace` reports for a plain K1 dispatch on top of the kernel's own device-clock span
+# (dispatch ramp + end-of-kernel drain), measured on the same launches: profiles/r03_k1_clock_calibration.txt
+DISPATCH_OFFSET_US = 0.8
+STAMPS_ONLY = 1 << 30      # mppi_profile_enable argument: device-clock stamps on every launch, HIP events on none
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
 
 
@@ -146,12 +158,20 @@ def cpu_baseline(wl, budget_s=15.0):
     return out
 
 
+def _stats(xs):
+    xs = sorted(x for x in xs if x is not None and x > 0)
+    if not xs:
+        return None
+    return {"n": len(xs), "avg": sum(xs) / len(xs), "median": xs[len(xs) // 2], "min": xs[0], "max": xs[-1]}
+
+
 def k1_hbm_cold(ctrl, n=32):
     """K1 alone with its noise rows HBM-cold: the same launch (C-ABI mppi_rollout_cost on the last
     command's problem block) cycled over NBUF row buffers of 4*K*T*nu bytes each, >= 1.5 GiB in total,
     so that no launch finds its rows in the 256 MiB Infinity Cache (inside a command K1 runs right
     after the generator wrote the 201 MB draw and part of its reads are cache hits: `frac` above is
-    that in-pipeline figure, this one is the pure-HBM one).  Device-clock span per launch, like `frac`."""
+    that in-pipeline figure, this one is the pure-HBM one).  One untimed pass over every buffer first
+    (warm-up, not in the statistics); then `n` launches, per-launch device-clock spans, MEDIAN quoted."""
     import ctypes as C
     from pytorch_mppi_amd import _native as N
     from pytorch_mppi_amd.mppi import _ptr
@@ -169,17 +189,86 @@ def k1_hbm_cold(ctrl, n=32):
             p.z = _ptr(bufs[i])
             N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
         torch.cuda.synchronize()
-        lib.mppi_profile_enable(1 << 30)                        # device-clock stamps only
+        lib.mppi_profile_enable(STAMPS_ONLY)                    # device-clock stamps only
         for i in range(n):
             p.z = _ptr(bufs[i % nbuf])
             N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
-        a, b, cn, ce = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_int64(0)
-        N.check(lib.mppi_profile_read2(C.byref(a), C.byref(b), C.byref(cn), C.byref(ce)), "mppi_profile_read2")
+        dev, _ = N.profile_read_launches()
         lib.mppi_profile_enable(0)
     finally:
         p.z = z_save
-    return {"avg_launch_us": b.value / max(1, cn.value) * 1e3, "launches": int(cn.value), "buffers": nbuf,
+    st_ = _stats(dev)
+    return {"launch_us_device_span": st_, "warmup_launches_excluded": nbuf, "buffers": nbuf,
             "bytes_cycled": 4 * n_el * nbuf}
+
+
+def latency_synced(ctrl, x0, warmup=3, iters=20):
+    """The reference's timing protocol (/root/reference/tests/benchmark_mppi.py:84-113): warm-ups without the
+    shift, then per iteration reset() + state.clone() outside the clock, synchronize, ONE command, synchronize.
+    Returns milliseconds: the reference's 10 %-trimmed mean, plus median / min / max."""
+    for _ in range(warmup):
+        ctrl.command(x0, shift_nominal_trajectory=False)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        ctrl.reset()
+        s_ = x0.clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctrl.command(s_)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    trim = max(1, len(ts) // 10)
+    tr = ts[trim:-trim] if len(ts) > 2 * trim else ts
+    return {"trimmed_mean_ms": sum(tr) / len(tr) * 1e3, "median_ms": ts[len(ts) // 2] * 1e3, "min_ms": ts[0] * 1e3,
+            "max_ms": ts[-1] * 1e3, "iters": iters,
+            "protocol": "reference tests/benchmark_mppi.py:84-113 (reset, sync, one command, sync)"}
+
+
+def _self_spawn(n, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves (one process per GPU,
+    rendezvous on 127.0.0.1) and hand their exit code back.  Rank 0's JSON line goes straight to our stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    if "MPPI_BENCH_BACKEND" not in env and torch.cuda.device_count() < n:
+        # fewer GPUs than ranks (the 1-GPU development box): RCCL refuses two ranks on one device, so the
+        # ranks share the GPUs round-robin and the record exchange is staged through gloo -- a rig for the
+        # N > 1 CODE PATH, not a measurement; the JSON line says so (config.backend)
+        env["MPPI_BENCH_BACKEND"] = "gloo"
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def exchange_time_us(ctrl, dist, barrier, n=30):
+    """The collective part of a sharded command alone: all-gather of the (2 + T*nu)-element shard record + K5
+    (rank-order combine), issued back to back `n` times on the last command's problem block; max over ranks by
+    construction (barrier on both sides).  Path = what command() itself uses."""
+    p = ctrl._last
+    if p is None:
+        return None
+    comm = ctrl._shard.native_comm(ctrl.d)
+    if comm is not None:
+        path = "engine-owned RCCL communicator: ncclAllGather + K5 on the command's stream (mppi_exchange_combine)"
+        one = lambda: ctrl._exchange_native(p, comm)
+    else:
+        path = ("torch.distributed all_gather_into_tensor (" + dist.get_backend() + ") + K5"
+                + (", record staged through the host: TEST RIG" if dist.get_backend() == "gloo" else ""))
+        one = lambda: ctrl._combine(p, ctrl._shard.all_gather(p._keep["record"]))
+    for _ in range(3):
+        one()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one()
+    barrier()
+    return {"us_per_exchange": (time.perf_counter() - t0) / n * 1e6, "path": path, "calls": n}
 
 
 def main():
@@ -197,11 +286,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            _self_spawn(args.gpus, sys.argv[1:])               # does not return
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if os.environ.get("MPPI_BENCH_SPAWN_ONLY") == "1":
+        # plumbing check without a GPU (tests/test_dist_gloo.py): the self-started ranks rendezvous on gloo, agree on
+        # the world size, rank 0 prints one line
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            tot = torch.ones(1)
+            dist.all_reduce(tot)
+            ok = int(tot) == world
+            dist.destroy_process_group()
+        else:
+            ok = True
+        if rank == 0:
+            print(json.dumps({"spawn_check": bool(ok), "n_gpus": world}), flush=True)
+        return
     dist = None
-    # MPPI_BENCH_BACKEND=gloo: test rig for the N>1 code path on a 1-GPU box (ranks share cuda:0 and
-    # the record all-gather is staged through the host); the driver's runs use nccl = RCCL over xGMI
+    # MPPI_BENCH_BACKEND=gloo: test rig for the N>1 code path on a box with fewer GPUs than ranks (ranks share
+    # the devices and the record all-gather is staged through the host); real runs use nccl = RCCL over xGMI
     backend = os.environ.get("MPPI_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
@@ -243,28 +349,31 @@ def main():
         torch.cuda.synchronize()
 
     from pytorch_mppi_amd import _native as N
-    import ctypes as C
     lib = N.lib()
     for _ in range(args.warmup):
         ctrl.command(x0)
-    # device-clock stamps on every K1 launch of the timed region, kernel-attached HIP events on every
-    # EVENT_EVERY-th (an event-attached launch carries two extra dispatch packets, ~5 us: attaching
-    # them to every launch would cost the timed region 5 %)
-    lib.mppi_profile_enable(EVENT_EVERY)
+    # device-clock stamps on every K1 launch of the timed region: no extra packets, no events (see the docstring)
+    lib.mppi_profile_enable(STAMPS_ONLY)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctrl.command(x0)
     barrier()
     dt = time.perf_counter() - t0
-    k1_sum, k1_dev, k1_n, k1_ne = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_int64(0)
-    N.check(lib.mppi_profile_read2(C.byref(k1_sum), C.byref(k1_dev), C.byref(k1_n), C.byref(k1_ne)), "mppi_profile_read2")
+    k1_dev_us, _ = N.profile_read_launches()
     lib.mppi_profile_enable(0)
+    dump = os.environ.get("MPPI_BENCH_DUMP_LAUNCHES")
+    if dump and rank == 0:
+        # per-launch device-clock spans of the timed region, for tools/clock_calibration.py (matched against the
+        # rocprofv3 trace of this very process)
+        json.dump({"k1_device_span_us": k1_dev_us, "warmup": args.warmup, "steps": args.steps,
+                   "k1_launches_before_timed_region": (1 if kind != "pendulum" else 0) + args.warmup}, open(dump, "w"))
     if world > 1:
         tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     ranks_identical = None
+    exchange = None
     if world > 1:
         # every rank must hold bit-identical U after the rank-order combine (K5)
         mine = ctrl.U.detach().reshape(-1).contiguous()
@@ -274,6 +383,7 @@ def main():
         dist.all_gather_into_tensor(allU, mine)
         allU = allU.view(world, -1)
         ranks_identical = bool(all(torch.equal(allU[0], allU[r]) for r in range(world)))
+        exchange = exchange_time_us(ctrl, dist, barrier)
     ms_per_step = dt / args.steps * 1e3
     value = Kglobal * args.steps / dt
     n_eff = None
@@ -284,18 +394,32 @@ def main():
             dist.all_reduce(s2, op=dist.ReduceOp.SUM)      # omega is normalised globally by K5
         n_eff = 1.0 / float(s2)
 
-    # ---- roofline of K1 from the HIP events recorded inside the timed region ----
-    k1 = k1_n.value
-    k1_ms_events = k1_sum.value / max(1, k1_ne.value)   # HIP events attached to the launch (incl. dispatch packets)
-    k1_ms_device = k1_dev.value / max(1, k1)      # the kernel's own span on the device wall clock
-    k1_ms = k1_ms_device if k1_ms_device > 0 else k1_ms_events
+    # ---- HIP events, the conventional clock, in a pass of their own (rank 0 reports; every rank runs the
+    # commands so that sharded controllers stay in step) ----
+    lib.mppi_profile_enable(1)
+    for _ in range(12):
+        ctrl.command(x0)
+    _, k1_ev_us = N.profile_read_launches()
+    lib.mppi_profile_enable(0)
+    barrier()
+
+    # ---- roofline of K1 ----
+    dev_st = _stats(k1_dev_us)
+    ev_st = _stats(k1_ev_us)
+    k1_us_span = dev_st["avg"] if dev_st else 0.0
+    k1_us = k1_us_span + DISPATCH_OFFSET_US if dev_st else 0.0
     Klocal = ctrl.K_local
     alg_bytes = 4 * Klocal * T * nu + 4 * Klocal
+    clock_note = ("avg_launch_us = mean over the K1 launches of the timed region of (device wall-clock span: min workgroup "
+                  f"entry .. max exit) + {DISPATCH_OFFSET_US} us dispatch offset = the rocprofv3 --kernel-trace figure "
+                  "(calibration on the same launches: profiles/r03_k1_clock_calibration.txt); *_device_span = the span "
+                  "alone; *_hip_events = hipExtLaunchKernelGGL start/stop pairs in a separate pass (reads ~3 us long: "
+                  "profiles/r03_event_clock.txt)")
     roofline = None
-    if k1 and kind == "mlp":
+    if dev_st and kind == "mlp":
         # C4/C5: the rollout is a chain of two dense layers per state evaluation -> fp32 MFMA bound
         flops = 2.0 * ((nx + nu) * 256 + 256 * nx) * Klocal * T
-        ach = flops / (k1_ms * 1e-3) / 1e12
+        ach = flops / (k1_us * 1e-6) / 1e12
         exact = os.environ.get("MPPI_MLP_EXACT") == "1"
         # what the matrix pipe actually executes in the split kernel: per (16 samples x timestep) 96 bf16
         # + 24 fp16 MFMAs of 16x16x32 (2*16*16*32 flop each); the exact kernel executes the algorithmic flops
@@ -303,27 +427,27 @@ def main():
         roofline = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                     "kernel": "rollout_mlp_mfma_kernel (fp32 MFMA)" if exact else "rollout_mlp_split_kernel (bf16x3 / fp16x2 MFMA)",
-                    "avg_launch_us": k1_ms * 1e3,
-                    "avg_launch_us_hip_events": k1_ms_events * 1e3,
+                    "avg_launch_us": k1_us, "avg_launch_us_device_span": k1_us_span, "launch_us_device_span": dev_st,
+                    "avg_launch_us_hip_events": ev_st["avg"] if ev_st else None, "timing": clock_note,
                     "algorithmic_flops": flops,
                     "peak_note": "peak = dense fp32 MFMA (157.3 TFLOP/s): the path computes in fp32 (dtype f32, results at fp32 "
                                  "accuracy); `achieved` = algorithmic fp32 flops / launch time",
-                    "executed_mfma_tflops": executed / (k1_ms * 1e-3) / 1e12,
-                    "executed_frac_of_bf16_dense_peak": None if exact else executed / (k1_ms * 1e-3) / 1e12 / 2500.0,
-                    "limiter": "VALU issue of one wave per SIMD (v_exp + v_rcp per hidden activation), not the matrix pipe"}
-    elif k1:
+                    "executed_mfma_tflops": executed / (k1_us * 1e-6) / 1e12,
+                    "executed_frac_of_bf16_dense_peak": None if exact else executed / (k1_us * 1e-6) / 1e12 / 2500.0,
+                    "limiter": "VALU issue (v_exp + v_rcp per hidden activation), not the matrix pipe"}
+    elif dev_st:
+        ach = alg_bytes / (k1_us * 1e-6) / 1e9
         if ctrl.last_draw == "philox-k1":
-            # no-HBM mode: the normals never exist in memory; report the time against the
+            # no-HBM mode: the normals never exist in memory before K1; report the time against the
             # external-z byte count for orientation only
-            ach = alg_bytes / (k1_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "rollout_cost_kernel<..., PHILOX>", "avg_launch_us": k1_ms * 1e3,
-                        "avg_launch_us_hip_events": k1_ms_events * 1e3,
+                        "kernel": "rollout_cost_kernel<..., PHILOX>", "avg_launch_us": k1_us,
+                        "avg_launch_us_device_span": k1_us_span, "launch_us_device_span": dev_st,
+                        "avg_launch_us_hip_events": ev_st["avg"] if ev_st else None, "timing": clock_note,
                         "note": "rng=philox: K1 generates the normals (Philox4x32-10 + Box-Muller) and WRITES them "
                                 "once for K3 -- it is VALU/RNG-bound, 'achieved' is those bytes / time"}
         else:
-            ach = alg_bytes / (k1_ms * 1e-3) / 1e9
             # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: separate
             # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 note); null if not collected
             # for this exact workload/mode
@@ -334,26 +458,29 @@ def main():
                     traffic = pmc[f"{args.workload}/{args.rng}"]["rollout_cost_kernel"]["traffic_bytes"]
             except Exception:
                 traffic = None
-            cold = k1_hbm_cold(ctrl) if not args.no_extras else None
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                        "kernel": "rollout_cost_kernel", "avg_launch_us": k1_ms * 1e3,
-                        "avg_launch_us_hip_events": k1_ms_events * 1e3,
-                        "timing": "kernel span on the device wall clock (min workgroup entry .. max exit per "
-                                  "launch, every K1 launch of the timed region); HIP events attached to every "
-                                  f"{EVENT_EVERY}th of those launches are reported beside it and include the "
-                                  "dispatch packets",
+                        "kernel": "rollout_cost_kernel", "avg_launch_us": k1_us,
+                        "avg_launch_us_device_span": k1_us_span, "launch_us_device_span": dev_st,
+                        "frac_device_span": alg_bytes / (k1_us_span * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "avg_launch_us_hip_events": ev_st["avg"] if ev_st else None,
+                        "timing": clock_note,
                         "algorithmic_bytes": alg_bytes,
                         "frac_of_measured_copy_ceiling": ach / HBM_COPY_CEILING_GBS,
                         "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                           "passes of this command; a lookup, not measured in this run)" if traffic else None,
                         "frac_note": "`frac` is K1 inside the command pipeline, where part of the 201 MB draw the "
                                      "generator just wrote is still in the 256 MiB Infinity Cache; `frac_hbm_cold` is "
-                                     "the same launch with rows that are in HBM only"}
-            if cold:
-                ach_c = alg_bytes / (cold["avg_launch_us"] * 1e-6) / 1e9
+                                     "the same launch with rows that are in HBM only (median of the launches behind one "
+                                     "untimed pass over every buffer, + the same dispatch offset)"}
+            # the HBM-cold pass allocates 1.6 GB and takes a while: rank 0 only, after the barrier above, with the
+            # other ranks parked at the barrier below
+            cold = k1_hbm_cold(ctrl) if (rank == 0 and not args.no_extras) else None
+            if cold and cold["launch_us_device_span"]:
+                us_c = cold["launch_us_device_span"]["median"] + DISPATCH_OFFSET_US
+                ach_c = alg_bytes / (us_c * 1e-6) / 1e9
                 roofline.update({"frac_hbm_cold": ach_c / HBM_PEAK_GBS, "achieved_hbm_cold": ach_c,
-                                 "avg_launch_us_hbm_cold": cold["avg_launch_us"], "hbm_cold_sample": cold})
+                                 "median_launch_us_hbm_cold": us_c, "hbm_cold_sample": cold})
 
     out = {
         "metric": "rollouts/sec (K x T state evals) per .command() call",
@@ -367,7 +494,15 @@ def main():
         "state_evals_per_s": value * T,
         "roofline": roofline,
     }
+    if world > 1:
+        out["config"]["backend"] = ("nccl (RCCL over xGMI), one rank per GPU" if backend == "nccl" else
+                                    f"{backend}: TEST RIG -- {world} ranks share {torch.cuda.device_count()} GPU(s), record "
+                                    "exchange staged through the host; exercises the N > 1 code path, not a measurement")
+        out["config"]["world_size"] = dist.get_world_size()
+        out["config"]["collective_per_command"] = exchange
 
+    if rank == 0 and world == 1:
+        out["latency_ms_synced"] = latency_synced(ctrl, x0)
     if rank == 0 and world == 1 and not args.no_extras:
         # other noise modes of the same workload (short runs), for the record
         extras = {}
@@ -404,18 +539,19 @@ def main():
             nw = 100 if wl == "c2" else 8
             for _ in range(3):
                 cw.command(xw)
-            lib.mppi_profile_enable(EVENT_EVERY)
+            lib.mppi_profile_enable(STAMPS_ONLY)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(nw):
                 cw.command(xw)
             torch.cuda.synchronize()
             dw = time.perf_counter() - t1
-            e_, d2_, n_, ne_ = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_int64(0)
-            N.check(lib.mppi_profile_read2(C.byref(e_), C.byref(d2_), C.byref(n_), C.byref(ne_)), "mppi_profile_read2")
+            dv, _ = N.profile_read_launches()
             lib.mppi_profile_enable(0)
-            k1us = d2_.value / max(1, n_.value) * 1e3
-            rec = {"workload": d_, "rollouts_per_s": K_ * nw / dw, "ms_per_step": dw / nw * 1e3, "k1_avg_us": k1us}
+            dvs = _stats(dv)
+            k1us = (dvs["avg"] + DISPATCH_OFFSET_US) if dvs else 0.0
+            rec = {"workload": d_, "rollouts_per_s": K_ * nw / dw, "ms_per_step": dw / nw * 1e3, "k1_avg_us": k1us,
+                   "latency_ms_synced": latency_synced(cw, xw)}
             if kind_ == "mlp" and k1us > 0:
                 fl = 2.0 * ((nx_ + nu_) * 256 + 256 * nx_) * K_ * T_
                 rec["k1_tflops"] = fl / (k1us * 1e-6) / 1e12
@@ -452,8 +588,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 16
+#define MPPI_ABI_VERSION 17
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -253,8 +253,12 @@ int mppi_finalize(const MppiProblem* p, int apply, void* stream);
  * and the last one to finish combines the partial records and applies K4 -- IF the caller passes
  * omega == NULL and cost_total_non_zero == NULL; both are functions of the outputs that ARE written:
  *   cost_total_non_zero = exp(-(cost_total - record[0]) / lambda),  omega = cost_total_non_zero / record[1].
- * The WORKSPACE MUST BE ZERO-FILLED ONCE before its first use (the arrival ticket lives in its last
- * 4 elements; every command leaves it at zero). */
+ * The WORKSPACE MUST BE ZERO-FILLED ONCE before its first use: the arrival ticket of this form lives in the LAST 4
+ * elements of the buffer as the caller describes it -- at workspace + workspace_elems - 4, a place that does not
+ * depend on the problem's shape -- and every command leaves it at zero.  Problems of different shapes may therefore
+ * share one buffer, as long as every one of them is handed the SAME (workspace, workspace_elems) pair (sized for the
+ * largest: mppi_workspace_elems) and they run in stream order.  A launch that faulted may leave the ticket non-zero:
+ * zero those 4 elements again (hipMemsetAsync) before reusing the buffer. */
 int mppi_command(const MppiProblem* p, int apply, void* stream);
 /* process-wide count of mppi_command calls that ran in the single-launch form (tests, bench) */
 int64_t mppi_stat_single_launch_commands(void);
@@ -290,17 +294,23 @@ int mppi_register_model(int32_t model_id, int32_t nx, int32_t nu, void* rollout_
 
 /* Measurement hooks (bench.py).  mppi_profile_enable(every): while enabled (every >= 1), each K1
  * launch (mppi_rollout_cost) stamps wall_clock64() at workgroup entry and exit -- min(entry) /
- * max(exit) per launch is the kernel's own span on the device clock, what `rocprofv3
- * --kernel-trace` reports, and costs nothing measurable -- and every `every`-th launch is
- * additionally made with hipExtLaunchKernelGGL start/stop events attached to the KERNEL ITSELF (not
- * to the stream around it).  An event-attached launch carries two extra dispatch packets (~5 us), so
- * sampling keeps the timed region honest.  mppi_profile_enable(0) switches both off.
- * mppi_profile_read2 synchronises, returns the sums in milliseconds with the number of launches
- * stamped (`count`) and of launches with events (`count_events`), and clears the record;
- * mppi_profile_read returns the event part only. */
+ * max(exit) per launch is the kernel's own span on the device clock: no extra packets, nothing measurable
+ * added, but it misses the dispatch ramp in front of the first wave and the drain behind the last (a
+ * constant ~0.8-1.1 us against `rocprofv3 --kernel-trace` on the same launches) -- and every `every`-th
+ * launch is additionally made with hipExtLaunchKernelGGL start/stop events.  Those are NOT neutral: the
+ * start event is a marker packet in front of the kernel and an event-carrying dispatch ends with a
+ * system-scope release (~3 us longer than the same kernel launched plainly), so pass a large `every`
+ * (e.g. 1 << 30) inside a timed region and sample events in a pass of their own.
+ * mppi_profile_enable(0) switches both off.
+ * mppi_profile_read_launches synchronises and returns, per launch since the last read (at most `capacity`;
+ * `count` = how many there were), the device-clock span and the event-pair time in MICROSECONDS (-1 where
+ * a launch carried no events), and clears the record; mppi_profile_read2 returns the sums in milliseconds
+ * with the number of launches stamped (`count`) and of launches with events (`count_events`);
+ * mppi_profile_read the event part only. */
 int mppi_profile_enable(int every);
 int mppi_profile_read(double* sum_ms, int64_t* count_events);
 int mppi_profile_read2(double* sum_ms_events, double* sum_ms_device, int64_t* count, int64_t* count_events);
+int mppi_profile_read_launches(double* device_us, double* dispatch_us, int64_t capacity, int64_t* count);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
@@ -85,6 +85,7 @@ SYMBOLS = {
     "mppi_profile_enable": (C.c_int, [C.c_int]),
     "mppi_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mppi_profile_read2": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mppi_profile_read_launches": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -134,6 +135,17 @@ def check(code, what):
     if code != 0:
         msg = lib().mppi_last_error().decode(errors="replace")
         raise RuntimeError(f"{what} failed (code {code}): {msg}")
+
+
+def profile_read_launches(capacity=8192):
+    """Per-launch K1 timings since the last read: (device_span_us[], dispatch_us[]) as Python lists;
+    dispatch_us[i] is None where launch i was not sampled (include/mppi_amd.h, measurement hooks)."""
+    dev = (C.c_double * capacity)()
+    disp = (C.c_double * capacity)()
+    n = C.c_int64(0)
+    check(lib().mppi_profile_read_launches(dev, disp, capacity, C.byref(n)), "mppi_profile_read_launches")
+    m = min(int(n.value), capacity)
+    return [dev[i] for i in range(m)], [disp[i] if disp[i] >= 0 else None for i in range(m)]
 
 
 def noise_rows4(T, nu):

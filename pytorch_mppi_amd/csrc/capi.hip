@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <hip/hip_ext.h>
 #include "dispatch.hpp"
 #include "update.hpp"
 
@@ -47,6 +48,116 @@ extern "C" int64_t mppi_noise_pitch(int32_t K, int32_t dtype) {
   const int64_t row = (int64_t)K * bps;
   if (row >= (2 << 20) && row % (2 << 20) == 0) return K + (1 << 20) / bps;
   return K;
+}
+
+// ---- measurement hook -------------------------------------------------------------------------
+// Two clocks per K1 launch while enabled:
+//  * the kernel's own span on the device wall clock (min workgroup entry .. max exit), EVERY launch: no
+//    extra packets, no perturbation.  It misses the dispatch ramp in front of the first wave and the
+//    end-of-kernel drain behind the last one: rocprofv3 --kernel-trace reads a constant ~0.8-1.1 us more
+//    on the same launches (profiles/r03_k1_clock_calibration.txt);
+//  * on every `every`-th launch a hipExtLaunchKernelGGL start/stop event pair.  NOT a neutral clock
+//    (tools/micro/event_clock.hip, profiles/r03_event_clock.txt): the start event is a marker packet in
+//    front of the kernel, an event-carrying dispatch ends with a system-scope release, and
+//    hipEventElapsedTime of kernel-bound events is end - end -- an event-attached launch reads ~3 us
+//    longer than the same kernel launched plainly.  Kept because HIP events are the conventional clock;
+//    bench.py takes it in a separate pass behind the timed region.
+namespace {
+constexpr int PROF_MAX = 8192;
+int g_prof_every = 0;                      // 0 = off; N = HIP events on every N-th K1 launch
+int g_prof_n = 0;                          // launches stamped since the last read
+hipEvent_t g_prof_ev[PROF_MAX][2];         // event pairs, created on first use
+bool g_prof_has_ev[PROF_MAX];              // does launch i carry events?
+int g_prof_created = 0;
+unsigned long long* g_prof_ts = nullptr;   // device: PROF_MAX x {min entry, max exit}
+double prof_dispatch_ms(int i) {           // < 0: launch i carried no events
+  if (!g_prof_has_ev[i]) return -1.0;
+  float ms = 0;
+  if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess) return -1.0;
+  if (hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+}  // namespace
+namespace mppi {
+bool profile_next_events(hipEvent_t* start, hipEvent_t* stop, unsigned long long** tstamp) {
+  if (tstamp) *tstamp = nullptr;
+  *start = *stop = nullptr;
+  if (g_prof_every <= 0 || g_prof_n >= PROF_MAX) return false;
+  const int i = g_prof_n++;
+  if (tstamp && g_prof_ts) *tstamp = g_prof_ts + 2 * (size_t)i;
+  g_prof_has_ev[i] = false;
+  if (i % g_prof_every != 0) return false;
+  if (i >= g_prof_created) {
+    // pairs are created densely up to i so that index == launch number
+    for (int j = g_prof_created; j <= i; ++j) {
+      if (hipEventCreate(&g_prof_ev[j][0]) != hipSuccess) return false;
+      if (hipEventCreate(&g_prof_ev[j][1]) != hipSuccess) return false;
+      g_prof_created = j + 1;
+    }
+  }
+  *start = g_prof_ev[i][0];
+  *stop = g_prof_ev[i][1];
+  g_prof_has_ev[i] = true;
+  return true;
+}
+}  // namespace mppi
+extern "C" int mppi_profile_enable(int every) {
+  g_prof_every = every > 0 ? every : 0;
+  if (every > 0) {
+    g_prof_n = 0;
+    // measurement set-up (outside any timed region): stamp slots {min = ~0, max = 0}
+    if (!g_prof_ts && hipMalloc((void**)&g_prof_ts, sizeof(unsigned long long) * 2 * PROF_MAX) != hipSuccess) g_prof_ts = nullptr;
+    if (g_prof_ts) {
+      static unsigned long long init[2 * PROF_MAX];
+      for (int i = 0; i < PROF_MAX; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+      if (hipMemcpy(g_prof_ts, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(g_prof_ts); g_prof_ts = nullptr; }
+    }
+  }
+  return 0;
+}
+extern "C" int mppi_profile_read_launches(double* device_us, double* dispatch_us, int64_t capacity, int64_t* count) {
+  const int n = g_prof_n;
+  if (count) *count = n;
+  static unsigned long long host[2 * PROF_MAX];
+  bool have_dev = false;
+  if (g_prof_ts && n > 0) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(host, g_prof_ts, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hipfail((int)e, "mppi_profile_read_launches");
+    have_dev = true;
+  }
+  int dev_id = 0, khz = 100000;
+  (void)hipGetDevice(&dev_id);
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev_id);
+  for (int i = 0; i < n && i < capacity; ++i) {
+    if (device_us)
+      device_us[i] = (have_dev && host[2 * i + 1] > host[2 * i]) ? (double)(host[2 * i + 1] - host[2 * i]) / (double)khz * 1e3 : -1.0;
+    if (dispatch_us) {
+      const double ms = prof_dispatch_ms(i);
+      dispatch_us[i] = ms < 0 ? -1.0 : ms * 1e3;
+    }
+  }
+  g_prof_n = 0;
+  return 0;
+}
+extern "C" int mppi_profile_read2(double* sum_ms_events, double* sum_ms_device, int64_t* count, int64_t* count_events) {
+  static double dev_us[PROF_MAX], disp_us[PROF_MAX];
+  int64_t n = 0;
+  if (int e = mppi_profile_read_launches(dev_us, disp_us, PROF_MAX, &n)) return e;
+  double dev = 0, ev = 0;
+  int64_t ne = 0;
+  for (int i = 0; i < n; ++i) {
+    if (dev_us[i] > 0) dev += dev_us[i] * 1e-3;
+    if (disp_us[i] >= 0) { ev += disp_us[i] * 1e-3; ++ne; }
+  }
+  if (sum_ms_device) *sum_ms_device = dev;
+  if (sum_ms_events) *sum_ms_events = ev;
+  if (count) *count = n;
+  if (count_events) *count_events = ne;
+  return 0;
+}
+extern "C" int mppi_profile_read(double* sum_ms, int64_t* count_events) {
+  return mppi_profile_read2(sum_ms, nullptr, nullptr, count_events);
 }
 
 namespace {
@@ -119,7 +230,11 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.proc_sd = (const T*)p->process_noise_sd;
   a.fuse = -1;
   a.W = a.theta = nullptr; a.S = 0;
-  a.ticket = reinterpret_cast<unsigned*>(ws + (c.total - 4));
+  // The arrival ticket of the single-launch command sits in the LAST 4 elements of the caller's buffer
+  // (workspace + workspace_elems - 4): a place that does not depend on (K, T, nu, num_envs), so that
+  // problems of different shapes may share one zero-filled workspace -- at `carve().total - 4` a smaller
+  // problem's ticket lay inside a larger problem's scratch, which K1 / K3 overwrite with floats.
+  a.ticket = reinterpret_cast<unsigned*>(ws + (p->workspace_elems - 4));
   a.n_env = p->num_envs > 1 ? p->num_envs : 1;
   if (a.n_env > 1 && (p->state_per_sample || p->n_sampler_rows > 0 || p->states != nullptr || p->base_seq != nullptr ||
                       p->S > 0 || p->noise_src == MPPI_NOISE_ACTIONS))
@@ -183,89 +298,6 @@ int do_rollout(const MppiProblem* p, hipStream_t st, int fuse = -1, bool kmppi =
    : (p)->dtype == MPPI_F32 ? (expr_f32)                                \
    : (p)->dtype == MPPI_F64 ? (expr_f64)                                \
                             : fail(MPPI_E_BADARG, "bad dtype"))
-
-// ---- measurement hook -------------------------------------------------------------------------
-namespace {
-constexpr int PROF_MAX = 8192;
-int g_prof_every = 0;                      // 0 = off; N = HIP events on every N-th K1 launch
-int g_prof_n = 0;                          // launches stamped since the last read
-hipEvent_t g_prof_ev[PROF_MAX][2];         // event pairs, created on first use
-bool g_prof_has_ev[PROF_MAX];              // does launch i carry events?
-int g_prof_created = 0;
-unsigned long long* g_prof_ts = nullptr;   // device: PROF_MAX x {min entry, max exit}
-}  // namespace
-namespace mppi {
-bool profile_next_events(hipEvent_t* start, hipEvent_t* stop, unsigned long long** tstamp) {
-  if (tstamp) *tstamp = nullptr;
-  *start = *stop = nullptr;
-  if (g_prof_every <= 0 || g_prof_n >= PROF_MAX) return false;
-  const int i = g_prof_n++;
-  if (tstamp && g_prof_ts) *tstamp = g_prof_ts + 2 * (size_t)i;
-  g_prof_has_ev[i] = false;
-  if (i % g_prof_every != 0) return false;
-  if (i >= g_prof_created) {
-    // pairs are created densely up to i so that index == launch number
-    for (int j = g_prof_created; j <= i; ++j) {
-      if (hipEventCreate(&g_prof_ev[j][0]) != hipSuccess) return false;
-      if (hipEventCreate(&g_prof_ev[j][1]) != hipSuccess) return false;
-      g_prof_created = j + 1;
-    }
-  }
-  *start = g_prof_ev[i][0];
-  *stop = g_prof_ev[i][1];
-  g_prof_has_ev[i] = true;
-  return true;
-}
-}  // namespace mppi
-extern "C" int mppi_profile_enable(int every) {
-  g_prof_every = every > 0 ? every : 0;
-  if (every > 0) {
-    g_prof_n = 0;
-    // measurement set-up (outside any timed region): stamp slots {min = ~0, max = 0}
-    if (!g_prof_ts && hipMalloc((void**)&g_prof_ts, sizeof(unsigned long long) * 2 * PROF_MAX) != hipSuccess) g_prof_ts = nullptr;
-    if (g_prof_ts) {
-      static unsigned long long init[2 * PROF_MAX];
-      for (int i = 0; i < PROF_MAX; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
-      if (hipMemcpy(g_prof_ts, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(g_prof_ts); g_prof_ts = nullptr; }
-    }
-  }
-  return 0;
-}
-extern "C" int mppi_profile_read2(double* sum_ms_events, double* sum_ms_device, int64_t* count, int64_t* count_events) {
-  const int n = g_prof_n;
-  double dev = 0;
-  if (g_prof_ts && n > 0) {
-    static unsigned long long host[2 * PROF_MAX];
-    hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(host, g_prof_ts, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hipfail((int)e, "mppi_profile_read2");
-    int dev_id = 0, khz = 100000;
-    (void)hipGetDevice(&dev_id);
-    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev_id);
-    for (int i = 0; i < n; ++i)
-      if (host[2 * i + 1] > host[2 * i]) dev += (double)(host[2 * i + 1] - host[2 * i]) / (double)khz;   // ticks / kHz = ms
-  }
-  if (sum_ms_device) *sum_ms_device = dev;
-  if (count) *count = n;
-  return mppi_profile_read(sum_ms_events, count_events);
-}
-extern "C" int mppi_profile_read(double* sum_ms, int64_t* count_events) {
-  double s = 0;
-  int64_t ne = 0;
-  for (int i = 0; i < g_prof_n; ++i) {
-    if (!g_prof_has_ev[i]) continue;
-    hipError_t e = hipEventSynchronize(g_prof_ev[i][1]);
-    float ms = 0;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]);
-    if (e != hipSuccess) return hipfail((int)e, "mppi_profile_read");
-    s += ms;
-    ++ne;
-  }
-  if (sum_ms) *sum_ms = s;
-  if (count_events) *count_events = ne;
-  g_prof_n = 0;
-  return 0;
-}
 
 extern "C" int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
 extern "C" int64_t mppi_problem_size(void) { return (int64_t)sizeof(MppiProblem); }

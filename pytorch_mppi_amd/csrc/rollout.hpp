@@ -983,7 +983,7 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
     if (smem > 64 * 1024) /* long horizons / DMA ring: the opt-in limit (160 KiB/CU) */            \
       (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                 (int)smem);                                                        \
-    if (ev0 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a);      \
+    if (ev1 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a);      \
     else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, a);                                     \
   } while (0)
 #define MPPI_LAUNCH(NOISE_)                                                                        \

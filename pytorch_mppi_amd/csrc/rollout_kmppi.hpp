@@ -312,7 +312,7 @@ static int launch_rollout_kmppi(const KArgs<T>& a, hipStream_t st) {
   do {                                                                                                       \
     if (smem > 64 * 1024)                                                                                    \
       (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    if (ev0 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, b);                \
+    if (ev1 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, b);                \
     else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, b);                                               \
   } while (0)
     if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCHK((rollout_kmppi_kernel<Model, MPPI_NOISE_PHILOX>));

@@ -490,7 +490,7 @@ static int launch_b3(const KArgs<float>& a_in, hipStream_t st) {
   profile_next_events(&ev0, &ev1, &a.tstamp);
 #define MPPI_LAUNCH1(KERNEL)                                                                         \
   do {                                                                                               \
-    if (ev0 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a);        \
+    if (ev1 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a);        \
     else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, a);                                       \
   } while (0)
 #define MPPI_LAUNCH(NOISE_)                                                                          \

@@ -22,35 +22,72 @@ class NativeComm:
     """An RCCL communicator owned by the C-ABI (include/mppi_amd.h, csrc/dist.hip): the record
     all-gather of a sharded command is then issued by the engine itself on the caller's stream --
     no torch.distributed call, no pool stream, no cross-stream wait on the per-command path.
-    torch.distributed (any backend) is only used ONCE, to ship rank 0's 128-byte RCCL id."""
+    torch.distributed (any backend) is only used at start-up: to agree that EVERY rank can take this path
+    (a rank that silently fell back to torch.distributed while the others call ncclAllGather would hang the
+    job), and to ship rank 0's 128-byte RCCL id.  Destroyed by a finalizer (or `close()`)."""
 
     def __init__(self, rank, world_size, device, group=None):
+        import weakref
         from . import _native as N
         lib = N.lib()
-        if not lib.mppi_dist_available():
-            raise RuntimeError("RCCL not found by the engine library: " + lib.mppi_last_error().decode(errors="replace"))
+        multi = world_size > 1
+        if multi and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("NativeComm with world_size > 1 needs an initialised torch.distributed group for the id hand-out")
+        on_dev = multi and dist.get_backend(group) == "nccl"
+        flag_dev = device if on_dev else "cpu"
+
+        def all_ranks(ok):
+            """collective AND over the ranks of the group (identity at world_size 1)"""
+            if not multi:
+                return bool(ok)
+            f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=flag_dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(f.item()))
+
+        # 1. everything that can fail locally BEFORE any rank enters the id broadcast: library support, and on
+        #    rank 0 the id itself
         idbuf = (C.c_char * 128)()
-        if world_size > 1:
-            if not (dist.is_available() and dist.is_initialized()):
-                raise RuntimeError("NativeComm with world_size > 1 needs an initialised torch.distributed group for the id hand-out")
+        why = ""
+        ok = bool(lib.mppi_dist_available())
+        if not ok:
+            why = "RCCL not found by the engine library: " + lib.mppi_last_error().decode(errors="replace")
+        if ok and rank == 0 and lib.mppi_dist_unique_id(idbuf) != 0:
+            ok, why = False, "mppi_dist_unique_id: " + lib.mppi_last_error().decode(errors="replace")
+        if not all_ranks(ok):
+            raise RuntimeError(why or "another rank cannot use the engine-owned RCCL communicator")
+        # 2. ship the id
+        if multi:
             src = dist.get_global_rank(group, 0) if group is not None else 0
-            on_dev = dist.get_backend(group) == "nccl"
-            t = torch.zeros(128, dtype=torch.uint8, device=device if on_dev else "cpu")
+            t = torch.zeros(128, dtype=torch.uint8, device=flag_dev)
             if rank == 0:
-                N.check(lib.mppi_dist_unique_id(idbuf), "mppi_dist_unique_id")
                 t.copy_(torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8))
             dist.broadcast(t, src=src, group=group)
             idbuf.raw = bytes(t.cpu().numpy().tobytes())
-        else:
-            N.check(lib.mppi_dist_unique_id(idbuf), "mppi_dist_unique_id")
+        # 3. ncclCommInitRank on every rank, then agree on the outcome: one failure sends ALL ranks back to
+        #    torch.distributed together
         comm = C.c_void_p()
         with torch.cuda.device(device):
-            N.check(lib.mppi_dist_init(idbuf, int(rank), int(world_size), C.byref(comm)), "mppi_dist_init")
+            rc = lib.mppi_dist_init(idbuf, int(rank), int(world_size), C.byref(comm))
+        why = "" if rc == 0 else "mppi_dist_init: " + lib.mppi_last_error().decode(errors="replace")
+        if not all_ranks(rc == 0):
+            if rc == 0 and comm.value:
+                lib.mppi_dist_destroy(comm)
+            raise RuntimeError(why or "mppi_dist_init failed on another rank")
         self._lib, self.handle, self.world_size = lib, comm, int(world_size)
+        self._finalizer = weakref.finalize(self, NativeComm._destroy, lib, comm)
+
+    @staticmethod
+    def _destroy(lib, handle):
+        if handle is not None and handle.value:
+            try:
+                lib.mppi_dist_destroy(handle)
+            except Exception:       # interpreter shutdown: the library may be gone already
+                pass
 
     def close(self):
-        if self.handle is not None and self.handle.value:
-            self._lib.mppi_dist_destroy(self.handle)
+        if self.handle is not None:
+            self._finalizer.detach()
+            NativeComm._destroy(self._lib, self.handle)
             self.handle = None
 
 
@@ -69,13 +106,20 @@ class ShardPlan:
     def native_comm(self, device):
         """The engine-owned RCCL communicator for this plan, or None: when the process group is
         RCCL-backed (backend "nccl": one rank per GPU), or at world_size 1 (measurement / test rig).
-        MPPI_NATIVE_RCCL=0 keeps the exchange on torch.distributed."""
+        MPPI_NATIVE_RCCL=0 keeps the exchange on torch.distributed.  The decision is COLLECTIVE: whether this
+        rank wants the native path (environment, device) enters the same all-reduce(MIN) as what can fail
+        inside NativeComm, so either every rank gets a communicator or every rank gets None."""
         if self._native is None:
             self._native = False
-            if os.environ.get("MPPI_NATIVE_RCCL", "1") != "0" and torch.device(device).type == "cuda":
-                ok = self.world_size == 1 or (dist.is_available() and dist.is_initialized()
-                                              and dist.get_backend(self.group) == "nccl")
-                if ok:
+            group_ok = self.world_size == 1 or (dist.is_available() and dist.is_initialized()
+                                                and dist.get_backend(self.group) == "nccl")
+            if group_ok:        # same on every rank (a property of the group), so every rank enters or none does
+                want = os.environ.get("MPPI_NATIVE_RCCL", "1") != "0" and torch.device(device).type == "cuda"
+                if self.world_size > 1:
+                    f = torch.tensor([1 if want else 0], dtype=torch.int32, device=device)
+                    dist.all_reduce(f, op=dist.ReduceOp.MIN, group=self.group)
+                    want = bool(int(f.item()))
+                if want:
                     try:
                         self._native = NativeComm(self.rank, self.world_size, device, self.group)
                     except RuntimeError:

@@ -119,3 +119,20 @@ def test_sharded_controllers_share_one_initial_sequence_and_draw_distinct_sample
     for rank, same, distinct, changed in res:
         assert all(same), (rank, same)
         assert distinct and changed
+
+
+def test_bench_self_spawn_plumbing_without_a_gpu():
+    """`python bench.py --gpus 2` outside any launcher must start its own two ranks (torch.distributed.run on
+    127.0.0.1) and print ONE line from rank 0 -- checked here without a GPU through MPPI_BENCH_SPAWN_ONLY=1 (the ranks
+    rendezvous on gloo and agree on the world size); the real thing is tests/test_gpu_sharding.py."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MPPI_BENCH_SPAWN_ONLY"] = "1"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"spawn_check": True, "n_gpus": 2}

@@ -245,6 +245,28 @@ def test_bench_two_ranks_prints_one_valid_json_line():
 
 
 
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what the driver runs): bench.py starts its own two ranks;
+    on this 1-GPU box they share cuda:0 and exchange through gloo (labelled a test rig in config.backend)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MPPI_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--workload", "c2"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["K_global"] == 2 * d["config"]["K_per_gpu"]
+    assert d["config"]["ranks_hold_identical_U"] is True and d["value"] > 0
+    ex = d["config"]["collective_per_command"]
+    assert ex["us_per_exchange"] > 0 and ex["calls"] > 0
+    if torch.cuda.device_count() < 2:
+        assert "TEST RIG" in d["config"]["backend"]
+
+
 def test_sharded_kmppi_with_the_interpolation_inside_k1_rolls_out_its_own_global_rows():
     """KMPPI under `shard=` on the fused-interpolation path with in-kernel Philox: every shard must draw the rows of
     ITS global samples (counter = global k) and see the null-action row on shard 0 only -- its cost_total is the slice
