@@ -174,6 +174,12 @@ int mppi_noise_fill_philox(const MppiProblem* p, void* z_tnk4, void* stream);
  * HBM-bound kernels).  MPPI_E_UNSUPPORTED for control widths without a compiled instantiation. */
 int mppi_noise_fill_philox_coloured(const MppiProblem* p, void* eps_tnk4, void* stream);
 
+/* Test / debug seam: the process-noise normals the fused multi-rollout K1 (rollout_samples M in 2..4, p->process_noise_sd
+ * set) draws in-kernel for command p->call -- its own Philox key (seed ^ tag), counter (sample, (t*4 + m)*ceil(nx/4) +
+ * block, call) -- written to `out` as (M,K,T,nx) row-major.  Generated by the same device function the kernel calls, so a
+ * checker (the oracle) can be fed exactly the numbers the rollout consumed. */
+int mppi_process_noise_export(const MppiProblem* p, void* out_mktx, void* stream);
+
 /* (K,T,nu) row-major standard normals (the reference's layout, mppi.py:203) -> TNK4 */
 int mppi_noise_from_ktn(const MppiProblem* p, const void* z_ktn, void* z_tnk4, void* stream);
 

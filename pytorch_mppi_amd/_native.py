@@ -60,6 +60,7 @@ SYMBOLS = {
     "mppi_noise_fill_philox": (C.c_int, [_PP, _vp, _vp]),
     "mppi_noise_fill_philox_coloured": (C.c_int, [_PP, _vp, _vp]),
     "mppi_noise_from_ktn": (C.c_int, [_PP, _vp, _vp, _vp]),
+    "mppi_process_noise_export": (C.c_int, [_PP, _vp, _vp]),
     "mppi_kmppi_interp": (C.c_int, [_PP, _vp, _vp]),
     "mppi_rollout_cost": (C.c_int, [_PP, _vp]),
     "mppi_rollout_cost_kmppi": (C.c_int, [_PP, _vp]),

@@ -4,6 +4,7 @@
 // thread-local error string.
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <hip/hip_ext.h>
 #include "dispatch.hpp"
@@ -423,6 +424,40 @@ extern "C" int mppi_upload_small(const void* src_host, int64_t nbytes, void* dst
   return hipfail(upload_small<512>(src_host, nbytes, dst_device, (hipStream_t)stream), "mppi_upload_small");
 }
 
+// ---- test / debug seam: the process-noise normals of the fused multi-rollout K1 ---------------------------
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) process_noise_export_kernel(unsigned long long seed, unsigned long long call, long long k_offset,
+                                                                     int K, int Tn, int M, int nx, T* __restrict__ out) {
+  const int k = blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= K) return;
+  const int nxb = (nx + 3) / 4;
+  for (int t = blockIdx.y; t < Tn; t += gridDim.y)
+    for (int m = 0; m < M; ++m)
+      for (int q = 0; q < nxb; ++q) {
+        T w[4];
+        philox_normal4<T>(seed ^ PROCESS_NOISE_KEY_TAG, call, k_offset + k, ((long long)t * PROCESS_NOISE_MM + m) * nxb + q, w);
+        for (int i = 0; i < 4; ++i)
+          if (4 * q + i < nx) out[(((long long)m * K + k) * Tn + t) * nx + 4 * q + i] = w[i];
+      }
+}
+}  // namespace
+extern "C" int mppi_process_noise_export(const MppiProblem* p, void* out, void* stream) {
+  if (p == nullptr || out == nullptr || p->K <= 0 || p->T <= 0 || p->nx <= 0) return fail(MPPI_E_BADARG, "mppi_process_noise_export: bad argument");
+  const int M = p->rollout_samples > 1 ? p->rollout_samples : 1;
+  if (M > PROCESS_NOISE_MM) return fail(MPPI_E_UNSUPPORTED, "mppi_process_noise_export: the fused stream is defined for M <= 4");
+  const dim3 grid((p->K + BLOCK - 1) / BLOCK, p->T < 64 ? p->T : 64);
+  if (p->dtype == MPPI_F32)
+    hipLaunchKernelGGL(process_noise_export_kernel<float>, grid, dim3(BLOCK), 0, (hipStream_t)stream, p->seed, p->call, p->k_offset,
+                       p->K, p->T, M, p->nx, (float*)out);
+  else if (p->dtype == MPPI_F64)
+    hipLaunchKernelGGL(process_noise_export_kernel<double>, grid, dim3(BLOCK), 0, (hipStream_t)stream, p->seed, p->call, p->k_offset,
+                       p->K, p->T, M, p->nx, (double*)out);
+  else
+    return fail(MPPI_E_BADARG, "bad dtype");
+  return hipfail((int)hipGetLastError(), "mppi_process_noise_export");
+}
+
 extern "C" int mppi_smppi_shift(int32_t dtype, int32_t T, int32_t nu, const void* U, const void* u_init, const void* A, double dt,
                                 void* U_out, void* A_out, void* B_out, void* stream) {
   if (T <= 0 || nu <= 0 || !U || !u_init || !A || !U_out || !A_out || !B_out) return fail(MPPI_E_BADARG, "mppi_smppi_shift: bad argument");
@@ -449,8 +484,8 @@ extern "C" int mppi_kmppi_trajectory(int32_t dtype, int32_t T, int32_t S, int32_
 extern "C" int mppi_rollout_cost(const MppiProblem* p, void* stream) {
   return BY_DTYPE(p, do_rollout<float>(p, (hipStream_t)stream), do_rollout<double>(p, (hipStream_t)stream));
 }
-static long long g_kmppi_fused_rollouts = 0;
-extern "C" int64_t mppi_stat_kmppi_fused_rollouts(void) { return g_kmppi_fused_rollouts; }
+static std::atomic<long long> g_kmppi_fused_rollouts{0};   // controllers may be driven from several host threads
+extern "C" int64_t mppi_stat_kmppi_fused_rollouts(void) { return g_kmppi_fused_rollouts.load(); }
 extern "C" int mppi_rollout_cost_kmppi(const MppiProblem* p, void* stream) {
   const int r = BY_DTYPE(p, do_rollout<float>(p, (hipStream_t)stream, -1, true), do_rollout<double>(p, (hipStream_t)stream, -1, true));
   if (r == 0) ++g_kmppi_fused_rollouts;
@@ -504,8 +539,8 @@ extern "C" int mppi_finalize(const MppiProblem* p, int apply, void* stream) {
                   do_finalize<double>(p, apply, (hipStream_t)stream));
 }
 
-static long long g_single_launch_commands = 0;
-extern "C" int64_t mppi_stat_single_launch_commands(void) { return g_single_launch_commands; }
+static std::atomic<long long> g_single_launch_commands{0};
+extern "C" int64_t mppi_stat_single_launch_commands(void) { return g_single_launch_commands.load(); }
 
 extern "C" int mppi_command(const MppiProblem* p, int apply, void* stream) {
   // small problems: K1's launch carries K3 and K4 as well when the caller left omega and

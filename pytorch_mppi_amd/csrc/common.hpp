@@ -180,6 +180,11 @@ __device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned
   out[0] = (T)a; out[1] = (T)b; out[2] = (T)d; out[3] = (T)e;
 }
 
+// Process noise of the fused multi-rollout K1 (rollout.hpp, rollout_stream_multi): its own Philox key (seed ^ tag)
+// and counter (sample, (t * PROCESS_NOISE_MM + m) * ceil(nx/4) + block, command)
+constexpr unsigned long long PROCESS_NOISE_KEY_TAG = 0x5A5A5A5AA5A5A5A5ull;
+constexpr int PROCESS_NOISE_MM = 4;
+
 // one row-of-4 of the noise stream for (jb, local sample k)
 template <typename T>
 __device__ __forceinline__ void load4(const T* __restrict__ z, long long K, long long jb, int k,

@@ -135,7 +135,7 @@ __device__ __forceinline__ void rollout_step(const KArgs<T>& a, const ActionCons
 // Process noise: x[i] += sd[i] * n,  n ~ N(0,1) from the engine's Philox with its own key (seed ^ tag)
 // and counter (sample, (t * MM + m) * ceil(NX/4) + block, command) -- oracle/philox.py restates it.
 // ---------------------------------------------------------------------------------------------
-constexpr unsigned long long PROCESS_NOISE_KEY_TAG = 0x5A5A5A5AA5A5A5A5ull;
+// (PROCESS_NOISE_KEY_TAG / PROCESS_NOISE_MM: common.hpp -- mppi_process_noise_export restates the counter scheme)
 
 template <class Model, typename T, int NOISE, bool DIAG, int MM>
 __device__ __forceinline__ void rollout_stream_multi(const KArgs<T>& a, const ActionConsts<T, Model::NU>& ac,
@@ -190,6 +190,7 @@ __device__ __forceinline__ void rollout_stream_multi(const KArgs<T>& a, const Ac
 #pragma unroll
             for (int q = 0; q < NXB; ++q) {
               T w[4];
+              static_assert(MM == PROCESS_NOISE_MM, "the process-noise counter scheme is defined for MM = PROCESS_NOISE_MM copies");
               philox_normal4<T>(a.seed ^ PROCESS_NOISE_KEY_TAG, a.call, a.k_offset + k, ((long long)t * MM + m) * NXB + q, w);
 #pragma unroll
               for (int i = 0; i < 4; ++i)

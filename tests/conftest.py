@@ -12,3 +12,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs the live reference checkout at /root/reference")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    # parity-margin ledger of the -m gpu tests (tests/margins.py) -> gpurun_out/parity_margins.json
+    try:
+        import margins
+        margins.dump()
+    except Exception:
+        pass

@@ -183,3 +183,17 @@ def engine_controller(cfg, d, *, native=True, device="cuda", dtype=None, **extra
         kw["num_support_pts"] = cfg["S"]
     return cls(f, q, cfg["nx"], torch.tensor(cfg["sigma"], dtype=dtype), num_samples=cfg["K"],
                horizon=cfg["T"], device=device, U_init=t(d, "U_init", dtype).clone(), **kw)
+
+
+def problem_as(p, dtype, **override):
+    """The same oracle Problem in another dtype -- the fp32 twin whose distance from the fp64 run is the noise floor of
+    the SURVEY 7.3 criterion.  Callables that capture tensors of a fixed dtype must be overridden."""
+    import dataclasses
+    kw = {}
+    for f in dataclasses.fields(orc.Problem):
+        if not f.init:
+            continue
+        v = getattr(p, f.name)
+        kw[f.name] = v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v
+    kw.update(override)
+    return orc.Problem(**kw)

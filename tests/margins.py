@@ -1,0 +1,45 @@
+"""Parity-margin ledger (VERDICT r02 'weak' 1a): every fp32 / fp64 parity comparison of the -m gpu tests records
+how much of its tolerance it used -- err/scale of the engine against the fp64 reference, floor/scale of the reference's
+own fp32 run against it, the relative tolerance asserted -- and conftest.py writes the ledger to
+gpurun_out/parity_margins.json at session end (copied to profiles/r03_parity_margins.json for the record)."""
+import json
+import os
+
+_LEDGER = []
+
+
+def record(test, quantity, err_over_scale, floor_over_scale=None, rtol=None, note=None):
+    _LEDGER.append({"test": test, "quantity": quantity, "err_over_scale": float(err_over_scale),
+                    "floor_over_scale": None if floor_over_scale is None else float(floor_over_scale),
+                    "rtol": rtol, "note": note})
+
+
+def check(test, quantity, got, ref64, ref32=None, rtol=1e-5, scale_floor=0.0, note=None):
+    """SURVEY 7.3 criterion on one quantity: err(engine vs ref64) <= max(rtol * scale, 2 * err(ref32 vs ref64)), scale =
+    max |ref64| (optionally floored), recorded in the ledger whether it passes or not.  Returns (err/scale, floor/scale)."""
+    import numpy as np
+    g = np.asarray(got, dtype=np.float64)
+    r = np.asarray(ref64, dtype=np.float64)
+    scale = max(float(np.abs(r).max()), scale_floor) or 1.0
+    err = float(np.abs(g - r).max())
+    floor = float(np.abs(np.asarray(ref32, dtype=np.float64) - r).max()) if ref32 is not None else 0.0
+    record(test, quantity, err / scale, floor / scale if ref32 is not None else None, rtol, note)
+    assert err <= max(rtol * scale, 2 * floor), (test, quantity, "err/scale", err / scale, "ref32 floor/scale", floor / scale, "rtol", rtol)
+    return err / scale, floor / scale
+
+
+def dump(path=None):
+    if not _LEDGER:
+        return None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = path or os.path.join(root, "gpurun_out", "parity_margins.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    worst = {}
+    for e in _LEDGER:
+        key = e["test"].split("[")[0] + " :: " + e["quantity"]
+        w = worst.get(key)
+        if w is None or e["err_over_scale"] > w["err_over_scale"]:
+            worst[key] = e
+    json.dump({"criterion": "err(engine vs fp64 reference) <= max(rtol * scale, 2 * err(reference fp32 vs fp64)); scale = max |fp64 reference|",
+               "entries": len(_LEDGER), "worst_per_test_and_quantity": worst, "all": _LEDGER}, open(path, "w"), indent=1)
+    return path

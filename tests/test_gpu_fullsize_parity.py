@@ -21,6 +21,9 @@ import numpy as np
 import pytest
 import torch
 
+import gpu_util
+import margins
+
 pytestmark = pytest.mark.gpu
 
 C2 = dict(kind="pendulum", K=8192, T=32, nx=2, nu=1)
@@ -63,16 +66,7 @@ def _controller(cfg, model, sigma, kw, U0, lam, rng, shard=None, K=None):
 
 
 def _consumed_normals(ctrl, p=None):
-    """The standard normals the last command's kernels read, as a (K_local,T,nu) host tensor."""
-    from pytorch_mppi_amd import _native as N
-    p = p or ctrl._last
-    K, T, nu = ctrl.K_local, ctrl.T, ctrl.nu
-    if "z_ktn" in p._keep and int(p.noise_src) == N.NOISE_KTN:
-        return p._keep["z_ktn"].cpu()
-    assert not int(p.noise_coloured)
-    pitch = int(p.noise_pitch) or K
-    rows = p._keep["z"].view(-1, pitch, 4)[:, :K]            # [J4][pitch][4]: the first K samples of every row
-    return rows.permute(1, 0, 2).reshape(K, -1)[:, :T * nu].reshape(K, T, nu).cpu()
+    return gpu_util.consumed_normals(ctrl, p)
 
 
 def _lambda_for(cost, n_eff_target):
@@ -103,28 +97,34 @@ def _pick_lambda(cfg, model, sigma, kw, U0, x0, rng, n_eff_target, shard=None):
     return lam
 
 
-def _check(name, got, r64, r32):
-    """SURVEY 7.3 criterion, per quantity, relative to the size of that quantity."""
+def _check(name, got, r64, r32, keys=("action", "U", "cost_total", "omega")):
+    """SURVEY 7.3 criterion, per quantity, relative to the size of that quantity; margins go to the ledger."""
     worst = {}
-    for k in ("action", "U", "cost_total", "omega"):
-        ref = r64[k].numpy().astype(np.float64)
-        scale = float(np.abs(ref).max())
-        err = float(np.abs(got[k].detach().cpu().numpy().astype(np.float64) - ref).max())
-        floor = float(np.abs(r32[k].numpy().astype(np.float64) - ref).max())
-        worst[k] = (err / scale, floor / scale)
-        assert err <= max(1e-5 * scale, 2 * floor), (name, k, "err/scale", err / scale, "ref32 floor/scale", floor / scale)
+    for k in keys:
+        worst[k] = margins.check(name, k, got[k].detach().cpu().numpy(), r64[k].numpy(), r32[k].numpy(), rtol=1e-5)
     return worst
 
 
-def _oracle_pair(cfg, mk, sigma, kw, lam, U0, x0, z):
+def _oracle_pair(cfg, mk, sigma, kw, lam, U0, x0, z, device="cpu"):
+    """fp64 (ground truth) and fp32 (the reference's own noise floor) runs of the oracle on the draw `z`.  device="cuda":
+    the same torch-op restatement with its tensors on the GPU (ATen kernels -- an implementation independent of the
+    engine's HIP kernels), for draws too large for the host cores in a test's time budget; results come back on the host."""
     from oracle import mppi_oracle as orc
     out = []
     for dt in (torch.float64, torch.float32):
-        f, q = mk(dt)
-        cast = {k: v.to(dt) for k, v in kw.items()}
-        p = orc.Problem(dynamics=f, running_cost=q, nx=cfg["nx"], noise_sigma=sigma.to(dt), K=z.shape[0], T=cfg["T"],
-                        lambda_=lam, **cast)
-        out.append(orc.command(p, U0.to(dt), x0.to(dt), z.to(dt), True))
+        to = lambda t: t.to(device=device, dtype=dt) if torch.is_tensor(t) else t
+        if device != "cpu" and cfg["kind"] == "mlp":
+            from oracle import dynamics as dyn
+            f, q = dyn.make_mlp(*[w.to(device=device, dtype=dt) for w in cfg["_weights"]])    # the model's constants, on `device`
+        else:
+            f, q = mk(dt)
+        cast = {k: to(v) for k, v in kw.items()}
+        import contextlib
+        with (torch.device(device) if device != "cpu" else contextlib.nullcontext()):     # constants the oracle creates follow
+            p = orc.Problem(dynamics=f, running_cost=q, nx=cfg["nx"], noise_sigma=to(sigma), K=z.shape[0], T=cfg["T"],
+                            lambda_=lam, **cast)
+            r = orc.command(p, to(U0), to(x0), to(z), True)
+        out.append({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in r.items()})
     return out
 
 
@@ -188,6 +188,81 @@ def test_c4_mlp_65536x64_philox_generator_mfma(regime):
     _run_case(C4, "philox", regime, "philox-fill")
 
 
+def test_c5_eight_shards_of_the_mlp_equal_oracle_on_the_global_draw():
+    """BASELINE config C5: the MLP dynamics (nx=16, H=256, nu=4), K = 524288 sharded over 8 ranks of 65536 -- emulated
+    back to back on one device exactly like the two-shard case below (per shard: generator launch with the shard's global
+    sample offsets, matrix-core K1, K3, K4 -> shard record; the all-gather is a stack; K5 combines in rank order on every
+    "rank").  Against the fp64 / fp32 oracle run on the GLOBAL draw of 524288 samples (torch-op restatement with its
+    tensors on the GPU: 33.5 M state evaluations per run)."""
+    cfg = dict(C4, K=8 * C4["K"])
+    model, mk, sigma, kw, x0, U0 = _setup(cfg)
+    cfg["_weights"] = (model.W1, model.b1, model.W2, model.b2)
+    lam = _pick_lambda(C4, model, sigma, kw, U0, x0, "philox", 1000.0)      # from an unsharded 65536-sample probe
+    world = 8
+    ctrls = [_controller(cfg, model, sigma, kw, U0, lam, "philox", shard=(r, world)) for r in range(world)]
+    assert all(c.K_local == C4["K"] and c.k_offset == r * C4["K"] for r, c in enumerate(ctrls))
+    ps = [c._begin(x0.cuda(), True) for c in ctrls]
+    assert all(c.last_draw == "philox-fill" for c in ctrls)
+    records = torch.stack([p._keep["record"] for p in ps])
+    for c, p in zip(ctrls, ps):
+        c._combine(p, records)
+    acts = [c._end(p) for c, p in zip(ctrls, ps)]
+    assert all(torch.equal(ctrls[0].U, c.U) for c in ctrls[1:]), "ranks must hold bit-identical U"
+    z = torch.cat([_consumed_normals(c, p) for c, p in zip(ctrls, ps)], dim=0)
+    assert z.shape == (cfg["K"], cfg["T"], cfg["nu"])
+    r64, r32 = _oracle_pair(cfg, mk, sigma, kw, lam, U0, x0, z, device="cuda")
+    got = dict(action=acts[0], U=ctrls[0].U, cost_total=torch.cat([c.cost_total for c in ctrls]),
+               omega=torch.cat([c.omega for c in ctrls]))
+    _check("c5: mlp 8 shards x 65536", got, r64, r32)
+    assert abs(float(got["omega"].double().sum()) - 1.0) < 1e-5
+    assert 50 <= _n_eff(r64["omega"]) <= 50000
+
+
+@pytest.mark.parametrize("regime", ["healthy", "peaked"])
+def test_c3_shape_full_sigma_mu_bounds_null_action_coloured_generator(regime):
+    """north_star: "correlated Gaussian noise sampled on-device via a Cholesky-factored noise_sigma".  C3's shape with a
+    NON-diagonal Sigma (12 x 12), a non-zero mean, action bounds and the null-action row, rng="philox": the generator launch
+    writes eps = chol(Sigma) z + mu (mppi.py:201-206), K1 / K3 run their diagonal form on the coloured rows, the action
+    cost uses the full Sigma^-1 (mppi.py:186-199).  The oracle gets the raw standard normals of the same command."""
+    import pytorch_mppi_amd as pm
+    from oracle import mppi_oracle as orc
+    cfg = C3
+    model, mk, _, _, x0, U0 = _setup(cfg)
+    K, T, nu, nx = cfg["K"], cfg["T"], cfg["nu"], cfg["nx"]
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(nu, nu, generator=g, dtype=torch.float64) * 0.3
+    sigma = (A @ A.T + 0.5 * torch.eye(nu, dtype=torch.float64))
+    mu = torch.randn(nu, generator=g, dtype=torch.float64) * 0.1
+    umax = torch.full((nu,), 1.4, dtype=torch.float64)
+
+    def make(lam):
+        return pm.MPPI(model.dynamics, model.running_cost, nx, sigma.float(), num_samples=K, horizon=T, device="cuda", lambda_=lam,
+                       U_init=U0.clone(), rng="philox", seed=4321, noise_mu=mu.float(), u_max=umax.float(), sample_null_action=True)
+    lam = 1.0
+    for _ in range(2):
+        probe = make(lam)
+        probe.command(x0.cuda())
+        lam = _lambda_for(probe.cost_total, 1000.0 if regime == "healthy" else 3.0)
+        del probe
+    ctrl = make(lam)
+    act = ctrl.command(x0.cuda())
+    assert ctrl.last_draw == "philox-fill" and int(ctrl._last.noise_coloured) == 1, "the generator must have coloured the rows"
+    z = gpu_util.device_philox_normals(ctrl, 1)
+    outs = []
+    for dt in (torch.float64, torch.float32):
+        f, q = mk(dt)
+        p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=sigma.to(dt), K=K, T=T, lambda_=lam, noise_mu=mu.to(dt),
+                        u_max=umax.to(dt), sample_null_action=True)
+        outs.append(orc.command(p, U0.to(dt), x0.to(dt), z.to(dt), True))
+    r64, r32 = outs
+    got = dict(action=act, U=ctrl.U, cost_total=ctrl.cost_total, omega=ctrl.omega, perturbed_action=ctrl.perturbed_action,
+               noise=ctrl.noise)
+    _check(f"c3 full Sigma + mu + bounds + null action / {regime}", got, r64, r32, keys=tuple(got))
+    assert torch.equal(ctrl.perturbed_action[0], torch.zeros(T, nu, device="cuda"))          # row bookkeeping: exact
+    n_eff = _n_eff(r64["omega"])
+    assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff
+
+
 def test_c3_two_shards_equal_oracle_on_global_draw():
     """C3 split over 2 shards (emulated back to back on one device, the all-gather is a stack):
     per-shard Philox rows are the rows of the global stream, K5 combines in rank order; against the
@@ -243,7 +318,8 @@ def test_c3_shape_kmppi_65536x64_s32_interpolation_inside_k1(rng, regime):
     if rng == "torch":
         z = ctrl._last_theta._keep["z_ktn"].cpu()
     else:
-        z = torch.from_numpy(oph.normals_ktn(4321, int(ctrl._last.call), K, S, nu))
+        z = gpu_util.device_philox_normals(ctrl, int(ctrl._last.call), Tn=S)     # the support-point draw, as consumed
+        assert float((z - torch.from_numpy(oph.normals_ktn(4321, int(ctrl._last.call), K, S, nu))).abs().max()) <= 4e-6
     outs = []
     for dt in (torch.float64, torch.float32):
         f, q = mk(dt)
@@ -253,12 +329,7 @@ def test_c3_shape_kmppi_65536x64_s32_interpolation_inside_k1(rng, regime):
         outs.append(orc.kmppi_command(p, torch.zeros(S, nu, dtype=dt), torch.zeros(T, nu, dtype=dt), x0.to(dt), z.to(dt), W, W_shift, True))
     r64, r32 = outs
     got = dict(action=act, U=ctrl.U, theta=ctrl.theta, cost_total=ctrl.cost_total, omega=ctrl.omega)
-    for k in ("action", "U", "theta", "cost_total", "omega"):
-        ref = r64[k].numpy().astype(np.float64)
-        scale = float(np.abs(ref).max())
-        err = float(np.abs(got[k].detach().cpu().numpy().astype(np.float64) - ref).max())
-        floor = float(np.abs(r32[k].numpy().astype(np.float64) - ref).max())
-        assert err <= max(1e-5 * scale, 2 * floor), (rng, regime, k, "err/scale", err / scale, "ref32 floor/scale", floor / scale)
+    _check(f"kmppi 65536x64 S=32 {rng}/{regime}", got, r64, r32, keys=("action", "U", "theta", "cost_total", "omega"))
     n_eff = _n_eff(r64["omega"])
     assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff
 
@@ -297,12 +368,7 @@ def test_c3_shape_smppi_65536x64_lifted_controls(regime):
         outs.append(orc.smppi_command(p, Ud0.to(dt), A0.to(dt), x0.to(dt), z.to(dt), -amax.to(dt), amax.to(dt), w_, dt_, True))
     r64, r32 = outs
     got = dict(action=act, U=ctrl.U, action_sequence=ctrl.action_sequence, cost_total=ctrl.cost_total, omega=ctrl.omega)
-    for k in got:
-        ref = r64[k].numpy().astype(np.float64)
-        scale = float(np.abs(ref).max())
-        err = float(np.abs(got[k].detach().cpu().numpy().astype(np.float64) - ref).max())
-        floor = float(np.abs(r32[k].numpy().astype(np.float64) - ref).max())
-        assert err <= max(1e-5 * scale, 2 * floor), (regime, k, "err/scale", err / scale, "ref32 floor/scale", floor / scale)
+    _check(f"smppi 65536x64 {regime}", got, r64, r32, keys=tuple(got))
     n_eff = _n_eff(r64["omega"])
     assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff
 

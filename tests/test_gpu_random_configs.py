@@ -11,6 +11,9 @@ import torch
 import pytorch_mppi_amd as pm
 from oracle import mppi_oracle as orc
 
+import golden_util as gu
+import margins
+
 pytestmark = pytest.mark.gpu
 # MPPI_EXTRA_SEEDS=n: n further seeds for each of the two randomised sweeps (long runs on the GPU box; 0 by default)
 _EXTRA = int(os.environ.get("MPPI_EXTRA_SEEDS", "0"))
@@ -81,7 +84,7 @@ def _generic_vs_oracle(seed, c):
     ctrl = pm.MPPI(f, q, c["nx"], c["sigma"].to(dt), num_samples=c["K"], horizon=c["T"], device="cuda",
                    U_init=c["U0"].to(dt), **kw)
     U = c["U0"]
-    tol = 1e-9 if dt == torch.float64 else 2e-5
+    tol = 1e-9 if dt == torch.float64 else 1e-5
     # fp32 runs: the bar is err <= max(tol, 2 * err(oracle_fp32 vs oracle_fp64)) -- the
     # reference's own fp32 arithmetic sits at that floor for ill-conditioned softmaxes
     B32, g32 = c["B"].float(), c["goal"].float()
@@ -107,6 +110,8 @@ def _generic_vs_oracle(seed, c):
             got = got.detach().cpu().double().numpy()
             ref = ref.numpy()
             scale = max(1.0, float(np.abs(ref).max()))
+            margins.record(f"generic random config {dt}", f"seed {seed} step {s} {name}", float(np.abs(got - ref).max()) / scale,
+                           floor.get(name, 0.0) / scale if floor else None, tol)
             np.testing.assert_allclose(got, ref, rtol=tol, atol=max(tol * scale, 2 * floor.get(name, 0.0)),
                                        err_msg=f"seed {seed} step {s} {name} {c['K']}x{c['T']}x{c['nu']}")
 
@@ -135,20 +140,21 @@ def test_fused_integrator_random_config_vs_fp64_oracle(seed):
     ctrl = pm.MPPI(m.dynamics, m.running_cost, nx, sigma.to(dt), num_samples=K, horizon=T, device="cuda", U_init=U0.to(dt),
                    **{k: cast(v) for k, v in kw64.items()})
     assert not ctrl._needs_generic()
-    tol = 1e-9 if dt == torch.float64 else 2e-5
+    tol = 1e-9 if dt == torch.float64 else 1e-5
+    p32 = gu.problem_as(p, torch.float32)               # the quad-toy callables hold no constants
     U = U0
     for s in range(2):
         z = torch.randn(K, T, nu, generator=g, dtype=torch.float64)
         r = orc.command(p, U, x0, z, s == 0)
+        r32 = orc.command(p32, U.float(), x0.float(), z.float(), s == 0) if dt == torch.float32 else None
         U = r["U"]
         ctrl.inject_noise(z.to(dt))
         a = ctrl.command(x0.to(dt).cuda(), shift_nominal_trajectory=(s == 0))
-        for name, got, ref in (("action", a, r["action"]), ("U", ctrl.U, r["U"]), ("cost_total", ctrl.cost_total, r["cost_total"]),
-                               ("omega", ctrl.omega, r["omega"])):
-            got = got.detach().cpu().double().numpy()
-            ref = ref.numpy()
-            np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())),
-                                       err_msg=f"seed {seed} step {s} {name} ({nx},{nu}) K={K} T={T} full={full}")
+        for name, got in (("action", a), ("U", ctrl.U), ("cost_total", ctrl.cost_total), ("omega", ctrl.omega)):
+            margins.check(f"fused integrator random config {dt}", f"seed {seed} step {s} {name} ({nx},{nu}) K={K} T={T} full={full}",
+                          got.detach().cpu().numpy(), r[name].numpy(), None if r32 is None else r32[name].numpy(), rtol=tol,
+                          scale_floor=1.0)
+        ctrl.U = U.to(dt).cuda()                        # both sides on the same nominal sequence for the next step
 
 
 @pytest.mark.parametrize("nu,dtype,full", [(8, torch.float64, False), (12, torch.float32, True), (9, torch.float64, False),
@@ -169,14 +175,16 @@ def test_kmppi_and_smppi_any_control_width(nu, dtype, full):
     Bd, gd = Bm.to(dtype).cuda(), goal.to(dtype).cuda()
     f = lambda s, a: s + a @ Bd.T
     q = lambda s, a: ((gd - s) ** 2).sum(-1)
-    tol = 1e-9 if dtype == torch.float64 else 3e-5
+    tol = 1e-9 if dtype == torch.float64 else 1e-5
     kw = dict(lambda_=8.0, u_max=umax)
     p = orc.Problem(dynamics=f64, running_cost=q64, nx=nx, noise_sigma=sigma, K=K, T=T, **kw)
+    B32, g32 = Bm.float(), goal.float()
+    p32 = gu.problem_as(p, torch.float32, dynamics=lambda s, a: s + a @ B32.T, running_cost=lambda s, a: ((g32 - s) ** 2).sum(-1))
+    is32 = dtype == torch.float32
 
-    def close(name, got, ref):
-        ref = ref.numpy()
-        np.testing.assert_allclose(got.detach().cpu().double().numpy(), ref, rtol=tol,
-                                   atol=tol * max(1.0, float(np.abs(ref).max())), err_msg=name)
+    def close(name, got, ref, ref32=None):
+        margins.check(f"kmppi/smppi any control width nu={nu} {dtype}", name, got.detach().cpu().numpy(), ref.numpy(),
+                      ref32.numpy() if (is32 and ref32 is not None) else None, rtol=tol, scale_floor=1.0)
 
     # ---- KMPPI ----
     W, W_shift, _, _ = orc.kmppi_matrices(T, S, torch.float64)
@@ -187,13 +195,14 @@ def test_kmppi_and_smppi_any_control_width(nu, dtype, full):
     for s in range(2):
         z = torch.randn(K, S, nu, generator=g, dtype=torch.float64)
         r = orc.kmppi_command(p, theta, U, x0, z, W, W_shift, True)
+        r32 = orc.kmppi_command(p32, theta.float(), U.float(), x0.float(), z.float(), W.float(), W_shift.float(), True) if is32 else r
         theta, U = r["theta"], r["U"]
         c.inject_noise(z.to(dtype))
         a = c.command(x0.to(dtype).cuda())
-        close(f"kmppi action {s}", a, r["action"])
-        close(f"kmppi cost {s}", c.cost_total, r["cost_total"])
-        close(f"kmppi theta {s}", c.theta, r["theta"])
-        close(f"kmppi U {s}", c.U, r["U"])
+        close(f"kmppi action {s}", a, r["action"], r32["action"])
+        close(f"kmppi cost {s}", c.cost_total, r["cost_total"], r32["cost_total"])
+        close(f"kmppi theta {s}", c.theta, r["theta"], r32["theta"])
+        close(f"kmppi U {s}", c.U, r["U"], r32["U"])
     # ---- SMPPI ----
     amax = torch.full((nu,), 1.5, dtype=torch.float64)
     U, Aseq = torch.zeros(T, nu, dtype=torch.float64), torch.zeros(T, nu, dtype=torch.float64)
@@ -203,12 +212,13 @@ def test_kmppi_and_smppi_any_control_width(nu, dtype, full):
     for s in range(2):
         z = torch.randn(K, T, nu, generator=g, dtype=torch.float64)
         r = orc.smppi_command(p, U, Aseq, x0, z, -amax, amax, 0.7, 0.5, True)
+        r32 = orc.smppi_command(p32, U.float(), Aseq.float(), x0.float(), z.float(), -amax.float(), amax.float(), 0.7, 0.5, True) if is32 else r
         U, Aseq = r["U"], r["action_sequence"]
         c.inject_noise(z.to(dtype))
         a = c.command(x0.to(dtype).cuda())
-        close(f"smppi action {s}", a, r["action"])
-        close(f"smppi cost {s}", c.cost_total, r["cost_total"])
-        close(f"smppi U {s}", c.U, r["U"])
+        close(f"smppi action {s}", a, r["action"], r32["action"])
+        close(f"smppi cost {s}", c.cost_total, r["cost_total"], r32["cost_total"])
+        close(f"smppi U {s}", c.U, r["U"], r32["U"])
 
 
 @pytest.mark.parametrize("dtype,full,K", [(torch.float32, False, 5000), (torch.float64, False, 2049), (torch.float32, True, 3000),
