@@ -18,7 +18,7 @@ launch stamps the device wall clock at workgroup entry and exit (C-ABI hook mppi
 mppi_profile_read_launches; min entry .. max exit = the kernel's own span, no extra packets in the timed
 region), plus DISPATCH_OFFSET_US, the constant part of a dispatch that span cannot see (ramp in front
 of the first wave, drain behind the last) -- calibrated against `rocprofv3 --kernel-trace` on the SAME
-launches (profiles/r03_k1_clock_calibration.txt), so that `avg_launch_us` is the figure rocprofv3
+launches (profiles/r03_k1_clock_calibration_<workload>.txt), so that `avg_launch_us` is the figure rocprofv3
 reports; `frac_device_span` is the span alone.  HIP events attached to a launch are NOT a neutral clock
 on this stack (an event-carrying dispatch reads ~3 us longer on every clock, rocprofv3 included:
 profiles/r03_event_clock.txt): they are sampled in a short pass of their own behind the timed region and
@@ -54,8 +54,12 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
 # What `rocprofv3 --kernel-trace` reports for a plain K1 dispatch on top of the kernel's own device-clock span
-# (dispatch ramp + end-of-kernel drain), measured on the same launches: profiles/r03_k1_clock_calibration.txt
-DISPATCH_OFFSET_US = 0.8
+# (dispatch ramp in front of the first wave + end-of-kernel drain behind the last), measured on the SAME launches of
+# this very command line under rocprofv3 (tools/clock_calibration.py -> profiles/r03_k1_clock_calibration_<workload>.txt:
+# c3 avg 1.82 / median 1.73, c4 1.39 / 1.40, c2 2.43 / 2.38 us; the HBM-cold launches, which do not start behind a
+# draining generator kernel: profiles/r03_k1_clock_calibration_c3_cold.txt)
+DISPATCH_OFFSET_US_BY_WORKLOAD = {"c3": 1.8, "c4": 1.4, "c2": 2.4}
+DISPATCH_OFFSET_US_COLD = 0.8
 STAMPS_ONLY = 1 << 30      # mppi_profile_enable argument: device-clock stamps on every launch, HIP events on none
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
 
@@ -198,8 +202,8 @@ def k1_hbm_cold(ctrl, n=32):
     finally:
         p.z = z_save
     st_ = _stats(dev)
-    return {"launch_us_device_span": st_, "warmup_launches_excluded": nbuf, "buffers": nbuf,
-            "bytes_cycled": 4 * n_el * nbuf}
+    return {"launch_us_device_span": st_, "launch_us_device_span_all": list(dev), "warmup_launches_excluded": nbuf,
+            "buffers": nbuf, "bytes_cycled": 4 * n_el * nbuf}
 
 
 def latency_synced(ctrl, x0, warmup=3, iters=20):
@@ -407,12 +411,13 @@ def main():
     dev_st = _stats(k1_dev_us)
     ev_st = _stats(k1_ev_us)
     k1_us_span = dev_st["avg"] if dev_st else 0.0
+    DISPATCH_OFFSET_US = DISPATCH_OFFSET_US_BY_WORKLOAD[args.workload]
     k1_us = k1_us_span + DISPATCH_OFFSET_US if dev_st else 0.0
     Klocal = ctrl.K_local
     alg_bytes = 4 * Klocal * T * nu + 4 * Klocal
     clock_note = ("avg_launch_us = mean over the K1 launches of the timed region of (device wall-clock span: min workgroup "
                   f"entry .. max exit) + {DISPATCH_OFFSET_US} us dispatch offset = the rocprofv3 --kernel-trace figure "
-                  "(calibration on the same launches: profiles/r03_k1_clock_calibration.txt); *_device_span = the span "
+                  f"(calibration on the same launches: profiles/r03_k1_clock_calibration_{args.workload}.txt); *_device_span = the span "
                   "alone; *_hip_events = hipExtLaunchKernelGGL start/stop pairs in a separate pass (reads ~3 us long: "
                   "profiles/r03_event_clock.txt)")
     roofline = None
@@ -472,12 +477,18 @@ def main():
                         "frac_note": "`frac` is K1 inside the command pipeline, where part of the 201 MB draw the "
                                      "generator just wrote is still in the 256 MiB Infinity Cache; `frac_hbm_cold` is "
                                      "the same launch with rows that are in HBM only (median of the launches behind one "
-                                     "untimed pass over every buffer, + the same dispatch offset)"}
+                                     "untimed pass over every buffer, + the dispatch offset measured for those launches)"}
             # the HBM-cold pass allocates 1.6 GB and takes a while: rank 0 only, after the barrier above, with the
             # other ranks parked at the barrier below
             cold = k1_hbm_cold(ctrl) if (rank == 0 and not args.no_extras) else None
             if cold and cold["launch_us_device_span"]:
-                us_c = cold["launch_us_device_span"]["median"] + DISPATCH_OFFSET_US
+                us_c = cold["launch_us_device_span"]["median"] + DISPATCH_OFFSET_US_COLD
+                if dump and rank == 0:     # the cold launches, for tools/clock_calibration.py (the LAST dispatches of K1 in the trace)
+                    dd = json.load(open(dump))
+                    dd["k1_cold_device_span_us"] = cold.pop("launch_us_device_span_all")
+                    json.dump(dd, open(dump, "w"))
+                cold.pop("launch_us_device_span_all", None)
+                cold["dispatch_offset_us"] = DISPATCH_OFFSET_US_COLD
                 ach_c = alg_bytes / (us_c * 1e-6) / 1e9
                 roofline.update({"frac_hbm_cold": ach_c / HBM_PEAK_GBS, "achieved_hbm_cold": ach_c,
                                  "median_launch_us_hbm_cold": us_c, "hbm_cold_sample": cold})
@@ -549,7 +560,7 @@ def main():
             dv, _ = N.profile_read_launches()
             lib.mppi_profile_enable(0)
             dvs = _stats(dv)
-            k1us = (dvs["avg"] + DISPATCH_OFFSET_US) if dvs else 0.0
+            k1us = (dvs["avg"] + DISPATCH_OFFSET_US_BY_WORKLOAD[wl]) if dvs else 0.0
             rec = {"workload": d_, "rollouts_per_s": K_ * nw / dw, "ms_per_step": dw / nw * 1e3, "k1_avg_us": k1us,
                    "latency_ms_synced": latency_synced(cw, xw)}
             if kind_ == "mlp" and k1us > 0:

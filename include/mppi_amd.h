@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 17
+#define MPPI_ABI_VERSION 18
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -268,6 +268,17 @@ int mppi_finalize(const MppiProblem* p, int apply, void* stream);
 int mppi_command(const MppiProblem* p, int apply, void* stream);
 /* process-wide count of mppi_command calls that ran in the single-launch form (tests, bench) */
 int64_t mppi_stat_single_launch_commands(void);
+/* The ON-CHIP form of mppi_command (ABI 18, csrc/rollout_onchip.hpp): noise_src == MPPI_NOISE_PHILOX with p->z == NULL
+ * ("no row array: the normals are a pure function of seed, call, sample, row") on a fused fp32 model with a diagonal
+ * Sigma, plain MPPI (no base_seq / smooth_weight / S), rollout_samples <= 1, no sampler rows, no `states`, one
+ * environment.  ONE launch generates each sample's normals, rolls out, keeps the bounded noise on chip (accumulation
+ * registers + LDS; what does not fit is generated a second time) and reduces it into one partial record
+ * {beta_b, eta_b, P_b} per 256-sample workgroup, relative to the workgroup's own minimum; a second, small launch
+ * combines the records in workgroup order (the algebra of mppi_combine) and applies K4.  No (K,T,nu) array is
+ * written or read.  Outputs as for the other forms (cost_total, record, U_out, action_out; omega / cost_total_non_zero
+ * when given).  Problems outside that scope with p->z == NULL run K1 + K3 with the rows generated twice, as before.
+ * MPPI_ONCHIP=0 in the environment disables the form (A/B runs).  Count of commands that took it: */
+int64_t mppi_stat_onchip_commands(void);
 
 /* K5 -- multi-GPU: combine `n_shards` records (all-gathered, rank order) exactly the same way
  * on every rank: beta = min beta_g; s_g = exp(-(beta_g-beta)/lambda); eta = sum s_g eta_g;

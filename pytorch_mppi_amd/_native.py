@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
@@ -74,6 +74,7 @@ SYMBOLS = {
     "mppi_finalize": (C.c_int, [_PP, C.c_int, _vp]),
     "mppi_command": (C.c_int, [_PP, C.c_int, _vp]),
     "mppi_stat_single_launch_commands": (C.c_int64, []),
+    "mppi_stat_onchip_commands": (C.c_int64, []),
     "mppi_stat_kmppi_fused_rollouts": (C.c_int64, []),
     "mppi_combine": (C.c_int, [_PP, _vp, C.c_int32, _vp]),
     "mppi_register_model": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),

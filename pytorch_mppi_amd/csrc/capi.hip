@@ -289,7 +289,7 @@ int do_rollout(const MppiProblem* p, hipStream_t st, int fuse = -1, bool kmppi =
       r = fn((const void*)&a, (void*)st);
     }
   }
-  if (r == MPPI_OK_FUSED) return r;
+  if (r == MPPI_OK_FUSED || r == MPPI_OK_ONCHIP) return r;
   return hipfail(r, "mppi_rollout_cost");
 }
 }  // namespace
@@ -541,6 +541,18 @@ extern "C" int mppi_finalize(const MppiProblem* p, int apply, void* stream) {
 
 static std::atomic<long long> g_single_launch_commands{0};
 extern "C" int64_t mppi_stat_single_launch_commands(void) { return g_single_launch_commands.load(); }
+static std::atomic<long long> g_onchip_commands{0};
+extern "C" int64_t mppi_stat_onchip_commands(void) { return g_onchip_commands.load(); }
+
+template <typename T>
+static int do_finalize_blocks(const MppiProblem* p, int apply, hipStream_t st) {
+  KArgs<T> a;
+  if (int e = make_args<T>(p, a)) return e;
+  if (!a.record || !a.cost) return fail(MPPI_E_BADARG, "finalize needs record and cost_total");
+  if (apply && !a.U_out) return fail(MPPI_E_BADARG, "finalize(apply) needs U_out");
+  onchip_carve(a);                       // one partial record per 256-sample workgroup of the on-chip K1
+  return hipfail(launch_finalize_blocks<T>(a, apply, st), "mppi_command (on-chip finalize)");
+}
 
 extern "C" int mppi_command(const MppiProblem* p, int apply, void* stream) {
   // small problems: K1's launch carries K3 and K4 as well when the caller left omega and
@@ -548,6 +560,12 @@ extern "C" int mppi_command(const MppiProblem* p, int apply, void* stream) {
   const int e1 = BY_DTYPE(p, do_rollout<float>(p, (hipStream_t)stream, apply ? 1 : 0),
                           do_rollout<double>(p, (hipStream_t)stream, apply ? 1 : 0));
   if (e1 == MPPI_OK_FUSED) { ++g_single_launch_commands; return 0; }
+  if (e1 == MPPI_OK_ONCHIP) {
+    // rng = engine generator, no row array (p->z == NULL): K1 generated, rolled out, kept the bounded noise on
+    // chip and left one partial record per workgroup (csrc/rollout_onchip.hpp); this launch combines them
+    ++g_onchip_commands;
+    return BY_DTYPE(p, do_finalize_blocks<float>(p, apply, (hipStream_t)stream), do_finalize_blocks<double>(p, apply, (hipStream_t)stream));
+  }
   if (e1) return e1;
   MppiProblem q = *p;
   // "generate once": K1 stored the Philox rows it generated, K3 re-reads them

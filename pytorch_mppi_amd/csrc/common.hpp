@@ -9,6 +9,8 @@ namespace mppi {
 
 // internal status of a K1 launcher: the launch carried the whole command (K3 + K4 included)
 constexpr int MPPI_OK_FUSED = -100;
+// ... or K1 + the workgroups' partial records (rollout_onchip.hpp): finalize_blocks_kernel completes the command
+constexpr int MPPI_OK_ONCHIP = -101;
 
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;            // threads per workgroup of the per-sample kernels
@@ -43,6 +45,17 @@ struct KArgs {
   const T *W, *theta;           // KMPPI inside K1 (rollout_kmppi.hpp): (T,S) operator, (S,nu) control points; else null
   int S;                        //   number of support points; z / seed / call then describe the SUPPORT-point stream
 };
+
+// the workspace of an on-chip command: one partial record per 256-sample workgroup
+//   block_min[0 .. nchunks)  beta_b | eta_part[0 .. nchunks)  eta_b | P_part[nchunks][Jpad]
+// (capi.hip's carve() sizes the buffer for K/256 partial records whatever the chunking)
+template <typename T>
+__host__ __device__ inline void onchip_carve(KArgs<T>& a) {
+  const int nchunks = (a.K + BLOCK - 1) / BLOCK;
+  a.nkc = nchunks;
+  a.R = 1;
+  a.P_part = a.eta_part + nchunks;
+}
 
 // MPPI_Batched: the view of the argument block for environment blockIdx.z.  The noise (z), all
 // parameters and the model are shared; state, nominal sequence, costs, weights, workspace and

@@ -906,6 +906,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
 
 }  // namespace mppi
 #include "rollout_kmppi.hpp"   // KMPPI: interpolation inside K1 (needs rollout_step)
+#include "rollout_onchip.hpp"  // rng="philox" without a (K,T,nu) array: generate, roll out, keep eps' on chip, partial records
 namespace mppi {
 
 // LDS-DMA ring depth (rows of 1 KiB per wave) for this launch, 0 = register ring.  One workgroup
@@ -939,6 +940,11 @@ template <class Model, typename T>
 static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
   constexpr int NU = Model::NU;
   if (a_in.W != nullptr) return launch_rollout_kmppi<Model, T>(a_in, st);   // mppi_rollout_cost_kmppi
+  {
+    // whole-command request on the engine's own generator with no row array: the on-chip form (or "not this path")
+    const int r = launch_rollout_onchip<Model, T>(a_in, st);
+    if (r != -1) return r;
+  }
   KArgs<T> a = a_in;
   const bool diag = a.diag != 0 || a.coloured != 0;   // a coloured stream runs the diagonal instantiation
   size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (a.diag != 0 ? 0 : 2 * NU * NU)) * sizeof(T);   // factors / Sigma^-1 of a coloured stream

@@ -1,0 +1,393 @@
+// rollout_onchip.hpp -- the rng="philox" command that moves NO (K,T,nu) array.
+//
+// The streaming command writes the draw once and reads it twice (generator -> K1 -> K3: 604 MB for 201.6 MB
+// of algorithmic input at C3).  With the engine's own generator the normals are a pure function of
+// (seed, call, sample, row), so here ONE launch does, per lane = sample,
+//   G  generate the rows of the sample (Philox4x32-10 + Box-Muller, common.hpp), a batch of super-steps at a time,
+//   R  roll out (mppi.py:297-332, :375-420, :186-199 -- the arithmetic of rollout_step), and KEEP the bounded
+//      noise eps' = clamp(U + eps) - U (:385) ON CHIP until the sample's weight is known:
+//        * the first 4 weighting tiles (240 / 256 values) in accumulation registers -- the kernel runs one wave
+//          per SIMD anyway (K = 65536 is one wave per SIMD of work), the AGPR half of the unified 512-entry
+//          register file is otherwise idle;
+//        * the next `nsl` super-steps in LDS ([row][thread][4], one conflict-free ds_write/read_b128 per row);
+//        * what does not fit is generated a second time in W (the generator is ~80 % of this kernel's time);
+//   W  the workgroup's own part of K3 (mppi.py:254-259, :268): weights relative to the WORKGROUP's minimum
+//      beta_b, eta_b, P_b[j] = sum_k w_k eps'_k[j] over its 256 samples -- the algebra of the single-launch
+//      command (rollout.hpp FUSE block) and of the multi-GPU combine.  Column sums by a transposing wave reduction
+//      on v_permlane32_swap / v_permlane16_swap / DPP (no LDS crossbar), the four waves' results combined once.
+// A second, small launch (finalize_blocks_kernel, update.hip) rescales and sums the K/256 partial records in
+// block order and applies K4.  Measured at C3 (tools/micro/k1ret_micro.hip, profiles/r03_k1ret_micro*.txt):
+// G alone 34.6 us (the chip-wide generator floor), G+R 41-45 us, whole kernel 72-78 us against 34 + 33 + 36 us
+// for generator + K1 + K3.
+// Scope: fp32, diagonal Sigma (not a coloured stream), plain MPPI (no SMPPI base sequence, no KMPPI), M = 1,
+// no sampler rows (the sample_null_action row is handled), no `states` output, one environment.
+#pragma once
+// (included from rollout.hpp, inside its include set)
+
+namespace mppi {
+
+template <int NU>
+struct OnChip {
+  static constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
+  static constexpr int PB = (12 / P4) > 0 ? (12 / P4) : 1;       // super-steps generated together (~12 rows: the Philox chains interleave)
+  static constexpr int SW = (16 / P4) > 0 ? (16 / P4) : 1;       // super-steps per weighting tile
+  static constexpr int TRW = SW * P4;                            // rows per tile (15 for nu = 12, else <= 16)
+  static constexpr int TC = TRW * 4;                             // columns per tile (<= 64)
+  static constexpr int NTA = 4;                                  // tiles kept in accumulation registers
+  static constexpr int AG_SS = NTA * SW, AG_ROWS = AG_SS * P4;   // 60 or 64 rows = 240 / 256 registers
+  static constexpr int RG = P4 >= 3 ? 1 : (P4 == 2 ? 2 : 4);     // super-steps regenerated together (>= 3 interleaved chains)
+  static constexpr bool OK = P4 <= 16 && (SW % RG) == 0;
+};
+
+// a model opts out with `static constexpr bool NO_KMPPI_FUSE = true` (the per-lane MLP: no registers to spare)
+template <class Model>
+constexpr bool onchip_model_ok() { return KmppiModelOk<Model>::value && OnChip<Model::NU>::OK; }
+
+__device__ __forceinline__ float keep_in_agpr(float v) {
+  float r;
+  asm volatile("; eps' -> %0" : "=a"(r) : "0"(v));
+  return r;
+}
+
+// bounded actions and noise of super-step ss from its standard normals: z (in) -> eps' (out), v (out);
+// exactly K1's arithmetic (rollout_step, DIAG): v = clamp(fma(z, sd, U + mu)), eps' = v - U.
+// Timesteps beyond the horizon (the padding of the last super-step) give eps' = 0.
+template <int NU, int SLOW>
+__device__ __forceinline__ void onchip_actions(const KArgs<float>& a, const ActionConsts<float, NU>& ac, const StepTables<float>& tb,
+                                               int orow, int ss, float (&z)[Stream<NU>::P4 * 4], float (&v)[Stream<NU>::P4 * 4]) {
+  constexpr int TT = Stream<NU>::TT;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int t = ss * TT + tt;
+    const bool in = t < a.Tn;
+    const int tq = in ? t : a.Tn - 1;
+    const float* __restrict__ Ut = tb.Ue + tq * NU;
+    const float* __restrict__ Umt = tb.Um + tq * NU;
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+      float w = fmaf(z[tt * NU + n], ac.sd[n], Umt[n]);                 // mppi.py:201-206, :380
+      if constexpr (SLOW == 1) w = orow == -1 ? 0.f : w;                // :390-392
+      w = clampT(w, ac.lo[n], ac.hi[n]);                                // :383
+      v[tt * NU + n] = w;
+      z[tt * NU + n] = in ? w - Ut[n] : 0.f;                            // :385
+    }
+  }
+}
+
+template <class Model, int SLOW>
+__device__ __forceinline__ void onchip_steps(const KArgs<float>& a, const ActionConsts<float, Model::NU>& ac, const Model& model,
+                                             const StepTables<float>& tb, int ss, const float (&e)[Stream<Model::NU>::P4 * 4],
+                                             const float (&v)[Stream<Model::NU>::P4 * 4], float (&x)[Model::NX], float& rollout,
+                                             float& pert) {
+  constexpr int NU = Model::NU, TT = Stream<NU>::TT;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int t = ss * TT + tt;
+    if (t < a.Tn) {
+      const float* __restrict__ Gt = tb.G + t * NU;
+      float u[NU];
+#pragma unroll
+      for (int n = 0; n < NU; ++n) {
+        const float en = e[tt * NU + n];
+        pert = fmaf(Gt[n], ac.abs_cost ? fabsf(en) : en, pert);         // :409, :415
+        u[n] = a.u_scale * v[tt * NU + n];                              // :313
+      }
+      model.step(x, u, t);                                              // :314
+      rollout += model.cost(x, u, t);                                   // :318-319
+    }
+  }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// Transposing wave reduction without the LDS crossbar: every lane holds v[0..64); afterwards lane l holds the
+// sum over the 64 lanes of v[l] (same contract as wave_reduce_transpose64, common.hpp; a different -- equally
+// fixed -- summation order).  s = 32 / 16: v_permlane32_swap / v_permlane16_swap exchange the halves of a
+// register PAIR in one instruction, so the keep/send selects disappear; s = 8 .. 1: pair sums through DPP
+// (row_ror:8 == lane^8, row_half_mirror pairs across bit 2, quad_perm for lane^2 / lane^1) and one select.
+// 141 VALU instructions per 64 columns against 189 + 63 ds_bpermute.
+__device__ __forceinline__ float wave_reduce_transpose64_dpp(float (&v)[64]) {
+  const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 32]), false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const bool up = (lane & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float X = v[i] + dpp_mov<0x128>(v[i]), Y = v[i + 8] + dpp_mov<0x128>(v[i + 8]);
+      v[i] = up ? Y : X;
+    }
+  }
+  {
+    const bool up = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float X = v[i] + dpp_mov<0x141>(v[i]), Y = v[i + 4] + dpp_mov<0x141>(v[i + 4]);
+      v[i] = up ? Y : X;
+    }
+  }
+  {
+    const bool up = (lane & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float X = v[i] + dpp_mov<0x4E>(v[i]), Y = v[i + 2] + dpp_mov<0x4E>(v[i + 2]);
+      v[i] = up ? Y : X;
+    }
+  }
+  {
+    const bool up = (lane & 1) != 0;
+    const float X = v[0] + dpp_mov<0xB1>(v[0]), Y = v[1] + dpp_mov<0xB1>(v[1]);
+    v[0] = up ? Y : X;
+  }
+  return v[0];
+}
+
+// LDS carve of the kernel (floats): Ue[J] Um[J] G[J] | red[4] | ex[4][ntiles*64] | keepL[nsl*P4][256][4]
+struct OnChipLds {
+  int J, ntiles, nsl, P4;
+  __host__ __device__ int tables() const { return (3 * J + 4 + 3) & ~3; }
+  __host__ __device__ int ex() const { return 4 * ntiles * 64; }
+  __host__ __device__ size_t bytes() const { return ((size_t)tables() + ex()) * 4 + (size_t)nsl * P4 * 256 * 16; }
+};
+
+template <class Model>
+__global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<float> a, const int nsl) {
+  using T = float;
+  constexpr int NX = Model::NX, NU = Model::NU;
+  using OC = OnChip<NU>;
+  constexpr int P4 = OC::P4, TT = OC::TT, PB = OC::PB, SW = OC::SW, TRW = OC::TRW, TC = OC::TC, NTA = OC::NTA, AG_SS = OC::AG_SS,
+                RG = OC::RG;
+  static_assert(K1_BLOCK == 256 && K1_BLOCK == BLOCK, "four waves per workgroup; onchip_carve (common.hpp) counts BLOCK-sample records");
+  if (a.tstamp != nullptr && threadIdx.x == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nss = (a.Tn + TT - 1) / TT;
+  const int ntiles = (nss + SW - 1) / SW;
+  const OnChipLds L{a.J, ntiles, nsl, P4};
+  T* Ue = reinterpret_cast<T*>(smem_raw);
+  T* Um = Ue + a.J;
+  T* G = Um + a.J;
+  T* red = G + a.J;
+  T* ex = Ue + L.tables();
+  float4* keepL = reinterpret_cast<float4*>(ex + L.ex());
+  for (int j = threadIdx.x; j < a.J; j += K1_BLOCK) {
+    const int n = j % NU;
+    const T u = u_eff(a, j);
+    Ue[j] = u;
+    Um[j] = u + a.mu[n];
+    G[j] = a.lambda_ * (u * a.sinv[n * NU + n]);
+  }
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int kraw = blockIdx.x * K1_BLOCK + threadIdx.x;
+  const bool active = kraw < a.K;
+  const int k = active ? kraw : a.K - 1;
+  const int orow = overwrite_row(a, a.k_offset + k);
+  const Model model(a);
+  T x[NX];
+  {
+    const T* __restrict__ s0 = a.state_per_sample ? a.state + (long long)k * NX : a.state;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = s0[i];                          // mppi.py:302-305
+  }
+  ActionConsts<T, NU> ac;
+  ac.load(a, nullptr);
+  float keepA[OC::AG_ROWS * 4];
+#pragma unroll
+  for (int i = 0; i < OC::AG_ROWS * 4; ++i) keepA[i] = keep_in_agpr(0.f);   // rows beyond a short horizon read as zero noise
+  __syncthreads();
+  const StepTables<T> tb{Ue, Um, G, nullptr, kraw - lane};
+  const long long kg = a.k_offset + k;
+  const bool slow = __any(orow == -1);
+
+  // ---- G + R: a batch of PB super-steps at a time ----
+  T rollout = 0.f, pert = 0.f;
+  constexpr int NCA = (AG_SS + PB - 1) / PB;     // batches that touch the accumulation registers (static indices)
+  for (int bi = 0; bi * PB < nss; ++bi) {
+    T zb[PB][P4 * 4], vb[PB][P4 * 4];
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+#pragma unroll
+      for (int i = 0; i < P4; ++i) {
+        T r[4];
+        philox_normal4<T>(a.seed, a.call, kg, (long long)(bi * PB + b) * P4 + i, r);   // rows past the horizon: unused
+        zb[b][4 * i + 0] = r[0]; zb[b][4 * i + 1] = r[1]; zb[b][4 * i + 2] = r[2]; zb[b][4 * i + 3] = r[3];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      const int ss = bi * PB + b;
+      if (slow) onchip_actions<NU, 1>(a, ac, tb, orow, ss, zb[b], vb[b]);
+      else onchip_actions<NU, 0>(a, ac, tb, orow, ss, zb[b], vb[b]);
+      onchip_steps<Model, 0>(a, ac, model, tb, ss, zb[b], vb[b], x, rollout, pert);
+    }
+    // keep eps': accumulation registers (static index -> a chain of uniform compares over the batch), then LDS
+    auto keep_lds = [&](int b) {
+      const int ss = bi * PB + b;
+      if (ss >= AG_SS && ss < AG_SS + nsl) {
+#pragma unroll
+        for (int i = 0; i < P4; ++i)
+          keepL[((ss - AG_SS) * P4 + i) * K1_BLOCK + threadIdx.x] = make_float4(zb[b][4 * i], zb[b][4 * i + 1], zb[b][4 * i + 2], zb[b][4 * i + 3]);
+      }
+    };
+    bool done = false;
+    static_for<0, NCA>([&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      if (bi == C) {
+        static_for<0, PB>([&](auto bb) {
+          constexpr int B = decltype(bb)::value, SS = C * PB + B;
+          if constexpr (SS < AG_SS) {
+#pragma unroll
+            for (int q = 0; q < P4 * 4; ++q) keepA[SS * P4 * 4 + q] = keep_in_agpr(zb[B][q]);
+          } else {
+            keep_lds(B);
+          }
+        });
+        done = true;
+      }
+    });
+    if (!done) {
+#pragma unroll
+      for (int b = 0; b < PB; ++b) keep_lds(b);
+    }
+  }
+  if (a.use_terminal) rollout += model.terminal(x);                     // :324-328
+  const T total = rollout + pert;                                       // :416
+  if (active) {
+    a.cost[k] = total;
+    if (a.pert != nullptr) a.pert[k] = pert;
+  }
+
+  // ---- W: this workgroup's partial record {beta_b, eta_b, P_b} ----
+  const T inv_lambda = T(1) / a.lambda_;
+  const T beta_b = block_min<T>(active ? total : inf_v<T>(), red);
+  const T wk = active ? weight_of<T>(total, beta_b, inv_lambda) : T(0);
+  const T eta_b = block_sum<T>(wk, red);
+  // a wave whose weights are all EXACTLY zero (fp32 exp underflow: a peaked softmax) adds exactly nothing
+  const bool live = __ballot(wk != T(0)) != 0ull;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    if (!live) { ex[(wv * ntiles + tile) * 64 + lane] = T(0); continue; }
+    T e[TRW][4];
+    bool got = false;
+    static_for<0, NTA>([&](auto tt) {
+      constexpr int TI = decltype(tt)::value;
+      if (tile == TI) {
+#pragma unroll
+        for (int i = 0; i < TRW; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) e[i][q] = keepA[(TI * TRW + i) * 4 + q];
+        got = true;
+      }
+    });
+    if (!got) {
+#pragma unroll
+      for (int g = 0; g < SW / RG; ++g) {
+        const int ss0 = tile * SW + g * RG;
+        if (ss0 < AG_SS + nsl) {                                         // kept in LDS (nsl is a multiple of RG)
+#pragma unroll
+          for (int i = 0; i < RG * P4; ++i) {
+            const float4 q4 = keepL[((ss0 - AG_SS) * P4 + i) * K1_BLOCK + threadIdx.x];
+            e[g * RG * P4 + i][0] = q4.x; e[g * RG * P4 + i][1] = q4.y; e[g * RG * P4 + i][2] = q4.z; e[g * RG * P4 + i][3] = q4.w;
+          }
+        } else if (ss0 < nss) {                                          // generated a second time
+          T zg[RG][P4 * 4], vg[P4 * 4];
+#pragma unroll
+          for (int s = 0; s < RG; ++s)
+#pragma unroll
+            for (int i = 0; i < P4; ++i) {
+              T r[4];
+              philox_normal4<T>(a.seed, a.call, kg, (long long)(ss0 + s) * P4 + i, r);
+              zg[s][4 * i + 0] = r[0]; zg[s][4 * i + 1] = r[1]; zg[s][4 * i + 2] = r[2]; zg[s][4 * i + 3] = r[3];
+            }
+#pragma unroll
+          for (int s = 0; s < RG; ++s) {
+            if (slow) onchip_actions<NU, 1>(a, ac, tb, orow, ss0 + s, zg[s], vg);
+            else onchip_actions<NU, 0>(a, ac, tb, orow, ss0 + s, zg[s], vg);
+#pragma unroll
+            for (int i = 0; i < P4; ++i)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) e[(g * RG + s) * P4 + i][q] = (ss0 + s) < nss ? zg[s][4 * i + q] : T(0);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < RG * P4; ++i) e[g * RG * P4 + i][0] = e[g * RG * P4 + i][1] = e[g * RG * P4 + i][2] = e[g * RG * P4 + i][3] = T(0);
+        }
+      }
+    }
+    T acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = i < TC ? wk * e[(i < TC ? i : 0) / 4][i % 4] : T(0);
+    ex[(wv * ntiles + tile) * 64 + lane] = wave_reduce_transpose64_dpp(acc);
+  }
+  __syncthreads();
+  // one combine over the four waves, in wave order; column j = tile * TC + c
+  for (int idx = threadIdx.x; idx < ntiles * 64; idx += K1_BLOCK) {
+    const int tile = idx >> 6, c = idx & 63, j = tile * TC + c;
+    if (c < TC && j < a.Jpad) {
+      const int o = tile * 64 + c;
+      a.P_part[(long long)blockIdx.x * a.Jpad + j] = (ex[o] + ex[ntiles * 64 + o]) + (ex[2 * ntiles * 64 + o] + ex[3 * ntiles * 64 + o]);
+    }
+  }
+  if (threadIdx.x == 0) {
+    a.eta_part[blockIdx.x] = eta_b;
+    a.block_min[blockIdx.x] = beta_b;
+  }
+  if (a.tstamp != nullptr) {
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
+  }
+}
+
+template <typename T>
+static bool onchip_problem_ok(const KArgs<T>& a) {
+  static const int off = [] { const char* e = getenv("MPPI_ONCHIP"); return e ? atoi(e) == 0 : 0; }();
+  return !off && sizeof(T) == 4 && a.fuse >= 0 && a.noise_src == MPPI_NOISE_PHILOX && a.z == nullptr && a.diag != 0 && !a.coloured &&
+         a.M == 1 && a.n_env == 1 && a.n_sampler == 0 && a.states == nullptr && a.B == nullptr && a.smooth_w == T(0) &&
+         a.e_scale == T(1) && a.W == nullptr && a.record != nullptr && (a.fuse == 0 || a.U_out != nullptr) &&
+         (a.K + K1_BLOCK - 1) / K1_BLOCK <= 8192;
+}
+
+// returns MPPI_OK_ONCHIP when the launch was issued, a positive HIP error, or -1: not this path
+template <class Model, typename T>
+static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
+  if constexpr (!std::is_same<T, float>::value || !onchip_model_ok<Model>()) {
+    return -1;
+  } else {
+    if (!onchip_problem_ok(a_in)) return -1;
+    constexpr int NU = Model::NU;
+    using OC = OnChip<NU>;
+    KArgs<T> a = a_in;
+    onchip_carve(a);
+    const int nss = (a.Tn + OC::TT - 1) / OC::TT;
+    const int ntiles = (nss + OC::SW - 1) / OC::SW;
+    OnChipLds L{a.J, ntiles, 0, OC::P4};
+    if (L.bytes() > 160 * 1024) return -1;
+    const long long room = (160 * 1024 - (long long)L.bytes()) / ((long long)OC::P4 * 256 * 16);
+    int nsl = nss - OC::AG_SS;
+    if (nsl < 0) nsl = 0;
+    if (nsl > room) nsl = (int)room;
+    nsl -= nsl % OC::RG;
+    L.nsl = nsl;
+    const size_t smem = L.bytes();
+    const dim3 grid(a.nkc), block(K1_BLOCK);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    profile_next_events(&ev0, &ev1, &a.tstamp);
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)rollout_onchip_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (ev1 != nullptr) hipExtLaunchKernelGGL(rollout_onchip_kernel<Model>, grid, block, smem, st, ev0, ev1, 0, a, nsl);
+    else hipLaunchKernelGGL(rollout_onchip_kernel<Model>, grid, block, smem, st, a, nsl);
+    const int e = (int)hipGetLastError();
+    return e != 0 ? e : MPPI_OK_ONCHIP;
+  }
+}
+
+}  // namespace mppi

@@ -700,6 +700,73 @@ __global__ void __launch_bounds__(BLOCK) finalize_kernel(const KArgs<T> a_in, in
   }
 }
 
+// K4 of the on-chip command (rollout_onchip.hpp): the K/256 workgroups left partial records relative to their OWN
+// minima -- beta_b = block_min[b], eta_b = eta_part[b], P_b = P_part[b][.] -- combined here in block order with the
+// algebra of the multi-GPU combine:  beta = min beta_b,  s_b = exp(-(beta_b - beta)/lambda),  eta = sum s_b eta_b,
+// P[j] = sum s_b P_b[j];  then K4 proper: record {beta, eta, P}, U_new = shift(U) + P/eta (mppi.py:258, :268-275).
+// grid.x = ceil(J/64) column blocks (+ blocks that only write omega / cost_total_non_zero when those are asked for);
+// dynamic LDS: nblk scale factors.
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) finalize_blocks_kernel(const KArgs<T> a, int apply, int ncolblocks, int nblk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
+  T* sb = reinterpret_cast<T*>(fb_smem);       // [nblk]
+  __shared__ T red[BLOCK / WAVE];
+  __shared__ T part[BLOCK / WAVE][WAVE];
+  const T inv_lambda = T(1) / a.lambda_;
+  T m = inf_v<T>();
+  for (int b = threadIdx.x; b < nblk; b += BLOCK) {
+    const T v = a.block_min[b];
+    sb[b] = v;
+    m = v < m ? v : m;
+  }
+  const T beta = block_min<T>(m, red);         // (its barriers publish sb)
+  T es = T(0);
+  for (int b = threadIdx.x; b < nblk; b += BLOCK) {
+    const T s = m_exp(-inv_lambda * (sb[b] - beta));
+    sb[b] = s;
+    es += s * a.eta_part[b];
+  }
+  const T eta = block_sum<T>(es, red);         // fixed order: strided slices, then the block tree
+  const T inv_eta = T(1) / eta;                // mppi.py:258
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.record[0] = beta; a.record[1] = eta; }
+  if ((int)blockIdx.x < ncolblocks) {
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    const int j = blockIdx.x * WAVE + lane;
+    T s = T(0);
+    if (j < a.J) {
+      int c = wv;
+      for (; c + 7 * (BLOCK / WAVE) < nblk; c += 8 * (BLOCK / WAVE)) {     // 8 loads in flight per lane
+        T v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = a.P_part[(long long)(c + q * (BLOCK / WAVE)) * a.Jpad + j];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s = m_fma(sb[c + q * (BLOCK / WAVE)], v[q], s);
+      }
+      for (; c < nblk; c += BLOCK / WAVE) s = m_fma(sb[c], a.P_part[(long long)c * a.Jpad + j], s);
+    }
+    part[wv][lane] = s;
+    __syncthreads();
+    if (threadIdx.x < WAVE && j < a.J) {
+      T P = part[0][lane];
+#pragma unroll
+      for (int i = 1; i < BLOCK / WAVE; ++i) P += part[i][lane];
+      a.record[2 + j] = P;
+      if (apply) {
+        const T un = u_eff(a, j) + P * inv_eta;                            // :268-270
+        a.U_out[j] = un;
+        if (a.action_out != nullptr && j < a.u_per_command * a.nu) a.action_out[j] = un;   // :271
+      }
+    }
+  }
+  if (a.wnz != nullptr || (apply && a.omega != nullptr)) {
+    for (int k = blockIdx.x * BLOCK + threadIdx.x; k < a.K; k += gridDim.x * BLOCK) {
+      const T w = weight_of<T>(a.cost[k], beta, inv_lambda);
+      if (a.wnz != nullptr) a.wnz[k] = w;
+      if (apply && a.omega != nullptr) a.omega[k] = inv_eta * w;
+    }
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) combine_kernel(const KArgs<T> a, const T* __restrict__ rec,
                                                         int G) {
@@ -953,6 +1020,20 @@ int launch_finalize(const KArgs<T>& a, int apply, hipStream_t st) {
 }
 
 template <typename T>
+int launch_finalize_blocks(const KArgs<T>& a, int apply, hipStream_t st) {
+  if (a.n_env > 1) return MPPI_E_UNSUPPORTED;
+  const int ncol = (a.J + WAVE - 1) / WAVE, nblk = a.nkc;
+  int nb = ncol;
+  if (a.wnz != nullptr || (apply && a.omega != nullptr)) {
+    int nbk = (a.K + 4 * BLOCK - 1) / (4 * BLOCK);
+    if (nbk > 256) nbk = 256;
+    nb = nbk > nb ? nbk : nb;
+  }
+  hipLaunchKernelGGL(finalize_blocks_kernel<T>, dim3(nb), dim3(BLOCK), (size_t)nblk * sizeof(T), st, a, apply, ncol, nblk);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
 int launch_combine(const KArgs<T>& a, const T* rec, int G, hipStream_t st) {
   if (a.n_env > 1) return MPPI_E_UNSUPPORTED;   // sharded MPPI_Batched: not built
   int nb = (a.J + BLOCK - 1) / BLOCK;
@@ -1030,6 +1111,7 @@ int launch_smppi_shift(int Tn, int nu, const T* U, const T* u_init, const T* A, 
   template int launch_cost_block_min<T>(const KArgs<T>&, hipStream_t);                    \
   template int launch_weights_partial<T>(const KArgs<T>&, hipStream_t);                   \
   template int launch_finalize<T>(const KArgs<T>&, int, hipStream_t);                     \
+  template int launch_finalize_blocks<T>(const KArgs<T>&, int, hipStream_t);              \
   template int launch_combine<T>(const KArgs<T>&, const T*, int, hipStream_t);              \
   template int launch_kmppi_sequences<T>(int, int, int, const T*, const T*, T*, int, const T*, const T*, T*, hipStream_t); \
   template int launch_smppi_shift<T>(int, int, const T*, const T*, const T*, T, T*, T*, T*, hipStream_t);

@@ -191,6 +191,13 @@ class MPPI:
         self.last_draw = None      # how the last command got its normals: "philox-fill" | "philox-k1" | None (other modes)
         self.coloured_fill = True  # rng="philox", full Sigma: let the generator launch apply chol(Sigma) (see _draw_noise)
         self.philox_fill = None    # rng="philox": generate in a separate launch (True) / inside K1 (False) / by horizon (None)
+        # rng="philox": the on-chip command (csrc/rollout_onchip.hpp) -- no (K,T,nu) array at all: one launch generates,
+        # rolls out, keeps the bounded noise in accumulation registers / LDS and leaves one partial record per workgroup,
+        # a second one combines them.  None: whenever the problem is in its scope (fp32, diagonal Sigma, plain MPPI,
+        # M = 1, no sampler rows) and too large for the single-launch form; True / False: force / forbid.
+        self.philox_onchip = None
+        self._onchip_refused = False
+        self._onchip_seen = 0
         self.ktn_direct = os.environ.get("MPPI_KTN_DIRECT", "1") != "0"   # rng="torch": read (K,T,nu) in place when possible
         self._force_collective = False
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
@@ -479,6 +486,10 @@ class MPPI:
             p.noise_src = N.NOISE_PHILOX
             p.call = self._call
             p.z = None
+            if self.philox_store and self._onchip_wanted(K, Tn, nu):
+                self.last_draw = "philox-onchip"
+                self._onchip_seen = int(lib.mppi_stat_onchip_commands())
+                return
             if self.philox_store:
                 # generate once, keep the rows for K3 to re-read: Philox + Box-Muller costs more per
                 # element than an HBM read
@@ -526,6 +537,22 @@ class MPPI:
             p.z = _ptr(z)
             return
         self._convert_noise(p)
+
+    def _onchip_wanted(self, K, Tn, nu):
+        """rng="philox": does this command go without a row array (include/mppi_amd.h, ABI 18; scope as checked again by
+        the engine, csrc/rollout_onchip.hpp `onchip_problem_ok`)?"""
+        if self.philox_onchip is False or self._onchip_refused:
+            return False
+        ok = (type(self) is MPPI and self.dtype == torch.float32 and self._diagonal_sigma and self.M == 1
+              and self.specific_action_sampler is None and Tn == self.T and not self._needs_generic()
+              and self._model.model_id != N.MODEL_MLP)      # the dense MLP has its own matrix-core K1
+        if not ok:
+            return False
+        if self.philox_onchip:
+            return True
+        # small problems run as ONE launch with the rows re-read out of L2 (rollout.hpp, FUSE): K <= 16384, T*nu <= 256
+        rows4 = N.noise_rows4(Tn, nu)
+        return not (K <= 16384 and 4 * rows4 <= 256)
 
     def _ktn_direct_ok(self, p, Tn, nu, z):
         return (self.ktn_direct and self.M == 1 and self.dtype == torch.float32 and self._diagonal_sigma and (Tn * nu) % 4 == 0
@@ -729,6 +756,11 @@ class MPPI:
                 self._convert_noise(p)
                 rc = launch()
             N.check(rc, "mppi_command")
+            if self.last_draw == "philox-onchip" and int(lib.mppi_stat_onchip_commands()) == self._onchip_seen:
+                # the engine ran K1 + K3 with the rows generated twice instead (a model without the on-chip kernel, ...):
+                # correct, slower -- store the rows from the next command on
+                self._onchip_refused = True
+                self.last_draw = "philox-twice"
             if p.noise_src == N.NOISE_PHILOX and p.z:
                 p.noise_src = N.NOISE_TNK4        # the rows K1 generated are in p.z now (lazy attributes)
             return p

@@ -51,6 +51,9 @@ def consumed_normals(ctrl, p=None):
     if "z_ktn" in p._keep and int(p.noise_src) == N.NOISE_KTN:
         return p._keep["z_ktn"].cpu()
     assert not int(p.noise_coloured)
+    if int(p.noise_src) == N.NOISE_PHILOX and not p.z:
+        # the on-chip command keeps no row array: the consumed draw is the stream itself (see the module docstring)
+        return device_philox_normals(ctrl, int(p.call))
     pitch = int(p.noise_pitch) or K
     rows = p._keep["z"].view(-1, pitch, 4)[:, :K]            # [J4][pitch][4]: the first K samples of every row
     return rows.permute(1, 0, 2).reshape(K, -1)[:, :T * nu].reshape(K, T, nu).cpu()

@@ -59,10 +59,15 @@ def _setup(cfg):
     return model, mk, sigma, kw, x0, U0
 
 
+ONCHIP = None      # rng="philox": None = the controller's own choice | False = the streaming command (rows in memory)
+
+
 def _controller(cfg, model, sigma, kw, U0, lam, rng, shard=None, K=None):
     import pytorch_mppi_amd as pm
-    return pm.MPPI(model.dynamics, model.running_cost, cfg["nx"], sigma, num_samples=K or cfg["K"], horizon=cfg["T"],
-                   device="cuda", lambda_=lam, U_init=U0.clone(), rng=rng, seed=4321, shard=shard, **kw)
+    c = pm.MPPI(model.dynamics, model.running_cost, cfg["nx"], sigma, num_samples=K or cfg["K"], horizon=cfg["T"],
+                device="cuda", lambda_=lam, U_init=U0.clone(), rng=rng, seed=4321, shard=shard, **kw)
+    c.philox_onchip = ONCHIP
+    return c
 
 
 def _consumed_normals(ctrl, p=None):
@@ -169,7 +174,22 @@ def test_c2_pendulum_8192x32_philox_in_k1(regime):
 
 @pytest.mark.parametrize("regime", ["healthy", "peaked"])
 def test_c3_quadtoy_65536x64_philox_generator_tnk4(regime):
-    _run_case(C3, "philox", regime, "philox-fill")
+    """the streaming command: generator launch -> rows in memory -> K1 -> K3 -> K4"""
+    global ONCHIP
+    ONCHIP = False
+    try:
+        _run_case(C3, "philox", regime, "philox-fill")
+    finally:
+        ONCHIP = None
+
+
+@pytest.mark.parametrize("regime", ["healthy", "peaked"])
+def test_c3_quadtoy_65536x64_philox_on_chip(regime):
+    """the bench's default path since round 3: the on-chip command (csrc/rollout_onchip.hpp), no (K,T,nu) array"""
+    from pytorch_mppi_amd import _native as N
+    n0 = int(N.lib().mppi_stat_onchip_commands())
+    _run_case(C3, "philox", regime, "philox-onchip")
+    assert int(N.lib().mppi_stat_onchip_commands()) > n0
 
 
 @pytest.mark.parametrize("regime", ["healthy", "peaked"])
@@ -263,16 +283,27 @@ def test_c3_shape_full_sigma_mu_bounds_null_action_coloured_generator(regime):
     assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff
 
 
-def test_c3_two_shards_equal_oracle_on_global_draw():
+@pytest.mark.parametrize("form", ["streaming", "on-chip"])
+def test_c3_two_shards_equal_oracle_on_global_draw(form):
     """C3 split over 2 shards (emulated back to back on one device, the all-gather is a stack):
     per-shard Philox rows are the rows of the global stream, K5 combines in rank order; against the
-    fp64 oracle run on the GLOBAL draw."""
+    fp64 oracle run on the GLOBAL draw.  Both forms of the per-shard command: rows in memory, and on chip."""
+    global ONCHIP
+    ONCHIP = False if form == "streaming" else None
+    try:
+        _two_shards(form)
+    finally:
+        ONCHIP = None
+
+
+def _two_shards(form):
     cfg = C3
     model, mk, sigma, kw, x0, U0 = _setup(cfg)
     lam = _pick_lambda(cfg, model, sigma, kw, U0, x0, "philox", 1000.0)
     world = 2
     ctrls = [_controller(cfg, model, sigma, kw, U0, lam, "philox", shard=(r, world)) for r in range(world)]
     ps = [c._begin(x0.cuda(), True) for c in ctrls]
+    assert all(c.last_draw == ("philox-fill" if form == "streaming" else "philox-onchip") for c in ctrls)
     records = torch.stack([p._keep["record"] for p in ps])
     for c, p in zip(ctrls, ps):
         c._combine(p, records)
@@ -282,7 +313,7 @@ def test_c3_two_shards_equal_oracle_on_global_draw():
     r64, r32 = _oracle_pair(cfg, mk, sigma, kw, lam, U0, x0, z)
     got = dict(action=acts[0], U=ctrls[0].U, cost_total=torch.cat([c.cost_total for c in ctrls]),
                omega=torch.cat([c.omega for c in ctrls]))
-    _check("c3/2 shards", got, r64, r32)
+    _check(f"c3/2 shards/{form}", got, r64, r32)
     assert 50 <= _n_eff(r64["omega"]) <= 5000
 
 

@@ -1,0 +1,158 @@
+"""The on-chip rng="philox" command (csrc/rollout_onchip.hpp, include/mppi_amd.h ABI 18): no (K,T,nu) array -- one launch
+generates, rolls out, keeps the bounded noise in accumulation registers / LDS and leaves a partial record per workgroup,
+a second one combines them.  Checked against
+  * the streaming form of the SAME command (generator launch -> K1 -> K3 -> K4; same seed => same Philox stream => the
+    same normals): cost_total to 1e-6 of its scale, U / action / omega to the 1e-5 rule;
+  * the fp64 oracle on the normals of that stream (device_philox_normals), SURVEY 7.3 criterion, margins to the ledger;
+over shapes that exercise every storage class of the kernel (accumulation registers only / + LDS / + second generation),
+ragged K, short and long horizons, control widths with 1..5 rows per super-step, bounds, the null-action row,
+per-sample initial states, terminal cost, |noise| cost, u_per_command > 1, shift on/off, several commands in a row."""
+import numpy as np
+import pytest
+import torch
+
+import gpu_util
+import margins
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(kind, nx, nu):
+    import pytorch_mppi_amd as pm
+    from oracle import dynamics as dyn
+    if kind == "pendulum":
+        return pm.models.Pendulum(), (lambda dt: (dyn.pendulum_dynamics, dyn.pendulum_cost))
+    if kind == "integrator":
+        return pm.models.Integrator(nx, nu), (lambda dt: dyn.make_quadtoy(nx, nu))
+    if kind == "linear":
+        g = torch.Generator().manual_seed(11)
+        B, goal = torch.randn(nx, nu, generator=g) * 0.3, torch.randn(nx, generator=g)
+        return pm.models.LinearGoal(B, goal), (lambda dt: dyn.make_linear_goal(B.to(dt), goal.to(dt))[:2])
+    raise ValueError(kind)
+
+
+def _make(kind, nx, nu, K, T, onchip, lam=1.0, seed=99, sigma=None, **kw):
+    import pytorch_mppi_amd as pm
+    model, mk = _models(kind, nx, nu)
+    g = torch.Generator().manual_seed(5)
+    U0 = torch.randn(T, nu, generator=g) * 0.1
+    sigma = sigma if sigma is not None else (torch.eye(nu) * 0.7 if nu > 1 else torch.tensor(0.7))
+    c = pm.MPPI(model.dynamics, model.running_cost, nx, sigma, num_samples=K, horizon=T, device="cuda", lambda_=lam,
+                U_init=U0.clone(), rng="philox", seed=seed, **kw)
+    c.philox_onchip = onchip
+    return c, mk, sigma, U0
+
+
+def _onchip_count():
+    from pytorch_mppi_amd import _native as N
+    return int(N.lib().mppi_stat_onchip_commands())
+
+
+CASES = [
+    # kind, nx, nu, K, T, extra ctor kwargs      (built-in fused models: see csrc/rollout_*.hip for the (nx, nu) lists)
+    ("integrator", 16, 12, 65536, 64, {}),                                   # C3: registers + LDS + second generation
+    ("integrator", 16, 12, 1000, 64, {}),                                    # ragged K (tail workgroup 232 of 256 lanes)
+    ("integrator", 16, 12, 20000, 7, {}),                                    # short horizon: registers only, one partial tile
+    ("integrator", 6, 4, 30000, 100, dict(u_min=torch.tensor([-0.5] * 4), u_max=torch.tensor([0.8] * 4))),   # 1 row per step, LDS
+    ("integrator", 8, 4, 17000, 50, dict(sample_null_action=True)),          # the null-action row
+    ("integrator", 12, 6, 17000, 40, dict(noise_abs_cost=True, u_per_command=3)),   # nu = 6: 3 rows = 2 timesteps per super-step
+    ("integrator", 4, 2, 40000, 130, {}),                                    # nu = 2: two timesteps per row
+    ("linear", 10, 3, 17000, 33, dict(u_scale=2.0)),                         # nu = 3: 3 rows = 4 timesteps per super-step
+    ("linear", 6, 3, 17000, 21, dict(sample_null_action=True, u_min=torch.tensor([-1.0] * 3), u_max=torch.tensor([0.7] * 3))),
+    ("pendulum", 2, 1, 20000, 48, dict(u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0))),   # nu = 1: four timesteps per row
+    ("pendulum", 2, 1, 300, 300, {}),                                        # long horizon at small K (forced on-chip)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-nx{c[1]}-nu{c[2]}-K{c[3]}-T{c[4]}" for c in CASES])
+def test_onchip_command_matches_streaming_command_and_fp64_oracle(case):
+    from oracle import mppi_oracle as orc
+    kind, nx, nu, K, T, kw = case
+    # a healthy lambda from a probe command (cost spread of this problem)
+    probe, _, _, _ = _make(kind, nx, nu, K, T, False, **kw)
+    x0 = torch.randn(nx, generator=torch.Generator().manual_seed(3))
+    probe.command(x0.cuda())
+    lam = float(probe.cost_total.double().std()) * 0.5 + 1e-3
+    del probe
+    a, mk, sigma, U0 = _make(kind, nx, nu, K, T, True, lam=lam, **kw)
+    b, _, _, _ = _make(kind, nx, nu, K, T, False, lam=lam, **kw)
+    n0 = _onchip_count()
+    for step, shift in enumerate((True, False, True)):
+        U_before = a.U.clone()
+        act_a = a.command(x0.cuda(), shift_nominal_trajectory=shift)
+        act_b = b.command(x0.cuda(), shift_nominal_trajectory=shift)
+        assert a.last_draw == "philox-onchip", a.last_draw
+        assert b.last_draw in ("philox-fill", "philox-k1"), b.last_draw
+        sc = float(b.cost_total.abs().max())
+        assert float((a.cost_total - b.cost_total).abs().max()) <= 1e-6 * sc
+        for name, xa, xb in (("U", a.U, b.U), ("action", act_a, act_b), ("omega", a.omega, b.omega),
+                             ("cost_total_non_zero", a.cost_total_non_zero, b.cost_total_non_zero)):
+            s = max(float(xb.abs().max()), 1e-30)
+            assert float((xa - xb).abs().max()) <= 1e-5 * s, (name, step)
+        # fp64 / fp32 oracle on the normals of the stream
+        z = gpu_util.device_philox_normals(a, a._call)
+        out = []
+        for dt in (torch.float64, torch.float32):
+            f, q = mk(dt)
+            cast = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in kw.items()}
+            p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=sigma.to(dt), K=K, T=T, lambda_=lam, **cast)
+            out.append(orc.command(p, U_before.cpu().to(dt), x0.to(dt), z.to(dt), shift))
+        r64, r32 = out
+        got = dict(action=act_a, U=a.U, cost_total=a.cost_total, omega=a.omega)
+        for key in got:
+            margins.check(f"onchip/{kind}-nu{nu}-K{K}-T{T}/step{step}", key, got[key].detach().cpu().numpy(),
+                          r64[key].numpy(), r32[key].numpy(), rtol=1e-5)
+        # the lazily materialised arrays come from the same stream
+        if step == 0 and K * T * nu <= 4_000_000:
+            assert torch.allclose(a.noise, b.noise, rtol=0, atol=1e-6)
+            assert torch.allclose(a.perturbed_action, b.perturbed_action, rtol=0, atol=1e-6)
+    assert _onchip_count() - n0 == 3, "every command of the first controller ran in the on-chip form"
+
+
+def test_onchip_per_sample_states_and_terminal_cost():
+    import pytorch_mppi_amd as pm
+    nx, nu, K, T = 12, 4, 20000, 30
+    g = torch.Generator().manual_seed(1)
+    model = pm.models.LinearGoal(torch.randn(nx, nu, generator=g) * 0.3, torch.randn(nx, generator=g))
+    U0 = torch.randn(T, nu, generator=g) * 0.1
+    X0 = torch.randn(K, nx, generator=g)
+
+    def make(onchip):
+        c = pm.MPPI(model.dynamics, model.running_cost, nx, torch.eye(nu) * 0.5, num_samples=K, horizon=T, device="cuda",
+                    lambda_=20.0, U_init=U0.clone(), rng="philox", seed=7, terminal_state_cost=model.terminal_state_cost)
+        c.philox_onchip = onchip
+        return c
+    a, b = make(True), make(False)
+    n0 = _onchip_count()
+    aa, ab = a.command(X0.cuda()), b.command(X0.cuda())
+    assert _onchip_count() - n0 == 1 and a.last_draw == "philox-onchip"
+    assert float((a.cost_total - b.cost_total).abs().max()) <= 1e-6 * float(b.cost_total.abs().max())
+    assert float((aa - ab).abs().max()) <= 1e-5 * max(1.0, float(ab.abs().max()))
+    assert torch.allclose(a.states, b.states, rtol=0, atol=1e-5)
+
+
+def test_onchip_peaked_softmax_and_determinism():
+    """N_eff of a few: most waves' weights are exactly zero and are skipped; same seed => same bits on every run."""
+    nx, nu, K, T = 16, 12, 65536, 64
+    x0 = torch.randn(nx, generator=torch.Generator().manual_seed(3)).cuda()
+    a, _, _, _ = _make("integrator", nx, nu, K, T, True, lam=0.02)
+    b, _, _, _ = _make("integrator", nx, nu, K, T, False, lam=0.02)
+    c, _, _, _ = _make("integrator", nx, nu, K, T, True, lam=0.02)
+    aa, ab, ac = a.command(x0), b.command(x0), c.command(x0)
+    n_eff = 1.0 / float((b.omega.double() ** 2).sum())
+    assert n_eff < 30, n_eff
+    assert torch.equal(aa, ac) and torch.equal(a.U, c.U) and torch.equal(a.cost_total, c.cost_total)
+    assert float((a.U - b.U).abs().max()) <= 1e-5 * float(b.U.abs().max())
+
+
+def test_onchip_scope_falls_back_without_error():
+    """Outside the form's scope (full Sigma here) the same call runs the streaming command."""
+    import pytorch_mppi_amd as pm
+    nx, nu, K, T = 6, 4, 20000, 40
+    model = pm.models.Integrator(nx, nu)
+    S = torch.eye(nu) * 0.5
+    S[0, 1] = S[1, 0] = 0.1
+    c = pm.MPPI(model.dynamics, model.running_cost, nx, S, num_samples=K, horizon=T, device="cuda", lambda_=5.0, rng="philox", seed=3)
+    n0 = _onchip_count()
+    c.command(torch.zeros(nx).cuda())
+    assert _onchip_count() == n0 and c.last_draw == "philox-fill"

@@ -27,10 +27,18 @@ def main(db, dump, pattern, out=None):
         lines.append(f"# device span avg {avg_dev:.3f} us | rocprofv3 avg {avg_roc:.3f} us (median {sorted(sel)[len(sel) // 2]:.3f}) | "
                      f"difference avg {sum(diffs) / len(diffs):.3f} median {s[len(s) // 2]:.3f} min {s[0]:.3f} max {s[-1]:.3f} us")
         lines.append(f"# => rocprofv3 = device span + {sum(diffs) / len(diffs):.2f} us on these launches ({(avg_roc / avg_dev - 1) * 100:.2f} %)")
+    cold = d.get("k1_cold_device_span_us")
+    if cold:
+        # the HBM-cold pass of bench.py (k1_hbm_cold): the LAST len(cold) dispatches of the kernel in the trace
+        selc = roc[-len(cold):]
+        dc = sorted(b - a for a, b in zip(cold, selc))
+        med = lambda v: sorted(v)[len(v) // 2]
+        lines.append(f"# HBM-cold launches (last {len(cold)} dispatches): device span median {med(cold):.3f} avg {sum(cold) / len(cold):.3f} us | rocprofv3 median "
+                     f"{med(selc):.3f} avg {sum(selc) / len(selc):.3f} us | difference avg {sum(dc) / len(dc):.3f} median {dc[len(dc) // 2]:.3f} min {dc[0]:.3f} max {dc[-1]:.3f} us")
     txt = "\n".join(lines) + "\n"
     if out:
         open(out, "w").write(txt)
-    print("\n".join(lines[-3:]))
+    print("\n".join(lines[-4:]))
 
 
 if __name__ == "__main__":
