@@ -1,13 +1,16 @@
 #!/usr/bin/env python
 """bench.py -- rollouts/sec per `.command()` call (BASELINE.json metric) on N MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2|c4] [--rng philox|philox-fused|torch-native|torch]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2|c4] [--rng philox|philox-stream|philox-fused|torch-native|torch]
 
 A "step" is one full `MPPI.command(state)`: on-device noise draw, fused rollout+cost (K1),
 exp-weighting + weighted update (K3/K4) and, for N>1, the single record all-gather + combine.
 Default noise mode: rng="philox" -- the engine's own Philox4x32-10 + Box-Muller generator on the
-device (for a draw of C3's size: one generator launch, then K1 streams the rows; "philox-fused"
-forces the generation into K1); "torch-native" / "torch" draw with torch.randn instead.
+device.  Since round 3 a command of C3's kind runs ON CHIP (csrc/rollout_onchip.hpp): one launch generates
+every sample's normals, rolls out, keeps the bounded noise in accumulation registers / LDS and leaves a
+partial record per workgroup, a second one combines them -- no (K,T,nu) array is written or read.
+"philox-stream" is the form with the rows in memory (generator launch -> K1 streams them -> K3 re-reads
+them -> K4), "philox-fused" lets K1 generate and store them; "torch-native" / "torch" draw with torch.randn.
 Default workload = BASELINE.json configs[2] ("c3": 12-DoF quadratic toy dynamics, K=65536, T=64,
 nx=16, nu=12, fp32) -- the configuration the north_star's roofline target is quoted on; K is
 per GPU (weak scaling: the sample axis is sharded, K_global = N*65536).
@@ -56,10 +59,12 @@ HBM_COPY_CEILING_GBS = 6290.0
 # What `rocprofv3 --kernel-trace` reports for a plain K1 dispatch on top of the kernel's own device-clock span
 # (dispatch ramp in front of the first wave + end-of-kernel drain behind the last), measured on the SAME launches of
 # this very command line under rocprofv3 (tools/clock_calibration.py -> profiles/r03_k1_clock_calibration_<workload>.txt:
-# c3 avg 1.82 / median 1.73, c4 1.39 / 1.40, c2 2.43 / 2.38 us; the HBM-cold launches, which do not start behind a
+# c3 avg 1.82 / 1.55 / 1.83 in three runs (median 1.56-1.82), c4 1.39 / 1.40, c2 2.43 / 2.38 us; the on-chip K1 1.73; the HBM-cold launches, which do not start behind a
 # draining generator kernel: profiles/r03_k1_clock_calibration_c3_cold.txt)
-DISPATCH_OFFSET_US_BY_WORKLOAD = {"c3": 1.8, "c4": 1.4, "c2": 2.4}
+DISPATCH_OFFSET_US_BY_WORKLOAD = {"c3": 1.7, "c4": 1.4, "c2": 2.4}
 DISPATCH_OFFSET_US_COLD = 0.8
+DISPATCH_OFFSET_US_ONCHIP = 1.7      # profiles/r03_k1_clock_calibration_c3_onchip.txt
+K1_KERNEL_PATTERN = {"pendulum": "rollout_cost_kernel", "integrator": "rollout_cost_kernel", "mlp": "rollout_mlp_split_kernel"}
 STAMPS_ONLY = 1 << 30      # mppi_profile_enable argument: device-clock stamps on every launch, HIP events on none
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
 
@@ -87,9 +92,12 @@ def make_controller(pm, wl, device, rng, shard, K):
     # which must stay O(1) for a healthy softmax (N_eff >> 1)
     U0 = torch.randn(T, nu, dtype=dtype) * 0.02
     ctrl = pm.MPPI(model.dynamics, model.running_cost, nx, sigma, num_samples=K, horizon=T, device=device,
-                   U_init=U0, rng="philox" if rng == "philox-fused" else rng, seed=1234, shard=shard, **kw)
+                   U_init=U0, rng="philox" if rng.startswith("philox") else rng, seed=1234, shard=shard, **kw)
     if rng == "philox-fused":
         ctrl.philox_fill = False                  # force the generation into K1
+        ctrl.philox_onchip = False
+    if rng == "philox-stream":
+        ctrl.philox_onchip = False                # rows in memory: generator launch (long horizons) -> K1 -> K3 -> K4
     return ctrl, x0.to(device), model
 
 
@@ -281,7 +289,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--rng", default="philox", choices=["torch", "torch-native", "philox", "philox-fused"])
+    ap.add_argument("--rng", default="philox", choices=["torch", "torch-native", "philox", "philox-stream", "philox-fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -370,8 +378,10 @@ def main():
     if dump and rank == 0:
         # per-launch device-clock spans of the timed region, for tools/clock_calibration.py (matched against the
         # rocprofv3 trace of this very process)
-        json.dump({"k1_device_span_us": k1_dev_us, "warmup": args.warmup, "steps": args.steps,
-                   "k1_launches_before_timed_region": (1 if kind != "pendulum" else 0) + args.warmup}, open(dump, "w"))
+        onchip_now = ctrl.last_draw == "philox-onchip"
+        json.dump({"warmup": args.warmup, "steps": args.steps, "regions": {
+            "headline": {"pattern": "rollout_onchip_kernel" if onchip_now else K1_KERNEL_PATTERN[kind], "spans_us": k1_dev_us,
+                         "launches_before": (1 if kind != "pendulum" else 0) + args.warmup}}}, open(dump, "w"))
     if world > 1:
         tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -406,6 +416,59 @@ def main():
     _, k1_ev_us = N.profile_read_launches()
     lib.mppi_profile_enable(0)
     barrier()
+
+    # ---- the headline command runs ON CHIP: its K1 reads no (K,T,nu) array, the HBM roofline does not describe it.
+    # It gets its own object (`onchip`); `roofline` is measured on the STREAMING form of the same command (rows in
+    # memory: what rng="torch", injected noise, a full Sigma, SMPPI / KMPPI and M > 1 run), timed here, right behind the
+    # headline region, with the same clock ----
+    onchip = None
+    roof_ctrl = ctrl
+    if ctrl.last_draw == "philox-onchip":
+        oc_dev, oc_ev = _stats(k1_dev_us), _stats(k1_ev_us)
+        cs, xs, _ = make_controller(pm, args.workload, device, "philox-stream", shard, Kglobal)
+        cs.lambda_ = ctrl.lambda_
+        for _ in range(args.warmup):
+            cs.command(xs)
+        lib.mppi_profile_enable(STAMPS_ONLY)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            cs.command(xs)
+        barrier()
+        dts = time.perf_counter() - t1
+        k1_dev_us, _ = N.profile_read_launches()
+        lib.mppi_profile_enable(1)
+        for _ in range(12):
+            cs.command(xs)
+        _, k1_ev_us = N.profile_read_launches()
+        lib.mppi_profile_enable(0)
+        barrier()
+        if world > 1:
+            tt = torch.tensor([dts], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = float(tt)
+        if dump and rank == 0:
+            dd = json.load(open(dump))
+            dd["regions"]["streaming"] = {"pattern": K1_KERNEL_PATTERN[kind], "spans_us": k1_dev_us, "launches_before": args.warmup}
+            json.dump(dd, open(dump, "w"))
+        roof_ctrl = cs
+        oc_us = (oc_dev["avg"] + DISPATCH_OFFSET_US_ONCHIP) if oc_dev else 0.0
+        ext_bytes = 4 * ctrl.K_local * T * nu + 4 * ctrl.K_local
+        onchip = {"kernel": "rollout_onchip_kernel (csrc/rollout_onchip.hpp) + finalize_blocks_kernel",
+                  "no_hbm_mode": True,
+                  "avg_launch_us": oc_us, "avg_launch_us_device_span": oc_dev["avg"] if oc_dev else None,
+                  "launch_us_device_span": oc_dev, "avg_launch_us_hip_events": oc_ev["avg"] if oc_ev else None,
+                  "dispatch_offset_us": DISPATCH_OFFSET_US_ONCHIP,
+                  "hbm_bytes_algorithmic": 4 * ctrl.K_local + 4 * (ctrl.K_local // 256 + 1) * (T * nu + 2),
+                  "external_z_equivalent_GBs": ext_bytes / (oc_us * 1e-6) / 1e9 if oc_us else None,
+                  "bound": "VALU: Philox4x32-10 + Box-Muller of the sample's T*nu normals (generated once, ~half of them a "
+                           "second time in the weighting phase: the rest stays in accumulation registers / LDS), ~80 % of the "
+                           "kernel (tools/micro/onchip_parts.hip, profiles/r03_onchip_parts.txt)",
+                  "streaming_form_ms_per_step": dts / args.steps * 1e3,
+                  "speedup_vs_streaming_form": (dts / args.steps) / (dt / args.steps),
+                  "note": "SURVEY.md 8d: with the engine's generator inside K1 the algorithmic HBM bytes collapse to O(K) and the "
+                          "kernel is RNG-bound -- no bandwidth fraction is claimed for it; `roofline` below is the HBM-bound K1 "
+                          "of the streaming form of the SAME command, measured in this run"}
 
     # ---- roofline of K1 ----
     dev_st = _stats(k1_dev_us)
@@ -442,7 +505,7 @@ def main():
                     "limiter": "VALU issue (v_exp + v_rcp per hidden activation), not the matrix pipe"}
     elif dev_st:
         ach = alg_bytes / (k1_us * 1e-6) / 1e9
-        if ctrl.last_draw == "philox-k1":
+        if roof_ctrl.last_draw == "philox-k1":
             # no-HBM mode: the normals never exist in memory before K1; report the time against the
             # external-z byte count for orientation only
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -480,12 +543,13 @@ def main():
                                      "untimed pass over every buffer, + the dispatch offset measured for those launches)"}
             # the HBM-cold pass allocates 1.6 GB and takes a while: rank 0 only, after the barrier above, with the
             # other ranks parked at the barrier below
-            cold = k1_hbm_cold(ctrl) if (rank == 0 and not args.no_extras) else None
+            cold = k1_hbm_cold(roof_ctrl) if (rank == 0 and not args.no_extras) else None
             if cold and cold["launch_us_device_span"]:
                 us_c = cold["launch_us_device_span"]["median"] + DISPATCH_OFFSET_US_COLD
                 if dump and rank == 0:     # the cold launches, for tools/clock_calibration.py (the LAST dispatches of K1 in the trace)
                     dd = json.load(open(dump))
-                    dd["k1_cold_device_span_us"] = cold.pop("launch_us_device_span_all")
+                    dd["regions"]["hbm_cold"] = {"pattern": K1_KERNEL_PATTERN[kind], "spans_us": cold.pop("launch_us_device_span_all"),
+                                                 "launches_before": -1}     # -1: the LAST dispatches of the kernel in the trace
                     json.dump(dd, open(dump, "w"))
                 cold.pop("launch_us_device_span_all", None)
                 cold["dispatch_offset_us"] = DISPATCH_OFFSET_US_COLD
@@ -505,6 +569,12 @@ def main():
         "state_evals_per_s": value * T,
         "roofline": roofline,
     }
+    if onchip is not None:
+        out["onchip"] = onchip
+        if roofline is not None:
+            roofline["measured_on"] = ("the streaming form of this command (rng=philox rows in memory: generator launch -> K1 -> K3 -> K4; "
+                                       f"{onchip['streaming_form_ms_per_step']:.4f} ms per command here), timed in this run right behind the "
+                                       "headline region; the headline command itself is the on-chip form (see `onchip`)")
     if world > 1:
         out["config"]["backend"] = ("nccl (RCCL over xGMI), one rank per GPU" if backend == "nccl" else
                                     f"{backend}: TEST RIG -- {world} ranks share {torch.cuda.device_count()} GPU(s), record "
@@ -517,7 +587,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         # other noise modes of the same workload (short runs), for the record
         extras = {}
-        for mode in ("philox", "philox-fused", "torch-native", "torch"):
+        for mode in ("philox", "philox-stream", "philox-fused", "torch-native", "torch"):
             if mode == args.rng:
                 continue
             c2, x2, _ = make_controller(pm, args.workload, device, mode, None, Kglobal)

@@ -33,7 +33,10 @@ struct OnChip {
   static constexpr int SW = (16 / P4) > 0 ? (16 / P4) : 1;       // super-steps per weighting tile
   static constexpr int TRW = SW * P4;                            // rows per tile (15 for nu = 12, else <= 16)
   static constexpr int TC = TRW * 4;                             // columns per tile (<= 64)
-  static constexpr int NTA = 4;                                  // tiles kept in accumulation registers
+#ifndef MPPI_ONCHIP_NTA
+#define MPPI_ONCHIP_NTA 4
+#endif
+  static constexpr int NTA = MPPI_ONCHIP_NTA;                    // tiles kept in registers (the first 4: accumulation registers)
   static constexpr int AG_SS = NTA * SW, AG_ROWS = AG_SS * P4;   // 60 or 64 rows = 240 / 256 registers
   static constexpr int RG = P4 >= 3 ? 1 : (P4 == 2 ? 2 : 4);     // super-steps regenerated together (>= 3 interleaved chains)
   static constexpr bool OK = P4 <= 16 && (SW % RG) == 0;
@@ -49,34 +52,52 @@ __device__ __forceinline__ float keep_in_agpr(float v) {
   return r;
 }
 
-// bounded actions and noise of super-step ss from its standard normals: z (in) -> eps' (out), v (out);
-// exactly K1's arithmetic (rollout_step, DIAG): v = clamp(fma(z, sd, U + mu)), eps' = v - U.
-// Timesteps beyond the horizon (the padding of the last super-step) give eps' = 0.
-template <int NU, int SLOW>
-__device__ __forceinline__ void onchip_actions(const KArgs<float>& a, const ActionConsts<float, NU>& ac, const StepTables<float>& tb,
-                                               int orow, int ss, float (&z)[Stream<NU>::P4 * 4], float (&v)[Stream<NU>::P4 * 4]) {
-  constexpr int TT = Stream<NU>::TT;
+// The three per-(t,n) tables of K1 (rollout.hpp StepTables) padded to whole super-steps and 16-byte aligned: a
+// super-step is P4 ds_read_b128 per table whatever nu is, issued together, and everything behind them is register
+// arithmetic.  (Per-element reads under the `t < T` test compile to a branch, a ds_read_b32 and a full LDS round trip
+// PER ELEMENT: measured 48 us of rollout instead of 8.)  Padding entries are zero.
+template <int NU>
+struct OnChipRow {
+  float ue[Stream<NU>::P4 * 4], um[Stream<NU>::P4 * 4], g[Stream<NU>::P4 * 4];
+  __device__ __forceinline__ void load(const StepTables<float>& tb, int ss, bool with_g) {
+    constexpr int P4 = Stream<NU>::P4;
+    const float4* __restrict__ pe = reinterpret_cast<const float4*>(__builtin_assume_aligned(tb.Ue, 16)) + ss * P4;
+    const float4* __restrict__ pm = reinterpret_cast<const float4*>(__builtin_assume_aligned(tb.Um, 16)) + ss * P4;
+    const float4* __restrict__ pg = reinterpret_cast<const float4*>(__builtin_assume_aligned(tb.G, 16)) + ss * P4;
 #pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    const int t = ss * TT + tt;
-    const bool in = t < a.Tn;
-    const int tq = in ? t : a.Tn - 1;
-    const float* __restrict__ Ut = tb.Ue + tq * NU;
-    const float* __restrict__ Umt = tb.Um + tq * NU;
-#pragma unroll
-    for (int n = 0; n < NU; ++n) {
-      float w = fmaf(z[tt * NU + n], ac.sd[n], Umt[n]);                 // mppi.py:201-206, :380
-      if constexpr (SLOW == 1) w = orow == -1 ? 0.f : w;                // :390-392
-      w = clampT(w, ac.lo[n], ac.hi[n]);                                // :383
-      v[tt * NU + n] = w;
-      z[tt * NU + n] = in ? w - Ut[n] : 0.f;                            // :385
+    for (int i = 0; i < P4; ++i) {
+      const float4 e4 = pe[i], m4 = pm[i];
+      ue[4 * i] = e4.x; ue[4 * i + 1] = e4.y; ue[4 * i + 2] = e4.z; ue[4 * i + 3] = e4.w;
+      um[4 * i] = m4.x; um[4 * i + 1] = m4.y; um[4 * i + 2] = m4.z; um[4 * i + 3] = m4.w;
+      if (with_g) {
+        const float4 g4 = pg[i];
+        g[4 * i] = g4.x; g[4 * i + 1] = g4.y; g[4 * i + 2] = g4.z; g[4 * i + 3] = g4.w;
+      }
     }
+  }
+};
+
+// bounded actions and noise of one super-step from its standard normals: z (in) -> eps' (out), v (out);
+// exactly K1's arithmetic (rollout_step, DIAG): v = clamp(fma(z, sd, U + mu)), eps' = v - U.
+// (Timesteps beyond the horizon -- the padding of the last super-step -- give values nobody reads.)
+template <int NU, int SLOW>
+__device__ __forceinline__ void onchip_actions(const ActionConsts<float, NU>& ac, const OnChipRow<NU>& row, int orow,
+                                               float (&z)[Stream<NU>::P4 * 4], float (&v)[Stream<NU>::P4 * 4]) {
+#pragma unroll
+  for (int f = 0; f < Stream<NU>::P4 * 4; ++f) {
+    const int n = f % NU;
+    float w = fmaf(z[f], ac.sd[n], row.um[f]);                          // mppi.py:201-206, :380
+    if constexpr (SLOW == 1) w = orow == -1 ? 0.f : w;                  // :390-392
+    w = clampT(w, ac.lo[n], ac.hi[n]);                                  // :383
+    v[f] = w;
+    z[f] = w - row.ue[f];                                               // :385
   }
 }
 
-template <class Model, int SLOW>
+// PLAIN: no |noise| cost and u_scale == 1 (the common case, wave-uniform): no select and no multiply per control
+template <class Model, bool PLAIN>
 __device__ __forceinline__ void onchip_steps(const KArgs<float>& a, const ActionConsts<float, Model::NU>& ac, const Model& model,
-                                             const StepTables<float>& tb, int ss, const float (&e)[Stream<Model::NU>::P4 * 4],
+                                             const OnChipRow<Model::NU>& row, int ss, const float (&e)[Stream<Model::NU>::P4 * 4],
                                              const float (&v)[Stream<Model::NU>::P4 * 4], float (&x)[Model::NX], float& rollout,
                                              float& pert) {
   constexpr int NU = Model::NU, TT = Stream<NU>::TT;
@@ -84,13 +105,12 @@ __device__ __forceinline__ void onchip_steps(const KArgs<float>& a, const Action
   for (int tt = 0; tt < TT; ++tt) {
     const int t = ss * TT + tt;
     if (t < a.Tn) {
-      const float* __restrict__ Gt = tb.G + t * NU;
       float u[NU];
 #pragma unroll
       for (int n = 0; n < NU; ++n) {
         const float en = e[tt * NU + n];
-        pert = fmaf(Gt[n], ac.abs_cost ? fabsf(en) : en, pert);         // :409, :415
-        u[n] = a.u_scale * v[tt * NU + n];                              // :313
+        pert = fmaf(row.g[tt * NU + n], (!PLAIN && ac.abs_cost) ? fabsf(en) : en, pert);   // :409, :415
+        u[n] = PLAIN ? v[tt * NU + n] : a.u_scale * v[tt * NU + n];     // :313
       }
       model.step(x, u, t);                                              // :314
       rollout += model.cost(x, u, t);                                   // :318-319
@@ -153,10 +173,11 @@ __device__ __forceinline__ float wave_reduce_transpose64_dpp(float (&v)[64]) {
   return v[0];
 }
 
-// LDS carve of the kernel (floats): Ue[J] Um[J] G[J] | red[4] | ex[4][ntiles*64] | keepL[nsl*P4][256][4]
+// LDS carve of the kernel (floats): Ue[Jp] Um[Jp] G[Jp] | red[4] | ex[4][ntiles*64] | keepL[nsl*P4][256][4],
+// Jp = the horizon padded to whole super-steps (a multiple of 4: every part starts on a 16-byte boundary)
 struct OnChipLds {
-  int J, ntiles, nsl, P4;
-  __host__ __device__ int tables() const { return (3 * J + 4 + 3) & ~3; }
+  int Jp, ntiles, nsl, P4;
+  __host__ __device__ int tables() const { return 3 * Jp + 4; }
   __host__ __device__ int ex() const { return 4 * ntiles * 64; }
   __host__ __device__ size_t bytes() const { return ((size_t)tables() + ex()) * 4 + (size_t)nsl * P4 * 256 * 16; }
 };
@@ -173,19 +194,21 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int nss = (a.Tn + TT - 1) / TT;
   const int ntiles = (nss + SW - 1) / SW;
-  const OnChipLds L{a.J, ntiles, nsl, P4};
+  const int Jp = nss * P4 * 4;
+  const OnChipLds L{Jp, ntiles, nsl, P4};
   T* Ue = reinterpret_cast<T*>(smem_raw);
-  T* Um = Ue + a.J;
-  T* G = Um + a.J;
-  T* red = G + a.J;
+  T* Um = Ue + Jp;
+  T* G = Um + Jp;
+  T* red = G + Jp;
   T* ex = Ue + L.tables();
   float4* keepL = reinterpret_cast<float4*>(ex + L.ex());
-  for (int j = threadIdx.x; j < a.J; j += K1_BLOCK) {
+  for (int j = threadIdx.x; j < Jp; j += K1_BLOCK) {
+    const bool in = j < a.J;
     const int n = j % NU;
-    const T u = u_eff(a, j);
+    const T u = in ? u_eff(a, j) : T(0);
     Ue[j] = u;
-    Um[j] = u + a.mu[n];
-    G[j] = a.lambda_ * (u * a.sinv[n * NU + n]);
+    Um[j] = in ? u + a.mu[n] : T(0);
+    G[j] = in ? a.lambda_ * (u * a.sinv[n * NU + n]) : T(0);
   }
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int kraw = blockIdx.x * K1_BLOCK + threadIdx.x;
@@ -203,11 +226,12 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
   ac.load(a, nullptr);
   float keepA[OC::AG_ROWS * 4];
 #pragma unroll
-  for (int i = 0; i < OC::AG_ROWS * 4; ++i) keepA[i] = keep_in_agpr(0.f);   // rows beyond a short horizon read as zero noise
+  for (int i = 0; i < OC::AG_ROWS * 4; ++i) keepA[i] = i < 256 ? keep_in_agpr(0.f) : 0.f;   // rows beyond a short horizon read as zero noise
   __syncthreads();
   const StepTables<T> tb{Ue, Um, G, nullptr, kraw - lane};
   const long long kg = a.k_offset + k;
   const bool slow = __any(orow == -1);
+  const bool plain = !a.abs_cost && a.u_scale == 1.f;
 
   // ---- G + R: a batch of PB super-steps at a time ----
   T rollout = 0.f, pert = 0.f;
@@ -226,10 +250,21 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
       const int ss = bi * PB + b;
-      if (slow) onchip_actions<NU, 1>(a, ac, tb, orow, ss, zb[b], vb[b]);
-      else onchip_actions<NU, 0>(a, ac, tb, orow, ss, zb[b], vb[b]);
-      onchip_steps<Model, 0>(a, ac, model, tb, ss, zb[b], vb[b], x, rollout, pert);
+#if defined(MPPI_ONCHIP_EXP) && (MPPI_ONCHIP_EXP & 8)    // experiment (tools/micro/onchip_parts.hip): no rollout arithmetic
+#pragma unroll
+      for (int q = 0; q < P4 * 4; ++q) rollout += zb[b][q];
+      continue;
+#endif
+      OnChipRow<NU> row;
+      row.load(tb, ss < nss ? ss : nss - 1, true);
+      if (slow) onchip_actions<NU, 1>(ac, row, orow, zb[b], vb[b]);
+      else onchip_actions<NU, 0>(ac, row, orow, zb[b], vb[b]);
+      if (plain) onchip_steps<Model, true>(a, ac, model, row, ss, zb[b], vb[b], x, rollout, pert);
+      else onchip_steps<Model, false>(a, ac, model, row, ss, zb[b], vb[b], x, rollout, pert);
     }
+#if defined(MPPI_ONCHIP_EXP) && (MPPI_ONCHIP_EXP & 4)      // experiment: nothing kept
+    continue;
+#endif
     // keep eps': accumulation registers (static index -> a chain of uniform compares over the batch), then LDS
     auto keep_lds = [&](int b) {
       const int ss = bi * PB + b;
@@ -247,7 +282,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
           constexpr int B = decltype(bb)::value, SS = C * PB + B;
           if constexpr (SS < AG_SS) {
 #pragma unroll
-            for (int q = 0; q < P4 * 4; ++q) keepA[SS * P4 * 4 + q] = keep_in_agpr(zb[B][q]);
+            for (int q = 0; q < P4 * 4; ++q) keepA[SS * P4 * 4 + q] = (SS * P4 * 4 + q) < 256 ? keep_in_agpr(zb[B][q]) : zb[B][q];
           } else {
             keep_lds(B);
           }
@@ -267,6 +302,9 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
     if (a.pert != nullptr) a.pert[k] = pert;
   }
 
+#if defined(MPPI_ONCHIP_EXP) && (MPPI_ONCHIP_EXP & 1)      // experiment: generate + roll out only
+  return;
+#endif
   // ---- W: this workgroup's partial record {beta_b, eta_b, P_b} ----
   const T inv_lambda = T(1) / a.lambda_;
   const T beta_b = block_min<T>(active ? total : inf_v<T>(), red);
@@ -298,7 +336,11 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
             const float4 q4 = keepL[((ss0 - AG_SS) * P4 + i) * K1_BLOCK + threadIdx.x];
             e[g * RG * P4 + i][0] = q4.x; e[g * RG * P4 + i][1] = q4.y; e[g * RG * P4 + i][2] = q4.z; e[g * RG * P4 + i][3] = q4.w;
           }
+#if defined(MPPI_ONCHIP_EXP) && (MPPI_ONCHIP_EXP & 2)      // experiment: no second generation (zeros instead)
+        } else if (ss0 < 0) {
+#else
         } else if (ss0 < nss) {                                          // generated a second time
+#endif
           T zg[RG][P4 * 4], vg[P4 * 4];
 #pragma unroll
           for (int s = 0; s < RG; ++s)
@@ -310,8 +352,10 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
             }
 #pragma unroll
           for (int s = 0; s < RG; ++s) {
-            if (slow) onchip_actions<NU, 1>(a, ac, tb, orow, ss0 + s, zg[s], vg);
-            else onchip_actions<NU, 0>(a, ac, tb, orow, ss0 + s, zg[s], vg);
+            OnChipRow<NU> row;
+            row.load(tb, (ss0 + s) < nss ? ss0 + s : nss - 1, false);
+            if (slow) onchip_actions<NU, 1>(ac, row, orow, zg[s], vg);
+            else onchip_actions<NU, 0>(ac, row, orow, zg[s], vg);
 #pragma unroll
             for (int i = 0; i < P4; ++i)
 #pragma unroll
@@ -369,7 +413,7 @@ static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
     onchip_carve(a);
     const int nss = (a.Tn + OC::TT - 1) / OC::TT;
     const int ntiles = (nss + OC::SW - 1) / OC::SW;
-    OnChipLds L{a.J, ntiles, 0, OC::P4};
+    OnChipLds L{nss * OC::P4 * 4, ntiles, 0, OC::P4};
     if (L.bytes() > 160 * 1024) return -1;
     const long long room = (160 * 1024 - (long long)L.bytes()) / ((long long)OC::P4 * 256 * 16);
     int nsl = nss - OC::AG_SS;
