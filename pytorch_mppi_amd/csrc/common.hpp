@@ -133,6 +133,19 @@ __device__ __forceinline__ float m_sin_moderate(float x) {
 __device__ __forceinline__ double m_sin_moderate(double x) { return sin(x); }
 __device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
+// (used by the functor bodies pytorch_mppi_amd/trace.py writes from torch callables)
+__device__ __forceinline__ float m_log(float x) { return logf(x); }
+__device__ __forceinline__ double m_log(double x) { return log(x); }
+__device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float m_floor(float x) { return floorf(x); }
+__device__ __forceinline__ double m_floor(double x) { return floor(x); }
+__device__ __forceinline__ float m_pow(float a, float b) { return powf(a, b); }
+__device__ __forceinline__ double m_pow(double a, double b) { return pow(a, b); }
+__device__ __forceinline__ float m_atan2(float a, float b) { return atan2f(a, b); }
+__device__ __forceinline__ double m_atan2(double a, double b) { return atan2(a, b); }
+template <typename T> __device__ __forceinline__ T m_min(T a, T b) { return a < b ? a : b; }
+template <typename T> __device__ __forceinline__ T m_max(T a, T b) { return a > b ? a : b; }
 __device__ __forceinline__ float m_fma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double m_fma(double a, double b, double c) { return fma(a, b, c); }
 

@@ -80,7 +80,7 @@ class MPPI:
                  sample_null_action=False,
                  specific_action_sampler: typing.Optional[SpecificActionSampler] = None,
                  noise_abs_cost=False,
-                 *, rng="torch", seed=None, shard=None):
+                 *, rng="torch", seed=None, shard=None, auto_jit=None):
         self.d = torch.device(device) if not isinstance(device, torch.device) else device
         self.dtype = noise_sigma.dtype                                   # mppi.py:88
         if self.dtype not in _DT:
@@ -209,6 +209,12 @@ class MPPI:
         # (jit.compile_model(..., step_dependent=True); the device functor always sees the timestep)
         if m is not None and bool(step_dependent_dynamics) == bool(getattr(m, "step_dependent", False)):
             self._model = m
+        self.jit_note = None
+        if m is None and self.d.type == "cuda" and self.M == 1 and (
+                auto_jit if auto_jit is not None else os.environ.get("MPPI_AUTO_JIT", "1") != "0"):
+            # plain torch callables (the reference's plugin API): try to trace them into a device functor
+            # (pytorch_mppi_amd/trace.py -> jit.compile_model); outside the traceable subset the generic path stays
+            self._model = self._try_trace(dynamics, running_cost, terminal_state_cost, bool(step_dependent_dynamics))
         if self._model is not None and (self._model.nx != self.nx or self._model.nu != self.nu):
             raise ValueError(f"native model dims ({self._model.nx},{self._model.nu}) != (nx,nu)=({self.nx},{self.nu})")
         if self._shard is not None and self._shard.world_size > 1 and rng != "philox":
@@ -226,6 +232,24 @@ class MPPI:
         self._ws_need = {}
         self._dev_index = (self.d.index if self.d.index is not None else
                            (torch.cuda.current_device() if self.d.type == "cuda" and torch.cuda.is_available() else 0))
+
+    def _try_trace(self, dynamics, running_cost, terminal_state_cost, step_dependent):
+        import logging
+        from . import jit, trace
+        log = logging.getLogger("pytorch_mppi_amd")
+        try:
+            m = jit.from_torch(dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent=step_dependent)
+        except trace.TraceUnsupported as e:
+            self.jit_note = f"generic path: {e}"
+            log.info("pytorch_mppi_amd: dynamics / running_cost stay on the generic (callback) path: %s", e)
+            return None
+        except Exception as e:           # a callable that fails on symbolic inputs in its own way, a failed hipcc run, ...
+            self.jit_note = f"generic path: {type(e).__name__}: {e}"
+            log.info("pytorch_mppi_amd: dynamics / running_cost stay on the generic (callback) path: %s: %s", type(e).__name__, e)
+            return None
+        self.jit_note = f"fused: traced {m.traced_ops} operations per sample into {m.name}"
+        log.info("pytorch_mppi_amd: %s", self.jit_note)
+        return m
 
     # ------------------------------------------------------------------------------------------
     # parameter resolution (host, once per change)

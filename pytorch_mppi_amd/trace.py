@@ -1,0 +1,866 @@
+"""From a plain torch callable to a device functor.
+
+The reference's plugin API is "any Python callable on batched tensors" (/root/reference/src/pytorch_mppi/mppi.py:63-64,
+:147-154, :314, :318, :325).  `jit.compile_model` fuses user dynamics when the formulas are given once more as C++
+snippets; this module WRITES those snippets: it runs the callable once on symbolic per-sample tensors (batch of one,
+every element an expression node), records the arithmetic, and prints it as the `step` / `cost` / `terminal` bodies
+`jit.compile_model` compiles around csrc/rollout.hpp.
+
+Symbolic tensors are NOT torch.Tensor subclasses: `SymT` implements the tensor methods users call on states and actions
+(indexing, views, arithmetic, reductions, elementwise maths), `__torch_function__` for the torch.* / torch.nn.functional
+entry points (torch.cat, torch.clamp, F.linear through an nn.Module, ...) and `__array_ufunc__` for numpy ufuncs applied
+to tensors (the reference's own pendulum uses np.sin / np.clip on tensors: tests/pendulum.py:45-46).  Shapes are concrete
+(numpy arrays of node ids with a batch axis of size 1), so every view / broadcast / concatenation is numpy's.
+
+Scope: elementwise maths, + - * / ** %, clamp / where / min / max, small constant matrices (captured tensors, nn.Linear
+weights), cat / stack / slicing / views, sum / mean / prod over non-batch axes.  Anything else -- data-dependent control
+flow, integer indexing by values, in-place writes into the inputs, ops not listed -- raises `TraceUnsupported`, and
+the caller keeps the generic path.  The traced functor is VERIFIED before use: compiled for the host (g++) and compared
+with the callable on random batches (1e-9 relative, fp64)."""
+import ctypes as C
+import hashlib
+import math
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import torch
+
+
+class TraceUnsupported(Exception):
+    pass
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# expression graph (hash-consed, constants folded)
+# ---------------------------------------------------------------------------------------------------------------
+_UNARY = {"neg": lambda a: -a, "sin": math.sin, "cos": math.cos, "tan": math.tan, "tanh": math.tanh, "exp": math.exp,
+          "log": math.log, "sqrt": math.sqrt, "abs": abs, "floor": math.floor,
+          "sigmoid": lambda a: 1.0 / (1.0 + math.exp(-a)), "sign": lambda a: (a > 0) - (a < 0)}
+_BINARY = {"add": lambda a, b: a + b, "sub": lambda a, b: a - b, "mul": lambda a, b: a * b, "div": lambda a, b: a / b,
+           "min": min, "max": max, "pow": lambda a, b: a ** b, "atan2": math.atan2,
+           "floormod": lambda a, b: a - math.floor(a / b) * b, "fmod": math.fmod}
+_CMP = {"lt": lambda a, b: a < b, "le": lambda a, b: a <= b, "gt": lambda a, b: a > b, "ge": lambda a, b: a >= b,
+        "eq": lambda a, b: a == b, "ne": lambda a, b: a != b}
+
+
+class Graph:
+    def __init__(self, max_nodes=60000):
+        self.nodes = []          # tuples: ("c", float) | ("x", i) | ("u", n) | ("t",) | ("y", i) | (op, ids...)
+        self.index = {}
+        self.max_nodes = max_nodes
+
+    def _mk(self, node):
+        i = self.index.get(node)
+        if i is None:
+            if len(self.nodes) >= self.max_nodes:
+                raise TraceUnsupported(f"more than {self.max_nodes} operations per sample")
+            i = len(self.nodes)
+            self.nodes.append(node)
+            self.index[node] = i
+        return i
+
+    def const(self, v):
+        v = float(v)
+        return self._mk(("c", v if v != 0.0 else 0.0))       # -0.0 folded into 0.0
+
+    def leaf(self, kind, i=None):
+        return self._mk((kind,) if i is None else (kind, int(i)))
+
+    def cval(self, i):
+        n = self.nodes[i]
+        return n[1] if n[0] == "c" else None
+
+    def un(self, op, a):
+        ca = self.cval(a)
+        if ca is not None:
+            try:
+                return self.const(_UNARY[op](ca))
+            except (ValueError, OverflowError):
+                pass
+        if op == "neg" and self.nodes[a][0] == "neg":
+            return self.nodes[a][1]
+        return self._mk((op, a))
+
+    def bin(self, op, a, b):
+        ca, cb = self.cval(a), self.cval(b)
+        if ca is not None and cb is not None:
+            try:
+                return self.const(_BINARY[op](ca, cb))
+            except (ValueError, OverflowError, ZeroDivisionError):
+                pass
+        if op == "add":
+            if ca == 0.0:
+                return b
+            if cb == 0.0:
+                return a
+        elif op == "sub":
+            if cb == 0.0:
+                return a
+            if ca == 0.0:
+                return self.un("neg", b)
+        elif op == "mul":
+            if ca == 1.0:
+                return b
+            if cb == 1.0:
+                return a
+            # (0 * x is NOT folded to 0: x may be inf / nan in torch, and the verification would not see it)
+            if ca == -1.0:
+                return self.un("neg", b)
+            if cb == -1.0:
+                return self.un("neg", a)
+        elif op == "div":
+            if cb == 1.0:
+                return a
+            if cb is not None and cb != 0.0 and math.isfinite(1.0 / cb) and (1.0 / cb) * cb == 1.0:
+                return self.bin("mul", a, self.const(1.0 / cb))      # exact reciprocal (powers of two): same value
+        elif op == "pow":
+            if cb is not None and cb == int(cb) and 0 <= int(cb) <= 8:
+                e = int(cb)
+                if e == 0:
+                    return self.const(1.0)
+                r = a
+                for _ in range(e - 1):                               # torch.pow with a small integer exponent: repeated products
+                    r = self.bin("mul", r, a)
+                return r
+            if cb == 0.5:
+                return self.un("sqrt", a)
+        if op in ("add", "mul", "min", "max") and a > b:
+            a, b = b, a                                              # commutative: one node for both orders
+        return self._mk((op, a, b))
+
+    def cmp(self, op, a, b):
+        return self._mk((op, a, b))
+
+    def select(self, c, a, b):
+        if a == b:
+            return a
+        return self._mk(("select", c, a, b))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# symbolic tensor
+# ---------------------------------------------------------------------------------------------------------------
+def _is_tensor_like(v):
+    return isinstance(v, (torch.Tensor, np.ndarray))
+
+
+class SymT:
+    """Per-sample symbolic tensor: `a` is an int64 ndarray of node ids, full shape including the batch axis (size 1)."""
+    __array_priority__ = 1000
+
+    def __init__(self, g, a, boolean=False):
+        self.g = g
+        self.a = np.asarray(a, dtype=np.int64)
+        self.boolean = boolean
+
+    # -- construction ------------------------------------------------------------------------------------------
+    def _lift(self, v):
+        if isinstance(v, SymT):
+            return v
+        if isinstance(v, SymS):
+            return SymT(self.g, np.array(v.i, dtype=np.int64))
+        if isinstance(v, torch.Tensor):
+            if v.dtype == torch.bool:
+                raise TraceUnsupported("boolean constant tensors")
+            v = v.detach().cpu().double().numpy()
+        if isinstance(v, np.ndarray):
+            if v.size > 65536:
+                raise TraceUnsupported("constant tensor with more than 65536 elements")
+            return SymT(self.g, np.vectorize(self.g.const, otypes=[np.int64])(v.astype(np.float64)))
+        if isinstance(v, (int, float, np.floating, np.integer)):
+            return SymT(self.g, np.array(self.g.const(float(v)), dtype=np.int64))
+        raise TraceUnsupported(f"operand of type {type(v).__name__}")
+
+    def _ew2(self, op, other, reverse=False, cmp=False):
+        o = self._lift(other)
+        a, b = (o.a, self.a) if reverse else (self.a, o.a)
+        try:
+            a, b = np.broadcast_arrays(a, b)
+        except ValueError as e:
+            raise TraceUnsupported(f"broadcast: {e}")
+        f = self.g.cmp if cmp else self.g.bin
+        out = np.empty(a.shape, dtype=np.int64)
+        fa, fb, fo = a.reshape(-1), b.reshape(-1), out.reshape(-1)
+        for i in range(fo.size):
+            fo[i] = f(op, int(fa[i]), int(fb[i]))
+        return SymT(self.g, out, boolean=cmp)
+
+    def _ew1(self, op):
+        out = np.empty(self.a.shape, dtype=np.int64)
+        fa, fo = self.a.reshape(-1), out.reshape(-1)
+        for i in range(fo.size):
+            fo[i] = self.g.un(op, int(fa[i]))
+        return SymT(self.g, out)
+
+    # -- python protocol ----------------------------------------------------------------------------------------
+    def __add__(self, o): return self._ew2("add", o)
+    def __radd__(self, o): return self._ew2("add", o, True)
+    def __sub__(self, o): return self._ew2("sub", o)
+    def __rsub__(self, o): return self._ew2("sub", o, True)
+    def __mul__(self, o): return self._ew2("mul", o)
+    def __rmul__(self, o): return self._ew2("mul", o, True)
+    def __truediv__(self, o): return self._ew2("div", o)
+    def __rtruediv__(self, o): return self._ew2("div", o, True)
+    def __pow__(self, o): return self._ew2("pow", o)
+    def __rpow__(self, o): return self._ew2("pow", o, True)
+    def __mod__(self, o): return self._ew2("floormod", o)           # torch's % is Python's: sign of the divisor
+    def __neg__(self): return self._ew1("neg")
+    def __pos__(self): return self
+    def __abs__(self): return self._ew1("abs")
+    def __lt__(self, o): return self._ew2("lt", o, cmp=True)
+    def __le__(self, o): return self._ew2("le", o, cmp=True)
+    def __gt__(self, o): return self._ew2("gt", o, cmp=True)
+    def __ge__(self, o): return self._ew2("ge", o, cmp=True)
+    def __matmul__(self, o): return self.matmul(o)
+    def __rmatmul__(self, o): return self._lift(o).matmul(self)
+    def __bool__(self): raise TraceUnsupported("data-dependent control flow (a tensor used as a Python bool)")
+    def __float__(self): raise TraceUnsupported("tensor converted to a Python number")
+    __int__ = __index__ = __float__
+    def __array__(self, *a, **k): raise TraceUnsupported("tensor converted to a numpy array")
+    def __len__(self): return self.a.shape[0]
+    def __iter__(self): return (self[i] for i in range(self.a.shape[0]))
+
+    def __getitem__(self, idx):
+        def chk(i):
+            if isinstance(i, (SymT, SymS)):
+                raise TraceUnsupported("indexing by a traced value")
+            if isinstance(i, torch.Tensor):
+                return i.detach().cpu().numpy()
+            return i
+        idx = tuple(chk(i) for i in idx) if isinstance(idx, tuple) else chk(idx)
+        try:
+            return SymT(self.g, self.a[idx], self.boolean)
+        except (IndexError, TypeError) as e:
+            raise TraceUnsupported(f"indexing: {e}")
+
+    def __setitem__(self, idx, v):
+        v = self._lift(v)
+        idx = tuple(i.detach().cpu().numpy() if isinstance(i, torch.Tensor) else i for i in idx) if isinstance(idx, tuple) else idx
+        try:
+            self.a[idx] = v.a          # (the traced inputs are handed to the callable as copies: an in-place write
+        except (IndexError, ValueError, TypeError) as e:    # into `state` stays local, like state.clone() first)
+            raise TraceUnsupported(f"item assignment: {e}")
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        if method != "__call__" or kw.get("out") is not None:
+            raise TraceUnsupported(f"numpy {ufunc.__name__}.{method}")
+        name = _NP_UFUNCS.get(ufunc.__name__)
+        if name is None:
+            raise TraceUnsupported(f"numpy ufunc {ufunc.__name__}")
+        return _call(self.g, name, inputs, {})
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", str(func))
+        g = _graph_of(args, kwargs)
+        if name in ("__get__",):          # attribute descriptors (Tensor.T, .shape, ...) reach here for some builds
+            raise TraceUnsupported(f"torch attribute {func}")
+        return _call(g, name, args, kwargs)
+
+    # -- attributes ---------------------------------------------------------------------------------------------
+    @property
+    def shape(self): return torch.Size(self.a.shape)
+    @property
+    def ndim(self): return self.a.ndim
+    @property
+    def dtype(self): return torch.float64
+    @property
+    def device(self): return torch.device("cpu")
+    @property
+    def T(self): return SymT(self.g, self.a.T)
+    @property
+    def mT(self): return SymT(self.g, np.swapaxes(self.a, -1, -2))
+    @property
+    def requires_grad(self): return False
+    @property
+    def is_cuda(self): return False
+    def size(self, d=None): return self.shape if d is None else self.a.shape[d]
+    def dim(self): return self.a.ndim
+    def numel(self): return self.a.size
+    def t(self): return self.T
+
+    # -- no-ops / views -----------------------------------------------------------------------------------------
+    def clone(self, *a, **k): return SymT(self.g, self.a.copy(), self.boolean)
+    def contiguous(self, *a, **k): return self
+    def detach(self): return self
+    def to(self, *a, **k): return self
+    def type_as(self, o): return self
+    def float(self): return self
+    def double(self): return self
+    def cpu(self): return self
+    def cuda(self, *a, **k): return self
+    def requires_grad_(self, *a, **k): return self
+
+    def _shape_args(self, s):
+        if len(s) == 1 and isinstance(s[0], (tuple, list, torch.Size)):
+            s = tuple(s[0])
+        return tuple(int(v) for v in s)
+
+    def view(self, *s):
+        try:
+            return SymT(self.g, self.a.reshape(self._shape_args(s)), self.boolean)
+        except ValueError as e:
+            raise TraceUnsupported(f"view: {e}")
+    reshape = view
+
+    def view_as(self, o): return self.view(*o.shape)
+    def reshape_as(self, o): return self.view(*o.shape)
+    def flatten(self, start_dim=0, end_dim=-1):
+        sh = list(self.a.shape)
+        e = end_dim % len(sh)
+        s = start_dim % len(sh)
+        return self.view(*(sh[:s] + [-1] + sh[e + 1:]))
+    def unsqueeze(self, d): return SymT(self.g, np.expand_dims(self.a, d if d >= 0 else d + self.a.ndim + 1), self.boolean)
+    def squeeze(self, d=None):
+        if d is None:
+            return SymT(self.g, np.squeeze(self.a), self.boolean)
+        return SymT(self.g, np.squeeze(self.a, d), self.boolean) if self.a.shape[d] == 1 else self
+    def expand(self, *s):
+        s = self._shape_args(s)
+        s = tuple(self.a.shape[i - (len(s) - self.a.ndim)] if v == -1 else v for i, v in enumerate(s))
+        try:
+            return SymT(self.g, np.broadcast_to(self.a, s), self.boolean)
+        except ValueError as e:
+            raise TraceUnsupported(f"expand: {e}")
+    def expand_as(self, o): return self.expand(*o.shape)
+    def repeat(self, *s): return SymT(self.g, np.tile(self.a, self._shape_args(s)), self.boolean)
+    def transpose(self, d0, d1): return SymT(self.g, np.swapaxes(self.a, d0, d1), self.boolean)
+    def permute(self, *d): return SymT(self.g, np.transpose(self.a, self._shape_args(d)), self.boolean)
+    def unbind(self, dim=0): return tuple(SymT(self.g, np.take(self.a, i, axis=dim)) for i in range(self.a.shape[dim]))
+    def chunk(self, n, dim=0): return tuple(SymT(self.g, p) for p in np.array_split(self.a, n, axis=dim))
+    def split(self, size, dim=0):
+        if isinstance(size, int):
+            cuts = list(range(size, self.a.shape[dim], size))
+        else:
+            cuts = list(np.cumsum(size)[:-1])
+        return tuple(SymT(self.g, p) for p in np.split(self.a, cuts, axis=dim))
+    def narrow(self, dim, start, length):
+        sl = [slice(None)] * self.a.ndim
+        sl[dim] = slice(start, start + length)
+        return SymT(self.g, self.a[tuple(sl)])
+    def select(self, dim, index): return SymT(self.g, np.take(self.a, index, axis=dim))
+
+    # -- elementwise --------------------------------------------------------------------------------------------
+    def sin(self): return self._ew1("sin")
+    def cos(self): return self._ew1("cos")
+    def tan(self): return self._ew1("tan")
+    def tanh(self): return self._ew1("tanh")
+    def exp(self): return self._ew1("exp")
+    def log(self): return self._ew1("log")
+    def sqrt(self): return self._ew1("sqrt")
+    def abs(self): return self._ew1("abs")
+    def neg(self): return self._ew1("neg")
+    def floor(self): return self._ew1("floor")
+    def sign(self): return self._ew1("sign")
+    def sigmoid(self): return self._ew1("sigmoid")
+    def relu(self): return self._ew2("max", 0.0)
+    def square(self): return self._ew2("mul", self)
+    def reciprocal(self): return SymT(self.g, np.array(self.g.const(1.0)))._ew2("div", self)
+    def rsqrt(self): return self.sqrt().reciprocal()
+    def add(self, o, alpha=1): return self + (o if alpha == 1 else o * alpha)
+    def sub(self, o, alpha=1): return self - (o if alpha == 1 else o * alpha)
+    def mul(self, o): return self * o
+    def div(self, o): return self / o
+    def pow(self, o): return self ** o
+    def remainder(self, o): return self % o
+    def fmod(self, o): return self._ew2("fmod", o)
+    def atan2(self, o): return self._ew2("atan2", o)
+    def maximum(self, o): return self._ew2("max", o)
+    def minimum(self, o): return self._ew2("min", o)
+    def lt(self, o): return self < o
+    def le(self, o): return self <= o
+    def gt(self, o): return self > o
+    def ge(self, o): return self >= o
+
+    def clamp(self, min=None, max=None, out=None, **kw):
+        if out is not None or kw:
+            raise TraceUnsupported("clamp(out=...)")
+        r = self
+        if min is not None and max is not None and not isinstance(min, (SymT, torch.Tensor)) and not isinstance(max, (SymT, torch.Tensor)):
+            lo, hi = self._lift(min), self._lift(max)
+            out = np.empty(self.a.shape, dtype=np.int64)
+            fa, fo = self.a.reshape(-1), out.reshape(-1)
+            for i in range(fo.size):
+                fo[i] = self.g._mk(("clamp", int(fa[i]), int(lo.a), int(hi.a)))
+            return SymT(self.g, out)
+        if min is not None:
+            r = r._ew2("max", min)
+        if max is not None:
+            r = r._ew2("min", max)
+        return r
+    clip = clamp
+    def clamp_min(self, v): return self.clamp(min=v)
+    def clamp_max(self, v): return self.clamp(max=v)
+
+    def where(self, cond, other):          # Tensor.where(condition, other): self where cond else other
+        return _where(self.g, cond, self, other)
+
+    # -- reductions ---------------------------------------------------------------------------------------------
+    def _reduce(self, op, dim, keepdim):
+        a = self.a
+        if dim is None:
+            dims = tuple(range(a.ndim))
+        else:
+            dims = tuple(d % a.ndim for d in (dim if isinstance(dim, (tuple, list)) else (dim,)))
+        moved = np.moveaxis(a, dims, tuple(range(len(dims))))
+        flat = moved.reshape((-1,) + moved.shape[len(dims):])
+        out = flat[0].copy()
+        for r in range(1, flat.shape[0]):                       # index order, like a sequential sum
+            fo, fr = out.reshape(-1), flat[r].reshape(-1)
+            for i in range(fo.size):
+                fo[i] = self.g.bin(op, int(fo[i]), int(fr[i]))
+        if keepdim:
+            for d in sorted(dims):
+                out = np.expand_dims(out, d)
+        return SymT(self.g, out), flat.shape[0]
+
+    def sum(self, dim=None, keepdim=False, dtype=None):
+        return self._reduce("add", dim, keepdim)[0]
+    def prod(self, dim=None, keepdim=False):
+        return self._reduce("mul", dim, keepdim)[0]
+    def mean(self, dim=None, keepdim=False):
+        r, n = self._reduce("add", dim, keepdim)
+        return r / float(n)
+    def amax(self, dim=None, keepdim=False): return self._reduce("max", dim, keepdim)[0]
+    def amin(self, dim=None, keepdim=False): return self._reduce("min", dim, keepdim)[0]
+    def norm(self, p=2, dim=None, keepdim=False):
+        if p not in (2, 2.0, "fro"):
+            raise TraceUnsupported("norm with p != 2")
+        return (self * self).sum(dim, keepdim).sqrt()
+
+    def matmul(self, o):
+        o = self._lift(o)
+        a, b = self.a, o.a
+        if a.ndim == 0 or b.ndim == 0:
+            raise TraceUnsupported("matmul with a 0-d operand")
+        a2 = a if a.ndim > 1 else a[None, :]
+        b2 = b if b.ndim > 1 else b[:, None]
+        if a2.shape[-1] != b2.shape[-2]:
+            raise TraceUnsupported(f"matmul shapes {a.shape} @ {b.shape}")
+        try:
+            batch = np.broadcast_shapes(a2.shape[:-2], b2.shape[:-2])
+        except ValueError as e:
+            raise TraceUnsupported(f"matmul: {e}")
+        a2 = np.broadcast_to(a2, batch + a2.shape[-2:])
+        b2 = np.broadcast_to(b2, batch + b2.shape[-2:])
+        out = np.empty(batch + (a2.shape[-2], b2.shape[-1]), dtype=np.int64)
+        g = self.g
+        for bi in np.ndindex(*batch):
+            for i in range(a2.shape[-2]):
+                for j in range(b2.shape[-1]):
+                    acc = None
+                    for k in range(a2.shape[-1]):
+                        ia, ib = int(a2[bi + (i, k)]), int(b2[bi + (k, j)])
+                        if g.cval(ia) == 0.0 or g.cval(ib) == 0.0:
+                            # a structural zero of a CONSTANT matrix: torch adds 0 * x = 0 for finite x; dropping the term is
+                            # exact for finite states (the sparse B / selection matrices of test code)
+                            continue
+                        p = g.bin("mul", ia, ib)
+                        acc = p if acc is None else g.bin("add", acc, p)
+                    out[bi + (i, j)] = g.const(0.0) if acc is None else acc
+        if a.ndim == 1:
+            out = out[..., 0, :]
+        if b.ndim == 1:
+            out = out[..., 0]
+        return SymT(self.g, out)
+    mm = matmul
+    bmm = matmul
+    def dot(self, o): return (self * o).sum()
+
+
+class SymS:
+    """Symbolic Python scalar (the timestep `t` of step-dependent callables): arithmetic only."""
+    def __init__(self, g, i):
+        self.g, self.i = g, i
+
+    def _b(self, op, o, rev=False):
+        if isinstance(o, SymT):
+            return o._ew2(op, self, reverse=not rev)
+        if isinstance(o, SymS):
+            oi = o.i
+        elif isinstance(o, (int, float)):
+            oi = self.g.const(o)
+        elif isinstance(o, torch.Tensor):
+            return SymT(self.g, np.array(self.i))._ew2(op, o, reverse=rev)
+        else:
+            return NotImplemented
+        return SymS(self.g, self.g.bin(op, oi, self.i) if rev else self.g.bin(op, self.i, oi))
+
+    def __add__(self, o): return self._b("add", o)
+    def __radd__(self, o): return self._b("add", o, True)
+    def __sub__(self, o): return self._b("sub", o)
+    def __rsub__(self, o): return self._b("sub", o, True)
+    def __mul__(self, o): return self._b("mul", o)
+    def __rmul__(self, o): return self._b("mul", o, True)
+    def __truediv__(self, o): return self._b("div", o)
+    def __rtruediv__(self, o): return self._b("div", o, True)
+    def __pow__(self, o): return self._b("pow", o)
+    def __neg__(self): return SymS(self.g, self.g.un("neg", self.i))
+    def __bool__(self): raise TraceUnsupported("control flow on the timestep")
+    def __index__(self): raise TraceUnsupported("indexing by the timestep")
+    __int__ = __index__
+    def __float__(self): raise TraceUnsupported("the timestep converted to a Python float")
+    def __lt__(self, o): raise TraceUnsupported("comparison on the timestep")
+    __le__ = __gt__ = __ge__ = __lt__
+    __array_priority__ = 1000
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        args = tuple(SymT(a.g, np.array(a.i)) if isinstance(a, SymS) else a for a in args)
+        return _call(_graph_of(args, kwargs or {}), getattr(func, "__name__", str(func)), args, kwargs or {})
+
+
+_DUNDERS = {"__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__", "__pow__",
+            "__rpow__", "__mod__", "__neg__", "__pos__", "__abs__", "__lt__", "__le__", "__gt__", "__ge__", "__matmul__",
+            "__rmatmul__", "__getitem__"}
+_NP_UFUNCS = {"sin": "sin", "cos": "cos", "tan": "tan", "tanh": "tanh", "exp": "exp", "log": "log", "sqrt": "sqrt",
+              "absolute": "abs", "fabs": "abs", "negative": "neg", "square": "square", "add": "add", "subtract": "sub",
+              "multiply": "mul", "true_divide": "div", "divide": "div", "power": "pow", "maximum": "maximum",
+              "minimum": "minimum", "floor": "floor", "sign": "sign", "arctan2": "atan2", "remainder": "remainder",
+              "mod": "remainder", "fmod": "fmod", "clip": "clamp", "less": "lt", "greater": "gt", "less_equal": "le",
+              "greater_equal": "ge"}
+
+
+def _graph_of(args, kwargs):
+    def walk(v):
+        if isinstance(v, (SymT, SymS)):
+            return v.g
+        if isinstance(v, (tuple, list)):
+            for e in v:
+                g = walk(e)
+                if g is not None:
+                    return g
+        return None
+    for v in list(args) + list(kwargs.values()):
+        g = walk(v)
+        if g is not None:
+            return g
+    raise TraceUnsupported("no traced operand")
+
+
+def _as_sym(g, v):
+    if isinstance(v, SymT):
+        return v
+    return SymT(g, np.array(g.const(0.0)))._lift(v)
+
+
+def _where(g, cond, a, b):
+    if not isinstance(cond, SymT) or not cond.boolean:
+        raise TraceUnsupported("where() on a condition that does not come from a traced comparison")
+    a, b = _as_sym(g, a), _as_sym(g, b)
+    try:
+        c_, a_, b_ = np.broadcast_arrays(cond.a, a.a, b.a)
+    except ValueError as e:
+        raise TraceUnsupported(f"where: {e}")
+    out = np.empty(c_.shape, dtype=np.int64)
+    fc, fa, fb, fo = c_.reshape(-1), a_.reshape(-1), b_.reshape(-1), out.reshape(-1)
+    for i in range(fo.size):
+        fo[i] = g.select(int(fc[i]), int(fa[i]), int(fb[i]))
+    return SymT(g, out)
+
+
+def _call(g, name, args, kwargs):
+    """torch.* / torch.nn.functional.* / Tensor.* entry points by name."""
+    a0 = _as_sym(g, args[0]) if args and not isinstance(args[0], (tuple, list)) else None
+    rest = args[1:]
+    if name in ("cat", "concatenate", "concat", "stack", "hstack", "vstack"):
+        seq = [_as_sym(g, v).a for v in args[0]]
+        dim = kwargs.get("dim", rest[0] if rest else 0)
+        try:
+            if name == "stack":
+                return SymT(g, np.stack(seq, axis=dim))
+            if name == "hstack":
+                return SymT(g, np.hstack(seq))
+            if name == "vstack":
+                return SymT(g, np.vstack(seq))
+            return SymT(g, np.concatenate(seq, axis=dim))
+        except ValueError as e:
+            raise TraceUnsupported(f"{name}: {e}")
+    if name == "where":
+        if len(args) != 3:
+            raise TraceUnsupported("where(condition) without values")
+        return _where(g, args[0], args[1], args[2])
+    if name in ("zeros_like", "ones_like", "full_like", "empty_like"):
+        v = {"zeros_like": 0.0, "ones_like": 1.0, "empty_like": 0.0}.get(name, rest[0] if rest else kwargs.get("fill_value"))
+        return SymT(g, np.full(a0.a.shape, g.const(v), dtype=np.int64))
+    if name == "linear":                               # F.linear(input, weight, bias): nn.Linear inside a module
+        w = _as_sym(g, rest[0])
+        out = a0.matmul(w.T)
+        b = rest[1] if len(rest) > 1 else kwargs.get("bias")
+        return out + b if b is not None else out
+    if name in ("einsum", "index_select", "gather", "scatter", "nonzero", "argmax", "argmin", "sort", "topk", "max", "min") and \
+            not (name in ("max", "min") and len(args) == 2 and (isinstance(args[1], (SymT, torch.Tensor)))):
+        if name in ("max", "min") and len(args) == 1 and not kwargs:
+            return a0.amax() if name == "max" else a0.amin()
+        raise TraceUnsupported(f"torch.{name}")
+    if name in ("max", "min"):
+        return a0.maximum(args[1]) if name == "max" else a0.minimum(args[1])
+    if name in ("softplus",):
+        beta = kwargs.get("beta", 1.0)
+        return ((a0 * beta).exp() + 1.0).log() / beta
+    if name in ("dropout", "alpha_dropout", "feature_alpha_dropout"):
+        if kwargs.get("training", rest[1] if len(rest) > 1 else False):
+            raise TraceUnsupported("dropout in training mode")
+        return a0
+    if name in ("leaky_relu",):
+        slope = kwargs.get("negative_slope", rest[0] if rest else 0.01)
+        return _where(g, a0 > 0.0, a0, a0 * slope)
+    if name in ("elu", "gelu", "silu", "selu", "softmax", "log_softmax", "layer_norm", "batch_norm"):
+        if name == "silu":
+            return a0 * a0.sigmoid()
+        raise TraceUnsupported(f"torch.nn.functional.{name}")
+    if name in ("__getitem__",):
+        return a0[rest[0]]
+    meth = {"absolute": "abs", "negative": "neg", "true_divide": "div", "divide": "div", "multiply": "mul", "subtract": "sub",
+            "clip": "clamp", "arctan2": "atan2"}.get(name, name)
+    if a0 is not None and hasattr(SymT, meth) and (not meth.startswith("_") or meth in _DUNDERS):
+        f = getattr(a0, meth)
+        if callable(f):
+            return f(*rest, **kwargs)
+        return f
+    raise TraceUnsupported(f"torch function {name}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# tracing the three callables
+# ---------------------------------------------------------------------------------------------------------------
+def _flatten_result(r, want, what):
+    if isinstance(r, torch.Tensor):
+        raise TraceUnsupported(f"{what} returned a constant tensor (it does not depend on its inputs, or left the traced ops)")
+    if not isinstance(r, SymT):
+        raise TraceUnsupported(f"{what} returned {type(r).__name__}")
+    a = r.a.reshape(-1)
+    if a.size != want:
+        raise TraceUnsupported(f"{what} returned {tuple(r.a.shape)} per batch of one, expected {want} value(s)")
+    return [int(v) for v in a]
+
+
+def trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False):
+    """-> (Graph, step outputs [nx node ids], cost output id, terminal output id or None)"""
+    g = Graph()
+
+    def xs(kind, n, shape):
+        return SymT(g, np.array([g.leaf(kind, i) for i in range(n)], dtype=np.int64).reshape(shape))
+    t = SymS(g, g.leaf("t"))
+    extra = (t,) if step_dependent else ()
+    with torch.no_grad():
+        nxt = dynamics(xs("x", nx, (1, nx)), xs("u", nu, (1, nu)), *extra)
+        step_out = _flatten_result(nxt, nx, "dynamics")
+        c = running_cost(xs("x", nx, (1, nx)), xs("u", nu, (1, nu)), *extra)
+        cost_out = _flatten_result(c, 1, "running_cost")[0]
+        term_out = None
+        if terminal_state_cost is not None:
+            # (1, K=1, T=2, nx): the functor's terminal() sees the LAST state only -- any use of an earlier state or of
+            # the actions shows up as a 'y' / 'w' leaf in the result
+            st = np.array([[g.leaf("y", i) for i in range(nx)], [g.leaf("x", i) for i in range(nx)]], dtype=np.int64).reshape(1, 1, 2, nx)
+            ac = np.array([g.leaf("w", i) for i in range(2 * nu)], dtype=np.int64).reshape(1, 1, 2, nu)
+            tr = terminal_state_cost(SymT(g, st), SymT(g, ac))
+            term_out = _flatten_result(tr, 1, "terminal_state_cost")[0]
+            if _reaches(g, [term_out], ("y", "w")):
+                raise TraceUnsupported("terminal_state_cost uses more than the last state")
+    return g, step_out, cost_out, term_out
+
+
+def _reaches(g, roots, kinds):
+    seen, stack = set(), list(roots)
+    while stack:
+        i = stack.pop()
+        if i in seen:
+            continue
+        seen.add(i)
+        n = g.nodes[i]
+        if n[0] in kinds:
+            return True
+        if n[0] not in ("c", "x", "u", "t", "y", "w"):
+            stack.extend(n[1:])
+    return False
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# code generation
+# ---------------------------------------------------------------------------------------------------------------
+_FMT1 = {"neg": "(-{0})", "sin": "m_sin({0})", "cos": "m_cos({0})", "tan": "(m_sin({0}) / m_cos({0}))", "tanh": "m_tanh({0})",
+         "exp": "m_exp({0})", "log": "m_log({0})", "sqrt": "m_sqrt({0})", "abs": "m_abs({0})", "floor": "m_floor({0})",
+         "sigmoid": "(T(1) / (T(1) + m_exp(-{0})))", "sign": "(T({0} > T(0)) - T({0} < T(0)))"}
+_FMT2 = {"add": "({0} + {1})", "sub": "({0} - {1})", "mul": "({0} * {1})", "div": "({0} / {1})", "min": "m_min({0}, {1})",
+         "max": "m_max({0}, {1})", "pow": "m_pow({0}, {1})", "atan2": "m_atan2({0}, {1})",
+         "floormod": "({0} - m_floor({0} / {1}) * {1})", "fmod": "m_fmod({0}, {1})",
+         "lt": "({0} < {1})", "le": "({0} <= {1})", "gt": "({0} > {1})", "ge": "({0} >= {1})", "eq": "({0} == {1})", "ne": "({0} != {1})"}
+
+
+def _lit(v):
+    if math.isinf(v):
+        return "inf_v<T>()" if v > 0 else "(-inf_v<T>())"
+    if math.isnan(v):
+        raise TraceUnsupported("NaN constant")
+    return f"T({v!r})"
+
+
+def emit(g, roots, assign=None, ret=False):
+    """C++ statements computing `roots` (node ids): temporaries in topological order, then either `x[i] = ...;`
+    assignments (`assign` = list of targets) or `return ...;`."""
+    order, seen = [], set()
+    for r in roots:
+        stack = [(r, False)]
+        while stack:
+            i, done = stack.pop()
+            if done:
+                order.append(i)
+                continue
+            if i in seen:
+                continue
+            seen.add(i)
+            stack.append((i, True))
+            n = g.nodes[i]
+            if n[0] not in ("c", "x", "u", "t", "y", "w"):
+                for a in n[1:]:
+                    stack.append((a, False))
+    name = {}
+    lines = []
+    for i in order:
+        n = g.nodes[i]
+        k = n[0]
+        if k == "c":
+            name[i] = _lit(n[1])
+        elif k == "x":
+            name[i] = f"x[{n[1]}]"
+        elif k == "u":
+            name[i] = f"u[{n[1]}]"
+        elif k == "t":
+            name[i] = "T(t)"
+        elif k in ("y", "w"):
+            raise TraceUnsupported("internal: terminal leaf in a step / cost body")
+        else:
+            ops = [name[a] for a in n[1:]]
+            if k in _FMT1:
+                e = _FMT1[k].format(*ops)
+            elif k in _FMT2:
+                e = _FMT2[k].format(*ops)
+            elif k == "clamp":
+                e = f"clampT({ops[0]}, {ops[1]}, {ops[2]})"
+            elif k == "select":
+                e = f"({ops[0]} ? {ops[1]} : {ops[2]})"
+            else:
+                raise TraceUnsupported(f"internal: no code for {k}")
+            if k in ("lt", "le", "gt", "ge", "eq", "ne"):
+                lines.append(f"const bool v{i} = {e};")
+            else:
+                lines.append(f"const T v{i} = {e};")
+            name[i] = f"v{i}"
+    if assign is not None:
+        # x[] entries that are read by later assignments are protected by the temporaries above only when every output is a
+        # temporary or a leaf other than x[j], j != i: copy leaves first
+        outs = []
+        for tgt, r in zip(assign, roots):
+            if g.nodes[r][0] == "x" and name[r] != tgt:
+                lines.append(f"const T c{r} = {name[r]};")
+                outs.append((tgt, f"c{r}"))
+            else:
+                outs.append((tgt, name[r]))
+        for tgt, e in outs:
+            if tgt != e:
+                lines.append(f"{tgt} = {e};")
+    if ret:
+        lines.append(f"return {name[roots[0]]};")
+    return " ".join(lines)
+
+
+def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False):
+    """-> dict(step=..., cost=..., terminal=... or None, n_ops=...): the C++ bodies for jit.compile_model."""
+    g, so, co, to = trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost, step_dependent)
+    step = emit(g, so, assign=[f"x[{i}]" for i in range(nx)])
+    cost = emit(g, [co], ret=True)
+    term = emit(g, [to], ret=True) if to is not None else None
+    return dict(step=step, cost=cost, terminal=term, n_ops=len(g.nodes))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# verification on the host: the generated bodies compiled by g++ against the callable on random batches
+# ---------------------------------------------------------------------------------------------------------------
+_HOST = r'''
+#include <cmath>
+#include <limits>
+typedef double T;
+template <typename U> static inline U inf_v() { return std::numeric_limits<U>::infinity(); }
+static inline T m_sin(T x) { return std::sin(x); }
+static inline T m_cos(T x) { return std::cos(x); }
+static inline T m_exp(T x) { return std::exp(x); }
+static inline T m_tanh(T x) { return std::tanh(x); }
+static inline T m_log(T x) { return std::log(x); }
+static inline T m_sqrt(T x) { return std::sqrt(x); }
+static inline T m_abs(T x) { return std::fabs(x); }
+static inline T m_floor(T x) { return std::floor(x); }
+static inline T m_min(T a, T b) { return a < b ? a : b; }
+static inline T m_max(T a, T b) { return a > b ? a : b; }
+static inline T m_pow(T a, T b) { return std::pow(a, b); }
+static inline T m_atan2(T a, T b) { return std::atan2(a, b); }
+static inline T m_fmod(T a, T b) { return std::fmod(a, b); }
+static inline T clampT(T x, T lo, T hi) { return std::fmin(std::fmax(x, lo), hi); }
+static const int NX = %(nx)d, NU = %(nu)d;
+static inline void step_(T (&x)[NX], const T (&u)[NU], int t) { %(step)s }
+static inline T cost_(const T (&x)[NX], const T (&u)[NU], int t) { %(cost)s }
+static inline T term_(const T (&x)[NX]) { %(terminal)s }
+extern "C" void run(int B, const double* X, const double* U, int t, double* Xn, double* Cc, double* Tc) {
+  for (int b = 0; b < B; ++b) {
+    T x[NX], u[NU];
+    for (int i = 0; i < NX; ++i) x[i] = X[b * NX + i];
+    for (int n = 0; n < NU; ++n) u[n] = U[b * NU + n];
+    Cc[b] = cost_(x, u, t);
+    Tc[b] = term_(x);
+    step_(x, u, t);
+    for (int i = 0; i < NX; ++i) Xn[b * NX + i] = x[i];
+  }
+}
+'''
+
+
+def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, B=24, rtol=1e-9):
+    """Compile the generated bodies for the host and compare with the callables on random batches (fp64).
+    Raises TraceUnsupported on any disagreement (the caller keeps the generic path)."""
+    src = _HOST % dict(nx=nx, nu=nu, step=code["step"], cost=code["cost"], terminal=code["terminal"] or "return T(0);")
+    with tempfile.TemporaryDirectory() as d:
+        cpp, so = os.path.join(d, "v.cpp"), os.path.join(d, "v.so")
+        open(cpp, "w").write(src)
+        r = subprocess.run(["g++", "-O1", "-shared", "-fPIC", "-o", so, cpp], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise TraceUnsupported("generated code does not compile: " + r.stderr[-400:])
+        lib = C.CDLL(so)
+        gen = torch.Generator().manual_seed(12345)
+        for scale, t in ((1.0, 0), (3.0, 5), (0.1, 11)):
+            X = torch.randn(B, nx, generator=gen, dtype=torch.float64) * scale
+            U = torch.randn(B, nu, generator=gen, dtype=torch.float64) * scale
+            Xn, Cc, Tc = np.zeros((B, nx)), np.zeros(B), np.zeros(B)
+            p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+            Xa, Ua = np.ascontiguousarray(X.numpy()), np.ascontiguousarray(U.numpy())
+            lib.run(B, p(Xa), p(Ua), int(t), p(Xn), p(Cc), p(Tc))
+            extra = (t,) if step_dependent else ()
+            dev = "cpu"
+            with torch.no_grad():
+                try:
+                    ref_x = dynamics(X.clone(), U.clone(), *extra)
+                except RuntimeError:
+                    if not torch.cuda.is_available():
+                        raise
+                    dev = "cuda"                       # the callable captured device tensors
+                    ref_x = dynamics(X.to(dev), U.to(dev), *extra).cpu()
+                ref_c = running_cost(X.to(dev), U.to(dev), *extra).cpu()
+            pairs = [("dynamics", Xn, ref_x.detach().double().reshape(B, -1).numpy()),
+                     ("running_cost", Cc, ref_c.detach().double().reshape(-1).numpy())]
+            if terminal_state_cost is not None:
+                with torch.no_grad():
+                    ref_t = terminal_state_cost(X.to(dev).view(1, B, 1, nx), U.to(dev).view(1, B, 1, nu)).cpu()
+                pairs.append(("terminal_state_cost", Tc, ref_t.detach().double().reshape(-1).numpy()))
+            for what, got, ref in pairs:
+                if got.shape != ref.shape:
+                    raise TraceUnsupported(f"{what}: traced result has shape {got.shape}, the callable returns {ref.shape}")
+                s = max(1.0, float(np.abs(ref).max()))
+                err = float(np.abs(got - ref).max())
+                if not (err <= rtol * s):
+                    raise TraceUnsupported(f"{what}: traced functor differs from the callable by {err:.3g} (scale {s:.3g})")
+    return True
+
+
+def source_key(code, nx, nu):
+    return hashlib.sha256(repr((sorted((k, v) for k, v in code.items() if k != "n_ops"), nx, nu)).encode()).hexdigest()[:12]

@@ -89,3 +89,73 @@ def cart4():
         cost="const T dx = x[0] - p[1], dy = x[1] - p[2];"
              "return dx * dx + dy * dy + x[2] * x[2] + T(0.1) * (x[3] * x[3] + x[4] * x[4] + x[5] * x[5])"
              " + T(0.01) * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]);")
+
+
+# ---- plain torch callables for jit.from_torch (tests/test_trace.py, tests/test_gpu_from_torch.py) ----------------------
+# restated after the reference's own test callables: the gym pendulum with numpy ufuncs applied to tensors
+# (/root/reference/tests/pendulum.py:30-60) and the linear dynamics + quadratic goal cost with a terminal cost
+# (/root/reference/tests/test_mppi.py:25-51)
+def ref_pendulum_callables():
+    import math
+    import numpy as np
+
+    def dynamics(state, perturbed_action):
+        th = state[:, 0].view(-1, 1)
+        thdot = state[:, 1].view(-1, 1)
+        g, m, l, dt = 10, 1, 1, 0.05
+        u = torch.clamp(perturbed_action, -2, 2)
+        newthdot = thdot + (3 * g / (2 * l) * np.sin(th) + 3.0 / (m * l ** 2) * u) * dt
+        newthdot = np.clip(newthdot, -8, 8)
+        newth = th + newthdot * dt
+        return torch.cat((newth, newthdot), dim=1)
+
+    def angle_normalize(x):
+        return ((x + math.pi) % (2 * math.pi)) - math.pi
+
+    def running_cost(state, action):
+        theta, theta_dt = state[:, 0], state[:, 1]
+        return angle_normalize(theta) ** 2 + 0.1 * theta_dt ** 2
+
+    return dynamics, running_cost
+
+
+def ref_linear_callables(dtype=torch.float64):
+    B = torch.tensor([[1.0, 0.0], [0.0, -1.0]], dtype=dtype)
+    goal = torch.tensor([2.0, 2.0], dtype=dtype)
+
+    def dynamics(state, action):
+        return state + action @ B.to(state.device, state.dtype).T
+
+    def cost(state, action):
+        dx = goal.to(state.device, state.dtype) - state
+        return (dx ** 2).sum(dim=-1)
+
+    def terminal(states, actions):
+        dx = goal.to(states.device, states.dtype) - states[..., -1, :]
+        return (dx ** 2).sum(dim=-1)
+
+    return dynamics, cost, terminal
+
+
+def small_mlp_callables(nx=4, nu=2, hidden=8, seed=5):
+    """an nn.Module as dynamics: Linear -> Tanh -> Linear residual (the shape of /root/reference/tests/pendulum_approximate.py:47-67)"""
+    torch.manual_seed(seed)
+    net = torch.nn.Sequential(torch.nn.Linear(nx + nu, hidden), torch.nn.Tanh(), torch.nn.Linear(hidden, nx)).double()
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+
+    def dynamics(state, action):
+        return state + 0.1 * net.to(state.device, state.dtype)(torch.cat((state, action), dim=1))
+
+    def cost(state, action):
+        return (state ** 2).sum(dim=1) + 0.05 * torch.abs(action).sum(dim=1)
+
+    return dynamics, cost
+
+
+def traced_models():
+    """the traced + compiled forms of the callables above (built by __graft_entry__.build() so that the objects travel)"""
+    f, q = ref_pendulum_callables()
+    lf, lq, lt = ref_linear_callables()
+    mf, mq = small_mlp_callables()
+    return dict(pendulum=jit.from_torch(f, q, 2, 1), linear=jit.from_torch(lf, lq, 2, 2, lt), mlp=jit.from_torch(mf, mq, 4, 2))

@@ -1,0 +1,129 @@
+"""Plain torch callables through the UNCHANGED constructor call run fused: `MPPI(dynamics, running_cost,
+nx, sigma, device="cuda")` traces them (pytorch_mppi_amd/trace.py), compiles the functor (jit.compile_model) and takes the
+K1 path.  The reference's own test callables (restated in tests/jit_fixtures.py after /root/reference/tests/pendulum.py:30-60
+and tests/test_mppi.py:25-51), an nn.Module, against the fp64 oracle and against the callback path on the same draw."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import jit_fixtures as jf
+import margins
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(f, q, nx, sigma, dtype, K, T, term=None, **kw):
+    import pytorch_mppi_amd as pm
+    g = torch.Generator().manual_seed(2)
+    nu = 1 if sigma.dim() == 0 else sigma.shape[0]
+    U0 = (torch.randn(T, nu, generator=g) * 0.3).to(dtype)
+    mk = lambda auto: pm.MPPI(f, q, nx, sigma.to(dtype), num_samples=K, horizon=T, device="cuda", lambda_=kw.get("lambda_", 1.0),
+                              terminal_state_cost=term, U_init=U0.clone(), auto_jit=auto,
+                              **{k: v for k, v in kw.items() if k != "lambda_"})
+    return mk(True), mk(False), U0, nu
+
+
+def _oracle(f, q, nx, sigma, K, T, lam, U0, x0, z, term=None, **kw):
+    from oracle import mppi_oracle as orc
+    out = []
+    for dt in (torch.float64, torch.float32):
+        cast = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in kw.items()}
+        p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=sigma.to(dt), K=K, T=T, lambda_=lam, terminal_state_cost=term, **cast)
+        out.append(orc.command(p, U0.to(dt), x0.to(dt), z.to(dt), True))
+    return out
+
+
+@pytest.mark.parametrize("dtype,K,T", [(torch.float64, 100, 15), (torch.float32, 8192, 32)])
+def test_reference_pendulum_callables_run_fused(dtype, K, T):
+    f, q = jf.ref_pendulum_callables()
+    sigma = torch.tensor(10.0)
+    kw = dict(u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0), lambda_=1.0)
+    a, b, U0, nu = _pair(f, q, 2, sigma, dtype, K, T, **kw)
+    assert a.jit_note.startswith("fused") and not a._needs_generic(), a.jit_note
+    assert b._needs_generic()
+    # (numpy ufuncs on tensors only work on the host: on the callback path these callables raise for device tensors, in the
+    # reference too -- traced, they run on the GPU.  The comparison below is with the oracle, which calls them on the host.)
+    x0 = torch.tensor([math_pi(), 1.0])
+    z = torch.randn(K, T, nu, generator=torch.Generator().manual_seed(8)).to(dtype)
+    a.inject_noise(z)
+    ua = a.command(x0.to(dtype).cuda())
+    r64, r32 = _oracle(f, q, 2, sigma, K, T, 1.0, U0, x0, z, u_min=kw["u_min"], u_max=kw["u_max"])
+    for name, got in (("action", ua), ("U", a.U), ("cost_total", a.cost_total)):
+        if dtype == torch.float64:
+            s = max(1.0, float(r64[name].abs().max()))
+            assert float((got.cpu() - r64[name]).abs().max()) <= 1e-9 * s, name
+        else:
+            margins.check("from_torch/pendulum_f32", name, got.detach().cpu().numpy(), r64[name].numpy(), r32[name].numpy(), rtol=1e-5)
+    with pytest.raises(TypeError):
+        b.command(x0.to(dtype).cuda())
+
+
+def math_pi():
+    import math
+    return math.pi
+
+
+def test_reference_linear_dynamics_with_terminal_cost_run_fused():
+    f, q, term = jf.ref_linear_callables()
+    sigma = torch.eye(2, dtype=torch.float64)
+    K, T = 500, 20
+    a, b, U0, nu = _pair(f, q, 2, sigma, torch.float64, K, T, term=term, lambda_=1.0)
+    assert a.jit_note.startswith("fused") and not a._needs_generic(), a.jit_note
+    x0 = torch.zeros(2, dtype=torch.float64)
+    z = torch.randn(K, T, nu, generator=torch.Generator().manual_seed(9), dtype=torch.float64)
+    a.inject_noise(z)
+    b.inject_noise(z)
+    ua, ub = a.command(x0.cuda()), b.command(x0.cuda())
+    r64, _ = _oracle(f, q, 2, sigma, K, T, 1.0, U0, x0, z, term=term)
+    for name, got in (("action", ua), ("U", a.U), ("cost_total", a.cost_total)):
+        assert float((got.cpu() - r64[name]).abs().max()) <= 1e-9 * max(1.0, float(r64[name].abs().max())), name
+    assert float((ua - ub).abs().max()) <= 1e-9
+    assert torch.allclose(a.states, b.states, rtol=0, atol=1e-9)
+
+
+def test_nn_module_dynamics_run_fused():
+    f, q = jf.small_mlp_callables()
+    sigma = torch.eye(2, dtype=torch.float64) * 0.5
+    K, T = 700, 12
+    a, b, U0, nu = _pair(f, q, 4, sigma, torch.float64, K, T, lambda_=2.0)
+    assert a.jit_note.startswith("fused") and not a._needs_generic(), a.jit_note
+    x0 = torch.linspace(-1, 1, 4, dtype=torch.float64)
+    z = torch.randn(K, T, nu, generator=torch.Generator().manual_seed(10), dtype=torch.float64)
+    a.inject_noise(z)
+    b.inject_noise(z)
+    ua, ub = a.command(x0.cuda()), b.command(x0.cuda())
+    assert float((ua - ub).abs().max()) <= 1e-9 and float((a.cost_total - b.cost_total).abs().max()) <= 1e-9 * float(b.cost_total.abs().max())
+
+
+def test_untraceable_callables_stay_on_the_generic_path():
+    import pytorch_mppi_amd as pm
+
+    def f(s, a):
+        return s + a if float(s.sum()) > 0 else s - a       # data-dependent control flow
+
+    c = pm.MPPI(f, lambda s, a: (s ** 2).sum(-1), 2, torch.eye(2), num_samples=64, horizon=5, device="cuda", auto_jit=True)
+    assert c._needs_generic() and c.jit_note.startswith("generic path"), c.jit_note
+    c.command(torch.zeros(2).cuda())
+
+
+def test_traced_pendulum_command_time_at_c2_size():
+    """8192 x 32 through plain callables: the single-launch fused command, not the ~3 ms callback loop"""
+    import pytorch_mppi_amd as pm
+    f, q = jf.ref_pendulum_callables()
+    c = pm.MPPI(f, q, 2, torch.tensor(10.0), num_samples=8192, horizon=32, device="cuda", lambda_=1.0,
+                u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0), rng="philox", seed=1, auto_jit=True)
+    assert not c._needs_generic()
+    x0 = torch.tensor([math_pi(), 1.0]).cuda()
+    for _ in range(10):
+        c.command(x0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 200
+    for _ in range(n):
+        c.command(x0)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    margins.record("from_torch/pendulum_c2_size", "ms_per_command", ms, None, 0.05, "plain torch callables, traced; bound 0.05 ms")
+    assert ms <= 0.05, ms
