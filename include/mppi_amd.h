@@ -69,6 +69,10 @@ enum {
 };
 
 /* One command()'s worth of inputs/outputs.  Pointers marked [opt] may be NULL. */
+/* model_flags */
+#define MPPI_MODEL_FLAG_EXACT_FP32 1   /* MPPI_MODEL_MLP: some |W2| >= 3e4 lies outside the fp16 operand range of the split
+                                          matrix-core kernel -> run the exact fp32 MFMA kernel (no range limit) instead */
+
 typedef struct MppiProblem {
   /* ---- dimensions ---- */
   int32_t K;              /* samples held by THIS shard                                    */
@@ -96,6 +100,7 @@ typedef struct MppiProblem {
                                  the environment is the z axis of every launch grid          */
   int32_t noise_coloured;     /* p->z already holds eps = L z + mu (mppi_noise_fill_philox_coloured): kernels add U and
                                * bound only; the action cost still uses the true Sigma^-1 */
+  int32_t model_flags;        /* MPPI_MODEL_FLAG_*: per-model kernel choices the host knows about its parameters (ABI 18) */
   double lambda_;             /* mppi.py:96, read live                                     */
   double u_scale;             /* mppi.py:313                                               */
   uint64_t seed, call;        /* Philox key / per-command counter word                     */

@@ -17,6 +17,7 @@ E_UNSUPPORTED = -2
 E_DIST = -4
 MODEL_NONE, MODEL_PENDULUM, MODEL_INTEGRATOR, MODEL_LINEAR_GOAL, MODEL_MLP = 0, 1, 2, 3, 4
 MODEL_CUSTOM_BASE = 100
+MODEL_FLAG_EXACT_FP32 = 1
 
 _vp = C.c_void_p
 
@@ -31,7 +32,7 @@ class MppiProblem(C.Structure):
         ("sample_null_action", C.c_int32), ("n_sampler_rows", C.c_int32),
         ("state_per_sample", C.c_int32), ("shift", C.c_int32), ("use_terminal", C.c_int32),
         ("noise_src", C.c_int32), ("u_per_command", C.c_int32), ("rollout_samples", C.c_int32),
-        ("hidden", C.c_int32), ("num_envs", C.c_int32), ("noise_coloured", C.c_int32),
+        ("hidden", C.c_int32), ("num_envs", C.c_int32), ("noise_coloured", C.c_int32), ("model_flags", C.c_int32),
         ("lambda_", C.c_double), ("u_scale", C.c_double),
         ("seed", C.c_uint64), ("call", C.c_uint64), ("noise_pitch", C.c_int64),
         ("noise_rescale", C.c_double), ("smooth_weight", C.c_double),

@@ -213,6 +213,7 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.state_per_sample = p->state_per_sample; a.shift = p->shift; a.use_terminal = p->use_terminal;
   a.noise_src = p->noise_src; a.u_per_command = p->u_per_command; a.hidden = p->hidden;
   a.coloured = p->noise_coloured != 0;
+  a.model_flags = p->model_flags;
   a.lambda_ = (T)p->lambda_; a.u_scale = (T)p->u_scale;
   a.e_scale = (T)(p->noise_rescale == 0.0 ? 1.0 : p->noise_rescale); a.smooth_w = (T)p->smooth_weight;
   a.seed = p->seed; a.call = p->call;

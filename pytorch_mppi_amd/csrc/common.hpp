@@ -44,6 +44,7 @@ struct KArgs {
   unsigned* ticket;             // arrival counter of the single-launch command (workspace tail, kept at 0)
   const T *W, *theta;           // KMPPI inside K1 (rollout_kmppi.hpp): (T,S) operator, (S,nu) control points; else null
   int S;                        //   number of support points; z / seed / call then describe the SUPPORT-point stream
+  int model_flags;              // MPPI_MODEL_FLAG_* (include/mppi_amd.h)
 };
 
 // the workspace of an on-chip command: one partial record per 256-sample workgroup

@@ -225,6 +225,9 @@ __device__ __forceinline__ void rollout_stream_multi(const KArgs<T>& a, const Ac
   rollout = tot * inv_M + a.var_cost * cvar;                                      // :371-372
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "csrc/rollout.hpp: the single-launch command's publish / ticket protocol and the inline CDNA4 assembly are written for gfx950 only"
+#endif
 #ifndef MPPI_K1_BLOCK
 #define MPPI_K1_BLOCK 256   // threads per K1 workgroup (multiple of 64)
 #endif
@@ -743,7 +746,10 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
     // No grid barrier and no spinning: nobody waits for anybody.  Partial records cross CUs / XCDs
     // through agent-scope (sc1, write-through / L1-bypassing) stores and loads on BOTH sides -- per-XCD
     // L2s are not coherent, and plain stores would need an agent release fence that also writes back
-    // the freshly generated rows (~6 us).  omega and
+    // the freshly generated rows (~6 us).  The protocol therefore rests on gfx950's sc1 store / load
+    // semantics and on the explicit vmcnt(0) in front of the ticket, not on the language memory model
+    // (formally the relaxed accesses race): it is pinned to this architecture below and soaked by
+    // tests/test_gpu_edge_semantics.py (10^4 commands, two controllers on two streams).  omega and
     // cost_total_non_zero are NOT written (the caller opted in by passing NULL for both): they are
     // exp(-(cost_total - record[0]) / lambda) [/ record[1]].  The ticket lives in the workspace and
     // is left at 0 again.

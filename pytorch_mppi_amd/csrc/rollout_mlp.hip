@@ -28,7 +28,8 @@ int rollout_mlp(const KArgs<float>& a, hipStream_t st) {
   const char* fv = getenv("MPPI_MLP_VALU");
   const bool force_valu = fv != nullptr && fv[0] == '1';
   const char* fe = getenv("MPPI_MLP_EXACT");
-  const bool force_exact = fe != nullptr && fe[0] == '1';
+  // ... or the host found weights outside the split kernel's fp16 operand range (MPPI_MODEL_FLAG_EXACT_FP32)
+  const bool force_exact = (fe != nullptr && fe[0] == '1') || (a.model_flags & MPPI_MODEL_FLAG_EXACT_FP32) != 0;
   if (!force_valu && a.M == 1 && a.states == nullptr && a.B == nullptr && a.smooth_w == 0.f &&
       mlp_mfma_supported(a.nx, a.nu, a.hidden)) {
     // the matrix-core kernels read the engine's own layout: ask the caller to convert a (K,T,nu) draw

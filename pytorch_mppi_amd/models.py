@@ -68,6 +68,10 @@ class NativeModel:
     def _param_list(self):
         return []
 
+    def flags(self):
+        """MPPI_MODEL_FLAG_* for the problem block (include/mppi_amd.h)"""
+        return 0
+
     def param_blob(self, device, dtype):
         """Flat parameter vector in the layout csrc/models.hpp documents (cached per device/dtype)."""
         key = (str(device), dtype)
@@ -163,10 +167,15 @@ class MLPResidual(NativeModel):
         self.hidden = int(self.W1.shape[0])
         self.res_scale = float(res_scale)
         assert self.W1.shape == (self.hidden, self.nx + self.nu) and self.W2.shape == (self.nx, self.hidden)
-        # the matrix-core kernel runs layer 2 on two-piece fp16 operands (csrc/rollout_mlp_split.hip):
-        # its weights (-2 W2) must stay inside fp16's range
-        if float(self.W2.abs().max()) >= 3.0e4:
-            raise ValueError("MLPResidual: |W2| >= 3e4 is outside the fused matrix-core kernel's operand range")
+
+    def flags(self):
+        """The default matrix-core kernel runs layer 2 on two-piece fp16 operands (csrc/rollout_mlp_split.hip): its weights
+        (-2 W2) must stay inside fp16's range.  Weights beyond it -- checked here every time the parameter version changes,
+        i.e. also after `invalidate()` behind an in-place update -- select the exact fp32 MFMA kernel, which has no such limit."""
+        if getattr(self, "_flags_version", None) != self._param_version:
+            self._flags = N.MODEL_FLAG_EXACT_FP32 if float(torch.as_tensor(self.W2).abs().max()) >= 3.0e4 else 0
+            self._flags_version = self._param_version
+        return self._flags
 
     @classmethod
     def random(cls, nx, nu, hidden, seed=2, dtype=torch.float32, res_scale=0.1):

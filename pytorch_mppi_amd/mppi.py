@@ -399,6 +399,7 @@ class MPPI:
             p.k_offset = self.k_offset
             p.model_id = self._model.model_id if self._model is not None else N.MODEL_NONE
             p.hidden = self._model.hidden if self._model is not None else 0
+            p.model_flags = self._model.flags() if self._model is not None else 0
             p.sigma_diagonal = int(self._diagonal_sigma)
             p.noise_abs_cost = int(bool(self.noise_abs_cost))
             p.sample_null_action = int(bool(self.sample_null_action))
@@ -658,7 +659,18 @@ class MPPI:
     def _needs_generic(self):
         if self._model is None:
             return True
+        if getattr(self._model, "_captured", None) and self._model.stale():
+            import logging
+            self.jit_note = "generic path: a tensor the traced callables read was modified in place after tracing"
+            logging.getLogger("pytorch_mppi_amd").warning("pytorch_mppi_amd: %s", self.jit_note)
+            self._model = None
+            self._problem_cache.clear()
+            return True
         if self.M != 1 and not self._fused_multi_ok():
+            return True
+        if self._model.process_noise is not None and not (self.M > 1 and self._fused_multi_ok()):
+            # a model with process noise is stochastic whatever M is (models.NativeModel.with_process_noise); only the
+            # fused multi-rollout kernel draws it on the device -- everything else keeps the callables' own noise
             return True
         s = self.specific_action_sampler
         if s is not None and type(s).specific_dynamics is not SpecificActionSampler.specific_dynamics:

@@ -49,6 +49,7 @@ class Graph:
     def __init__(self, max_nodes=60000):
         self.nodes = []          # tuples: ("c", float) | ("x", i) | ("u", n) | ("t",) | ("y", i) | (op, ids...)
         self.index = {}
+        self.captured = []       # (tensor, version at trace time) of every torch tensor whose VALUES went into constants
         self.max_nodes = max_nodes
 
     def _mk(self, node):
@@ -164,6 +165,11 @@ class SymT:
         if isinstance(v, torch.Tensor):
             if v.dtype == torch.bool:
                 raise TraceUnsupported("boolean constant tensors")
+            if v.requires_grad:
+                # a TRAINABLE tensor: its values are expected to change (online learning of the dynamics, as in the
+                # reference's tests/pendulum_approximate.py) -- baking them into the functor would silently go stale
+                raise TraceUnsupported("the callable reads a tensor that requires grad (trainable parameters are not constants)")
+            self.g.captured.append((v, v._version))      # captured BY VALUE: the controller watches the version counter
             v = v.detach().cpu().double().numpy()
         if isinstance(v, np.ndarray):
             if v.size > 65536:
@@ -773,7 +779,7 @@ def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_depe
     step = emit(g, so, assign=[f"x[{i}]" for i in range(nx)])
     cost = emit(g, [co], ret=True)
     term = emit(g, [to], ret=True) if to is not None else None
-    return dict(step=step, cost=cost, terminal=term, n_ops=len(g.nodes))
+    return dict(step=step, cost=cost, terminal=term, n_ops=len(g.nodes), captured=g.captured)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -863,4 +869,4 @@ def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=Non
 
 
 def source_key(code, nx, nu):
-    return hashlib.sha256(repr((sorted((k, v) for k, v in code.items() if k != "n_ops"), nx, nu)).encode()).hexdigest()[:12]
+    return hashlib.sha256(repr((sorted((k, v) for k, v in code.items() if k in ("step", "cost", "terminal")), nx, nu)).encode()).hexdigest()[:12]

@@ -153,9 +153,20 @@ def small_mlp_callables(nx=4, nu=2, hidden=8, seed=5):
     return dynamics, cost
 
 
+def watched_linear_callables():
+    """a constant matrix the test later writes in place (tests/test_gpu_from_torch.py: the controller must notice)"""
+    B = torch.tensor([[1.0, 0.0], [0.0, -1.0]], dtype=torch.float64)
+    return (lambda s, a: s + a @ B.to(s.device).T), (lambda s, a: (s ** 2).sum(-1)), B
+
+
 def traced_models():
     """the traced + compiled forms of the callables above (built by __graft_entry__.build() so that the objects travel)"""
+    import concurrent.futures as cf
     f, q = ref_pendulum_callables()
     lf, lq, lt = ref_linear_callables()
     mf, mq = small_mlp_callables()
-    return dict(pendulum=jit.from_torch(f, q, 2, 1), linear=jit.from_torch(lf, lq, 2, 2, lt), mlp=jit.from_torch(mf, mq, 4, 2))
+    wf, wq, _ = watched_linear_callables()
+    jobs = dict(pendulum=(f, q, 2, 1), linear=(lf, lq, 2, 2, lt), mlp=(mf, mq, 4, 2), watched=(wf, wq, 2, 2))
+    with cf.ThreadPoolExecutor(max_workers=4) as ex:      # each ends in its own hipcc subprocess
+        futs = {k: ex.submit(jit.from_torch, *v) for k, v in jobs.items()}
+        return {k: v.result() for k, v in futs.items()}

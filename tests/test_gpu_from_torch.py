@@ -127,3 +127,25 @@ def test_traced_pendulum_command_time_at_c2_size():
     ms = (time.perf_counter() - t0) / n * 1e3
     margins.record("from_torch/pendulum_c2_size", "ms_per_command", ms, None, 0.05, "plain torch callables, traced; bound 0.05 ms")
     assert ms <= 0.05, ms
+
+
+def test_in_place_update_of_a_captured_tensor_sends_the_controller_back_to_the_callables():
+    """the functor holds the VALUES of the tensors the callables read; once one is written in place the fused model would
+    compute yesterday's dynamics -- the controller notices (version counter) and runs the callables again"""
+    import pytorch_mppi_amd as pm
+    f, q, B = jf.watched_linear_callables()
+    mk = lambda auto: pm.MPPI(f, q, 2, torch.eye(2, dtype=torch.float64), num_samples=256, horizon=6, device="cuda",
+                              U_init=torch.zeros(6, 2, dtype=torch.float64), auto_jit=auto)
+    a, b = mk(True), mk(False)
+    assert not a._needs_generic()
+    x0 = torch.ones(2, dtype=torch.float64).cuda()
+    z = torch.randn(256, 6, 2, generator=torch.Generator().manual_seed(4), dtype=torch.float64)
+    for c in (a, b):
+        c.inject_noise(z)
+    assert float((a.command(x0) - b.command(x0)).abs().max()) <= 1e-9
+    B[0, 1] = 0.5                                   # the dynamics change under the controller
+    for c in (a, b):
+        c.inject_noise(z)
+    ua, ub = a.command(x0), b.command(x0)
+    assert a._needs_generic() and a.jit_note.startswith("generic path")
+    assert float((ua - ub).abs().max()) <= 1e-9

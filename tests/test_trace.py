@@ -72,6 +72,22 @@ def test_in_place_write_into_the_state_is_local():
     _roundtrip(f, lambda s, a: (s ** 2).sum(-1), 2, 1)
 
 
+def test_trainable_parameters_are_not_baked_in_and_captured_tensors_are_watched():
+    net = torch.nn.Linear(3, 2).double()
+    f = lambda s, a: s + net(torch.cat((s, a), dim=1))
+    q = lambda s, a: (s ** 2).sum(-1)
+    with pytest.raises(trace.TraceUnsupported, match="requires grad"):
+        trace.generate(f, q, 2, 1)
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+    code = trace.generate(f, q, 2, 1)
+    caps = code["captured"]
+    assert len(caps) >= 2 and all(t._version == v for t, v in caps)
+    with torch.no_grad():
+        net.weight.mul_(2.0)
+    assert any(t._version != v for t, v in caps), "an in-place update of a captured tensor is visible to the watcher"
+
+
 @pytest.mark.parametrize("bad", ["control_flow", "item", "numpy", "shape", "constant", "uses_earlier_state"])
 def test_untraceable_callables_are_refused(bad):
     q = lambda s, a: (s ** 2).sum(-1)
