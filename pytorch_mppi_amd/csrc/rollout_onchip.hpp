@@ -6,7 +6,7 @@
 //   G  generate the rows of the sample (Philox4x32-10 + Box-Muller, common.hpp), a batch of super-steps at a time,
 //   R  roll out (mppi.py:297-332, :375-420, :186-199 -- the arithmetic of rollout_step), and KEEP the bounded
 //      noise eps' = clamp(U + eps) - U (:385) ON CHIP until the sample's weight is known:
-//        * the first 4 weighting tiles (240 / 256 values) in accumulation registers -- the kernel runs one wave
+//        * the first 5 weighting tiles (300 / 320 values) in registers, 256 of them accumulation registers -- the kernel runs one wave
 //          per SIMD anyway (K = 65536 is one wave per SIMD of work), the AGPR half of the unified 512-entry
 //          register file is otherwise idle;
 //        * the next `nsl` super-steps in LDS ([row][thread][4], one conflict-free ds_write/read_b128 per row);
@@ -34,10 +34,10 @@ struct OnChip {
   static constexpr int TRW = SW * P4;                            // rows per tile (15 for nu = 12, else <= 16)
   static constexpr int TC = TRW * 4;                             // columns per tile (<= 64)
 #ifndef MPPI_ONCHIP_NTA
-#define MPPI_ONCHIP_NTA 4
+#define MPPI_ONCHIP_NTA 5   // measured at C3: 4 tiles 82.8 us | 5 tiles 81.1 (214 VGPRs) | 6 tiles 80.9 with scratch (profiles/r03_onchip_parts.txt)
 #endif
   static constexpr int NTA = MPPI_ONCHIP_NTA;                    // tiles kept in registers (the first 4: accumulation registers)
-  static constexpr int AG_SS = NTA * SW, AG_ROWS = AG_SS * P4;   // 60 or 64 rows = 240 / 256 registers
+  static constexpr int AG_SS = NTA * SW, AG_ROWS = AG_SS * P4;   // 75 or 80 rows: 256 values in accumulation registers, the rest in VGPRs
   static constexpr int RG = P4 >= 3 ? 1 : (P4 == 2 ? 2 : 4);     // super-steps regenerated together (>= 3 interleaved chains)
   static constexpr bool OK = P4 <= 16 && (SW % RG) == 0;
 };

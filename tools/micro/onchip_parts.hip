@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
   const int K = argc > 1 ? atoi(argv[1]) : 65536, T = 64, nx = 16, nu = 12, J = T * nu;
   KArgs<float> a{};
   a.K = K; a.Tn = T; a.nx = nx; a.nu = nu; a.J = J; a.J4 = J / 4; a.Jpad = J; a.zp = K; a.diag = 1; a.noise_src = MPPI_NOISE_PHILOX;
-  a.lambda_ = 40.f; a.u_scale = 1.f; a.e_scale = 1.f; a.M = 1; a.n_env = 1; a.fuse = 1; a.seed = 1234; a.call = 7; a.u_per_command = 1;
+  a.lambda_ = argc > 2 ? (float)atof(argv[2]) : 40.f; a.u_scale = 1.f; a.e_scale = 1.f; a.M = 1; a.n_env = 1; a.fuse = 1; a.seed = 1234; a.call = 7; a.u_per_command = 1;
   auto dev = [](size_t n, float v) { std::vector<float> h(n, v); float* d; (void)hipMalloc(&d, n * 4); (void)hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice); return d; };
   a.state = dev(nx, 0.1f); a.U = dev(J, 0.01f); a.u_init = dev(nu, 0.f); a.mu = dev(nu, 0.f);
   std::vector<float> hL(nu * nu, 0.f);
@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
   (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   float c0; (void)hipMemcpy(&c0, a.cost, 4, hipMemcpyDeviceToHost);
-  printf("on-chip K1, K = %d, knocked out = %2d (1 weighting | 2 second generation | 4 keeping | 8 rollout): %.1f us per launch (back to back)  cost[0] = %g\n",
-         K, MPPI_ONCHIP_EXP, ms / n * 1e3, c0);
+  printf("on-chip K1, K = %d, lambda %g, knocked out = %2d (1 weighting | 2 second generation | 4 keeping | 8 rollout): %.1f us per launch (back to back)  cost[0] = %g\n",
+         K, a.lambda_, MPPI_ONCHIP_EXP, ms / n * 1e3, c0);
   return 0;
 }
