@@ -19,7 +19,8 @@
 // block order and applies K4.  Measured at C3 (tools/micro/k1ret_micro.hip, profiles/r03_k1ret_micro*.txt):
 // G alone 34.6 us (the chip-wide generator floor), G+R 41-45 us, whole kernel 72-78 us against 34 + 33 + 36 us
 // for generator + K1 + K3.
-// Scope: fp32, diagonal Sigma (not a coloured stream), plain MPPI (no SMPPI base sequence, no KMPPI), M = 1,
+// Scope: fp32, diagonal or full Sigma (colouring in the lane; not a generator-coloured stream), plain MPPI (no SMPPI base
+// sequence, no KMPPI), M = 1,
 // no sampler rows (the sample_null_action row is handled), no `states` output, one environment.
 #pragma once
 // (included from rollout.hpp, inside its include set)
@@ -80,13 +81,32 @@ struct OnChipRow {
 // bounded actions and noise of one super-step from its standard normals: z (in) -> eps' (out), v (out);
 // exactly K1's arithmetic (rollout_step, DIAG): v = clamp(fma(z, sd, U + mu)), eps' = v - U.
 // (Timesteps beyond the horizon -- the padding of the last super-step -- give values nobody reads.)
-template <int NU, int SLOW>
+// DIAG = false: eps = L z + mu with L = chol(Sigma) out of LDS (ac.Lm), a whole timestep at a time -- "correlated
+// Gaussian noise via a Cholesky-factored noise_sigma", applied in the lane that owns the sample (mppi.py:204-206).
+template <int NU, int SLOW, bool DIAG>
 __device__ __forceinline__ void onchip_actions(const ActionConsts<float, NU>& ac, const OnChipRow<NU>& row, int orow,
                                                float (&z)[Stream<NU>::P4 * 4], float (&v)[Stream<NU>::P4 * 4]) {
+  if constexpr (DIAG) {
+#pragma unroll
+    for (int f = 0; f < Stream<NU>::P4 * 4; ++f) v[f] = fmaf(z[f], ac.sd[f % NU], row.um[f]);   // mppi.py:201-206, :380
+  } else {
+#pragma unroll
+    for (int tt = 0; tt < Stream<NU>::TT; ++tt) {
+#pragma unroll
+      for (int n = 0; n < NU; ++n) {
+        float Lr[NU];
+        chol_row<float, NU>(ac.Lm, n, Lr);
+        float s = row.um[tt * NU + n];
+#pragma unroll
+        for (int m = 0; m <= n; ++m) s = fmaf(z[tt * NU + m], Lr[m], s);                         // L is lower triangular
+        v[tt * NU + n] = s;
+      }
+    }
+  }
 #pragma unroll
   for (int f = 0; f < Stream<NU>::P4 * 4; ++f) {
     const int n = f % NU;
-    float w = fmaf(z[f], ac.sd[n], row.um[f]);                          // mppi.py:201-206, :380
+    float w = v[f];
     if constexpr (SLOW == 1) w = orow == -1 ? 0.f : w;                  // :390-392
     w = clampT(w, ac.lo[n], ac.hi[n]);                                  // :383
     v[f] = w;
@@ -176,13 +196,13 @@ __device__ __forceinline__ float wave_reduce_transpose64_dpp(float (&v)[64]) {
 // LDS carve of the kernel (floats): Ue[Jp] Um[Jp] G[Jp] | red[4] | ex[4][ntiles*64] | keepL[nsl*P4][256][4],
 // Jp = the horizon padded to whole super-steps (a multiple of 4: every part starts on a 16-byte boundary)
 struct OnChipLds {
-  int Jp, ntiles, nsl, P4;
-  __host__ __device__ int tables() const { return 3 * Jp + 4; }
+  int Jp, ntiles, nsl, P4, nfac;     // nfac: 2 * nu * nu (chol(Sigma) | Sigma^-1) for a full Sigma, else 0
+  __host__ __device__ int tables() const { return 3 * Jp + 4 + ((nfac + 3) & ~3); }
   __host__ __device__ int ex() const { return 4 * ntiles * 64; }
   __host__ __device__ size_t bytes() const { return ((size_t)tables() + ex()) * 4 + (size_t)nsl * P4 * 256 * 16; }
 };
 
-template <class Model>
+template <class Model, bool DIAG>
 __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<float> a, const int nsl) {
   using T = float;
   constexpr int NX = Model::NX, NU = Model::NU;
@@ -195,11 +215,12 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
   const int nss = (a.Tn + TT - 1) / TT;
   const int ntiles = (nss + SW - 1) / SW;
   const int Jp = nss * P4 * 4;
-  const OnChipLds L{Jp, ntiles, nsl, P4};
+  const OnChipLds L{Jp, ntiles, nsl, P4, DIAG ? 0 : 2 * NU * NU};
   T* Ue = reinterpret_cast<T*>(smem_raw);
   T* Um = Ue + Jp;
   T* G = Um + Jp;
   T* red = G + Jp;
+  T* fac = red + 4;                      // [2*NU*NU] chol(Sigma) | Sigma^-1 (full Sigma only), 16-byte aligned
   T* ex = Ue + L.tables();
   float4* keepL = reinterpret_cast<float4*>(ex + L.ex());
   for (int j = threadIdx.x; j < Jp; j += K1_BLOCK) {
@@ -208,7 +229,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
     const T u = in ? u_eff(a, j) : T(0);
     Ue[j] = u;
     Um[j] = in ? u + a.mu[n] : T(0);
-    G[j] = in ? a.lambda_ * (u * a.sinv[n * NU + n]) : T(0);
+    if constexpr (DIAG) G[j] = in ? a.lambda_ * (u * a.sinv[n * NU + n]) : T(0);
   }
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int kraw = blockIdx.x * K1_BLOCK + threadIdx.x;
@@ -223,11 +244,23 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
     for (int i = 0; i < NX; ++i) x[i] = s0[i];                          // mppi.py:302-305
   }
   ActionConsts<T, NU> ac;
-  ac.load(a, nullptr);
+  ac.load(a, DIAG ? nullptr : fac);
   float keepA[OC::AG_ROWS * 4];
 #pragma unroll
   for (int i = 0; i < OC::AG_ROWS * 4; ++i) keepA[i] = i < 256 ? keep_in_agpr(0.f) : 0.f;   // rows beyond a short horizon read as zero noise
   __syncthreads();
+  if constexpr (!DIAG) {
+    // full Sigma: G[t,n] = lambda * sum_m Sigma^-1[n,m] U[t,m] needs the whole row of U and the factor block -> second pass
+    for (int j = threadIdx.x; j < Jp; j += K1_BLOCK) {
+      const int n = j % NU, t0 = j - n;
+      T g = T(0);
+      if (j < a.J) {
+        for (int m = 0; m < NU; ++m) g = fmaf(ac.Sm[n * NU + m], Ue[t0 + m], g);   // Sigma^-1 symmetric
+      }
+      G[j] = a.lambda_ * g;
+    }
+    __syncthreads();
+  }
   const StepTables<T> tb{Ue, Um, G, nullptr, kraw - lane};
   const long long kg = a.k_offset + k;
   const bool slow = __any(orow == -1);
@@ -257,8 +290,8 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
 #endif
       OnChipRow<NU> row;
       row.load(tb, ss < nss ? ss : nss - 1, true);
-      if (slow) onchip_actions<NU, 1>(ac, row, orow, zb[b], vb[b]);
-      else onchip_actions<NU, 0>(ac, row, orow, zb[b], vb[b]);
+      if (slow) onchip_actions<NU, 1, DIAG>(ac, row, orow, zb[b], vb[b]);
+      else onchip_actions<NU, 0, DIAG>(ac, row, orow, zb[b], vb[b]);
       if (plain) onchip_steps<Model, true>(a, ac, model, row, ss, zb[b], vb[b], x, rollout, pert);
       else onchip_steps<Model, false>(a, ac, model, row, ss, zb[b], vb[b], x, rollout, pert);
     }
@@ -354,8 +387,8 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
           for (int s = 0; s < RG; ++s) {
             OnChipRow<NU> row;
             row.load(tb, (ss0 + s) < nss ? ss0 + s : nss - 1, false);
-            if (slow) onchip_actions<NU, 1>(ac, row, orow, zg[s], vg);
-            else onchip_actions<NU, 0>(ac, row, orow, zg[s], vg);
+            if (slow) onchip_actions<NU, 1, DIAG>(ac, row, orow, zg[s], vg);
+            else onchip_actions<NU, 0, DIAG>(ac, row, orow, zg[s], vg);
 #pragma unroll
             for (int i = 0; i < P4; ++i)
 #pragma unroll
@@ -394,7 +427,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
 template <typename T>
 static bool onchip_problem_ok(const KArgs<T>& a) {
   static const int off = [] { const char* e = getenv("MPPI_ONCHIP"); return e ? atoi(e) == 0 : 0; }();
-  return !off && sizeof(T) == 4 && a.fuse >= 0 && a.noise_src == MPPI_NOISE_PHILOX && a.z == nullptr && a.diag != 0 && !a.coloured &&
+  return !off && sizeof(T) == 4 && a.fuse >= 0 && a.noise_src == MPPI_NOISE_PHILOX && a.z == nullptr && !a.coloured &&
          a.M == 1 && a.n_env == 1 && a.n_sampler == 0 && a.states == nullptr && a.B == nullptr && a.smooth_w == T(0) &&
          a.e_scale == T(1) && a.W == nullptr && a.record != nullptr && (a.fuse == 0 || a.U_out != nullptr) &&
          (a.K + K1_BLOCK - 1) / K1_BLOCK <= 8192;
@@ -413,7 +446,8 @@ static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
     onchip_carve(a);
     const int nss = (a.Tn + OC::TT - 1) / OC::TT;
     const int ntiles = (nss + OC::SW - 1) / OC::SW;
-    OnChipLds L{nss * OC::P4 * 4, ntiles, 0, OC::P4};
+    const bool diag = a.diag != 0;
+    OnChipLds L{nss * OC::P4 * 4, ntiles, 0, OC::P4, diag ? 0 : 2 * NU * NU};
     if (L.bytes() > 160 * 1024) return -1;
     const long long room = (160 * 1024 - (long long)L.bytes()) / ((long long)OC::P4 * 256 * 16);
     int nsl = nss - OC::AG_SS;
@@ -425,10 +459,15 @@ static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
     const dim3 grid(a.nkc), block(K1_BLOCK);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     profile_next_events(&ev0, &ev1, &a.tstamp);
-    if (smem > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)rollout_onchip_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (ev1 != nullptr) hipExtLaunchKernelGGL(rollout_onchip_kernel<Model>, grid, block, smem, st, ev0, ev1, 0, a, nsl);
-    else hipLaunchKernelGGL(rollout_onchip_kernel<Model>, grid, block, smem, st, a, nsl);
+#define MPPI_ONCHIP_LAUNCH(KERNEL)                                                                                  \
+  do {                                                                                                              \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    if (ev1 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a, nsl);                  \
+    else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, a, nsl);                                                 \
+  } while (0)
+    if (diag) MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, true>));
+    else MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, false>));
+#undef MPPI_ONCHIP_LAUNCH
     const int e = (int)hipGetLastError();
     return e != 0 ? e : MPPI_OK_ONCHIP;
   }

@@ -195,6 +195,7 @@ class MPPI:
         # rolls out, keeps the bounded noise in accumulation registers / LDS and leaves one partial record per workgroup,
         # a second one combines them.  None: whenever the problem is in its scope (fp32, diagonal Sigma, plain MPPI,
         # M = 1, no sampler rows) and too large for the single-launch form; True / False: force / forbid.
+        # (a full Sigma is coloured in the lane: L z + mu per timestep out of LDS)
         self.philox_onchip = None
         self._onchip_refused = False
         self._onchip_seen = 0
@@ -568,13 +569,18 @@ class MPPI:
         the engine, csrc/rollout_onchip.hpp `onchip_problem_ok`)?"""
         if self.philox_onchip is False or self._onchip_refused:
             return False
-        ok = (type(self) is MPPI and self.dtype == torch.float32 and self._diagonal_sigma and self.M == 1
+        ok = (type(self) is MPPI and self.dtype == torch.float32 and self.M == 1
               and self.specific_action_sampler is None and Tn == self.T and not self._needs_generic()
               and self._model.model_id != N.MODEL_MLP)      # the dense MLP has its own matrix-core K1
         if not ok:
             return False
         if self.philox_onchip:
             return True
+        if not self._diagonal_sigma:
+            # a full Sigma CAN run on chip (L z + mu per timestep in the lane, tested), but the factor rows come out of LDS
+            # every timestep and the kernel becomes LDS-issue-bound: 0.127 ms at C3 against 0.104 ms for rows coloured by the
+            # generator launch and streamed (profiles/r03_variants_philox.txt) -- only on request
+            return False
         # small problems run as ONE launch with the rows re-read out of L2 (rollout.hpp, FUSE): K <= 16384, T*nu <= 256
         rows4 = N.noise_rows4(Tn, nu)
         return not (K <= 16384 and 4 * rows4 <= 256)

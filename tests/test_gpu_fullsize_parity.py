@@ -238,9 +238,12 @@ def test_c5_eight_shards_of_the_mlp_equal_oracle_on_the_global_draw():
     assert 50 <= _n_eff(r64["omega"]) <= 50000
 
 
+@pytest.mark.parametrize("form", ["generator-coloured rows", "on-chip"])
 @pytest.mark.parametrize("regime", ["healthy", "peaked"])
-def test_c3_shape_full_sigma_mu_bounds_null_action_coloured_generator(regime):
-    """north_star: "correlated Gaussian noise sampled on-device via a Cholesky-factored noise_sigma".  C3's shape with a
+def test_c3_shape_full_sigma_mu_bounds_null_action_coloured_generator(regime, form):
+    """Both forms of the command: rows coloured by the generator launch and streamed (below), and the on-chip command with
+    L z + mu formed per timestep in the lane that owns the sample (csrc/rollout_onchip.hpp, DIAG = false).
+    north_star: "correlated Gaussian noise sampled on-device via a Cholesky-factored noise_sigma".  C3's shape with a
     NON-diagonal Sigma (12 x 12), a non-zero mean, action bounds and the null-action row, rng="philox": the generator launch
     writes eps = chol(Sigma) z + mu (mppi.py:201-206), K1 / K3 run their diagonal form on the coloured rows, the action
     cost uses the full Sigma^-1 (mppi.py:186-199).  The oracle gets the raw standard normals of the same command."""
@@ -256,8 +259,10 @@ def test_c3_shape_full_sigma_mu_bounds_null_action_coloured_generator(regime):
     umax = torch.full((nu,), 1.4, dtype=torch.float64)
 
     def make(lam):
-        return pm.MPPI(model.dynamics, model.running_cost, nx, sigma.float(), num_samples=K, horizon=T, device="cuda", lambda_=lam,
-                       U_init=U0.clone(), rng="philox", seed=4321, noise_mu=mu.float(), u_max=umax.float(), sample_null_action=True)
+        c = pm.MPPI(model.dynamics, model.running_cost, nx, sigma.float(), num_samples=K, horizon=T, device="cuda", lambda_=lam,
+                    U_init=U0.clone(), rng="philox", seed=4321, noise_mu=mu.float(), u_max=umax.float(), sample_null_action=True)
+        c.philox_onchip = True if form == "on-chip" else False      # (a full Sigma goes on chip only on request)
+        return c
     lam = 1.0
     for _ in range(2):
         probe = make(lam)
@@ -266,7 +271,10 @@ def test_c3_shape_full_sigma_mu_bounds_null_action_coloured_generator(regime):
         del probe
     ctrl = make(lam)
     act = ctrl.command(x0.cuda())
-    assert ctrl.last_draw == "philox-fill" and int(ctrl._last.noise_coloured) == 1, "the generator must have coloured the rows"
+    if form == "on-chip":
+        assert ctrl.last_draw == "philox-onchip", ctrl.last_draw
+    else:
+        assert ctrl.last_draw == "philox-fill" and int(ctrl._last.noise_coloured) == 1, "the generator must have coloured the rows"
     z = gpu_util.device_philox_normals(ctrl, 1)
     outs = []
     for dt in (torch.float64, torch.float32):
@@ -277,7 +285,7 @@ def test_c3_shape_full_sigma_mu_bounds_null_action_coloured_generator(regime):
     r64, r32 = outs
     got = dict(action=act, U=ctrl.U, cost_total=ctrl.cost_total, omega=ctrl.omega, perturbed_action=ctrl.perturbed_action,
                noise=ctrl.noise)
-    _check(f"c3 full Sigma + mu + bounds + null action / {regime}", got, r64, r32, keys=tuple(got))
+    _check(f"c3 full Sigma + mu + bounds + null action / {regime} / {form}", got, r64, r32, keys=tuple(got))
     assert torch.equal(ctrl.perturbed_action[0], torch.zeros(T, nu, device="cuda"))          # row bookkeeping: exact
     n_eff = _n_eff(r64["omega"])
     assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff

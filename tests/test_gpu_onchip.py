@@ -60,6 +60,11 @@ CASES = [
     ("linear", 10, 3, 17000, 33, dict(u_scale=2.0)),                         # nu = 3: 3 rows = 4 timesteps per super-step
     ("linear", 6, 3, 17000, 21, dict(sample_null_action=True, u_min=torch.tensor([-1.0] * 3), u_max=torch.tensor([0.7] * 3))),
     ("pendulum", 2, 1, 20000, 48, dict(u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0))),   # nu = 1: four timesteps per row
+    # full Sigma: L z + mu per timestep in the lane (the factor block in LDS), action cost with the whole Sigma^-1
+    ("integrator", 6, 4, 20000, 60, dict(sigma=torch.tensor([[0.9, 0.2, 0.0, -0.1], [0.2, 0.7, 0.1, 0.0], [0.0, 0.1, 0.5, 0.15], [-0.1, 0.0, 0.15, 0.8]]),
+                                         noise_mu=torch.tensor([0.05, -0.1, 0.0, 0.2]), sample_null_action=True,
+                                         u_min=torch.tensor([-1.0] * 4), u_max=torch.tensor([1.2] * 4))),
+    ("integrator", 12, 6, 17000, 33, dict(sigma=(torch.eye(6) * 0.6 + 0.1))),
     ("integrator", 4, 2, 300, 300, {}),                                      # long horizon at small K (forced on-chip); the pendulum is
                                                                              # chaotic over 300 steps: its fp32 floor swallows any bound
 ]
@@ -69,14 +74,16 @@ CASES = [
 def test_onchip_command_matches_streaming_command_and_fp64_oracle(case):
     from oracle import mppi_oracle as orc
     kind, nx, nu, K, T, kw = case
+    kw = dict(kw)
+    sig = kw.pop("sigma", None)
     # a healthy lambda from a probe command (cost spread of this problem)
-    probe, _, _, _ = _make(kind, nx, nu, K, T, False, **kw)
+    probe, _, _, _ = _make(kind, nx, nu, K, T, False, sigma=sig, **kw)
     x0 = torch.randn(nx, generator=torch.Generator().manual_seed(3))
     probe.command(x0.cuda())
     lam = float(probe.cost_total.double().std()) + 1e-3
     del probe
-    a, mk, sigma, U0 = _make(kind, nx, nu, K, T, True, lam=lam, **kw)
-    b, _, _, _ = _make(kind, nx, nu, K, T, False, lam=lam, **kw)
+    a, mk, sigma, U0 = _make(kind, nx, nu, K, T, True, lam=lam, sigma=sig, **kw)
+    b, _, _, _ = _make(kind, nx, nu, K, T, False, lam=lam, sigma=sig, **kw)
     n0 = _onchip_count()
     for step, shift in enumerate((True, False, True)):
         U_before = a.U.clone()
@@ -148,13 +155,12 @@ def test_onchip_peaked_softmax_and_determinism():
 
 
 def test_onchip_scope_falls_back_without_error():
-    """Outside the form's scope (full Sigma here) the same call runs the streaming command."""
+    """Outside the form's scope (fp64 here) the same call runs the streaming command."""
     import pytorch_mppi_amd as pm
     nx, nu, K, T = 6, 4, 20000, 40
     model = pm.models.Integrator(nx, nu)
-    S = torch.eye(nu) * 0.5
-    S[0, 1] = S[1, 0] = 0.1
-    c = pm.MPPI(model.dynamics, model.running_cost, nx, S, num_samples=K, horizon=T, device="cuda", lambda_=5.0, rng="philox", seed=3)
+    c = pm.MPPI(model.dynamics, model.running_cost, nx, torch.eye(nu, dtype=torch.float64) * 0.5, num_samples=K, horizon=T,
+                device="cuda", lambda_=5.0, rng="philox", seed=3)
     n0 = _onchip_count()
-    c.command(torch.zeros(nx).cuda())
+    c.command(torch.zeros(nx, dtype=torch.float64).cuda())
     assert _onchip_count() == n0 and c.last_draw == "philox-fill"
