@@ -581,9 +581,12 @@ class MPPI:
             # every timestep and the kernel becomes LDS-issue-bound: 0.127 ms at C3 against 0.104 ms for rows coloured by the
             # generator launch and streamed (profiles/r03_variants_philox.txt) -- only on request
             return False
-        # small problems run as ONE launch with the rows re-read out of L2 (rollout.hpp, FUSE): K <= 16384, T*nu <= 256
-        rows4 = N.noise_rows4(Tn, nu)
-        return not (K <= 16384 and 4 * rows4 <= 256)
+        # On chip every lane generates its own rows one after the other (~0.35 us per row-of-4 however small K is): the
+        # launch costs the same ~80 us at C3's horizon for K = 1024 and K = 65536, while the streaming form spreads the
+        # generation over the chip.  Measured at T = 64, nu = 12 (tools/k_sweep.py, profiles/r03_k_sweep.txt against
+        # r02_k_sweep.txt): K = 16384 0.083 vs 0.056 ms, K = 65536 0.087 vs 0.106, K >= 262144 8.0e8 vs 5.9e8 rollouts/s ->
+        # from three quarters of a full chip (one wave per SIMD = 65536 samples) upwards
+        return K >= 49152
 
     def _ktn_direct_ok(self, p, Tn, nu, z):
         return (self.ktn_direct and self.M == 1 and self.dtype == torch.float32 and self._diagonal_sigma and (Tn * nu) % 4 == 0

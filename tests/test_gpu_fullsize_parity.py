@@ -297,7 +297,7 @@ def test_c3_two_shards_equal_oracle_on_global_draw(form):
     per-shard Philox rows are the rows of the global stream, K5 combines in rank order; against the
     fp64 oracle run on the GLOBAL draw.  Both forms of the per-shard command: rows in memory, and on chip."""
     global ONCHIP
-    ONCHIP = False if form == "streaming" else None
+    ONCHIP = False if form == "streaming" else True      # (32768 samples per shard: below the size at which on-chip is the default)
     try:
         _two_shards(form)
     finally:

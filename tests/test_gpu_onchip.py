@@ -164,3 +164,29 @@ def test_onchip_scope_falls_back_without_error():
     n0 = _onchip_count()
     c.command(torch.zeros(nx, dtype=torch.float64).cuda())
     assert _onchip_count() == n0 and c.last_draw == "philox-fill"
+
+
+def test_onchip_with_a_traced_user_model_and_many_chunks():
+    """A model that came out of the tracer (tests/jit_fixtures.py: the reference's linear dynamics + goal cost + terminal cost as
+    plain callables) on the on-chip command, at a K that needs several workgroups per CU (K = 300000: 1172 workgroups),
+    against the streaming form of the same stream."""
+    import jit_fixtures as jf
+    import pytorch_mppi_amd as pm
+    f, q, term = jf.ref_linear_callables()
+
+    def make(onchip):
+        c = pm.MPPI(f, q, 2, torch.eye(2), num_samples=300000, horizon=40, device="cuda", lambda_=30.0, terminal_state_cost=term,
+                    u_min=torch.tensor([-1.0, -1.0]), u_max=torch.tensor([1.0, 1.0]), rng="philox", seed=11, auto_jit=True,
+                    U_init=torch.zeros(40, 2))     # (without it every controller draws its own random initial sequence)
+        assert not c._needs_generic(), c.jit_note
+        c.philox_onchip = onchip
+        return c
+    a, b = make(None), make(False)
+    x0 = torch.tensor([-1.0, 0.5]).cuda()
+    n0 = _onchip_count()
+    for _ in range(2):
+        ua, ub = a.command(x0), b.command(x0)
+    assert _onchip_count() - n0 == 2 and a.last_draw == "philox-onchip"
+    assert float((a.cost_total - b.cost_total).abs().max()) <= 1e-5 * float(b.cost_total.abs().max())
+    assert float((ua - ub).abs().max()) <= 1e-5 * max(1.0, float(ub.abs().max()))
+    assert float((a.U - b.U).abs().max()) <= 1e-5 * max(1.0, float(b.U.abs().max()))
