@@ -214,6 +214,13 @@ def k1_hbm_cold(ctrl, n=32):
             "buffers": nbuf, "bytes_cycled": 4 * n_el * nbuf}
 
 
+def _pmc_lookup(key, kernel):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[key][kernel]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def latency_synced(ctrl, x0, warmup=3, iters=20):
     """The reference's timing protocol (/root/reference/tests/benchmark_mppi.py:84-113): warm-ups without the
     shift, then per iteration reset() + state.clone() outside the clock, synchronize, ONE command, synchronize.
@@ -460,6 +467,9 @@ def main():
                   "launch_us_device_span": oc_dev, "avg_launch_us_hip_events": oc_ev["avg"] if oc_ev else None,
                   "dispatch_offset_us": DISPATCH_OFFSET_US_ONCHIP,
                   "hbm_bytes_algorithmic": 4 * ctrl.K_local + 4 * (ctrl.K_local // 256 + 1) * (T * nu + 2),
+                  "traffic": _pmc_lookup(f"{args.workload}/philox-onchip", "rollout_onchip_kernel") if world == 1 else None,
+                  "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                    "profiles/r03_pmc_onchip_*.txt; a lookup, not measured in this run)",
                   "external_z_equivalent_GBs": ext_bytes / (oc_us * 1e-6) / 1e9 if oc_us else None,
                   "bound": "VALU: Philox4x32-10 + Box-Muller of the sample's T*nu normals (generated once, ~half of them a "
                            "second time in the weighting phase: the rest stays in accumulation registers / LDS), ~80 % of the "
