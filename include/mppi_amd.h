@@ -274,8 +274,8 @@ int mppi_command(const MppiProblem* p, int apply, void* stream);
 /* process-wide count of mppi_command calls that ran in the single-launch form (tests, bench) */
 int64_t mppi_stat_single_launch_commands(void);
 /* The ON-CHIP form of mppi_command (ABI 18, csrc/rollout_onchip.hpp): noise_src == MPPI_NOISE_PHILOX with p->z == NULL
- * ("no row array: the normals are a pure function of seed, call, sample, row") on a fused fp32 model with a diagonal
- * Sigma, plain MPPI (no base_seq / smooth_weight / S), rollout_samples <= 1, no sampler rows, no `states`, one
+ * ("no row array: the normals are a pure function of seed, call, sample, row") on a fused fp32 model with a diagonal or full
+ * Sigma, MPPI or SMPPI (base_seq / noise_rescale / smooth_weight honoured; no S), rollout_samples <= 1, no sampler rows, no `states`, one
  * environment.  ONE launch generates each sample's normals, rolls out, keeps the bounded noise on chip (accumulation
  * registers + LDS; what does not fit is generated a second time) and reduces it into one partial record
  * {beta_b, eta_b, P_b} per 256-sample workgroup, relative to the workgroup's own minimum; a second, small launch

@@ -18,22 +18,26 @@ LIB = os.path.join(HERE, f"libmppi_amd{SUFFIX}.so")
 OBJ_DIR = os.path.join(CSRC, "build" + SUFFIX)
 SOURCES = ["capi.hip", "dist.hip", "update.hip", "rollout_pendulum.hip", "rollout_integrator.hip",
            "rollout_linear_goal.hip", "rollout_mlp.hip", "rollout_mlp_mfma.hip", "rollout_mlp_split.hip"]
-# translation units: (source, object name, extra flags).  The two heaviest sources are compiled as two units each
+# translation units: (source, object name, extra flags).  The two heaviest sources are compiled as several units each
 # (groups of model dimensions selected with a define) so that the parallel build is not one long compile
-_GROUPS = {"rollout_integrator.hip": "MPPI_INTEGRATOR_GROUP", "rollout_linear_goal.hip": "MPPI_LINEAR_GROUP"}
+_GROUPS = {"rollout_integrator.hip": ("MPPI_INTEGRATOR_GROUP", 4), "rollout_linear_goal.hip": ("MPPI_LINEAR_GROUP", 3),
+           "rollout_mlp.hip": ("MPPI_MLP_GROUP", 3)}
 
 
 def _units():
     units = []
     for src in SOURCES:
         if src in _GROUPS:
-            for g in (0, 1):
-                units.append((src, src.replace(".hip", f"_g{g}.o"), [f"-D{_GROUPS[src]}={g}"]))
+            for g in range(_GROUPS[src][1]):
+                units.append((src, src.replace(".hip", f"_g{g}.o"), [f"-D{_GROUPS[src][0]}={g}"]))
         else:
             units.append((src, src.replace(".hip", ".o"), []))
-    # longest first: the pool starts the big ones before the small ones
-    heavy = {"rollout_integrator.hip": 0, "rollout_linear_goal.hip": 1, "update.hip": 2, "rollout_mlp.hip": 3}
-    return sorted(units, key=lambda u: heavy.get(u[0], 9))
+    # longest first (measured seconds per unit on the build container, 8 at a time): the pool starts the big ones first
+    cost = {"update.o": 165, "rollout_linear_goal_g2.o": 126, "rollout_integrator_g2.o": 90, "rollout_integrator_g0.o": 88,
+            "rollout_integrator_g1.o": 83, "rollout_linear_goal_g0.o": 79, "rollout_mlp_g0.o": 78, "rollout_mlp_g1.o": 75,
+            "rollout_mlp_g2.o": 75, "rollout_pendulum.o": 70, "rollout_linear_goal_g1.o": 68, "rollout_integrator_g3.o": 45,
+            "rollout_mlp_split.o": 27}
+    return sorted(units, key=lambda u: -cost.get(u[1], 5))
 # -ffp-contract=fast: mul+add pairs fuse into v_fma / v_pk_fma.  torch eager rounds twice where
 # the kernels round once, a <= 1 ulp difference per operation that the parity tests bound
 # (1e-5 relative fp32, 1e-9 fp64 on every public output of command()).

@@ -4,21 +4,53 @@
 #include "dispatch.hpp"
 #include "rollout.hpp"
 namespace mppi {
-#define MPPI_MLP_DIMS(X) X(16, 4) X(2, 1) X(4, 2)
+// One translation unit per (nx,nu) pair (MPPI_MLP_GROUP, set by _build.py; chained like rollout_integrator.hip): the per-lane
+// MLP with its runtime hidden width was a 224-second compile as one unit, the longest of the build.
+#ifndef MPPI_MLP_GROUP
+#define MPPI_MLP_GROUP 0
+#endif
+#define MPPI_MLP_DIMS_0(X) X(16, 4)
+#define MPPI_MLP_DIMS_1(X) X(2, 1)
+#define MPPI_MLP_DIMS_2(X) X(4, 2)
+#if MPPI_MLP_GROUP == 0
+#define MPPI_DIMS MPPI_MLP_DIMS_0
+#define MPPI_THIS rollout_mlp_valu
+#define MPPI_NEXT rollout_mlp_valu_g1
 bool supported_mlp(int nx, int nu, int hidden) {
   if (hidden <= 0) return false;
 #define X(NX, NU) if (nx == NX && nu == NU) return true;
-  MPPI_MLP_DIMS(X)
+  MPPI_MLP_DIMS_0(X) MPPI_MLP_DIMS_1(X) MPPI_MLP_DIMS_2(X)
 #undef X
   return false;
 }
+#elif MPPI_MLP_GROUP == 1
+#define MPPI_DIMS MPPI_MLP_DIMS_1
+#define MPPI_THIS rollout_mlp_valu_g1
+#define MPPI_NEXT rollout_mlp_valu_g2
+#else
+#define MPPI_DIMS MPPI_MLP_DIMS_2
+#define MPPI_THIS rollout_mlp_valu_g2
+#endif
+#ifdef MPPI_NEXT
+int MPPI_NEXT(const KArgs<float>& a, hipStream_t st);
+int MPPI_NEXT(const KArgs<double>& a, hipStream_t st);
+#endif
 template <typename T> static int go(const KArgs<T>& a, hipStream_t st) {
   if (a.mp == nullptr || a.hidden <= 0) return MPPI_E_BADARG;
 #define X(NX, NU) if (a.nx == NX && a.nu == NU) return launch_rollout<MlpModel<T, NX, NU>, T>(a, st);
-  MPPI_MLP_DIMS(X)
+  MPPI_DIMS(X)
 #undef X
+#ifdef MPPI_NEXT
+  return MPPI_NEXT(a, st);
+#else
   return MPPI_E_UNSUPPORTED;
+#endif
 }
+#if MPPI_MLP_GROUP != 0
+int MPPI_THIS(const KArgs<float>& a, hipStream_t st) { return go(a, st); }
+int MPPI_THIS(const KArgs<double>& a, hipStream_t st) { return go(a, st); }
+}  // namespace mppi
+#else
 int rollout_mlp(const KArgs<float>& a, hipStream_t st) {
   if (a.W != nullptr) return MPPI_E_UNSUPPORTED;   // KMPPI: the matrix-core kernels read raw action rows (two-launch form)
   // fp32 + (nx,nu)=(16,4): matrix-core kernels.  hidden = 256: 16-bit MFMAs on split operands (bf16 x 3
@@ -41,3 +73,4 @@ int rollout_mlp(const KArgs<float>& a, hipStream_t st) {
 }
 int rollout_mlp(const KArgs<double>& a, hipStream_t st) { return go(a, st); }
 }  // namespace mppi
+#endif

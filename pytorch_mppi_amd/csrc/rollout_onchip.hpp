@@ -19,8 +19,8 @@
 // block order and applies K4.  Measured at C3 (tools/micro/k1ret_micro.hip, profiles/r03_k1ret_micro*.txt):
 // G alone 34.6 us (the chip-wide generator floor), G+R 41-45 us, whole kernel 72-78 us against 34 + 33 + 36 us
 // for generator + K1 + K3.
-// Scope: fp32, diagonal or full Sigma (colouring in the lane; not a generator-coloured stream), plain MPPI (no SMPPI base
-// sequence, no KMPPI), M = 1,
+// Scope: fp32, diagonal or full Sigma (colouring in the lane; not a generator-coloured stream), MPPI and SMPPI (base sequence,
+// 1/dt rescaling, smoothness cost) but not KMPPI, M = 1,
 // no sampler rows (the sample_null_action row is handled), no `states` output, one environment.
 #pragma once
 // (included from rollout.hpp, inside its include set)
@@ -83,7 +83,8 @@ struct OnChipRow {
 // (Timesteps beyond the horizon -- the padding of the last super-step -- give values nobody reads.)
 // DIAG = false: eps = L z + mu with L = chol(Sigma) out of LDS (ac.Lm), a whole timestep at a time -- "correlated
 // Gaussian noise via a Cholesky-factored noise_sigma", applied in the lane that owns the sample (mppi.py:204-206).
-template <int NU, int SLOW, bool DIAG>
+// ESC: the bounded noise is rescaled (SMPPI: eps' = (v - B) / dt, mppi.py:544)
+template <int NU, bool DIAG, bool ESC = false>
 __device__ __forceinline__ void onchip_actions(const ActionConsts<float, NU>& ac, const OnChipRow<NU>& row, int orow,
                                                float (&z)[Stream<NU>::P4 * 4], float (&v)[Stream<NU>::P4 * 4]) {
   if constexpr (DIAG) {
@@ -107,24 +108,35 @@ __device__ __forceinline__ void onchip_actions(const ActionConsts<float, NU>& ac
   for (int f = 0; f < Stream<NU>::P4 * 4; ++f) {
     const int n = f % NU;
     float w = v[f];
-    if constexpr (SLOW == 1) w = orow == -1 ? 0.f : w;                  // :390-392
+    w = orow == -1 ? 0.f : w;                                           // :390-392 (one v_cndmask per control)
     w = clampT(w, ac.lo[n], ac.hi[n]);                                  // :383
     v[f] = w;
-    z[f] = w - row.ue[f];                                               // :385
+    z[f] = ESC ? (w - row.ue[f]) * ac.e_scale : w - row.ue[f];          // :385 (SMPPI :544)
   }
 }
 
-// PLAIN: no |noise| cost and u_scale == 1 (the common case, wave-uniform): no select and no multiply per control
+// PLAIN: no |noise| cost, u_scale == 1, no SMPPI terms (the common case, wave-uniform): no select and no multiply per control
 template <class Model, bool PLAIN>
 __device__ __forceinline__ void onchip_steps(const KArgs<float>& a, const ActionConsts<float, Model::NU>& ac, const Model& model,
                                              const OnChipRow<Model::NU>& row, int ss, const float (&e)[Stream<Model::NU>::P4 * 4],
-                                             const float (&v)[Stream<Model::NU>::P4 * 4], float (&x)[Model::NX], float& rollout,
-                                             float& pert) {
+                                             const float (&v)[Stream<Model::NU>::P4 * 4], float (&x)[Model::NX], float (&vprev)[Model::NU],
+                                             float& rollout, float& pert) {
   constexpr int NU = Model::NU, TT = Stream<NU>::TT;
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     const int t = ss * TT + tt;
     if (t < a.Tn) {
+      if (!PLAIN && a.smooth_w != 0.f) {
+        // SMPPI smoothness cost w * |u_scale * (v[t] - v[t-1])|^2 (mppi.py:559-562), as rollout_step has it
+        float d2 = 0.f;
+#pragma unroll
+        for (int n = 0; n < NU; ++n) {
+          const float d = v[tt * NU + n] - vprev[n];
+          d2 = fmaf(d, d, d2);
+          vprev[n] = v[tt * NU + n];
+        }
+        if (t > 0) rollout = fmaf(a.smooth_w, d2, rollout);
+      }
       float u[NU];
 #pragma unroll
       for (int n = 0; n < NU; ++n) {
@@ -226,10 +238,10 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
   for (int j = threadIdx.x; j < Jp; j += K1_BLOCK) {
     const bool in = j < a.J;
     const int n = j % NU;
-    const T u = in ? u_eff(a, j) : T(0);
+    const T u = in ? u_base(a, j) : T(0);         // what the noise is added to and measured from (SMPPI: A + U dt)
     Ue[j] = u;
     Um[j] = in ? u + a.mu[n] : T(0);
-    if constexpr (DIAG) G[j] = in ? a.lambda_ * (u * a.sinv[n * NU + n]) : T(0);
+    if constexpr (DIAG) G[j] = in ? a.lambda_ * ((a.B != nullptr ? u_eff(a, j) : u) * a.sinv[n * NU + n]) : T(0);   // always the true U
   }
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int kraw = blockIdx.x * K1_BLOCK + threadIdx.x;
@@ -255,7 +267,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
       const int n = j % NU, t0 = j - n;
       T g = T(0);
       if (j < a.J) {
-        for (int m = 0; m < NU; ++m) g = fmaf(ac.Sm[n * NU + m], Ue[t0 + m], g);   // Sigma^-1 symmetric
+        for (int m = 0; m < NU; ++m) g = fmaf(ac.Sm[n * NU + m], a.B != nullptr ? u_eff(a, t0 + m) : Ue[t0 + m], g);   // Sigma^-1 symmetric
       }
       G[j] = a.lambda_ * g;
     }
@@ -263,8 +275,10 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
   }
   const StepTables<T> tb{Ue, Um, G, nullptr, kraw - lane};
   const long long kg = a.k_offset + k;
-  const bool slow = __any(orow == -1);
-  const bool plain = !a.abs_cost && a.u_scale == 1.f;
+  const bool plain = !a.abs_cost && a.u_scale == 1.f && a.e_scale == 1.f && a.smooth_w == 0.f;
+  T vprev[NU];
+#pragma unroll
+  for (int n = 0; n < NU; ++n) vprev[n] = T(0);
 
   // ---- G + R: a batch of PB super-steps at a time ----
   T rollout = 0.f, pert = 0.f;
@@ -290,10 +304,13 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
 #endif
       OnChipRow<NU> row;
       row.load(tb, ss < nss ? ss : nss - 1, true);
-      if (slow) onchip_actions<NU, 1, DIAG>(ac, row, orow, zb[b], vb[b]);
-      else onchip_actions<NU, 0, DIAG>(ac, row, orow, zb[b], vb[b]);
-      if (plain) onchip_steps<Model, true>(a, ac, model, row, ss, zb[b], vb[b], x, rollout, pert);
-      else onchip_steps<Model, false>(a, ac, model, row, ss, zb[b], vb[b], x, rollout, pert);
+      if (plain) {
+        onchip_actions<NU, DIAG>(ac, row, orow, zb[b], vb[b]);
+        onchip_steps<Model, true>(a, ac, model, row, ss, zb[b], vb[b], x, vprev, rollout, pert);
+      } else {
+        onchip_actions<NU, DIAG, true>(ac, row, orow, zb[b], vb[b]);
+        onchip_steps<Model, false>(a, ac, model, row, ss, zb[b], vb[b], x, vprev, rollout, pert);
+      }
     }
 #if defined(MPPI_ONCHIP_EXP) && (MPPI_ONCHIP_EXP & 4)      // experiment: nothing kept
     continue;
@@ -387,8 +404,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
           for (int s = 0; s < RG; ++s) {
             OnChipRow<NU> row;
             row.load(tb, (ss0 + s) < nss ? ss0 + s : nss - 1, false);
-            if (slow) onchip_actions<NU, 1, DIAG>(ac, row, orow, zg[s], vg);
-            else onchip_actions<NU, 0, DIAG>(ac, row, orow, zg[s], vg);
+            onchip_actions<NU, DIAG, true>(ac, row, orow, zg[s], vg);      // (e_scale == 1 multiplies by one)
 #pragma unroll
             for (int i = 0; i < P4; ++i)
 #pragma unroll
@@ -428,8 +444,8 @@ template <typename T>
 static bool onchip_problem_ok(const KArgs<T>& a) {
   static const int off = [] { const char* e = getenv("MPPI_ONCHIP"); return e ? atoi(e) == 0 : 0; }();
   return !off && sizeof(T) == 4 && a.fuse >= 0 && a.noise_src == MPPI_NOISE_PHILOX && a.z == nullptr && !a.coloured &&
-         a.M == 1 && a.n_env == 1 && a.n_sampler == 0 && a.states == nullptr && a.B == nullptr && a.smooth_w == T(0) &&
-         a.e_scale == T(1) && a.W == nullptr && a.record != nullptr && (a.fuse == 0 || a.U_out != nullptr) &&
+         a.M == 1 && a.n_env == 1 && a.n_sampler == 0 && a.states == nullptr && a.W == nullptr && a.record != nullptr &&
+         (a.fuse == 0 || a.U_out != nullptr) &&
          (a.K + K1_BLOCK - 1) / K1_BLOCK <= 8192;
 }
 
@@ -440,6 +456,13 @@ static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
     return -1;
   } else {
     if (!onchip_problem_ok(a_in)) return -1;
+#ifndef MPPI_ONCHIP_FULL_SIGMA
+    // The full-Sigma form (DIAG = false: L z + mu per timestep in the lane) is written and was tested at full size, but it is
+    // LDS-issue-bound on the factor rows -- 0.127 ms at C3 against 0.104 ms for rows coloured by the generator launch and
+    // streamed (profiles/r03_variants_philox.txt) -- and doubled this header's compile time in every model unit: not
+    // instantiated unless the build defines MPPI_ONCHIP_FULL_SIGMA.
+    if (a_in.diag == 0) return -1;
+#endif
     constexpr int NU = Model::NU;
     using OC = OnChip<NU>;
     KArgs<T> a = a_in;
@@ -466,7 +489,9 @@ static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
     else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, a, nsl);                                                 \
   } while (0)
     if (diag) MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, true>));
+#ifdef MPPI_ONCHIP_FULL_SIGMA
     else MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, false>));
+#endif
 #undef MPPI_ONCHIP_LAUNCH
     const int e = (int)hipGetLastError();
     return e != 0 ? e : MPPI_OK_ONCHIP;

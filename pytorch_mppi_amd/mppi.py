@@ -569,18 +569,19 @@ class MPPI:
         the engine, csrc/rollout_onchip.hpp `onchip_problem_ok`)?"""
         if self.philox_onchip is False or self._onchip_refused:
             return False
-        ok = (type(self) is MPPI and self.dtype == torch.float32 and self.M == 1
+        ok = (type(self).__name__ in ("MPPI", "SMPPI") and self.dtype == torch.float32 and self.M == 1
               and self.specific_action_sampler is None and Tn == self.T and not self._needs_generic()
               and self._model.model_id != N.MODEL_MLP)      # the dense MLP has its own matrix-core K1
         if not ok:
             return False
+        if not self._diagonal_sigma:
+            # a full Sigma CAN run on chip (L z + mu per timestep in the lane; csrc/rollout_onchip.hpp behind
+            # MPPI_ONCHIP_FULL_SIGMA, tested at full size), but the factor rows come out of LDS every timestep and the
+            # kernel becomes LDS-issue-bound: 0.127 ms at C3 against 0.104 ms for rows coloured by the generator launch
+            # and streamed (profiles/r03_variants_philox.txt) -- not in the product build
+            return False
         if self.philox_onchip:
             return True
-        if not self._diagonal_sigma:
-            # a full Sigma CAN run on chip (L z + mu per timestep in the lane, tested), but the factor rows come out of LDS
-            # every timestep and the kernel becomes LDS-issue-bound: 0.127 ms at C3 against 0.104 ms for rows coloured by the
-            # generator launch and streamed (profiles/r03_variants_philox.txt) -- only on request
-            return False
         # On chip every lane generates its own rows one after the other (~0.35 us per row-of-4 however small K is): the
         # launch costs the same ~80 us at C3's horizon for K = 1024 and K = 65536, while the streaming form spreads the
         # generation over the chip.  Measured at T = 64, nu = 12 (tools/k_sweep.py, profiles/r03_k_sweep.txt against

@@ -238,11 +238,10 @@ def test_c5_eight_shards_of_the_mlp_equal_oracle_on_the_global_draw():
     assert 50 <= _n_eff(r64["omega"]) <= 50000
 
 
-@pytest.mark.parametrize("form", ["generator-coloured rows", "on-chip"])
 @pytest.mark.parametrize("regime", ["healthy", "peaked"])
-def test_c3_shape_full_sigma_mu_bounds_null_action_coloured_generator(regime, form):
-    """Both forms of the command: rows coloured by the generator launch and streamed (below), and the on-chip command with
-    L z + mu formed per timestep in the lane that owns the sample (csrc/rollout_onchip.hpp, DIAG = false).
+def test_c3_shape_full_sigma_mu_bounds_null_action_coloured_generator(regime, form="generator-coloured rows"):
+    """(The on-chip command has a full-Sigma form too -- L z + mu per timestep in the lane -- which passed this very test; it
+    measured slower than the path below and is not part of the product build: csrc/rollout_onchip.hpp, MPPI_ONCHIP_FULL_SIGMA.)
     north_star: "correlated Gaussian noise sampled on-device via a Cholesky-factored noise_sigma".  C3's shape with a
     NON-diagonal Sigma (12 x 12), a non-zero mean, action bounds and the null-action row, rng="philox": the generator launch
     writes eps = chol(Sigma) z + mu (mppi.py:201-206), K1 / K3 run their diagonal form on the coloured rows, the action
@@ -373,9 +372,11 @@ def test_c3_shape_kmppi_65536x64_s32_interpolation_inside_k1(rng, regime):
     assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff
 
 
+@pytest.mark.parametrize("form", ["streaming", "on-chip"])
 @pytest.mark.parametrize("regime", ["healthy", "peaked"])
-def test_c3_shape_smppi_65536x64_lifted_controls(regime):
-    """SMPPI (mppi.py:451-570) at the headline shape on the engine's Philox rows: shift of both sequences and
+def test_c3_shape_smppi_65536x64_lifted_controls(regime, form):
+    """Both forms of the command (rows in memory; on chip: csrc/rollout_onchip.hpp with the base sequence, the 1/dt rescaling
+    and the smoothness cost).  SMPPI (mppi.py:451-570) at the headline shape on the engine's Philox rows: shift of both sequences and
     the base sequence in one launch, K1 with the smoothness cost, K3 / K4 with the 1/dt rescaling; against
     `oracle.smppi_command` in fp64 / fp32 on the consumed draw (action = integrated action sequence)."""
     import pytorch_mppi_amd as pm
@@ -387,8 +388,10 @@ def test_c3_shape_smppi_65536x64_lifted_controls(regime):
     amax = torch.full((nu,), 1.2)
 
     def make(lam):
-        return pm.SMPPI(model.dynamics, model.running_cost, cfg["nx"], sigma, num_samples=K, horizon=T, device="cuda", lambda_=lam,
-                        rng="philox", seed=4321, U_init=U0.clone(), action_max=amax, w_action_seq_cost=w_, delta_t=dt_)
+        c = pm.SMPPI(model.dynamics, model.running_cost, cfg["nx"], sigma, num_samples=K, horizon=T, device="cuda", lambda_=lam,
+                     rng="philox", seed=4321, U_init=U0.clone(), action_max=amax, w_action_seq_cost=w_, delta_t=dt_)
+        c.philox_onchip = None if form == "on-chip" else False
+        return c
     lam = 1.0
     for _ in range(2):
         probe = make(lam)
@@ -399,6 +402,7 @@ def test_c3_shape_smppi_65536x64_lifted_controls(regime):
     A0 = ctrl.action_sequence.detach().cpu().clone()     # = U_init (mppi.py:479-483); the lifted control starts at zero
     Ud0 = ctrl.U.detach().cpu().clone()
     act = ctrl.command(x0.cuda())
+    assert ctrl.last_draw == ("philox-onchip" if form == "on-chip" else "philox-fill"), ctrl.last_draw
     z = _consumed_normals(ctrl)
     outs = []
     for dt in (torch.float64, torch.float32):
@@ -407,7 +411,7 @@ def test_c3_shape_smppi_65536x64_lifted_controls(regime):
         outs.append(orc.smppi_command(p, Ud0.to(dt), A0.to(dt), x0.to(dt), z.to(dt), -amax.to(dt), amax.to(dt), w_, dt_, True))
     r64, r32 = outs
     got = dict(action=act, U=ctrl.U, action_sequence=ctrl.action_sequence, cost_total=ctrl.cost_total, omega=ctrl.omega)
-    _check(f"smppi 65536x64 {regime}", got, r64, r32, keys=tuple(got))
+    _check(f"smppi 65536x64 {regime} {form}", got, r64, r32, keys=tuple(got))
     n_eff = _n_eff(r64["omega"])
     assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff
 
