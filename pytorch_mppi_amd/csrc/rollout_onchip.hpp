@@ -6,22 +6,23 @@
 //   G  generate the rows of the sample (Philox4x32-10 + Box-Muller, common.hpp), a batch of super-steps at a time,
 //   R  roll out (mppi.py:297-332, :375-420, :186-199 -- the arithmetic of rollout_step), and KEEP the bounded
 //      noise eps' = clamp(U + eps) - U (:385) ON CHIP until the sample's weight is known:
-//        * the first 5 weighting tiles (300 / 320 values) in registers, 256 of them accumulation registers -- the kernel runs one wave
-//          per SIMD anyway (K = 65536 is one wave per SIMD of work), the AGPR half of the unified 512-entry
-//          register file is otherwise idle;
+//        * the first 5 weighting tiles (300 / 320 values) in registers, 256 of them accumulation registers -- the
+//          kernel runs one wave per SIMD anyway (K = 65536 is one wave per SIMD of work), the AGPR half of the
+//          unified 512-entry register file is otherwise idle;
 //        * the next `nsl` super-steps in LDS ([row][thread][4], one conflict-free ds_write/read_b128 per row);
-//        * what does not fit is generated a second time in W (the generator is ~80 % of this kernel's time);
+//        * what does not fit is generated a second time in W (the generator is ~60 % of this kernel's time);
 //   W  the workgroup's own part of K3 (mppi.py:254-259, :268): weights relative to the WORKGROUP's minimum
 //      beta_b, eta_b, P_b[j] = sum_k w_k eps'_k[j] over its 256 samples -- the algebra of the single-launch
 //      command (rollout.hpp FUSE block) and of the multi-GPU combine.  Column sums by a transposing wave reduction
 //      on v_permlane32_swap / v_permlane16_swap / DPP (no LDS crossbar), the four waves' results combined once.
 // A second, small launch (finalize_blocks_kernel, update.hip) rescales and sums the K/256 partial records in
-// block order and applies K4.  Measured at C3 (tools/micro/k1ret_micro.hip, profiles/r03_k1ret_micro*.txt):
-// G alone 34.6 us (the chip-wide generator floor), G+R 41-45 us, whole kernel 72-78 us against 34 + 33 + 36 us
-// for generator + K1 + K3.
-// Scope: fp32, diagonal or full Sigma (colouring in the lane; not a generator-coloured stream), MPPI and SMPPI (base sequence,
-// 1/dt rescaling, smoothness cost) but not KMPPI, M = 1,
-// no sampler rows (the sample_null_action row is handled), no `states` output, one environment.
+// block order and applies K4.  Measured at C3 (tools/micro/onchip_parts.hip on THIS kernel, profiles/r03_onchip_parts.txt,
+// r03_final_*; prototypes: tools/micro/k1ret_micro.hip): G alone 33.9 us (the chip-wide generator floor), + R 15, + keeping 3,
+// W 29 (second generation 17.5, reduction 11.5): 81-83 us back to back, 88-90 us inside the command, against 34 + 33 + 36 us for
+// generator + K1 + K3; 1.6 MB of HBM traffic per launch by PMC against 604 MB.
+// Scope: fp32, diagonal Sigma (a full-Sigma form -- L z + mu per timestep in the lane -- is below, behind MPPI_ONCHIP_FULL_SIGMA:
+// tested, slower than generator-coloured rows), MPPI and SMPPI (base sequence, 1/dt rescaling, smoothness cost) but not KMPPI,
+// M = 1, no sampler rows (the sample_null_action row is handled), no `states` output, one environment.
 #pragma once
 // (included from rollout.hpp, inside its include set)
 
@@ -37,7 +38,7 @@ struct OnChip {
 #ifndef MPPI_ONCHIP_NTA
 #define MPPI_ONCHIP_NTA 5   // measured at C3: 4 tiles 82.8 us | 5 tiles 81.1 (214 VGPRs) | 6 tiles 80.9 with scratch (profiles/r03_onchip_parts.txt)
 #endif
-  static constexpr int NTA = MPPI_ONCHIP_NTA;                    // tiles kept in registers (the first 4: accumulation registers)
+  static constexpr int NTA = MPPI_ONCHIP_NTA;                    // tiles kept in registers (the first 256 values: accumulation registers)
   static constexpr int AG_SS = NTA * SW, AG_ROWS = AG_SS * P4;   // 75 or 80 rows: 256 values in accumulation registers, the rest in VGPRs
   static constexpr int RG = P4 >= 3 ? 1 : (P4 == 2 ? 2 : 4);     // super-steps regenerated together (>= 3 interleaved chains)
   static constexpr bool OK = P4 <= 16 && (SW % RG) == 0;
@@ -56,7 +57,7 @@ __device__ __forceinline__ float keep_in_agpr(float v) {
 // The three per-(t,n) tables of K1 (rollout.hpp StepTables) padded to whole super-steps and 16-byte aligned: a
 // super-step is P4 ds_read_b128 per table whatever nu is, issued together, and everything behind them is register
 // arithmetic.  (Per-element reads under the `t < T` test compile to a branch, a ds_read_b32 and a full LDS round trip
-// PER ELEMENT: measured 48 us of rollout instead of 8.)  Padding entries are zero.
+// PER ELEMENT: measured 48 us of rollout instead of 15.)  Padding entries are zero.
 template <int NU>
 struct OnChipRow {
   float ue[Stream<NU>::P4 * 4], um[Stream<NU>::P4 * 4], g[Stream<NU>::P4 * 4];
