@@ -166,6 +166,17 @@ template <> __device__ __forceinline__ double inf_v<double>() { return __builtin
 // ---------------------------------------------------------------------------------------------
 struct U4 { unsigned x, y, z, w; };
 
+// a ^ b ^ c in ONE instruction: gfx950's v_bitop3_b32 (any 3-input bitwise function; 0x96 = the truth table of the 3-way
+// XOR).  hipcc emits two v_xor_b32 for the C expression -- 40 of the ~100 VALU instructions of a Philox4x32-10 call, and
+// the generator is what the on-chip command's time is made of.
+__host__ __device__ __forceinline__ unsigned xor3(unsigned a, unsigned b, unsigned c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+
 __host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
   constexpr unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
@@ -173,9 +184,9 @@ __host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned
     unsigned long long p0 = (unsigned long long)M0 * c.x;
     unsigned long long p1 = (unsigned long long)M1 * c.z;
     U4 n;
-    n.x = (unsigned)(p1 >> 32) ^ c.y ^ k0;
+    n.x = xor3((unsigned)(p1 >> 32), c.y, k0);
     n.y = (unsigned)p1;
-    n.z = (unsigned)(p0 >> 32) ^ c.w ^ k1;
+    n.z = xor3((unsigned)(p0 >> 32), c.w, k1);
     n.w = (unsigned)p0;
     c = n;
     k0 += W0;

@@ -85,8 +85,9 @@ struct OnChipRow {
 // DIAG = false: eps = L z + mu with L = chol(Sigma) out of LDS (ac.Lm), a whole timestep at a time -- "correlated
 // Gaussian noise via a Cholesky-factored noise_sigma", applied in the lane that owns the sample (mppi.py:204-206).
 // ESC: the bounded noise is rescaled (SMPPI: eps' = (v - B) / dt, mppi.py:544)
+// `null_in_wave` (wave-uniform): some lane of the wave is the sample_null_action row
 template <int NU, bool DIAG, bool ESC = false>
-__device__ __forceinline__ void onchip_actions(const ActionConsts<float, NU>& ac, const OnChipRow<NU>& row, int orow,
+__device__ __forceinline__ void onchip_actions(const ActionConsts<float, NU>& ac, const OnChipRow<NU>& row, int orow, bool null_in_wave,
                                                float (&z)[Stream<NU>::P4 * 4], float (&v)[Stream<NU>::P4 * 4]) {
   if constexpr (DIAG) {
 #pragma unroll
@@ -105,11 +106,14 @@ __device__ __forceinline__ void onchip_actions(const ActionConsts<float, NU>& ac
       }
     }
   }
+  if (null_in_wave) {                                                   // mppi.py:390-392: the only wave that pays for the select
+#pragma unroll
+    for (int f = 0; f < Stream<NU>::P4 * 4; ++f) v[f] = orow == -1 ? 0.f : v[f];
+  }
 #pragma unroll
   for (int f = 0; f < Stream<NU>::P4 * 4; ++f) {
     const int n = f % NU;
     float w = v[f];
-    w = orow == -1 ? 0.f : w;                                           // :390-392 (one v_cndmask per control)
     w = clampT(w, ac.lo[n], ac.hi[n]);                                  // :383
     v[f] = w;
     z[f] = ESC ? (w - row.ue[f]) * ac.e_scale : w - row.ue[f];          // :385 (SMPPI :544)
@@ -276,6 +280,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
   }
   const StepTables<T> tb{Ue, Um, G, nullptr, kraw - lane};
   const long long kg = a.k_offset + k;
+  const bool null_in_wave = __any(orow == -1);
   const bool plain = !a.abs_cost && a.u_scale == 1.f && a.e_scale == 1.f && a.smooth_w == 0.f;
   T vprev[NU];
 #pragma unroll
@@ -306,10 +311,10 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
       OnChipRow<NU> row;
       row.load(tb, ss < nss ? ss : nss - 1, true);
       if (plain) {
-        onchip_actions<NU, DIAG>(ac, row, orow, zb[b], vb[b]);
+        onchip_actions<NU, DIAG>(ac, row, orow, null_in_wave, zb[b], vb[b]);
         onchip_steps<Model, true>(a, ac, model, row, ss, zb[b], vb[b], x, vprev, rollout, pert);
       } else {
-        onchip_actions<NU, DIAG, true>(ac, row, orow, zb[b], vb[b]);
+        onchip_actions<NU, DIAG, true>(ac, row, orow, null_in_wave, zb[b], vb[b]);
         onchip_steps<Model, false>(a, ac, model, row, ss, zb[b], vb[b], x, vprev, rollout, pert);
       }
     }
@@ -405,7 +410,8 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
           for (int s = 0; s < RG; ++s) {
             OnChipRow<NU> row;
             row.load(tb, (ss0 + s) < nss ? ss0 + s : nss - 1, false);
-            onchip_actions<NU, DIAG, true>(ac, row, orow, zg[s], vg);      // (e_scale == 1 multiplies by one)
+            if (plain) onchip_actions<NU, DIAG>(ac, row, orow, null_in_wave, zg[s], vg);
+            else onchip_actions<NU, DIAG, true>(ac, row, orow, null_in_wave, zg[s], vg);
 #pragma unroll
             for (int i = 0; i < P4; ++i)
 #pragma unroll
