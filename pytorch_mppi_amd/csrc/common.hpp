@@ -359,4 +359,60 @@ __device__ __forceinline__ T wave_reduce_transpose64(T (&v)[64]) {
   return v[0];
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// fp32: the same transposing wave reduction without the LDS crossbar (a different -- equally fixed -- summation order; every
+// caller uses this one function, so paths that must agree bit for bit still do).  s = 32 / 16: v_permlane32_swap / v_permlane16_swap exchange the halves of a
+// register PAIR in one instruction, so the keep/send selects disappear; s = 8 .. 1: pair sums through DPP
+// (row_ror:8 == lane^8, row_half_mirror pairs across bit 2, quad_perm for lane^2 / lane^1) and one select.
+// 141 VALU instructions per 64 columns against 189 + 63 ds_bpermute.
+template <>
+__device__ __forceinline__ float wave_reduce_transpose64<float>(float (&v)[64]) {
+  const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 32]), false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const bool up = (lane & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float X = v[i] + dpp_mov<0x128>(v[i]), Y = v[i + 8] + dpp_mov<0x128>(v[i + 8]);
+      v[i] = up ? Y : X;
+    }
+  }
+  {
+    const bool up = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float X = v[i] + dpp_mov<0x141>(v[i]), Y = v[i + 4] + dpp_mov<0x141>(v[i + 4]);
+      v[i] = up ? Y : X;
+    }
+  }
+  {
+    const bool up = (lane & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float X = v[i] + dpp_mov<0x4E>(v[i]), Y = v[i + 2] + dpp_mov<0x4E>(v[i + 2]);
+      v[i] = up ? Y : X;
+    }
+  }
+  {
+    const bool up = (lane & 1) != 0;
+    const float X = v[0] + dpp_mov<0xB1>(v[0]), Y = v[1] + dpp_mov<0xB1>(v[1]);
+    v[0] = up ? Y : X;
+  }
+  return v[0];
+}
+
+
 }  // namespace mppi

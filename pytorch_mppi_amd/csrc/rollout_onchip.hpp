@@ -155,61 +155,6 @@ __device__ __forceinline__ void onchip_steps(const KArgs<float>& a, const Action
   }
 }
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-
-// Transposing wave reduction without the LDS crossbar: every lane holds v[0..64); afterwards lane l holds the
-// sum over the 64 lanes of v[l] (same contract as wave_reduce_transpose64, common.hpp; a different -- equally
-// fixed -- summation order).  s = 32 / 16: v_permlane32_swap / v_permlane16_swap exchange the halves of a
-// register PAIR in one instruction, so the keep/send selects disappear; s = 8 .. 1: pair sums through DPP
-// (row_ror:8 == lane^8, row_half_mirror pairs across bit 2, quad_perm for lane^2 / lane^1) and one select.
-// 141 VALU instructions per 64 columns against 189 + 63 ds_bpermute.
-__device__ __forceinline__ float wave_reduce_transpose64_dpp(float (&v)[64]) {
-  const int lane = threadIdx.x & (WAVE - 1);
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 32]), false, false);
-    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
-    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  {
-    const bool up = (lane & 8) != 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float X = v[i] + dpp_mov<0x128>(v[i]), Y = v[i + 8] + dpp_mov<0x128>(v[i + 8]);
-      v[i] = up ? Y : X;
-    }
-  }
-  {
-    const bool up = (lane & 4) != 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float X = v[i] + dpp_mov<0x141>(v[i]), Y = v[i + 4] + dpp_mov<0x141>(v[i + 4]);
-      v[i] = up ? Y : X;
-    }
-  }
-  {
-    const bool up = (lane & 2) != 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float X = v[i] + dpp_mov<0x4E>(v[i]), Y = v[i + 2] + dpp_mov<0x4E>(v[i + 2]);
-      v[i] = up ? Y : X;
-    }
-  }
-  {
-    const bool up = (lane & 1) != 0;
-    const float X = v[0] + dpp_mov<0xB1>(v[0]), Y = v[1] + dpp_mov<0xB1>(v[1]);
-    v[0] = up ? Y : X;
-  }
-  return v[0];
-}
-
 // LDS carve of the kernel (floats): Ue[Jp] Um[Jp] G[Jp] | red[4] | ex[4][ntiles*64] | keepL[nsl*P4][256][4],
 // Jp = the horizon padded to whole super-steps (a multiple of 4: every part starts on a 16-byte boundary)
 struct OnChipLds {
@@ -426,7 +371,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
     T acc[64];
 #pragma unroll
     for (int i = 0; i < 64; ++i) acc[i] = i < TC ? wk * e[(i < TC ? i : 0) / 4][i % 4] : T(0);
-    ex[(wv * ntiles + tile) * 64 + lane] = wave_reduce_transpose64_dpp(acc);
+    ex[(wv * ntiles + tile) * 64 + lane] = wave_reduce_transpose64<float>(acc);
   }
   __syncthreads();
   // one combine over the four waves, in wave order; column j = tile * TC + c
