@@ -648,11 +648,16 @@ __device__ __forceinline__ T fixed_sum(const T* __restrict__ p, int n, T* red) {
 // sum over the nkc block partials of column j: 4 waves take every 4th chunk (independent loads,
 // 8 in flight), then a fixed-order combine through LDS.  Valid for threadIdx.x < 64 on return.
 template <typename T>
-__device__ __forceinline__ T column_sum(const KArgs<T>& a, int j, T (*part)[WAVE]) {
+__device__ __forceinline__ T column_sum(const KArgs<T>& a, int j, T (*part)[WAVE], int npre = 0, const T* pv = nullptr) {
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   T s = T(0);
   if (j < a.Jpad) {
     int c = wv;
+    if (npre == 16) {                      // the caller loaded this wave's first 16 partials already (same order, same sum)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s += pv[q];
+      c += 16 * (BLOCK / WAVE);
+    }
     for (; c + 7 * (BLOCK / WAVE) < a.nkc; c += 8 * (BLOCK / WAVE)) {
       T v[8];
 #pragma unroll
@@ -677,13 +682,21 @@ __global__ void __launch_bounds__(BLOCK) finalize_kernel(const KArgs<T> a_in, in
   const KArgs<T> a = env_view(a_in);
   __shared__ T red[BLOCK / WAVE];
   __shared__ T part[BLOCK / WAVE][WAVE];
+  // the first 16 partials of this wave's column slice are requested BEFORE the two reductions: one memory round trip less
+  // in a launch that is a chain of them (column_sum keeps the summation order: the prefetched values are its first terms)
+  constexpr int PF = 16, WV = BLOCK / WAVE;
+  const int jp = blockIdx.x * WAVE + (threadIdx.x & (WAVE - 1)), wvp = threadIdx.x / WAVE;
+  const bool pre = (int)blockIdx.x < ncolblocks && jp < a.Jpad && a.nkc >= PF * WV;
+  T pv[PF];
+#pragma unroll
+  for (int q = 0; q < PF; ++q) pv[q] = pre ? a.P_part[(long long)(wvp + q * WV) * a.Jpad + jp] : T(0);
   const T beta = shard_beta(a, red);
   const T eta = fixed_sum<T>(a.eta_part, a.nkc, red);
   const T inv_eta = T(1) / eta;                                        // mppi.py:258
   if (blockIdx.x == 0 && threadIdx.x == 0) { a.record[0] = beta; a.record[1] = eta; }
   if ((int)blockIdx.x < ncolblocks) {
     const int j = blockIdx.x * WAVE + (threadIdx.x & (WAVE - 1));
-    const T P = column_sum<T>(a, j, part);
+    const T P = column_sum<T>(a, j, part, pre ? PF : 0, pv);
     if (threadIdx.x < WAVE && j < a.J) {
       a.record[2 + j] = P;
       if (apply) {
@@ -713,6 +726,16 @@ __global__ void __launch_bounds__(BLOCK) finalize_blocks_kernel(const KArgs<T> a
   __shared__ T red[BLOCK / WAVE];
   __shared__ T part[BLOCK / WAVE][WAVE];
   const T inv_lambda = T(1) / a.lambda_;
+  // the first 32 records of this wave's column slice are requested BEFORE the reductions below: their round trip runs under
+  // the minimum / eta passes instead of behind them (the launch is a chain of dependent memory round trips and little else)
+  constexpr int PF = 32, WV = BLOCK / WAVE;
+  const int lane_ = threadIdx.x & (WAVE - 1), wv_ = threadIdx.x / WAVE;
+  const int j_ = blockIdx.x * WAVE + lane_;
+  const bool cols = (int)blockIdx.x < ncolblocks && j_ < a.J;
+  const bool pre = cols && nblk >= PF * WV;
+  T pv[PF];
+#pragma unroll
+  for (int q = 0; q < PF; ++q) pv[q] = pre ? a.P_part[(long long)(wv_ + q * WV) * a.Jpad + j_] : T(0);
   T m = inf_v<T>();
   for (int b = threadIdx.x; b < nblk; b += BLOCK) {
     const T v = a.block_min[b];
@@ -735,6 +758,20 @@ __global__ void __launch_bounds__(BLOCK) finalize_blocks_kernel(const KArgs<T> a
     T s = T(0);
     if (j < a.J) {
       int c = wv;
+      if (pre) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) s = m_fma(sb[c + q * WV], pv[q], s);
+        c += PF * WV;
+      }
+      // 32 loads in flight per lane: the records are read once, by 12 workgroups -- nothing but these round trips decides
+      // this launch's time (256 records: two batches per wave)
+      for (; c + 31 * (BLOCK / WAVE) < nblk; c += 32 * (BLOCK / WAVE)) {
+        T v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = a.P_part[(long long)(c + q * (BLOCK / WAVE)) * a.Jpad + j];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) s = m_fma(sb[c + q * (BLOCK / WAVE)], v[q], s);
+      }
       for (; c + 7 * (BLOCK / WAVE) < nblk; c += 8 * (BLOCK / WAVE)) {     // 8 loads in flight per lane
         T v[8];
 #pragma unroll
