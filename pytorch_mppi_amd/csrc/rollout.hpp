@@ -562,6 +562,74 @@ __device__ __forceinline__ void rollout_stream(const KArgs<T>& a, const ActionCo
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// HEAVY models (`static constexpr bool HEAVY = true`: traced networks, jit.from_torch -- a step of thousands of
+// instructions).  The streams above unroll the step once per ring slot and timestep of a super-step, in three per-wave
+// variants: dozens of copies per kernel, which is right for a 20-instruction integrator and wrong here (minutes of
+// hipcc, and a loop body far beyond the instruction cache).  This stream keeps ONE copy of the step: a rolled loop over
+// super-steps and timesteps, the timestep's controls picked out of the row registers by selects, the next rows one
+// super-step ahead (their latency hides behind TT heavy steps), the general per-lane variant (sampler rows, states).
+// ---------------------------------------------------------------------------------------------
+template <class M, class = void>
+struct model_heavy : std::false_type {};
+template <class M>
+struct model_heavy<M, std::enable_if_t<M::HEAVY>> : std::true_type {};
+
+template <class Model, typename T, int NOISE, bool DIAG>
+__device__ __forceinline__ void rollout_stream_heavy(const KArgs<T>& a, const ActionConsts<T, Model::NU>& ac,
+                                                     const Model& model, const StepTables<T>& tb, int k, bool active,
+                                                     int orow, T (&x)[Model::NX], T& rollout, T& pert) {
+  static_assert(NOISE != MPPI_NOISE_KTN, "heavy models take their rows in the engine's layout");
+  constexpr int NU = Model::NU;
+  constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
+  T vprev[NU];
+#pragma unroll
+  for (int n = 0; n < NU; ++n) vprev[n] = T(0);
+  const int nss = (a.Tn + TT - 1) / TT, last = nss - 1;
+  T cur[P4 * 4], nxt[P4 * 4];
+  auto get = [&](int ss, T (&dst)[P4 * 4]) {
+    if constexpr (NOISE == MPPI_NOISE_PHILOX) {
+#pragma unroll
+      for (int i = 0; i < P4; ++i) {
+        T r[4];
+        const long long jb = (long long)ss * P4 + i;
+        noise4<T, NOISE>(a, jb, k, r);
+        if (a.z != nullptr && active && jb < a.J4) store4<T>(const_cast<T*>(a.z), a.zp, jb, k, r);   // "generate once"
+        dst[4 * i + 0] = r[0]; dst[4 * i + 1] = r[1]; dst[4 * i + 2] = r[2]; dst[4 * i + 3] = r[3];
+      }
+    } else {
+      ring_fetch<T, NOISE, NU>(a, ss, k, dst);
+    }
+  };
+  get(0, cur);
+#pragma nounroll
+  for (int ss = 0; ss < nss; ++ss) {
+    if constexpr (NOISE != MPPI_NOISE_PHILOX) get(ss < last ? ss + 1 : last, nxt);
+#pragma nounroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int t = ss * TT + tt;
+      if (t >= a.Tn) break;                                    // wave-uniform
+      T zt[NU];
+#pragma unroll
+      for (int n = 0; n < NU; ++n) {
+        T v = cur[n];
+        static_for<1, TT>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          v = tt == j ? cur[j * NU + n] : v;
+        });
+        zt[n] = v;
+      }
+      rollout_step<Model, T, NOISE, DIAG, 2>(a, ac, model, tb, k, active, orow, t, zt, x, vprev, rollout, pert);
+    }
+    if constexpr (NOISE != MPPI_NOISE_PHILOX) {
+#pragma unroll
+      for (int i = 0; i < P4 * 4; ++i) cur[i] = nxt[i];
+    } else {
+      if (ss < last) get(ss + 1, cur);
+    }
+  }
+}
+
 // NOISE: MPPI_NOISE_TNK4 | _PHILOX | _ACTIONS (compile-time);  DIAG: diagonal Sigma;
 // DMA_ROWS > 0: the rows travel through the LDS-DMA ring (fp32 row streams), 0: register ring
 // FUSE: the whole command of a small problem in this ONE launch (see the block behind the chunk loop)
@@ -613,8 +681,9 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
 
   constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT, D = Ring<NU, T>::D;
   T ring[D][P4 * 4];
+  constexpr bool HEAVY = model_heavy<Model>::value;
   auto ring_prologue = [&]() {
-    if constexpr (NOISE != MPPI_NOISE_PHILOX && NOISE != MPPI_NOISE_KTN) {
+    if constexpr (NOISE != MPPI_NOISE_PHILOX && NOISE != MPPI_NOISE_KTN && !HEAVY) {
       const int last = (a.Tn + TT - 1) / TT - 1;
 #pragma unroll
       for (int d = 0; d < D; ++d) ring_fetch<T, NOISE, NU>(a, d < last ? d : last, k, ring[d]);
@@ -693,6 +762,8 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
     } else {
       rollout_stream_dma<Model, T, NOISE, DIAG, 0, DMA_ROWS>(a, ac, model, tb, k, active, orow, ring_wave, x, rollout, pert);
     }
+  } else if constexpr (HEAVY) {
+    if constexpr (NOISE != MPPI_NOISE_KTN) rollout_stream_heavy<Model, T, NOISE, DIAG>(a, ac, model, tb, k, active, orow, x, rollout, pert);
   } else {
     if (slow)
       rollout_stream<Model, T, NOISE, DIAG, 2>(a, ac, model, tb, k, active, orow, ring, x, rollout, pert);
@@ -952,6 +1023,9 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
     if (r != -1) return r;
   }
   KArgs<T> a = a_in;
+  // heavy models (one rolled copy of the step): rows in the engine's layout only (the caller converts a (K,T,nu) draw
+  // on MPPI_E_UNSUPPORTED), one state rollout per action sequence
+  if (model_heavy<Model>::value && (a.noise_src == MPPI_NOISE_KTN || a.M > 1)) return MPPI_E_UNSUPPORTED;
   const bool diag = a.diag != 0 || a.coloured != 0;   // a coloured stream runs the diagonal instantiation
   size_t smem = (size_t)(3 * a.J + BLOCK / WAVE + (a.diag != 0 ? 0 : 2 * NU * NU)) * sizeof(T);   // factors / Sigma^-1 of a coloured stream
   if (a.noise_src == MPPI_NOISE_KTN) {
@@ -1019,8 +1093,10 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
   if (a.M > 1) {
     // several state rollouts per action sequence: rows in memory (the caller fills / converts them), plain MPPI
     if (a.M > 4 || (a.noise_src != MPPI_NOISE_TNK4) || a.B != nullptr || a.smooth_w != T(0)) return MPPI_E_UNSUPPORTED;
-    if (diag) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_TNK4, true, 0, false, 4>));
-    else MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_TNK4, false, 0, false, 4>));
+    if constexpr (!model_heavy<Model>::value) {
+      if (diag) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_TNK4, true, 0, false, 4>));
+      else MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_TNK4, false, 0, false, 4>));
+    }
     return (int)hipGetLastError();
   }
   if (fuse) {
@@ -1035,7 +1111,7 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
     else if (dma == 15) MPPI_LAUNCH_DMA(MPPI_NOISE_ACTIONS, 15);
     else MPPI_LAUNCH(MPPI_NOISE_ACTIONS);
   } else if (a.noise_src == MPPI_NOISE_KTN) {
-    if constexpr (Ktn<NU>::OK && sizeof(T) == 4) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_KTN, true>));
+    if constexpr (Ktn<NU>::OK && sizeof(T) == 4 && !model_heavy<Model>::value) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_KTN, true>));
   } else {
     if (dma == 30) MPPI_LAUNCH_DMA(MPPI_NOISE_TNK4, 30);
     else if (dma == 15) MPPI_LAUNCH_DMA(MPPI_NOISE_TNK4, 15);

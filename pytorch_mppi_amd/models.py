@@ -22,7 +22,11 @@ from . import _native as N
 
 
 class NativeModel:
+    """The built-in models are time-invariant: their callables accept and ignore the timestep argument of
+    `step_dependent_dynamics=True` controllers (mppi.py:147-154), so the same fused kernel serves both settings
+    (`step_dependent = None`: either)."""
     model_id = N.MODEL_NONE
+    step_dependent = None
     nx = 0
     nu = 0
     hidden = 0
@@ -52,10 +56,10 @@ class NativeModel:
         return nxt + self.process_noise.to(device=nxt.device, dtype=nxt.dtype) * torch.randn_like(nxt)
 
     # -- torch callables in the reference's plugin convention ----------------------------------
-    def dynamics(self, state, action):
+    def dynamics(self, state, action, t=None):
         raise NotImplementedError
 
-    def running_cost(self, state, action):
+    def running_cost(self, state, action, t=None):
         raise NotImplementedError
 
     def terminal_state_cost(self, states, actions):
@@ -92,7 +96,7 @@ class Pendulum(NativeModel):
     model_id = N.MODEL_PENDULUM
     nx, nu = 2, 1
 
-    def dynamics(self, state, action):
+    def dynamics(self, state, action, t=None):
         th = state[:, 0:1]
         thdot = state[:, 1:2]
         u = torch.clamp(action, -2, 2)                                   # pendulum.py:41-42
@@ -101,7 +105,7 @@ class Pendulum(NativeModel):
         newth = th + newthdot * 0.05                                     # :46
         return self._noisy(torch.cat((newth, newthdot), dim=1))
 
-    def running_cost(self, state, action):
+    def running_cost(self, state, action, t=None):
         an = ((state[:, 0] + math.pi) % (2 * math.pi)) - math.pi         # :52-53
         return an ** 2 + 0.1 * state[:, 1] ** 2                          # :56-61
 
@@ -115,12 +119,12 @@ class Integrator(NativeModel):
         super().__init__()
         self.nx, self.nu = int(nx), int(nu)
 
-    def dynamics(self, state, action):
+    def dynamics(self, state, action, t=None):
         nxt = state.clone()
         nxt[..., :self.nu] = nxt[..., :self.nu] + action
         return self._noisy(nxt)
 
-    def running_cost(self, state, action):
+    def running_cost(self, state, action, t=None):
         return (state ** 2).sum(dim=-1)
 
 
@@ -142,11 +146,11 @@ class LinearGoal(NativeModel):
     def _on(self, ref):
         return self.B.to(ref.device, ref.dtype), self.goal.to(ref.device, ref.dtype)
 
-    def dynamics(self, state, action):
+    def dynamics(self, state, action, t=None):
         B, _ = self._on(state)
         return self._noisy(state + action @ B.T)
 
-    def running_cost(self, state, action):
+    def running_cost(self, state, action, t=None):
         _, goal = self._on(state)
         return ((goal - state) ** 2).sum(dim=-1)
 
@@ -193,12 +197,12 @@ class MLPResidual(NativeModel):
     def _param_list(self):
         return [self.W1, self.b1, self.W2, self.b2, torch.tensor([self.res_scale], dtype=torch.float64)]
 
-    def dynamics(self, state, action):
+    def dynamics(self, state, action, t=None):
         W1, b1, W2, b2 = (t.to(state.device, state.dtype) for t in (self.W1, self.b1, self.W2, self.b2))
         h = torch.tanh(torch.cat((state, action), dim=1) @ W1.T + b1)
         return self._noisy(state + self.res_scale * (h @ W2.T + b2))
 
-    def running_cost(self, state, action):
+    def running_cost(self, state, action, t=None):
         return (state ** 2).sum(dim=-1)
 
 

@@ -208,7 +208,9 @@ class MPPI:
         m = native_model_of(dynamics, running_cost, terminal_state_cost)
         # step-dependent callbacks (mppi.py:147-154): fused when the native model's callables take t too
         # (jit.compile_model(..., step_dependent=True); the device functor always sees the timestep)
-        if m is not None and bool(step_dependent_dynamics) == bool(getattr(m, "step_dependent", False)):
+        # the built-in models ignore t (step_dependent None: either setting)
+        if m is not None and (getattr(m, "step_dependent", False) is None
+                              or bool(step_dependent_dynamics) == bool(getattr(m, "step_dependent", False))):
             self._model = m
         self.jit_note = None
         if m is None and self.d.type == "cuda" and self.M == 1 and (
@@ -389,6 +391,8 @@ class MPPI:
             raise RuntimeError("pytorch_mppi_amd runs on the MI355X only: construct the controller with "
                                "device='cuda' (there is no CPU compute path)")
         Tn = Tn or self.T
+        if getattr(self._model, "_param_tensors", None):
+            self._model.refresh_params()           # a traced model's trainable tensors: re-gathered when written (jit.py)
         key = self._static_key(Tn)
         hit = self._problem_cache.get(Tn)
         if hit is None or hit[0] != key:
@@ -669,6 +673,8 @@ class MPPI:
     def _needs_generic(self):
         if self._model is None:
             return True
+        if getattr(self._model, "_param_tensors", None):
+            self._model.refresh_params()           # trainable tensors of a traced model: new values, same functor
         if getattr(self._model, "_captured", None) and self._model.stale():
             import logging
             self.jit_note = "generic path: a tensor the traced callables read was modified in place after tracing"
@@ -691,7 +697,8 @@ class MPPI:
     def _fused_multi_ok(self):
         """M > 1 rollouts per action sequence inside K1 (csrc/rollout.hpp rollout_stream_multi): plain MPPI,
         at most 4 copies of the state per lane; anything else runs the reference's callback loop."""
-        return type(self) is MPPI and 1 < self.M <= 4 and self.specific_action_sampler is None
+        return (type(self) is MPPI and 1 < self.M <= 4 and self.specific_action_sampler is None
+                and not getattr(self._model, "heavy", False))
 
     def _command(self, state, shift):
         p = self._begin(state, shift)
@@ -858,7 +865,10 @@ class MPPI:
         N.check(lib.mppi_prepare(C.byref(p), st), "mppi_prepare")
         p.perturbed_action = p.noise = p.pert_cost = None
         self._perturbed_action, self._noise = pa, noise
-        rollout_cost, self._states, actions = self._compute_rollout_costs(pa)
+        # (no autograd graph through the callbacks: a dynamics network with trainable parameters -- the reference's
+        # tests/pendulum_approximate.py -- would otherwise drag requires_grad into cost_total and keep T steps of history)
+        with torch.no_grad():
+            rollout_cost, self._states, actions = self._compute_rollout_costs(pa)
         self._actions = actions / self.u_scale if actions is not None else None
         torch.add(rollout_cost, pert, out=cost_total)                     # mppi.py:416
         N.check(lib.mppi_cost_block_min(C.byref(p), st), "mppi_cost_block_min")
@@ -1375,10 +1385,11 @@ class MPPI_Batched:
             NK = Nn * K
             state = states.unsqueeze(1).expand(Nn, K, self.nx).reshape(NK, self.nx)   # :848-850
             rollout = torch.zeros(Nn, K, device=self.d, dtype=self.dtype)
-            for t in range(T):
-                u = c.u_scale * pa[:, :, t].reshape(NK, nu)
-                state = c._dynamics_fn(state, u, t)
-                rollout = rollout + c._running_cost_fn(state, u, t).reshape(Nn, K)
+            with torch.no_grad():                                         # (see _generic_total_cost)
+                for t in range(T):
+                    u = c.u_scale * pa[:, :, t].reshape(NK, nu)
+                    state = c._dynamics_fn(state, u, t)
+                    rollout = rollout + c._running_cost_fn(state, u, t).reshape(Nn, K)
             torch.add(rollout, pert, out=cost_total)                      # :861
             N.check(lib.mppi_cost_block_min(C.byref(p), st), "mppi_cost_block_min")
         if p.noise_src == N.NOISE_PHILOX and p.z:

@@ -50,6 +50,9 @@ class Graph:
         self.nodes = []          # tuples: ("c", float) | ("x", i) | ("u", n) | ("t",) | ("y", i) | (op, ids...)
         self.index = {}
         self.captured = []       # (tensor, version at trace time) of every torch tensor whose VALUES went into constants
+        self.param_tensors = []  # (tensor, base): TRAINABLE tensors -- element i is the leaf ("p", base + i), read from the
+        self._param_base = {}    # model's parameter vector at run time (re-gathered when the tensor's version moves)
+        self.n_params = 0
         self.max_nodes = max_nodes
 
     def _mk(self, node):
@@ -68,6 +71,18 @@ class Graph:
 
     def leaf(self, kind, i=None):
         return self._mk((kind,) if i is None else (kind, int(i)))
+
+    def param_leaves(self, t, max_params=32768):
+        """node ids (shape of t) of the run-time parameter leaves of a trainable tensor"""
+        base = self._param_base.get(id(t))
+        if base is None:
+            if self.n_params + t.numel() > max_params:
+                raise TraceUnsupported(f"more than {max_params} trainable parameters")
+            base = self.n_params
+            self._param_base[id(t)] = base
+            self.param_tensors.append((t, base))         # (keeps t alive: id(t) stays unique)
+            self.n_params += t.numel()
+        return np.array([self.leaf("p", base + i) for i in range(t.numel())], dtype=np.int64).reshape(tuple(t.shape))
 
     def cval(self, i):
         n = self.nodes[i]
@@ -165,10 +180,12 @@ class SymT:
         if isinstance(v, torch.Tensor):
             if v.dtype == torch.bool:
                 raise TraceUnsupported("boolean constant tensors")
-            if v.requires_grad:
+            if isinstance(v, torch.nn.Parameter) or v.requires_grad:
                 # a TRAINABLE tensor: its values are expected to change (online learning of the dynamics, as in the
-                # reference's tests/pendulum_approximate.py) -- baking them into the functor would silently go stale
-                raise TraceUnsupported("the callable reads a tensor that requires grad (trainable parameters are not constants)")
+                # reference's tests/pendulum_approximate.py:47-67,140-170) -- baking them into the functor would go stale
+                # with the first optimizer step.  Its elements become reads of the model's parameter vector p[]: the
+                # functor stays valid, the vector is re-gathered when the tensor's version counter moves.
+                return SymT(self.g, self.g.param_leaves(v))
             self.g.captured.append((v, v._version))      # captured BY VALUE: the controller watches the version counter
             v = v.detach().cpu().double().numpy()
         if isinstance(v, np.ndarray):
@@ -679,7 +696,7 @@ def _reaches(g, roots, kinds):
         n = g.nodes[i]
         if n[0] in kinds:
             return True
-        if n[0] not in ("c", "x", "u", "t", "y", "w"):
+        if n[0] not in ("c", "x", "u", "t", "y", "w", "p"):
             stack.extend(n[1:])
     return False
 
@@ -720,7 +737,7 @@ def emit(g, roots, assign=None, ret=False):
             seen.add(i)
             stack.append((i, True))
             n = g.nodes[i]
-            if n[0] not in ("c", "x", "u", "t", "y", "w"):
+            if n[0] not in ("c", "x", "u", "t", "y", "w", "p"):
                 for a in n[1:]:
                     stack.append((a, False))
     name = {}
@@ -736,6 +753,8 @@ def emit(g, roots, assign=None, ret=False):
             name[i] = f"u[{n[1]}]"
         elif k == "t":
             name[i] = "T(t)"
+        elif k == "p":
+            name[i] = f"p[{n[1]}]"
         elif k in ("y", "w"):
             raise TraceUnsupported("internal: terminal leaf in a step / cost body")
         else:
@@ -779,7 +798,16 @@ def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_depe
     step = emit(g, so, assign=[f"x[{i}]" for i in range(nx)])
     cost = emit(g, [co], ret=True)
     term = emit(g, [to], ret=True) if to is not None else None
-    return dict(step=step, cost=cost, terminal=term, n_ops=len(g.nodes), captured=g.captured)
+    return dict(step=step, cost=cost, terminal=term, n_ops=len(g.nodes), captured=g.captured, param_tensors=g.param_tensors,
+                n_params=g.n_params)
+
+
+def gather_params(param_tensors, n_params):
+    """the model's parameter vector: the trainable tensors' current values, flattened at their bases (on their own device)"""
+    if not param_tensors:
+        return None
+    with torch.no_grad():
+        return torch.cat([t.detach().reshape(-1).double() for t, _ in param_tensors])
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -805,10 +833,12 @@ static inline T m_atan2(T a, T b) { return std::atan2(a, b); }
 static inline T m_fmod(T a, T b) { return std::fmod(a, b); }
 static inline T clampT(T x, T lo, T hi) { return std::fmin(std::fmax(x, lo), hi); }
 static const int NX = %(nx)d, NU = %(nu)d;
+static const double* p;
 static inline void step_(T (&x)[NX], const T (&u)[NU], int t) { %(step)s }
 static inline T cost_(const T (&x)[NX], const T (&u)[NU], int t) { %(cost)s }
 static inline T term_(const T (&x)[NX]) { %(terminal)s }
-extern "C" void run(int B, const double* X, const double* U, int t, double* Xn, double* Cc, double* Tc) {
+extern "C" void run(int B, const double* X, const double* U, int t, double* Xn, double* Cc, double* Tc, const double* P) {
+  p = P;
   for (int b = 0; b < B; ++b) {
     T x[NX], u[NU];
     for (int i = 0; i < NX; ++i) x[i] = X[b * NX + i];
@@ -833,37 +863,47 @@ def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=Non
         if r.returncode != 0:
             raise TraceUnsupported("generated code does not compile: " + r.stderr[-400:])
         lib = C.CDLL(so)
+        P = gather_params(code.get("param_tensors"), code.get("n_params", 0))
+        Pa = np.ascontiguousarray(P.cpu().numpy()) if P is not None else np.zeros(1)
         gen = torch.Generator().manual_seed(12345)
+        forms = [("cpu", torch.float64), ("cuda", torch.float64), ("cpu", torch.float32), ("cuda", torch.float32)]
+        if not torch.cuda.is_available():
+            forms = [f for f in forms if f[0] == "cpu"]
+        form = None                                    # (device, dtype) the callables accept: found on the first batch
         for scale, t in ((1.0, 0), (3.0, 5), (0.1, 11)):
             X = torch.randn(B, nx, generator=gen, dtype=torch.float64) * scale
             U = torch.randn(B, nu, generator=gen, dtype=torch.float64) * scale
             Xn, Cc, Tc = np.zeros((B, nx)), np.zeros(B), np.zeros(B)
             p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
             Xa, Ua = np.ascontiguousarray(X.numpy()), np.ascontiguousarray(U.numpy())
-            lib.run(B, p(Xa), p(Ua), int(t), p(Xn), p(Cc), p(Tc))
+            lib.run(B, p(Xa), p(Ua), int(t), p(Xn), p(Cc), p(Tc), p(Pa))
             extra = (t,) if step_dependent else ()
-            dev = "cpu"
             with torch.no_grad():
-                try:
-                    ref_x = dynamics(X.clone(), U.clone(), *extra)
-                except RuntimeError:
-                    if not torch.cuda.is_available():
-                        raise
-                    dev = "cuda"                       # the callable captured device tensors
-                    ref_x = dynamics(X.to(dev), U.to(dev), *extra).cpu()
-                ref_c = running_cost(X.to(dev), U.to(dev), *extra).cpu()
+                if form is None:
+                    for i, cand in enumerate(forms):   # the callable may have captured device tensors / fp32 weights
+                        try:
+                            dynamics(X.to(*cand, copy=True), U.to(*cand, copy=True), *extra)
+                            form = cand
+                            break
+                        except RuntimeError:
+                            if i == len(forms) - 1:
+                                raise
+                dev, dt = form
+                ref_x = dynamics(X.to(dev, dt, copy=True), U.to(dev, dt, copy=True), *extra).cpu()
+                ref_c = running_cost(X.to(dev, dt), U.to(dev, dt), *extra).cpu()
+            tol = rtol if dt == torch.float64 else max(rtol, 2e-5)
             pairs = [("dynamics", Xn, ref_x.detach().double().reshape(B, -1).numpy()),
                      ("running_cost", Cc, ref_c.detach().double().reshape(-1).numpy())]
             if terminal_state_cost is not None:
                 with torch.no_grad():
-                    ref_t = terminal_state_cost(X.to(dev).view(1, B, 1, nx), U.to(dev).view(1, B, 1, nu)).cpu()
+                    ref_t = terminal_state_cost(X.to(dev, dt).view(1, B, 1, nx), U.to(dev, dt).view(1, B, 1, nu)).cpu()
                 pairs.append(("terminal_state_cost", Tc, ref_t.detach().double().reshape(-1).numpy()))
             for what, got, ref in pairs:
                 if got.shape != ref.shape:
                     raise TraceUnsupported(f"{what}: traced result has shape {got.shape}, the callable returns {ref.shape}")
                 s = max(1.0, float(np.abs(ref).max()))
                 err = float(np.abs(got - ref).max())
-                if not (err <= rtol * s):
+                if not (err <= tol * s):
                     raise TraceUnsupported(f"{what}: traced functor differs from the callable by {err:.3g} (scale {s:.3g})")
     return True
 

@@ -1,6 +1,8 @@
 """User models used by tests/test_gpu_jit_models.py.  Defined here (not in the test) so that
 `__graft_entry__.build()` can compile them in the build container: the objects land in
 pytorch_mppi_amd/_jit/ (in-tree, hash-named) and travel to the GPU box with the snapshot."""
+import math
+
 import torch
 
 import pytorch_mppi_amd as pm
@@ -153,6 +155,40 @@ def small_mlp_callables(nx=4, nu=2, hidden=8, seed=5):
     return dynamics, cost
 
 
+def approx_pendulum_callables(hidden=32, seed=25, dtype=torch.double):
+    """learned dynamics in the shape of /root/reference/tests/pendulum_approximate.py:47-67,98-108: a TRAINABLE residual
+    network (nx+nu -> hidden -> hidden -> nx, tanh) whose parameters the user's training loop keeps writing between
+    commands; the action clamped, the angle wrapped after the step.  Returns (dynamics, running_cost, network)."""
+    torch.manual_seed(seed)
+    net = torch.nn.Sequential(torch.nn.Linear(3, hidden), torch.nn.Tanh(), torch.nn.Linear(hidden, hidden), torch.nn.Tanh(),
+                              torch.nn.Linear(hidden, 2)).to(dtype)
+    wrap = lambda a: ((a + math.pi) % (2 * math.pi)) - math.pi
+
+    def dynamics(state, perturbed_action):
+        u = torch.clamp(perturbed_action, -2.0, 2.0)
+        nxt = state + net(torch.cat((state, u), dim=1))
+        nxt[:, 0] = wrap(nxt[:, 0])
+        return nxt
+
+    def cost(state, action):
+        return wrap(state[:, 0]) ** 2 + 0.1 * state[:, 1] ** 2
+
+    return dynamics, cost, net
+
+
+def train_a_little(net, steps=3, seed=0):
+    """a few optimizer steps on random targets: what happens to the network between two commands"""
+    g = torch.Generator().manual_seed(seed)
+    p0 = next(net.parameters())
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    for _ in range(steps):
+        xu = torch.randn(64, 3, generator=g, dtype=torch.float64).to(p0.device, p0.dtype)
+        y = torch.randn(64, 2, generator=g, dtype=torch.float64).to(p0.device, p0.dtype)
+        opt.zero_grad()
+        ((net(xu) - y) ** 2).mean().backward()
+        opt.step()
+
+
 def watched_linear_callables():
     """a constant matrix the test later writes in place (tests/test_gpu_from_torch.py: the controller must notice)"""
     B = torch.tensor([[1.0, 0.0], [0.0, -1.0]], dtype=torch.float64)
@@ -166,7 +202,8 @@ def traced_models():
     lf, lq, lt = ref_linear_callables()
     mf, mq = small_mlp_callables()
     wf, wq, _ = watched_linear_callables()
-    jobs = dict(pendulum=(f, q, 2, 1), linear=(lf, lq, 2, 2, lt), mlp=(mf, mq, 4, 2), watched=(wf, wq, 2, 2))
-    with cf.ThreadPoolExecutor(max_workers=4) as ex:      # each ends in its own hipcc subprocess
+    af, aq, _ = approx_pendulum_callables()
+    jobs = dict(pendulum=(f, q, 2, 1), linear=(lf, lq, 2, 2, lt), mlp=(mf, mq, 4, 2), watched=(wf, wq, 2, 2), approx=(af, aq, 2, 1))
+    with cf.ThreadPoolExecutor(max_workers=5) as ex:      # each ends in its own hipcc subprocess
         futs = {k: ex.submit(jit.from_torch, *v) for k, v in jobs.items()}
         return {k: v.result() for k, v in futs.items()}

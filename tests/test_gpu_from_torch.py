@@ -149,3 +149,69 @@ def test_in_place_update_of_a_captured_tensor_sends_the_controller_back_to_the_c
     ua, ub = a.command(x0), b.command(x0)
     assert a._needs_generic() and a.jit_note.startswith("generic path")
     assert float((ua - ub).abs().max()) <= 1e-9
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_learned_dynamics_stay_fused_while_the_network_is_trained(dtype):
+    """/root/reference/tests/pendulum_approximate.py: the dynamics are a trainable 3 -> 32 -> 32 -> 2 tanh network that the
+    user's loop retrains between commands.  Its parameters are run-time inputs of the traced functor (one rolled copy of the
+    ~3700-operation step, weights through scalar loads): the controller stays on the fused kernels across optimizer steps
+    and commands what the callback loop commands on the same draw -- nothing is recompiled."""
+    f, q, net = jf.approx_pendulum_callables(dtype=dtype)
+    net.cuda()
+    K, T = (1000, 30) if dtype == torch.float64 else (4096, 30)          # (the reference example's K x T)
+    kw = dict(u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0), lambda_=1.0)
+    a, b, U0, nu = _pair(f, q, 2, torch.tensor(1.0), dtype, K, T, **kw)
+    assert a.jit_note.startswith("fused") and not a._needs_generic(), a.jit_note
+    assert a._model.heavy and a._model._n_params == 1250 and b._needs_generic()
+    model = a._model
+    x0 = torch.tensor([2.5, -0.8], dtype=dtype).cuda()
+    gen = torch.Generator().manual_seed(21)
+    tol = 1e-9 if dtype == torch.float64 else 2e-4
+    for rnd in range(3):
+        z = torch.randn(K, T, nu, generator=gen, dtype=torch.float64).to(dtype)
+        for c in (a, b):
+            c.inject_noise(z)
+        ua, ub = a.command(x0), b.command(x0)
+        assert a._model is model and not a._needs_generic(), a.jit_note
+        s = max(1.0, float(b.cost_total.abs().max()))
+        bad = ((a.cost_total - b.cost_total).abs() > tol * s).double().mean().item()
+        if dtype == torch.float64:
+            assert bad == 0.0, rnd
+            assert float((ua - ub).abs().max()) <= tol * max(1.0, float(ub.abs().max())), (rnd, ua, ub)
+        else:
+            # fp32 against fp32: the angle wrap makes the learned dynamics discontinuous at +-pi, so a sample that passes
+            # within rounding of the seam may take the other branch in the other implementation -- isolated samples only
+            assert bad <= 2e-3, (rnd, bad)
+            assert float((ua - ub).abs().max()) <= 5e-3 * max(1.0, float(ub.abs().max())), (rnd, ua, ub)
+        if rnd == 0:
+            jf.train_a_little(net, steps=3, seed=rnd)                    # optimizer.step(): in-place updates
+        elif rnd == 1:
+            for p_ in net.parameters():                                  # frozen for control (pendulum_approximate.py:150-170)
+                p_.requires_grad_(False)
+            net.load_state_dict({k: v * 0.9 for k, v in net.state_dict().items()})
+
+
+def test_learned_dynamics_command_time():
+    """the same learned dynamics at the C2 problem size (8192 x 32, fp32): one rolled copy of the step in K1"""
+    import pytorch_mppi_amd as pm
+    f, q, net = jf.approx_pendulum_callables(dtype=torch.float32)
+    net.cuda()
+    mk = lambda auto: pm.MPPI(f, q, 2, torch.tensor(1.0), num_samples=8192, horizon=32, device="cuda", lambda_=1.0,
+                              u_min=torch.tensor(-2.0), u_max=torch.tensor(2.0), rng="philox", seed=1, auto_jit=auto)
+    x0 = torch.tensor([2.5, -0.8]).cuda()
+    out = {}
+    for name, auto, n in (("fused", True, 100), ("callbacks", False, 10)):
+        c = mk(auto)
+        assert c._needs_generic() == (not auto)
+        for _ in range(3):
+            c.command(x0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            c.command(x0)
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / n * 1e3
+    margins.record("from_torch/learned_pendulum_c2_size", "ms_per_command", out["fused"], None, 0.5,
+                   "trainable 3-32-32-2 tanh network traced with run-time parameters; callback loop: %.3f ms" % out["callbacks"])
+    assert out["fused"] <= 0.5 and out["fused"] * 4 <= out["callbacks"], out

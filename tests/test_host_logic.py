@@ -81,8 +81,11 @@ def test_native_model_detection():
     assert models.native_model_of(m.dynamics, lambda s, a: s.sum(-1)) is None
     assert models.native_model_of(m.dynamics, _lin().running_cost) is None          # different object
     assert models.native_model_of(models.Pendulum().dynamics, models.Pendulum().running_cost, lambda s, a: 0) is None
+    # the built-in models are time-invariant and take (state, action, t) too: fused under either setting (mppi.py:147-154)
     c = pm.MPPI(m.dynamics, m.running_cost, 2, torch.eye(2, dtype=torch.double), step_dependent_dynamics=True)
-    assert c._model is None
+    assert c._model is m
+    x, u = torch.zeros(3, 2, dtype=torch.double), torch.ones(3, 2, dtype=torch.double)
+    assert torch.equal(m.dynamics(x, u, 4), m.dynamics(x, u)) and torch.equal(m.running_cost(x, u, 4), m.running_cost(x, u))
 
 
 def test_native_models_equal_oracle_callables():

@@ -72,20 +72,44 @@ def test_in_place_write_into_the_state_is_local():
     _roundtrip(f, lambda s, a: (s ** 2).sum(-1), 2, 1)
 
 
-def test_trainable_parameters_are_not_baked_in_and_captured_tensors_are_watched():
+def test_trainable_parameters_are_read_at_run_time_and_captured_tensors_are_watched():
+    """nn.Parameter / requires_grad tensors are elements of the model's parameter vector p[] (their values change under the
+    user's training loop: /root/reference/tests/pendulum_approximate.py:140-170); plain tensors become constants and
+    their version counters are watched."""
     net = torch.nn.Linear(3, 2).double()
-    f = lambda s, a: s + net(torch.cat((s, a), dim=1))
+    scale = torch.tensor([2.0, 0.5], dtype=torch.float64)
+    f = lambda s, a: s + scale * net(torch.cat((s, a), dim=1))
     q = lambda s, a: (s ** 2).sum(-1)
-    with pytest.raises(trace.TraceUnsupported, match="requires grad"):
-        trace.generate(f, q, 2, 1)
+    code = _roundtrip(f, q, 2, 1)
+    assert code["n_params"] == 8 and "p[7]" in code["step"] and [b for _, b in code["param_tensors"]] in ([0, 6], [0, 2])
+    caps = code["captured"]
+    assert len(caps) == 1 and caps[0][0] is scale and all(t._version == v for t, v in caps)
+    # the SAME code follows the parameters: an optimizer-style in-place update, frozen or not
+    with torch.no_grad():
+        net.weight.mul_(-1.5)
+        net.bias.add_(0.25)
     for p_ in net.parameters():
         p_.requires_grad_(False)
-    code = trace.generate(f, q, 2, 1)
-    caps = code["captured"]
-    assert len(caps) >= 2 and all(t._version == v for t, v in caps)
+    assert trace.verify_on_host(code, f, q, 2, 1)
     with torch.no_grad():
-        net.weight.mul_(2.0)
+        scale.mul_(2.0)
     assert any(t._version != v for t, v in caps), "an in-place update of a captured tensor is visible to the watcher"
+    with pytest.raises(trace.TraceUnsupported):
+        trace.verify_on_host(code, f, q, 2, 1)        # ... and the stale constant is what the check catches
+
+
+def test_learned_pendulum_dynamics_of_the_reference_example():
+    """tests/pendulum_approximate.py:47-67 of the reference: 3 -> 32 -> 32 -> 2 tanh residual network, trainable, angle wrapped
+    by item assignment.  Traced once; the functor follows the network through training steps."""
+    f, q, net = jf.approx_pendulum_callables()
+    code = _roundtrip(f, q, 2, 1)
+    assert code["n_params"] == 3 * 32 + 32 + 32 * 32 + 32 + 32 * 2 + 2 and code["step"].count("m_tanh") == 64
+    assert not code["captured"]
+    jf.train_a_little(net)
+    assert trace.verify_on_host(code, f, q, 2, 1)
+    # an fp32 network is checked at fp32 accuracy
+    f32, q32, _ = jf.approx_pendulum_callables(hidden=8, dtype=torch.float32)
+    _roundtrip(f32, q32, 2, 1)
 
 
 @pytest.mark.parametrize("bad", ["control_flow", "item", "numpy", "shape", "constant", "uses_earlier_state"])
