@@ -50,7 +50,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 EXTRA = {"update.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
          # MFMA results straight into VGPRs: every hidden activation is read by the VALU (tanh), and an
          # AGPR accumulator costs a v_accvgpr_read per value in a VALU-bound kernel
-         "rollout_mlp_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+         # (-fno-slp-vectorize: the fp16 residual of the activation split is one v_fma_mix_f32 per value only when the
+         # SLP vectorizer does not pair two of them into v_cvt_f32_f16 x 2 + v_pk_fma_f32 first)
+         "rollout_mlp_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
          # the KMPPI-fused K1 (rollout_kmppi.hpp) pins 256 control points in the AGPRs and reads its 4 x nu
          # accumulator tile with the VALU: same flag for every unit that instantiates it (jit.py passes it too)
          "rollout_integrator.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],

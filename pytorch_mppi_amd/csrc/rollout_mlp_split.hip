@@ -224,6 +224,16 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
     }
     A2[j] = split_pack8_h(v);
   }
+  // The 192 layer-1 weight registers live in the ACCUMULATION registers for the whole launch: an MFMA reads its A
+  // operand from an AGPR directly.  Left to the allocator they were "spilled" there and copied back in front of every
+  // use -- 131 v_accvgpr_read + 24 v_accvgpr_mov per loop iteration of a kernel that is bound by VALU issue (and 256
+  // VGPRs).  Pinned: 222-243 VGPRs, no copies, 759 -> 604 plain VALU instructions per two tile-steps.
+#pragma unroll
+  for (int m = 0; m < HT; ++m) {
+    asm volatile("" : "+a"(A1[m].h));
+    asm volatile("" : "+a"(A1[m].m));
+    asm volatile("" : "+a"(A1[m].l));
+  }
   rowsum += __shfl_xor(rowsum, 16, WAVE);
   rowsum += __shfl_xor(rowsum, 32, WAVE);
   float b2r[4];
@@ -374,6 +384,8 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
       // (phase 0: r = 1/(2^h + 1); phase 1: fp16 split + pack).  VPU independent exp -> add -> rcp chains per
       // unit: the transcendental results are needed a few instructions after their issue.
       constexpr int VPU = B3_VPU, NUNIT = 2 * (16 / VPU);
+      float minus_one = -1.0f;
+      asm volatile("" : "+v"(minus_one));
       auto valu_unit = [&](auto j_c, auto unit_c) {
         constexpr int j = decltype(j_c)::value, unit = decltype(unit_c)::value;
         constexpr int grp = unit >> 1, phase = unit & 1, buf = j & 1;
@@ -392,8 +404,20 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
           for (int v = v0; v < v0 + VPU; v += 2) {
             const int i = v >> 3, e0 = v & 7, q = e0 >> 1;
             const unsigned hp = cvt_pk_f16(f32x2{rr[i][e0], rr[i][e0 + 1]});   // round-to-nearest fp16 hi pieces
+#ifdef MPPI_SPLIT_NO_FMA_MIX
             const f32x2 hf = f16pair_to_f32(hp);
             const float r1a = rr[i][e0] - hf.x, r1b = rr[i][e0 + 1] - hf.y;     // exact
+#else
+            // r - float(hi) as ONE v_fma_mix_f32 per value (fp16 source operand converted inside the instruction:
+            // no v_cvt_f32_f16, same exact result).  hipcc selects it only for an fma whose multiplier it cannot
+            // fold (an opaque -1.0 in a VGPR) and only when the SLP vectorizer has not paired the two into a
+            // v_pk_fma_f32 first: this translation unit is built with -fno-slp-vectorize (_build.py; packed fp32
+            // arithmetic is no faster than two scalar instructions on gfx950 anyway, see valu_unit's note).
+            // In the loop: 874 -> 759 plain VALU instructions per two tile-steps, est. issue cycles 8932 -> 8458.
+            const f16x2_t hh = __builtin_bit_cast(f16x2_t, hp);
+            const float r1a = __builtin_fmaf((float)hh.x, minus_one, rr[i][e0]);          // exact
+            const float r1b = __builtin_fmaf((float)hh.y, minus_one, rr[i][e0 + 1]);
+#endif
             B2[buf][i].h[q] = hp;
             B2[buf][i].m[q] = cvt_pk_f16(f32x2{r1a, r1b});                      // |r - hi - mid| <= 2^-25
           }
