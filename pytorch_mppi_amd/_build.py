@@ -58,6 +58,11 @@ EXTRA = {"update.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
          "rollout_integrator.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
          "rollout_linear_goal.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 K1_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]     # for translation units built around csrc/rollout.hpp (jit.py)
+# heavy user models (jit.py) only: the SLP vectorizer pairs the products of a traced network into v_pk_mul_f32 before fp
+# contraction sees them (570 mul + add pairs instead of fmas in a 3700-operation step); packed fp32 arithmetic is no faster
+# than two scalar instructions on gfx950.  Light models keep the flags of the built-in units (a snippet model that restates a
+# built-in one compiles to the same kernel, bit for bit: tests/test_gpu_jit_models.py)
+K1_HEAVY_FLAGS = ["-fno-slp-vectorize"]
 
 
 def _hipcc():

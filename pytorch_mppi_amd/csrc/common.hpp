@@ -92,7 +92,21 @@ __device__ __forceinline__ float m_cos(float x) { return cosf(x); }
 __device__ __forceinline__ double m_cos(double x) { return cos(x); }
 __device__ __forceinline__ float m_exp(float x) { return expf(x); }
 __device__ __forceinline__ double m_exp(double x) { return exp(x); }
-__device__ __forceinline__ float m_tanh(float x) { return tanhf(x); }
+// tanhf without branches (the ocml routine is ~30 instructions behind two exec-mask branches; a traced network calls it
+// once per hidden unit and timestep).  |x| >= 0.25: t = e^(-2|x|), (1 - t) / (1 + t) on v_exp_f32 + v_rcp_f32 -- no
+// cancellation there (1 - t >= 0.39), ~3 ulp; |x| < 0.25: the odd Taylor polynomial through x^9 (next term < 1e-8
+// relative).  Both sides are evaluated, a select picks one; sign by v_bfi.
+__device__ __forceinline__ float m_tanh(float x) {
+  const float a = __builtin_fabsf(x);
+  const float t = __builtin_amdgcn_exp2f(a * -2.8853900817779268f);         // e^(-2a) = 2^(-2a log2 e)
+  const float big = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+  const float x2 = a * a;
+  float p = fmaf(x2, 62.0f / 2835.0f, -17.0f / 315.0f);
+  p = fmaf(x2, p, 2.0f / 15.0f);
+  p = fmaf(x2, p, -1.0f / 3.0f);
+  const float small = fmaf(a * x2, p, a);
+  return __builtin_copysignf(a < 0.25f ? small : big, x);
+}
 __device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
 __device__ __forceinline__ float m_fmod(float a, float b) { return fmodf(a, b); }
 __device__ __forceinline__ double m_fmod(double a, double b) { return fmod(a, b); }
