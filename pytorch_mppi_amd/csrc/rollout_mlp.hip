@@ -53,10 +53,9 @@ int MPPI_THIS(const KArgs<double>& a, hipStream_t st) { return go(a, st); }
 #else
 int rollout_mlp(const KArgs<float>& a, hipStream_t st) {
   if (a.W != nullptr) return MPPI_E_UNSUPPORTED;   // KMPPI: the matrix-core kernels read raw action rows (two-launch form)
-  // fp32 + (nx,nu)=(16,4): matrix-core kernels.  hidden = 256: 16-bit MFMAs on split operands (bf16 x 3
-  // for layer 1, fp16 x 2 for layer 2; fp32-level accuracy, rollout_mlp_split.hip); hidden in {64,128,256} with MPPI_MLP_EXACT=1
-  // (or where the split kernel has no instantiation): the exact-fp32 MFMA kernel, bit-for-bit an fmaf
-  // chain -- the checker of the former.  MPPI_MLP_VALU=1 forces the per-lane form (A/B measurements).
+  // fp32 + (nx,nu)=(16,4), hidden in {64,128,256}: matrix-core kernels.  Default: 16-bit MFMAs on split operands (bf16 x 3
+  // for layer 1, fp16 x 2 for layer 2; fp32-level accuracy, rollout_mlp_split.hip); with MPPI_MLP_EXACT=1 (or weights
+  // outside the fp16 operand range): the exact-fp32 MFMA kernel, bit-for-bit an fmaf chain -- the checker of the former.  MPPI_MLP_VALU=1 forces the per-lane form (A/B measurements).
   const char* fv = getenv("MPPI_MLP_VALU");
   const bool force_valu = fv != nullptr && fv[0] == '1';
   const char* fe = getenv("MPPI_MLP_EXACT");

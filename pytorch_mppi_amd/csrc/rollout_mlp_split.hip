@@ -531,12 +531,14 @@ static int launch_b3(const KArgs<float>& a_in, hipStream_t st) {
 }
 
 bool mlp_split_supported(int nx, int nu, int hidden) {
-  return nx == B3_NX && nu == B3_NU && hidden == 256;
+  return nx == B3_NX && nu == B3_NU && (hidden == 64 || hidden == 128 || hidden == 256);
 }
 
 int rollout_mlp_split(const KArgs<float>& a, hipStream_t st) {
   if (a.mp == nullptr) return MPPI_E_BADARG;
   if (!mlp_split_supported(a.nx, a.nu, a.hidden) || a.states != nullptr) return MPPI_E_UNSUPPORTED;
+  if (a.hidden == 64) return launch_b3<4>(a, st);
+  if (a.hidden == 128) return launch_b3<8>(a, st);
   return launch_b3<16>(a, st);
 }
 

@@ -288,7 +288,7 @@ def test_mlp_matrix_core_kernels_match_valu_kernel_and_fp64_oracle(H, K, full_si
         return c, a
 
     z = torch.randn(K, T, nu, generator=g) if rng == "torch" else None
-    c_b, a_b = run("split")            # hidden != 256: falls to the exact kernel
+    c_b, a_b = run("split")            # (hidden 64 / 128 / 256: all three widths have a split instantiation)
     if z is None:
         z = gpu_util.device_philox_normals(c_b, 1)       # the draw all three kernels consume (call 1 of seed 77)
     c_m, a_m = run("exact")
