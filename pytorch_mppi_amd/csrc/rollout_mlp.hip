@@ -61,8 +61,9 @@ int rollout_mlp(const KArgs<float>& a, hipStream_t st) {
   const char* fe = getenv("MPPI_MLP_EXACT");
   // ... or the host found weights outside the split kernel's fp16 operand range (MPPI_MODEL_FLAG_EXACT_FP32)
   const bool force_exact = (fe != nullptr && fe[0] == '1') || (a.model_flags & MPPI_MODEL_FLAG_EXACT_FP32) != 0;
-  if (!force_valu && a.M == 1 && a.states == nullptr && a.B == nullptr && a.smooth_w == 0.f &&
-      mlp_mfma_supported(a.nx, a.nu, a.hidden)) {
+  const bool smppi = a.B != nullptr || a.smooth_w != 0.f;      // lifted controls: the split kernel has the base sequence,
+  if (!force_valu && a.M == 1 && a.states == nullptr &&        // the 1/dt rescaling and the smoothness cost; the exact one not
+      mlp_mfma_supported(a.nx, a.nu, a.hidden) && !(smppi && (force_exact || !mlp_split_supported(a.nx, a.nu, a.hidden)))) {
     // the matrix-core kernels read the engine's own layout: ask the caller to convert a (K,T,nu) draw
     if (a.noise_src == MPPI_NOISE_KTN) return MPPI_E_UNSUPPORTED;
     if (!force_exact && mlp_split_supported(a.nx, a.nu, a.hidden)) return rollout_mlp_split(a, st);

@@ -242,7 +242,10 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
 
   ActionConsts<float, NU> ac;
   ac.load(a, DIAG ? nullptr : fac);
-  for (int j = threadIdx.x; j < a.J; j += B3_THREADS) Ue[j] = u_eff(a, j);
+  // Ue = the sequence the noise is added to and measured from (SMPPI: the host's base A + U dt, mppi.py:540); the action
+  // cost table G is built from the lifted nominal U itself (u_eff) either way
+  const bool smppi = a.B != nullptr;
+  for (int j = threadIdx.x; j < a.J; j += B3_THREADS) Ue[j] = u_base(a, j);
   __syncthreads();
   for (int j = threadIdx.x; j < a.J; j += B3_THREADS) {
     const int n = j % NU, t0 = j - n;
@@ -252,13 +255,13 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
     if constexpr (DIAG) {
       if (a.coloured && !a.diag) {          // generator-coloured full Sigma: whole-row G from global
         gg = 0.f;
-        for (int m = 0; m < NU; ++m) gg = fmaf(a.sinv[n * NU + m], Ue[t0 + m], gg);
+        for (int m = 0; m < NU; ++m) gg = fmaf(a.sinv[n * NU + m], smppi ? u_eff(a, t0 + m) : Ue[t0 + m], gg);
       } else {
-        gg = uj * a.sinv[n * NU + n];
+        gg = (smppi ? u_eff(a, j) : uj) * a.sinv[n * NU + n];
       }
     } else {
       gg = 0.f;
-      for (int m = 0; m < NU; ++m) gg = fmaf(ac.Sm[n * NU + m], Ue[t0 + m], gg);
+      for (int m = 0; m < NU; ++m) gg = fmaf(ac.Sm[n * NU + m], smppi ? u_eff(a, t0 + m) : Ue[t0 + m], gg);
     }
     G[j] = a.lambda_ * gg;
   }
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
     const int kbase = chunk * B3_SAMPLES + wv * (NT * 16);
     int kk[NT], orow[NT];
     bool act[NT];
-    float x[NT][4], cpart[NT], ppart[NT];
+    float x[NT][4], cpart[NT], ppart[NT], vprev[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int kraw = kbase + 16 * i + s;
@@ -288,6 +291,7 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
       for (int r = 0; r < 4; ++r) x[i][r] = s0[4 * g + r];
       cpart[i] = 0.f;
       ppart[i] = 0.f;
+      vprev[i] = 0.f;
     }
 
     // nu = 4: one row-of-4 per (timestep, sample).  Lane (g,s) needs only component g of it unless the
@@ -340,8 +344,15 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
         if (orow[i] == -1) v = 0.f;
         else if (orow[i] >= 0) v = a.sampler[((long long)orow[i] * a.Tn + t) * NU + g];
         v = clampT(v, lo_g, hi_g);
-        const float e = v - Ut;
+        const float e = (v - Ut) * ac.e_scale;                                  // e_scale = 1 | 1/dt (SMPPI, mppi.py:544)
         ppart[i] = fmaf(Gt, ac.abs_cost ? fabsf(e) : e, ppart[i]);
+        if (a.smooth_w != 0.f) {
+          // SMPPI smoothness cost w |v[t] - v[t-1]|^2 (mppi.py:559-562), this lane's control dimension; the four
+          // dimensions of a sample meet in the reduction over g at the end of the chunk
+          const float d = v - vprev[i];
+          if (t > 0) cpart[i] = fmaf(a.smooth_w * d, d, cpart[i]);
+          vprev[i] = v;
+        }
         const float in[8] = {x[i][0], x[i][1], x[i][2], x[i][3], a.u_scale * v, g == 0 ? 1.0f : 0.0f, 0.f, 0.f};
         B1[i] = split_pack8(in);
       }

@@ -416,6 +416,59 @@ def test_c3_shape_smppi_65536x64_lifted_controls(regime, form):
     assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff
 
 
+@pytest.mark.parametrize("H", [256, 64])
+def test_smppi_with_mlp_dynamics_runs_on_the_matrix_cores(H, monkeypatch):
+    """SMPPI over the C4 MLP model (K 16384 x T 32): the split-operand MFMA kernel carries the base sequence, the 1/dt
+    rescaling and the smoothness cost (it used to send lifted controls to the per-lane VALU kernel, 13x slower).  Against
+    `oracle.smppi_command` in fp64 / fp32 on the consumed draw, and against the VALU kernel's clock."""
+    import time
+    import pytorch_mppi_amd as pm
+    from oracle import mppi_oracle as orc
+    cfg = dict(C4, K=16384, T=32, H=H)
+    model, mk, sigma, kw, x0, U0 = _setup(cfg)
+    K, T, nu = cfg["K"], cfg["T"], cfg["nu"]
+    dt_, w_ = 0.1, 0.7
+    amax = torch.full((nu,), 1.2)
+
+    def make(lam):
+        return pm.SMPPI(model.dynamics, model.running_cost, cfg["nx"], sigma, num_samples=K, horizon=T, device="cuda", lambda_=lam,
+                        rng="philox", seed=4321, U_init=U0.clone(), action_max=amax, w_action_seq_cost=w_, delta_t=dt_)
+    lam = 1.0
+    for _ in range(2):
+        probe = make(lam)
+        probe.command(x0.cuda())
+        lam = _lambda_for(probe.cost_total, 300.0)
+        del probe
+    ctrl = make(lam)
+    A0 = ctrl.action_sequence.detach().cpu().clone()
+    Ud0 = ctrl.U.detach().cpu().clone()
+    act = ctrl.command(x0.cuda())
+    z = _consumed_normals(ctrl)
+    outs = []
+    for dt in (torch.float64, torch.float32):
+        f, q = mk(dt)
+        p = orc.Problem(dynamics=f, running_cost=q, nx=cfg["nx"], noise_sigma=sigma.to(dt), K=K, T=T, lambda_=lam)
+        outs.append(orc.smppi_command(p, Ud0.to(dt), A0.to(dt), x0.to(dt), z.to(dt), -amax.to(dt), amax.to(dt), w_, dt_, True))
+    r64, r32 = outs
+    got = dict(action=act, U=ctrl.U, action_sequence=ctrl.action_sequence, cost_total=ctrl.cost_total, omega=ctrl.omega)
+    _check(f"smppi mlp H{H} 16384x32", got, r64, r32, keys=tuple(got))
+
+    def clock(c, n):
+        for _ in range(2):
+            c.command(x0.cuda())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            c.command(x0.cuda())
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    t_mfma = clock(ctrl, 10)
+    monkeypatch.setenv("MPPI_MLP_VALU", "1")
+    t_valu = clock(make(lam), 3)
+    margins.record(f"smppi mlp H{H} 16384x32", "ms_per_command", t_mfma * 1e3, None, None, "per-lane VALU kernel: %.3f ms" % (t_valu * 1e3))
+    assert t_mfma * 2.5 < t_valu, (t_mfma, t_valu)
+
+
 def test_c3_shape_mppi_batched_8_envs_x_8192_shared_draw():
     """MPPI_Batched (mppi.py:691-873) at C3's T, nx, nu with 8 environments x 8192 samples: ONE draw shared by
     all environments, environment = grid z of every launch, per-environment beta / eta / omega / U.  Each environment
