@@ -453,18 +453,25 @@ def test_smppi_with_mlp_dynamics_runs_on_the_matrix_cores(H, monkeypatch):
     got = dict(action=act, U=ctrl.U, action_sequence=ctrl.action_sequence, cost_total=ctrl.cost_total, omega=ctrl.omega)
     _check(f"smppi mlp H{H} 16384x32", got, r64, r32, keys=tuple(got))
 
-    def clock(c, n):
+    xd = x0.cuda()
+
+    def clock(c, n, batches):
+        """best batch mean: a one-off stall (the caching allocator trimming what the full-size tests before this one left
+        behind was measured at ~85 ms inside a 10-command loop) must not decide a kernel comparison"""
         for _ in range(2):
-            c.command(x0.cuda())
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            c.command(x0.cuda())
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n
-    t_mfma = clock(ctrl, 10)
+            c.command(xd)
+        best = float("inf")
+        for _ in range(batches):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                c.command(xd)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / n)
+        return best
+    t_mfma = clock(ctrl, 5, 4)
     monkeypatch.setenv("MPPI_MLP_VALU", "1")
-    t_valu = clock(make(lam), 3)
+    t_valu = clock(make(lam), 2, 2)
     margins.record(f"smppi mlp H{H} 16384x32", "ms_per_command", t_mfma * 1e3, None, None, "per-lane VALU kernel: %.3f ms" % (t_valu * 1e3))
     assert t_mfma * 2.5 < t_valu, (t_mfma, t_valu)
 
