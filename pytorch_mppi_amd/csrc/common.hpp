@@ -108,6 +108,14 @@ __device__ __forceinline__ float m_tanh(float x) {
   return __builtin_copysignf(a < 0.25f ? small : big, x);
 }
 __device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
+// (the rest of the scalar vocabulary of traced callables, pytorch_mppi_amd/trace.py)
+#define MPPI_M1(NAME, F32, F64)                                         \
+  __device__ __forceinline__ float NAME(float x) { return F32(x); }      \
+  __device__ __forceinline__ double NAME(double x) { return F64(x); }
+MPPI_M1(m_erf, erff, erf) MPPI_M1(m_atan, atanf, atan) MPPI_M1(m_asin, asinf, asin) MPPI_M1(m_acos, acosf, acos)
+MPPI_M1(m_sinh, sinhf, sinh) MPPI_M1(m_cosh, coshf, cosh) MPPI_M1(m_expm1, expm1f, expm1) MPPI_M1(m_log1p, log1pf, log1p)
+MPPI_M1(m_ceil, ceilf, ceil) MPPI_M1(m_rint, rintf, rint) MPPI_M1(m_trunc, truncf, trunc)
+#undef MPPI_M1
 __device__ __forceinline__ float m_fmod(float a, float b) { return fmodf(a, b); }
 __device__ __forceinline__ double m_fmod(double a, double b) { return fmod(a, b); }
 // Python / torch floor-mod `a % b` for b > 0 and |a / b| < 2^22: k = floor(a / b), r = a - k b.  fmod's

@@ -37,7 +37,10 @@ class TraceUnsupported(Exception):
 # ---------------------------------------------------------------------------------------------------------------
 _UNARY = {"neg": lambda a: -a, "sin": math.sin, "cos": math.cos, "tan": math.tan, "tanh": math.tanh, "exp": math.exp,
           "log": math.log, "sqrt": math.sqrt, "abs": abs, "floor": math.floor,
-          "sigmoid": lambda a: 1.0 / (1.0 + math.exp(-a)), "sign": lambda a: (a > 0) - (a < 0)}
+          "sigmoid": lambda a: 1.0 / (1.0 + math.exp(-a)), "sign": lambda a: (a > 0) - (a < 0),
+          "erf": math.erf, "atan": math.atan, "asin": math.asin, "acos": math.acos, "sinh": math.sinh, "cosh": math.cosh,
+          "expm1": math.expm1, "log1p": math.log1p, "ceil": math.ceil, "round": lambda a: float(np.round(a)),
+          "trunc": math.trunc}
 _BINARY = {"add": lambda a, b: a + b, "sub": lambda a, b: a - b, "mul": lambda a, b: a * b, "div": lambda a, b: a / b,
            "min": min, "max": max, "pow": lambda a, b: a ** b, "atan2": math.atan2,
            "floormod": lambda a, b: a - math.floor(a / b) * b, "fmod": math.fmod}
@@ -149,6 +152,14 @@ class Graph:
     def cmp(self, op, a, b):
         return self._mk((op, a, b))
 
+    def logic(self, op, a, b=None):
+        """boolean nodes: ("and" | "or" | "xor", a, b), ("not", a)"""
+        if op == "not":
+            return self.nodes[a][1] if self.nodes[a][0] == "not" else self._mk(("not", a))
+        if a > b:
+            a, b = b, a
+        return a if a == b and op != "xor" else self._mk((op, a, b))
+
     def select(self, c, a, b):
         if a == b:
             return a
@@ -236,6 +247,30 @@ class SymT:
     def __le__(self, o): return self._ew2("le", o, cmp=True)
     def __gt__(self, o): return self._ew2("gt", o, cmp=True)
     def __ge__(self, o): return self._ew2("ge", o, cmp=True)
+    def __eq__(self, o): return self._ew2("eq", o, cmp=True)
+    def __ne__(self, o): return self._ew2("ne", o, cmp=True)
+    __hash__ = object.__hash__
+    def eq(self, o): return self == o
+    def ne(self, o): return self != o
+    def _logic(self, op, o=None):
+        if not self.boolean or (o is not None and not (isinstance(o, SymT) and o.boolean)):
+            raise TraceUnsupported("logical operator on tensors that are not traced comparisons")
+        if o is None:
+            return SymT(self.g, np.vectorize(lambda i: self.g.logic("not", int(i)), otypes=[np.int64])(self.a), boolean=True)
+        try:
+            a, b = np.broadcast_arrays(self.a, o.a)
+        except ValueError as e:
+            raise TraceUnsupported(f"broadcast: {e}")
+        return SymT(self.g, np.vectorize(lambda i, j: self.g.logic(op, int(i), int(j)), otypes=[np.int64])(a, b), boolean=True)
+    def __and__(self, o): return self._logic("and", o)
+    def __or__(self, o): return self._logic("or", o)
+    def __xor__(self, o): return self._logic("xor", o)
+    def __invert__(self): return self._logic("not")
+    __rand__, __ror__ = __and__, __or__
+    def logical_and(self, o): return self._logic("and", o)
+    def logical_or(self, o): return self._logic("or", o)
+    def logical_xor(self, o): return self._logic("xor", o)
+    def logical_not(self): return self._logic("not")
     def __matmul__(self, o): return self.matmul(o)
     def __rmatmul__(self, o): return self._lift(o).matmul(self)
     def __bool__(self): raise TraceUnsupported("data-dependent control flow (a tensor used as a Python bool)")
@@ -379,8 +414,83 @@ class SymT:
     def floor(self): return self._ew1("floor")
     def sign(self): return self._ew1("sign")
     def sigmoid(self): return self._ew1("sigmoid")
-    def relu(self): return self._ew2("max", 0.0)
+    def relu(self, inplace=False): return self._ew2("max", 0.0)
+    relu_ = relu
     def square(self): return self._ew2("mul", self)
+    def erf(self): return self._ew1("erf")
+    def atan(self): return self._ew1("atan")
+    arctan = atan
+    def asin(self): return self._ew1("asin")
+    arcsin = asin
+    def acos(self): return self._ew1("acos")
+    arccos = acos
+    def sinh(self): return self._ew1("sinh")
+    def cosh(self): return self._ew1("cosh")
+    def expm1(self): return self._ew1("expm1")
+    def log1p(self): return self._ew1("log1p")
+    def log2(self): return self.log() * (1.0 / math.log(2.0))
+    def log10(self): return self.log() * (1.0 / math.log(10.0))
+    def exp2(self): return (self * math.log(2.0)).exp()
+    def ceil(self): return self._ew1("ceil")
+    def round(self, decimals=0):
+        if decimals != 0:
+            raise TraceUnsupported("round(decimals != 0)")
+        return self._ew1("round")
+    def trunc(self): return self._ew1("trunc")
+    fix = trunc
+    def frac(self): return self - self.trunc()
+    def lerp(self, end, weight): return self + (self._lift(end) - self) * weight
+    def addcmul(self, t1, t2, value=1): return self + (self._lift(t1) * t2) * value
+    def addcdiv(self, t1, t2, value=1): return self + (self._lift(t1) / t2) * value
+    def hypot(self, o): return (self * self + self._lift(o) * o).sqrt()
+    def logaddexp(self, o):
+        o = self._lift(o)
+        m = self.maximum(o)
+        return m + ((self - m).exp() + (o - m).exp()).log()
+    def flip(self, dims=None, *more):
+        dims = (dims,) + more if isinstance(dims, int) else tuple(dims)
+        return SymT(self.g, np.flip(self.a, axis=dims), self.boolean)
+    def roll(self, shifts, dims=None):
+        return SymT(self.g, np.roll(self.a, shifts, axis=dims), self.boolean)
+    def cumsum(self, dim, dtype=None):
+        a = np.moveaxis(self.a, dim, 0).copy()
+        for r in range(1, a.shape[0]):
+            fo, fp = a[r].reshape(-1), a[r - 1].reshape(-1)
+            a[r] = np.array([self.g.bin("add", int(p_), int(o_)) for p_, o_ in zip(fp, fo)], dtype=np.int64).reshape(a[r].shape)
+        return SymT(self.g, np.moveaxis(a, 0, dim))
+    def cumprod(self, dim, dtype=None):
+        a = np.moveaxis(self.a, dim, 0).copy()
+        for r in range(1, a.shape[0]):
+            fo, fp = a[r].reshape(-1), a[r - 1].reshape(-1)
+            a[r] = np.array([self.g.bin("mul", int(p_), int(o_)) for p_, o_ in zip(fp, fo)], dtype=np.int64).reshape(a[r].shape)
+        return SymT(self.g, np.moveaxis(a, 0, dim))
+    def outer(self, o):
+        o = self._lift(o)
+        return self.unsqueeze(-1) * o.unsqueeze(-2)
+    def diagonal(self, offset=0, dim1=0, dim2=1): return SymT(self.g, np.diagonal(self.a, offset, dim1, dim2), self.boolean)
+    def trace(self): return self.diagonal().sum(-1)
+    def diag(self, diagonal=0):
+        if self.a.ndim == 2:
+            return SymT(self.g, np.diagonal(self.a, diagonal), self.boolean)
+        if self.a.ndim == 1 and diagonal == 0:
+            out = np.full((self.a.size, self.a.size), self.g.const(0.0), dtype=np.int64)
+            out[np.arange(self.a.size), np.arange(self.a.size)] = self.a
+            return SymT(self.g, out)
+        raise TraceUnsupported("diag of this shape")
+    def tril(self, diagonal=0):
+        z = self.g.const(0.0)
+        m = np.tril(np.ones(self.a.shape[-2:], dtype=bool), diagonal)
+        return SymT(self.g, np.where(m, self.a, z))
+    def triu(self, diagonal=0):
+        z = self.g.const(0.0)
+        m = np.triu(np.ones(self.a.shape[-2:], dtype=bool), diagonal)
+        return SymT(self.g, np.where(m, self.a, z))
+    def cross(self, o, dim=-1):
+        o = self._lift(o)
+        a = [SymT(self.g, np.take(self.a, i, axis=dim)) for i in range(3)]
+        b = [SymT(self.g, np.take(np.broadcast_to(o.a, self.a.shape), i, axis=dim)) for i in range(3)]
+        c = [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+        return SymT(self.g, np.stack([v.a for v in c], axis=dim))
     def reciprocal(self): return SymT(self.g, np.array(self.g.const(1.0)))._ew2("div", self)
     def rsqrt(self): return self.sqrt().reciprocal()
     def add(self, o, alpha=1): return self + (o if alpha == 1 else o * alpha)
@@ -449,10 +559,38 @@ class SymT:
         return r / float(n)
     def amax(self, dim=None, keepdim=False): return self._reduce("max", dim, keepdim)[0]
     def amin(self, dim=None, keepdim=False): return self._reduce("min", dim, keepdim)[0]
+    def max(self, dim=None, keepdim=False):
+        """max() -> tensor; max(dim) -> (values, indices): only `.values` / [0] can be traced"""
+        if dim is None:
+            return self.amax()
+        if isinstance(dim, (SymT, torch.Tensor)):
+            return self.maximum(dim)
+        return _ValuesOnly(self.amax(dim, keepdim))
+    def min(self, dim=None, keepdim=False):
+        if dim is None:
+            return self.amin()
+        if isinstance(dim, (SymT, torch.Tensor)):
+            return self.minimum(dim)
+        return _ValuesOnly(self.amin(dim, keepdim))
+    def var(self, dim=None, unbiased=True, keepdim=False, correction=None):
+        if isinstance(dim, bool):                                   # var(unbiased)
+            dim, unbiased = None, dim
+        corr = (1 if unbiased else 0) if correction is None else correction
+        mean, n = self._reduce("add", dim, True)
+        d = self - mean / float(n)
+        return (d * d).sum(dim, keepdim) / float(n - corr)
+    def std(self, dim=None, unbiased=True, keepdim=False, correction=None):
+        return self.var(dim, unbiased, keepdim, correction).sqrt()
     def norm(self, p=2, dim=None, keepdim=False):
-        if p not in (2, 2.0, "fro"):
-            raise TraceUnsupported("norm with p != 2")
-        return (self * self).sum(dim, keepdim).sqrt()
+        if p in (2, 2.0, "fro", None):
+            return (self * self).sum(dim, keepdim).sqrt()
+        if p in (1, 1.0):
+            return self.abs().sum(dim, keepdim)
+        if p == float("inf"):
+            return self.abs().amax(dim, keepdim)
+        if isinstance(p, (int, float)) and p > 0:
+            return (self.abs() ** float(p)).sum(dim, keepdim) ** (1.0 / float(p))
+        raise TraceUnsupported(f"norm with p = {p}")
 
     def matmul(self, o):
         o = self._lift(o)
@@ -492,6 +630,18 @@ class SymT:
     mm = matmul
     bmm = matmul
     def dot(self, o): return (self * o).sum()
+
+
+class _ValuesOnly:
+    """result of Tensor.max(dim) / min(dim): the values can be traced, the indices cannot (they would be data-dependent)"""
+    def __init__(self, values): self.values = values
+    @property
+    def indices(self): raise TraceUnsupported("argmax / argmin indices")
+    def __getitem__(self, i):
+        if i == 0:
+            return self.values
+        raise TraceUnsupported("argmax / argmin indices")
+    def __iter__(self): raise TraceUnsupported("argmax / argmin indices (unpacking values, indices)")
 
 
 class SymS:
@@ -584,9 +734,49 @@ def _where(g, cond, a, b):
     return SymT(g, out)
 
 
+def _einsum(g, eq, ops):
+    """explicit-output einsum ("bi,ij->bj", "bi,ij,bj->b", ...) as sums of products, terms in index order"""
+    if not isinstance(eq, str):
+        raise TraceUnsupported("einsum in the sublist format")
+    eq = eq.replace(" ", "")
+    if "->" not in eq or "." in eq:
+        raise TraceUnsupported("einsum without an explicit output / with an ellipsis")
+    lhs, out = eq.split("->")
+    terms = lhs.split(",")
+    syms = [_as_sym(g, o) for o in ops]
+    if len(terms) != len(syms):
+        raise TraceUnsupported("einsum: operand count")
+    sizes = {}
+    for t, sy in zip(terms, syms):
+        if len(t) != sy.a.ndim:
+            raise TraceUnsupported(f"einsum: '{t}' against a {sy.a.ndim}-d operand")
+        for ch, n in zip(t, sy.a.shape):
+            if sizes.setdefault(ch, n) != n:
+                raise TraceUnsupported(f"einsum: size of index '{ch}'")
+    if any(c not in sizes for c in out) or len(set(out)) != len(out):
+        raise TraceUnsupported("einsum: output indices")
+    summed = [c for c in sizes if c not in out]
+    res = np.empty([sizes[c] for c in out], dtype=np.int64)
+    for oi in np.ndindex(*res.shape):
+        env = dict(zip(out, oi))
+        acc = None
+        for si in np.ndindex(*[sizes[c] for c in summed]):
+            env.update(zip(summed, si))
+            prod = None
+            for t, sy in zip(terms, syms):
+                node = int(sy.a[tuple(env[c] for c in t)])
+                prod = node if prod is None else g.bin("mul", prod, node)
+            if g.cval(prod) == 0.0:
+                continue                               # structural zero of constant operands (see matmul)
+            acc = prod if acc is None else g.bin("add", acc, prod)
+        res[oi] = g.const(0.0) if acc is None else acc
+    return SymT(g, res)
+
+
 def _call(g, name, args, kwargs):
     """torch.* / torch.nn.functional.* / Tensor.* entry points by name."""
-    a0 = _as_sym(g, args[0]) if args and not isinstance(args[0], (tuple, list)) else None
+    name = {"_threshold": "threshold"}.get(name, name)            # (F.threshold is the private function _threshold)
+    a0 = _as_sym(g, args[0]) if args and not isinstance(args[0], (tuple, list, str)) else None
     rest = args[1:]
     if name in ("cat", "concatenate", "concat", "stack", "hstack", "vstack"):
         seq = [_as_sym(g, v).a for v in args[0]]
@@ -613,13 +803,106 @@ def _call(g, name, args, kwargs):
         out = a0.matmul(w.T)
         b = rest[1] if len(rest) > 1 else kwargs.get("bias")
         return out + b if b is not None else out
-    if name in ("einsum", "index_select", "gather", "scatter", "nonzero", "argmax", "argmin", "sort", "topk", "max", "min") and \
-            not (name in ("max", "min") and len(args) == 2 and (isinstance(args[1], (SymT, torch.Tensor)))):
-        if name in ("max", "min") and len(args) == 1 and not kwargs:
-            return a0.amax() if name == "max" else a0.amin()
+    if name == "einsum":
+        ops = args[1] if len(args) == 2 and isinstance(args[1], (tuple, list)) else args[1:]
+        return _einsum(g, args[0], ops)
+    if name in ("index_select", "gather", "scatter", "nonzero", "argmax", "argmin", "sort", "topk", "argsort"):
         raise TraceUnsupported(f"torch.{name}")
     if name in ("max", "min"):
-        return a0.maximum(args[1]) if name == "max" else a0.minimum(args[1])
+        return getattr(a0, name)(*rest, **kwargs)
+    if name in ("linalg_norm", "linalg_vector_norm", "vector_norm", "norm"):
+        p_ = kwargs.get("ord", kwargs.get("p", rest[0] if rest else 2))
+        dim = kwargs.get("dim", rest[1] if len(rest) > 1 else None)
+        return a0.norm(2 if p_ is None else p_, dim, kwargs.get("keepdim", rest[2] if len(rest) > 2 else False))
+    if name == "normalize":                            # F.normalize(input, p=2, dim=1, eps=1e-12)
+        p_ = kwargs.get("p", rest[0] if rest else 2.0)
+        dim = kwargs.get("dim", rest[1] if len(rest) > 1 else 1)
+        eps = kwargs.get("eps", rest[2] if len(rest) > 2 else 1e-12)
+        return a0 / a0.norm(p_, dim, True).clamp(min=eps)
+    if name in ("addmm", "addmv", "baddbmm", "addbmm"):
+        if name == "addbmm":
+            raise TraceUnsupported("torch.addbmm")
+        prod = _as_sym(g, rest[0]).matmul(rest[1])
+        alpha, beta = kwargs.get("alpha", 1), kwargs.get("beta", 1)
+        return (a0 if beta == 1 else a0 * beta) + (prod if alpha == 1 else prod * alpha)
+    if name in ("mse_loss", "l1_loss", "smooth_l1_loss", "huber_loss"):
+        d = a0 - rest[0]
+        if name == "mse_loss":
+            e = d * d
+        elif name == "l1_loss":
+            e = d.abs()
+        else:
+            beta = kwargs.get("beta", 1.0) if name == "smooth_l1_loss" else kwargs.get("delta", 1.0)
+            ad = d.abs()
+            quad = d * d * (0.5 / beta) if name == "smooth_l1_loss" else d * d * 0.5
+            lin = ad - 0.5 * beta if name == "smooth_l1_loss" else (ad - 0.5 * beta) * beta
+            e = _where(g, ad < beta, quad, lin)
+        red = kwargs.get("reduction", "mean")
+        return e if red == "none" else (e.sum() if red == "sum" else e.mean())
+    if name in ("softmax", "log_softmax", "softmin"):
+        dim = kwargs.get("dim", rest[0] if rest else None)
+        if dim is None:
+            raise TraceUnsupported(f"{name} without dim")
+        x = -a0 if name == "softmin" else a0
+        sh = x - x.amax(dim, True)
+        if name == "log_softmax":
+            return sh - sh.exp().sum(dim, True).log()
+        e = sh.exp()
+        return e / e.sum(dim, True)
+    if name == "layer_norm":                           # F.layer_norm(input, normalized_shape, weight, bias, eps)
+        nshape = tuple(rest[0]) if not isinstance(rest[0], int) else (rest[0],)
+        w = kwargs.get("weight", rest[1] if len(rest) > 1 else None)
+        b = kwargs.get("bias", rest[2] if len(rest) > 2 else None)
+        eps = kwargs.get("eps", rest[3] if len(rest) > 3 else 1e-5)
+        dims = tuple(range(a0.a.ndim - len(nshape), a0.a.ndim))
+        mu = a0.mean(dims, True)
+        d = a0 - mu
+        y = d / ((d * d).mean(dims, True) + eps).sqrt()
+        if w is not None:
+            y = y * w
+        return y + b if b is not None else y
+    if name in ("hardtanh", "relu6", "elu", "selu", "celu", "gelu", "tanhshrink", "softsign", "mish", "hardswish",
+                "hardsigmoid", "logsigmoid", "log_sigmoid", "threshold", "softshrink", "hardshrink", "silu", "relu", "relu_", "elu_",
+                "hardtanh_", "threshold_"):
+        name = {"log_sigmoid": "logsigmoid"}.get(name, name.rstrip("_"))
+        if name == "relu":
+            return a0.relu()
+        if name == "silu":
+            return a0 * a0.sigmoid()
+        if name in ("hardtanh", "relu6"):
+            lo = 0.0 if name == "relu6" else kwargs.get("min_val", rest[0] if rest else -1.0)
+            hi = 6.0 if name == "relu6" else kwargs.get("max_val", rest[1] if len(rest) > 1 else 1.0)
+            return a0.clamp(float(lo), float(hi))
+        if name in ("elu", "celu"):
+            alpha = float(kwargs.get("alpha", rest[0] if rest else 1.0))
+            neg = (a0.expm1() if name == "elu" else (a0 / alpha).expm1()) * alpha
+            return _where(g, a0 > 0.0, a0, neg)
+        if name == "selu":
+            alpha, scale = 1.6732632423543772848170429916717, 1.0507009873554804934193349852946
+            return _where(g, a0 > 0.0, a0, a0.expm1() * alpha) * scale
+        if name == "gelu":
+            if kwargs.get("approximate", "none") == "tanh":
+                return a0 * 0.5 * (((a0 + a0 * a0 * a0 * 0.044715) * math.sqrt(2.0 / math.pi)).tanh() + 1.0)
+            return a0 * 0.5 * ((a0 * (1.0 / math.sqrt(2.0))).erf() + 1.0)
+        if name == "tanhshrink":
+            return a0 - a0.tanh()
+        if name == "softsign":
+            return a0 / (a0.abs() + 1.0)
+        if name == "mish":
+            return a0 * (a0.exp().log1p()).tanh()
+        if name == "hardswish":
+            return a0 * (a0 + 3.0).clamp(0.0, 6.0) * (1.0 / 6.0)
+        if name == "hardsigmoid":
+            return (a0 + 3.0).clamp(0.0, 6.0) * (1.0 / 6.0)
+        if name == "logsigmoid":
+            return -((-a0).exp().log1p())
+        if name == "threshold":
+            th, val = kwargs.get("threshold", rest[0] if rest else None), kwargs.get("value", rest[1] if len(rest) > 1 else None)
+            return _where(g, a0 > float(th), a0, _as_sym(g, float(val)))
+        lam = float(kwargs.get("lambd", rest[0] if rest else 0.5))
+        if name == "softshrink":
+            return _where(g, a0 > lam, a0 - lam, _where(g, a0 < -lam, a0 + lam, _as_sym(g, 0.0)))
+        return _where(g, a0.abs() > lam, a0, _as_sym(g, 0.0))                      # hardshrink
     if name in ("softplus",):
         beta = kwargs.get("beta", 1.0)
         return ((a0 * beta).exp() + 1.0).log() / beta
@@ -630,14 +913,13 @@ def _call(g, name, args, kwargs):
     if name in ("leaky_relu",):
         slope = kwargs.get("negative_slope", rest[0] if rest else 0.01)
         return _where(g, a0 > 0.0, a0, a0 * slope)
-    if name in ("elu", "gelu", "silu", "selu", "softmax", "log_softmax", "layer_norm", "batch_norm"):
-        if name == "silu":
-            return a0 * a0.sigmoid()
+    if name in ("batch_norm", "group_norm", "instance_norm", "embedding", "conv1d", "conv2d"):
         raise TraceUnsupported(f"torch.nn.functional.{name}")
     if name in ("__getitem__",):
         return a0[rest[0]]
     meth = {"absolute": "abs", "negative": "neg", "true_divide": "div", "divide": "div", "multiply": "mul", "subtract": "sub",
-            "clip": "clamp", "arctan2": "atan2"}.get(name, name)
+            "clip": "clamp", "arctan2": "atan2", "linalg_cross": "cross", "bitwise_and": "logical_and",
+            "bitwise_or": "logical_or", "bitwise_not": "logical_not", "bitwise_xor": "logical_xor"}.get(name, name)
     if a0 is not None and hasattr(SymT, meth) and (not meth.startswith("_") or meth in _DUNDERS):
         f = getattr(a0, meth)
         if callable(f):
@@ -706,11 +988,15 @@ def _reaches(g, roots, kinds):
 # ---------------------------------------------------------------------------------------------------------------
 _FMT1 = {"neg": "(-{0})", "sin": "m_sin({0})", "cos": "m_cos({0})", "tan": "(m_sin({0}) / m_cos({0}))", "tanh": "m_tanh({0})",
          "exp": "m_exp({0})", "log": "m_log({0})", "sqrt": "m_sqrt({0})", "abs": "m_abs({0})", "floor": "m_floor({0})",
-         "sigmoid": "(T(1) / (T(1) + m_exp(-{0})))", "sign": "(T({0} > T(0)) - T({0} < T(0)))"}
+         "sigmoid": "(T(1) / (T(1) + m_exp(-{0})))", "sign": "(T({0} > T(0)) - T({0} < T(0)))",
+         "erf": "m_erf({0})", "atan": "m_atan({0})", "asin": "m_asin({0})", "acos": "m_acos({0})", "sinh": "m_sinh({0})",
+         "cosh": "m_cosh({0})", "expm1": "m_expm1({0})", "log1p": "m_log1p({0})", "ceil": "m_ceil({0})", "round": "m_rint({0})",
+         "trunc": "m_trunc({0})", "not": "(!{0})"}
 _FMT2 = {"add": "({0} + {1})", "sub": "({0} - {1})", "mul": "({0} * {1})", "div": "({0} / {1})", "min": "m_min({0}, {1})",
          "max": "m_max({0}, {1})", "pow": "m_pow({0}, {1})", "atan2": "m_atan2({0}, {1})",
          "floormod": "({0} - m_floor({0} / {1}) * {1})", "fmod": "m_fmod({0}, {1})",
-         "lt": "({0} < {1})", "le": "({0} <= {1})", "gt": "({0} > {1})", "ge": "({0} >= {1})", "eq": "({0} == {1})", "ne": "({0} != {1})"}
+         "lt": "({0} < {1})", "le": "({0} <= {1})", "gt": "({0} > {1})", "ge": "({0} >= {1})", "eq": "({0} == {1})", "ne": "({0} != {1})",
+         "and": "({0} && {1})", "or": "({0} || {1})", "xor": "({0} != {1})"}
 
 
 def _lit(v):
@@ -769,7 +1055,7 @@ def emit(g, roots, assign=None, ret=False):
                 e = f"({ops[0]} ? {ops[1]} : {ops[2]})"
             else:
                 raise TraceUnsupported(f"internal: no code for {k}")
-            if k in ("lt", "le", "gt", "ge", "eq", "ne"):
+            if k in ("lt", "le", "gt", "ge", "eq", "ne", "and", "or", "xor", "not"):
                 lines.append(f"const bool v{i} = {e};")
             else:
                 lines.append(f"const T v{i} = {e};")
@@ -831,6 +1117,17 @@ static inline T m_max(T a, T b) { return a > b ? a : b; }
 static inline T m_pow(T a, T b) { return std::pow(a, b); }
 static inline T m_atan2(T a, T b) { return std::atan2(a, b); }
 static inline T m_fmod(T a, T b) { return std::fmod(a, b); }
+static inline T m_erf(T x) { return std::erf(x); }
+static inline T m_atan(T x) { return std::atan(x); }
+static inline T m_asin(T x) { return std::asin(x); }
+static inline T m_acos(T x) { return std::acos(x); }
+static inline T m_sinh(T x) { return std::sinh(x); }
+static inline T m_cosh(T x) { return std::cosh(x); }
+static inline T m_expm1(T x) { return std::expm1(x); }
+static inline T m_log1p(T x) { return std::log1p(x); }
+static inline T m_ceil(T x) { return std::ceil(x); }
+static inline T m_rint(T x) { return std::nearbyint(x); }
+static inline T m_trunc(T x) { return std::trunc(x); }
 static inline T clampT(T x, T lo, T hi) { return std::fmin(std::fmax(x, lo), hi); }
 static const int NX = %(nx)d, NU = %(nu)d;
 static const double* p;

@@ -176,6 +176,28 @@ def approx_pendulum_callables(hidden=32, seed=25, dtype=torch.double):
     return dynamics, cost, net
 
 
+def zoo_callables(seed=3):
+    """a network with the activations users actually pick (GELU -> erf on the device, ELU -> expm1, ReLU) and a cost made
+    of a Huber term, a norm and a logical mask: the wider operator vocabulary of the tracer on the GPU"""
+    import torch.nn.functional as F
+    torch.manual_seed(seed)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.GELU(), torch.nn.Linear(8, 8), torch.nn.ELU(), torch.nn.Linear(8, 8),
+                              torch.nn.ReLU(), torch.nn.Linear(8, 4)).double()
+    goal = torch.tensor([0.5, -0.25, 0.0, 1.0], dtype=torch.float64)
+
+    def dynamics(state, action):
+        nxt = state + 0.1 * net.to(state.device)(torch.cat((state, action), dim=1))
+        nxt[:, 3] = torch.atan(nxt[:, 3])
+        return nxt
+
+    def cost(state, action):
+        g_ = goal.to(state.device)
+        return (F.smooth_l1_loss(state, g_.expand_as(state), reduction="none", beta=0.5).sum(1) + 0.1 * torch.linalg.norm(action, dim=1)
+                + torch.where((state[:, 0] > 0.5) & (state[:, 1] < 0.0), 1.0, 0.0))
+
+    return dynamics, cost, net
+
+
 def train_a_little(net, steps=3, seed=0):
     """a few optimizer steps on random targets: what happens to the network between two commands"""
     g = torch.Generator().manual_seed(seed)
@@ -203,7 +225,9 @@ def traced_models():
     mf, mq = small_mlp_callables()
     wf, wq, _ = watched_linear_callables()
     af, aq, _ = approx_pendulum_callables()
-    jobs = dict(pendulum=(f, q, 2, 1), linear=(lf, lq, 2, 2, lt), mlp=(mf, mq, 4, 2), watched=(wf, wq, 2, 2), approx=(af, aq, 2, 1))
-    with cf.ThreadPoolExecutor(max_workers=5) as ex:      # each ends in its own hipcc subprocess
+    zf, zq, _ = zoo_callables()
+    jobs = dict(pendulum=(f, q, 2, 1), linear=(lf, lq, 2, 2, lt), mlp=(mf, mq, 4, 2), watched=(wf, wq, 2, 2), approx=(af, aq, 2, 1),
+                zoo=(zf, zq, 4, 2))
+    with cf.ThreadPoolExecutor(max_workers=6) as ex:      # each ends in its own hipcc subprocess
         futs = {k: ex.submit(jit.from_torch, *v) for k, v in jobs.items()}
         return {k: v.result() for k, v in futs.items()}

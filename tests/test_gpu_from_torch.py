@@ -215,3 +215,19 @@ def test_learned_dynamics_command_time():
     margins.record("from_torch/learned_pendulum_c2_size", "ms_per_command", out["fused"], None, 0.5,
                    "trainable 3-32-32-2 tanh network traced with run-time parameters; callback loop: %.3f ms" % out["callbacks"])
     assert out["fused"] <= 0.5 and out["fused"] * 4 <= out["callbacks"], out
+
+
+def test_wider_operator_vocabulary_runs_fused():
+    """GELU (erf), ELU (expm1), ReLU, atan by item assignment, Huber cost, norm, a logical mask: traced, compiled, and equal to
+    the callback loop on the same draw (fp64)."""
+    f, q, net = jf.zoo_callables()
+    sigma = torch.eye(2, dtype=torch.float64) * 0.5
+    K, T = 900, 14
+    a, b, U0, nu = _pair(f, q, 4, sigma, torch.float64, K, T, lambda_=1.5)
+    assert a.jit_note.startswith("fused") and not a._needs_generic(), a.jit_note
+    x0 = torch.linspace(-1, 1, 4, dtype=torch.float64)
+    z = torch.randn(K, T, nu, generator=torch.Generator().manual_seed(12), dtype=torch.float64)
+    a.inject_noise(z)
+    b.inject_noise(z)
+    ua, ub = a.command(x0.cuda()), b.command(x0.cuda())
+    assert float((ua - ub).abs().max()) <= 1e-9 and float((a.cost_total - b.cost_total).abs().max()) <= 1e-9 * float(b.cost_total.abs().max())

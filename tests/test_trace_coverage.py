@@ -1,0 +1,102 @@
+"""pytorch_mppi_amd/trace.py: the operator vocabulary.  Each case is a dynamics / running-cost pair a user might write with
+one family of torch operations; it must translate AND agree with the callable on random batches (host build, fp64, 1e-9):
+activations of nn.Sequential networks, normalisations, losses, einsum / addmm / bmm, reductions with dims, cumulative and
+reordering ops, the extra transcendental functions, logical masks."""
+import math
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from pytorch_mppi_amd import trace
+
+NX, NU = 3, 2
+Q = lambda s, a: (s ** 2).sum(-1)
+
+
+def _seq(act):
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(NX + NU, 6), act, nn.Linear(6, NX)).double()
+    return lambda s, a: s + net(torch.cat((s, a), 1))
+
+
+ACTS = dict(relu=nn.ReLU(), relu_inplace=nn.ReLU(inplace=True), elu=nn.ELU(), celu=nn.CELU(0.7), gelu=nn.GELU(),
+            gelu_tanh=nn.GELU(approximate="tanh"), selu=nn.SELU(), silu=nn.SiLU(), softplus=nn.Softplus(), sigmoid=nn.Sigmoid(),
+            leaky=nn.LeakyReLU(0.1), hardtanh=nn.Hardtanh(-0.5, 0.8), relu6=nn.ReLU6(), tanhshrink=nn.Tanhshrink(),
+            softsign=nn.Softsign(), mish=nn.Mish(), hardswish=nn.Hardswish(), hardsigmoid=nn.Hardsigmoid(),
+            logsigmoid=nn.LogSigmoid(), softshrink=nn.Softshrink(0.3), hardshrink=nn.Hardshrink(0.3), threshold=nn.Threshold(0.1, -2.0))
+
+
+@pytest.mark.parametrize("name", sorted(ACTS))
+def test_activation_modules(name):
+    f = _seq(ACTS[name])
+    code = trace.generate(f, Q, NX, NU)
+    assert trace.verify_on_host(code, f, Q, NX, NU)
+
+
+def _cases():
+    torch.manual_seed(1)
+    W = torch.randn(NX, NX, dtype=torch.float64)
+    ln = nn.LayerNorm(NX).double()
+    with torch.no_grad():
+        ln.weight.mul_(1.3)
+        ln.bias.add_(0.2)
+    u1 = lambda a: a[:, :1]
+    c = {}
+    c["layer_norm"] = (lambda s, a: s + 0.1 * ln(s) * u1(a), Q)
+    c["softmax"] = (lambda s, a: s + F.softmax(s, dim=-1) * u1(a), Q)
+    c["log_softmax_softmin"] = (lambda s, a: s + F.log_softmax(s, dim=1) * u1(a) + F.softmin(s, dim=1), Q)
+    c["einsum_matrix"] = (lambda s, a: torch.einsum("bi,ij->bj", s, W) + u1(a), Q)
+    c["einsum_quadratic_cost"] = (lambda s, a: s + u1(a), lambda s, a: torch.einsum("bi,ij,bj->b", s, W @ W.T, s))
+    c["quadratic_cost_matmul"] = (lambda s, a: s + u1(a), lambda s, a: ((s @ (W @ W.T)) * s).sum(1))
+    c["quadratic_cost_diag"] = (lambda s, a: s + u1(a), lambda s, a: (s @ (W @ W.T) @ s.T).diag())
+    c["linalg_norm"] = (lambda s, a: s / (1.0 + torch.linalg.norm(s, dim=1, keepdim=True)) + u1(a),
+                        lambda s, a: torch.linalg.vector_norm(s, ord=1, dim=1) + s.norm(p=3, dim=1) + torch.norm(a, dim=-1))
+    c["normalize"] = (lambda s, a: F.normalize(s, dim=1) + u1(a), Q)
+    c["cross"] = (lambda s, a: s + 0.1 * torch.cross(s, torch.cat((a, u1(a)), 1), dim=1) + 0.1 * torch.linalg.cross(s, s.roll(1, 1)), Q)
+
+    def rot(s, a):
+        co, sn = torch.cos(s[:, 2]), torch.sin(s[:, 2])
+        R = torch.stack((torch.stack((co, -sn), -1), torch.stack((sn, co), -1)), -2)          # (B,2,2)
+        v = torch.bmm(R, a.unsqueeze(-1)).squeeze(-1)
+        return torch.cat((s[:, :2] + 0.1 * v, s[:, 2:] + 0.05 * u1(a)), 1)
+    c["bmm_rotation"] = (rot, Q)
+    c["square_sign_remainder_fmod"] = (lambda s, a: torch.square(s) * torch.sign(u1(a)) + torch.remainder(s, 2.0) + torch.fmod(u1(a), 0.7), Q)
+    c["losses"] = (lambda s, a: s + u1(a),
+                   lambda s, a: F.mse_loss(s, torch.zeros_like(s), reduction="none").sum(1) + F.l1_loss(a, torch.ones_like(a), reduction="none").sum(1)
+                   + F.smooth_l1_loss(s, torch.zeros_like(s), reduction="none", beta=0.5).sum(1) + F.huber_loss(s, torch.ones_like(s), reduction="none", delta=0.7).sum(1))
+    c["cumsum_cumprod"] = (lambda s, a: torch.cumsum(s, dim=1) + 0.1 * torch.cumprod(s, dim=1) + u1(a), Q)
+    c["flip_roll"] = (lambda s, a: torch.flip(s, dims=(1,)) + torch.roll(s, 1, dims=1) * u1(a), Q)
+    c["addmm_addcmul_lerp"] = (lambda s, a: torch.addmm(u1(a).expand(-1, NX), s, W, beta=0.5, alpha=2.0)
+                               + torch.lerp(s, torch.ones_like(s), 0.3) + torch.addcmul(s, s, s, value=0.5) + torch.addcdiv(s, s, 2 + s ** 2), Q)
+    c["expm1_log1p_log2_exp2"] = (lambda s, a: torch.expm1(0.1 * s) + torch.log1p(s ** 2) + torch.log2(1 + s ** 2) + torch.exp2(0.1 * s) + torch.log10(2 + s ** 2) + u1(a), Q)
+    c["erf_atan_asin_acos"] = (lambda s, a: torch.erf(s) + torch.atan(s) + torch.asin(torch.tanh(s)) + torch.acos(torch.tanh(s)) + u1(a), Q)
+    c["sinh_cosh_hypot_logaddexp"] = (lambda s, a: torch.sinh(0.1 * s) + torch.cosh(0.1 * s) + torch.hypot(s, u1(a)) + torch.logaddexp(s, u1(a)), Q)
+    c["ceil_round_trunc_frac"] = (lambda s, a: torch.ceil(s) + torch.round(s * 3) + torch.trunc(s * 2) + torch.frac(s) + u1(a), Q)
+    c["var_std_mean"] = (lambda s, a: s + s.var(dim=1, keepdim=True) + s.std(dim=1, keepdim=True, unbiased=False) * u1(a) + s.mean(1, keepdim=True), Q)
+    c["max_min_with_dim"] = (lambda s, a: s + s.abs().max(dim=1, keepdim=True).values * u1(a) + torch.min(s, dim=1, keepdim=True)[0],
+                             lambda s, a: s.max(dim=1).values ** 2 + a.amax(1))
+    c["logical_masks"] = (lambda s, a: torch.where((s > 0) & (s < 1), s, -s) + torch.where((s < -1) | ~(s < 2), s * 0.5, s) + u1(a),
+                          lambda s, a: torch.where(torch.logical_and(s[:, 0] > 0, s[:, 1] != 0.25), s[:, 0], s[:, 1] ** 2) + (s[:, 2] == s[:, 2]) * 1.0)
+    outer = lambda s: s.unsqueeze(-1) * s.unsqueeze(-2)                       # per-sample (B, nx, nx)
+    c["outer_tril_triu_diagonal"] = (lambda s, a: s + outer(s).tril().sum(1) * 0.1 + outer(s).triu(1).sum(2) * 0.2
+                                     + outer(s).diagonal(dim1=-2, dim2=-1) * u1(a), Q)
+    return c
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_operator_families(name):
+    f, q = CASES[name]
+    code = trace.generate(f, q, NX, NU)
+    assert trace.verify_on_host(code, f, q, NX, NU)
+
+
+def test_indices_of_max_are_refused():
+    with pytest.raises(trace.TraceUnsupported):
+        trace.generate(lambda s, a: s + s.max(dim=1, keepdim=True).indices * 1.0, Q, NX, NU)
+    with pytest.raises(trace.TraceUnsupported):
+        trace.generate(lambda s, a: s + torch.argmax(s, dim=1, keepdim=True) * 1.0, Q, NX, NU)
