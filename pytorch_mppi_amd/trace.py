@@ -281,6 +281,11 @@ class SymT:
     def __iter__(self): return (self[i] for i in range(self.a.shape[0]))
 
     def __getitem__(self, idx):
+        if isinstance(idx, SymT) and idx.boolean:
+            # x[mask]: a data-dependent selection.  Only the read-modify-write idiom `x[mask] op= scalar` / `x[mask] = ...` can be
+            # traced (as a select under the mask): the result is a placeholder that takes scalar arithmetic and goes back into
+            # `x[mask] = ...` with the SAME mask
+            return _Masked(self.clone(), idx)
         def chk(i):
             if isinstance(i, (SymT, SymS)):
                 raise TraceUnsupported("indexing by a traced value")
@@ -294,12 +299,66 @@ class SymT:
             raise TraceUnsupported(f"indexing: {e}")
 
     def __setitem__(self, idx, v):
+        if isinstance(idx, SymT) and idx.boolean:
+            if isinstance(v, _Masked):
+                if v.mask is not idx and not (v.mask.a.shape == idx.a.shape and np.array_equal(v.mask.a, idx.a)):
+                    raise TraceUnsupported("x[mask] = y[other_mask]")
+                val = v.full
+            else:
+                val = self._lift(v)
+                if val.a.size != 1:
+                    raise TraceUnsupported("x[mask] = tensor (its length depends on the data)")
+            try:
+                self.a[...] = _where(self.g, idx, val, self).a
+            except ValueError as e:
+                raise TraceUnsupported(f"masked assignment: {e}")
+            return
+        if isinstance(v, _Masked):
+            raise TraceUnsupported("a masked selection used outside x[mask] = ...")
         v = self._lift(v)
         idx = tuple(i.detach().cpu().numpy() if isinstance(i, torch.Tensor) else i for i in idx) if isinstance(idx, tuple) else idx
         try:
             self.a[idx] = v.a          # (the traced inputs are handed to the callable as copies: an in-place write
         except (IndexError, ValueError, TypeError) as e:    # into `state` stays local, like state.clone() first)
             raise TraceUnsupported(f"item assignment: {e}")
+
+    # -- in-place forms: write through self.a (a numpy view of the parent's ids where torch would have a view) --------------
+    def _inplace(self, r):
+        try:
+            self.a[...] = np.broadcast_to(self._lift(r).a, self.a.shape)
+        except ValueError as e:
+            raise TraceUnsupported(f"in-place operation: {e}")
+        return self
+    def __iadd__(self, o): return self._inplace(self + o)
+    def __isub__(self, o): return self._inplace(self - o)
+    def __imul__(self, o): return self._inplace(self * o)
+    def __itruediv__(self, o): return self._inplace(self / o)
+    def __ipow__(self, o): return self._inplace(self ** o)
+    def __imod__(self, o): return self._inplace(self % o)
+    def add_(self, o, alpha=1): return self._inplace(self.add(o, alpha=alpha))
+    def sub_(self, o, alpha=1): return self._inplace(self.sub(o, alpha=alpha))
+    def mul_(self, o): return self._inplace(self * o)
+    def div_(self, o): return self._inplace(self / o)
+    def pow_(self, o): return self._inplace(self ** o)
+    def neg_(self): return self._inplace(-self)
+    def abs_(self): return self._inplace(self.abs())
+    def clamp_(self, min=None, max=None): return self._inplace(self.clamp(min, max))
+    clip_ = clamp_
+    def clamp_min_(self, v): return self._inplace(self.clamp(min=v))
+    def clamp_max_(self, v): return self._inplace(self.clamp(max=v))
+    def copy_(self, o, non_blocking=False): return self._inplace(o)
+    def fill_(self, v): return self._inplace(v)
+    def zero_(self): return self._inplace(0.0)
+    def tanh_(self): return self._inplace(self.tanh())
+    def sigmoid_(self): return self._inplace(self.sigmoid())
+    def sin_(self): return self._inplace(self.sin())
+    def cos_(self): return self._inplace(self.cos())
+    def exp_(self): return self._inplace(self.exp())
+    def sqrt_(self): return self._inplace(self.sqrt())
+    def remainder_(self, o): return self._inplace(self % o)
+    def fmod_(self, o): return self._inplace(self.fmod(o))
+    def masked_fill(self, mask, value): return _where(self.g, mask, _as_sym(self.g, value), self)
+    def masked_fill_(self, mask, value): return self._inplace(self.masked_fill(mask, value))
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kw):
         if method != "__call__" or kw.get("out") is not None:
@@ -414,8 +473,10 @@ class SymT:
     def floor(self): return self._ew1("floor")
     def sign(self): return self._ew1("sign")
     def sigmoid(self): return self._ew1("sigmoid")
-    def relu(self, inplace=False): return self._ew2("max", 0.0)
-    relu_ = relu
+    def relu(self, inplace=False):
+        r = self._ew2("max", 0.0)
+        return self._inplace(r) if inplace else r
+    def relu_(self): return self.relu(True)
     def square(self): return self._ew2("mul", self)
     def erf(self): return self._ew1("erf")
     def atan(self): return self._ew1("atan")
@@ -630,6 +691,30 @@ class SymT:
     mm = matmul
     bmm = matmul
     def dot(self, o): return (self * o).sum()
+
+
+class _Masked:
+    """`x[mask]` of a traced boolean mask: the full-shape values with the mask beside them.  Scalar arithmetic only; it can
+    go back into `x[mask] = ...` (see SymT.__setitem__); any other use is refused."""
+    def __init__(self, full, mask):
+        self.full, self.mask = full, mask
+
+    def _b(self, op, o, rev=False):
+        if isinstance(o, (SymT, SymS, _Masked)) or (isinstance(o, (torch.Tensor, np.ndarray)) and o.size != 1 if isinstance(o, np.ndarray) else
+                                                      isinstance(o, torch.Tensor) and o.numel() != 1):
+            raise TraceUnsupported("arithmetic between a masked selection and a tensor")
+        return _Masked(self.full._ew2(op, o, reverse=rev), self.mask)
+    def __add__(self, o): return self._b("add", o)
+    def __radd__(self, o): return self._b("add", o, True)
+    def __sub__(self, o): return self._b("sub", o)
+    def __rsub__(self, o): return self._b("sub", o, True)
+    def __mul__(self, o): return self._b("mul", o)
+    def __rmul__(self, o): return self._b("mul", o, True)
+    def __truediv__(self, o): return self._b("div", o)
+    def __mod__(self, o): return self._b("floormod", o)
+    def __neg__(self): return _Masked(-self.full, self.mask)
+    def __getattr__(self, name):
+        raise TraceUnsupported(f"a masked selection x[mask] used as a tensor (.{name}): its length depends on the data")
 
 
 class _ValuesOnly:
@@ -942,6 +1027,41 @@ def _flatten_result(r, want, what):
     return [int(v) for v in a]
 
 
+_FACTORIES = {"zeros", "ones", "empty", "full", "tensor", "as_tensor", "eye", "from_numpy", "linspace", "diag", "diag_embed",
+              "zeros_like", "ones_like", "full_like", "empty_like", "scalar_tensor", "asarray"}
+_RANDOM = {"randn", "rand", "randn_like", "rand_like", "normal", "randint", "bernoulli", "multinomial", "randperm", "poisson"}
+
+
+class _TraceMode(torch.overrides.TorchFunctionMode):
+    """While the callables run on symbolic inputs: floating tensors they CREATE (torch.zeros(B, nx) to be filled column by
+    column, torch.tensor([...]) constants) become symbolic constants too, so that item assignment of traced values into them
+    works; random draws are refused (not a function of state, action and timestep); everything else passes through."""
+    def __init__(self, g):
+        super().__init__()
+        self.g = g
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", str(func))
+
+        def has_sym(v):
+            return isinstance(v, (SymT, SymS, _Masked)) or (isinstance(v, (tuple, list)) and any(has_sym(e) for e in v))
+        if name in _RANDOM:
+            raise TraceUnsupported(f"torch.{name} inside the callable (random draws are not a function of state, action and timestep)")
+        if any(has_sym(v) for v in args) or any(has_sym(v) for v in kwargs.values()):
+            if any(isinstance(v, _Masked) for v in args):
+                raise TraceUnsupported("a masked selection x[mask] passed to a torch function")
+            if name == "__setitem__" and isinstance(args[0], torch.Tensor):
+                raise TraceUnsupported("item assignment of a traced value into a tensor created outside the traced callables")
+            args = tuple(SymT(a.g, np.array(a.i)) if isinstance(a, SymS) else a for a in args)
+            return _call(self.g, name, args, kwargs)
+        out = func(*args, **kwargs)
+        if name in _FACTORIES and isinstance(out, torch.Tensor) and out.is_floating_point() and out.numel() <= 65536 and not out.requires_grad:
+            vals = out.detach().cpu().double().numpy()
+            return SymT(self.g, np.vectorize(self.g.const, otypes=[np.int64])(vals))
+        return out
+
+
 def trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False):
     """-> (Graph, step outputs [nx node ids], cost output id, terminal output id or None)"""
     g = Graph()
@@ -950,7 +1070,7 @@ def trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost=None, st
         return SymT(g, np.array([g.leaf(kind, i) for i in range(n)], dtype=np.int64).reshape(shape))
     t = SymS(g, g.leaf("t"))
     extra = (t,) if step_dependent else ()
-    with torch.no_grad():
+    with torch.no_grad(), _TraceMode(g):
         nxt = dynamics(xs("x", nx, (1, nx)), xs("u", nu, (1, nu)), *extra)
         step_out = _flatten_result(nxt, nx, "dynamics")
         c = running_cost(xs("x", nx, (1, nx)), xs("u", nu, (1, nu)), *extra)
@@ -1189,6 +1309,9 @@ def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=Non
                 ref_x = dynamics(X.to(dev, dt, copy=True), U.to(dev, dt, copy=True), *extra).cpu()
                 ref_c = running_cost(X.to(dev, dt), U.to(dev, dt), *extra).cpu()
             tol = rtol if dt == torch.float64 else max(rtol, 2e-5)
+            if ref_x.numel() != B * nx or ref_c.numel() != B:
+                raise TraceUnsupported(f"the callables return {tuple(ref_x.shape)} / {tuple(ref_c.shape)} for a batch of {B}: not one "
+                                       f"next state ({nx} values) and one cost per sample")
             pairs = [("dynamics", Xn, ref_x.detach().double().reshape(B, -1).numpy()),
                      ("running_cost", Cc, ref_c.detach().double().reshape(-1).numpy())]
             if terminal_state_cost is not None:

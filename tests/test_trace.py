@@ -135,7 +135,10 @@ def test_untraceable_callables_are_refused(bad):
         f = lambda s, a: s + a
         term = lambda states, actions: (states[..., 0, :] ** 2).sum(-1)
     with pytest.raises(trace.TraceUnsupported):
-        trace.generate(f, q, 2, 2, term)
+        code = trace.generate(f, q, 2, 2, term)
+        # (a tensor the callable creates is a symbolic constant now: a dynamics that returns torch.zeros(1, 2) translates, and is
+        # caught where every translation is checked -- against the callable on a batch)
+        trace.verify_on_host(code, f, q, 2, 2, term)
 
 
 def test_verification_catches_a_wrong_translation():

@@ -100,3 +100,49 @@ def test_indices_of_max_are_refused():
         trace.generate(lambda s, a: s + s.max(dim=1, keepdim=True).indices * 1.0, Q, NX, NU)
     with pytest.raises(trace.TraceUnsupported):
         trace.generate(lambda s, a: s + torch.argmax(s, dim=1, keepdim=True) * 1.0, Q, NX, NU)
+
+
+def test_user_idioms_fill_a_created_tensor_in_place_ops_and_masked_updates():
+    """the ways people actually write dynamics: build the next state in a tensor they create, update columns in place, wrap
+    an angle with a boolean mask (the reference's own angular_diff_batch, tests/pendulum_approximate.py:87-92)"""
+    def f(s, a):
+        nxt = torch.zeros(s.shape[0], NX, dtype=s.dtype, device=s.device)
+        nxt[:, 0] = s[:, 0] + 0.1 * torch.cos(s[:, 2]) * a[:, 0]
+        nxt[:, 1] = s[:, 1] + 0.1 * torch.sin(s[:, 2]) * a[:, 0]
+        th = s[:, 2] + 0.3 * a[:, 1]
+        th[th > math.pi] -= 2 * math.pi
+        th[th < -math.pi] += 2 * math.pi
+        nxt[:, 2] = th
+        nxt[:, :2].mul_(0.99)
+        nxt += torch.tensor([0.01, 0.0, 0.0], dtype=s.dtype, device=s.device)
+        return nxt
+
+    def q(s, a):
+        c = (s[:, :2] ** 2).sum(1)
+        c[s[:, 0].abs() > 1.0] = 50.0
+        pen = a.clone().abs_().sum(1)
+        pen.clamp_(max=1.5)
+        return c + 0.1 * pen + s[:, 2].masked_fill(s[:, 2] < 0, 0.0)
+
+    code = trace.generate(f, q, NX, NU)
+    assert trace.verify_on_host(code, f, q, NX, NU)
+
+
+def test_views_write_through_like_torch():
+    def f(s, a):
+        s = s.clone()
+        v = s[:, 1:]                 # a view: the in-place update below changes s
+        v += a
+        return s
+
+    code = trace.generate(f, Q, NX, NU)
+    assert trace.verify_on_host(code, f, Q, NX, NU)
+
+
+def test_random_draws_and_data_dependent_selections_are_refused():
+    with pytest.raises(trace.TraceUnsupported, match="random"):
+        trace.generate(lambda s, a: s + 0.1 * torch.randn_like(a[:, :1]), Q, NX, NU)
+    with pytest.raises(trace.TraceUnsupported, match="random"):
+        trace.generate(lambda s, a: s + 0.1 * torch.randn(s.shape[0], NX, dtype=s.dtype), Q, NX, NU)
+    with pytest.raises(trace.TraceUnsupported, match="masked selection"):
+        trace.generate(lambda s, a: s + s[s > 0].sum(), Q, NX, NU)
