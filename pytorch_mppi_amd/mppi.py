@@ -213,11 +213,17 @@ class MPPI:
                               or bool(step_dependent_dynamics) == bool(getattr(m, "step_dependent", False))):
             self._model = m
         self.jit_note = None
-        if m is None and self.d.type == "cuda" and self.M == 1 and (
-                auto_jit if auto_jit is not None else os.environ.get("MPPI_AUTO_JIT", "1") != "0"):
+        self._jit_pending = None
+        # auto_jit: True / "sync" = trace and compile now (construction blocks for the hipcc run unless the object is cached);
+        # "async" = trace now, compile in a background thread -- commands run the callbacks until the fused kernels are
+        # there; False / "0" = off.  None: the environment's MPPI_AUTO_JIT (default "async")
+        mode = auto_jit if auto_jit is not None else os.environ.get("MPPI_AUTO_JIT", "async")
+        mode = {True: "sync", "1": "sync", False: "0", "": "0"}.get(mode, mode)
+        if m is None and self.d.type == "cuda" and self.M == 1 and mode != "0":
             # plain torch callables (the reference's plugin API): try to trace them into a device functor
             # (pytorch_mppi_amd/trace.py -> jit.compile_model); outside the traceable subset the generic path stays
-            self._model = self._try_trace(dynamics, running_cost, terminal_state_cost, bool(step_dependent_dynamics))
+            self._model = self._try_trace(dynamics, running_cost, terminal_state_cost, bool(step_dependent_dynamics),
+                                          background=(mode == "async"))
         if self._model is not None and (self._model.nx != self.nx or self._model.nu != self.nu):
             raise ValueError(f"native model dims ({self._model.nx},{self._model.nu}) != (nx,nu)=({self.nx},{self.nu})")
         if self._shard is not None and self._shard.world_size > 1 and rng != "philox":
@@ -236,12 +242,30 @@ class MPPI:
         self._dev_index = (self.d.index if self.d.index is not None else
                            (torch.cuda.current_device() if self.d.type == "cuda" and torch.cuda.is_available() else 0))
 
-    def _try_trace(self, dynamics, running_cost, terminal_state_cost, step_dependent):
+    def _try_trace(self, dynamics, running_cost, terminal_state_cost, step_dependent, background=False):
         import logging
         from . import jit, trace
         log = logging.getLogger("pytorch_mppi_amd")
         try:
-            m = jit.from_torch(dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent=step_dependent)
+            code = jit.trace_and_verify(dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent)
+            if background and not jit.traced_is_cached(code, self.nx, self.nu):
+                # the hipcc run (30 s - 2 min) happens beside the control loop: callbacks until it has finished
+                import threading
+                box = {}
+
+                def work():
+                    try:
+                        box["model"] = jit.compile_traced(code, dynamics, running_cost, self.nx, self.nu, terminal_state_cost,
+                                                          step_dependent=step_dependent)
+                    except Exception as e:                      # a failed hipcc run: stay on the callbacks
+                        box["error"] = e
+                th = threading.Thread(target=work, name="pytorch_mppi_amd-jit", daemon=True)
+                self._jit_pending = (th, box)
+                th.start()
+                self.jit_note = "generic path for now: the fused kernels of the traced callables are being compiled in the background"
+                log.warning("pytorch_mppi_amd: %s (auto_jit='sync' / MPPI_AUTO_JIT=sync waits for them instead)", self.jit_note)
+                return None
+            m = jit.compile_traced(code, dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent=step_dependent)
         except trace.TraceUnsupported as e:
             self.jit_note = f"generic path: {e}"
             log.info("pytorch_mppi_amd: dynamics / running_cost stay on the generic (callback) path: %s", e)
@@ -670,7 +694,34 @@ class MPPI:
         p.sampler_actions = _ptr(actions)
         p._keep["sampler"] = actions
 
+    def _adopt_background_model(self):
+        """the background compile of the traced callables (auto_jit="async") has finished: switch to the fused kernels"""
+        th, box = self._jit_pending
+        if th.is_alive():
+            return
+        self._jit_pending = None
+        import logging
+        log = logging.getLogger("pytorch_mppi_amd")
+        m = box.get("model")
+        if m is None:
+            self.jit_note = f"generic path: {type(box.get('error')).__name__}: {box.get('error')}"
+            log.warning("pytorch_mppi_amd: dynamics / running_cost stay on the generic (callback) path: %s", self.jit_note)
+            return
+        self._model = m
+        self._problem_cache.clear()
+        self.jit_note = f"fused: traced {m.traced_ops} operations per sample into {m.name} (compiled in the background)"
+        log.warning("pytorch_mppi_amd: %s", self.jit_note)
+
+    def wait_for_jit(self, timeout=None):
+        """Block until a background compile (auto_jit="async") has finished; True when the controller runs fused afterwards."""
+        if self._jit_pending is not None:
+            self._jit_pending[0].join(timeout)
+            self._adopt_background_model()
+        return self._model is not None
+
     def _needs_generic(self):
+        if self._model is None and self._jit_pending is not None:
+            self._adopt_background_model()
         if self._model is None:
             return True
         if getattr(self._model, "_param_tensors", None):

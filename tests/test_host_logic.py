@@ -217,3 +217,44 @@ def test_philox_known_answers_and_moments():
     z2 = oph.normals_ktn(seed=42, call=1, K=100, T=16, nu=3, k_offset=1000)
     assert np.array_equal(z2, z[1000:1100])
     assert not np.array_equal(oph.normals_ktn(42, 2, 8, 16, 3), z[:8])
+
+
+def test_background_jit_state_machine(monkeypatch):
+    """auto_jit="async": the callables are traced at construction, hipcc runs in a background thread, commands stay on the
+    callbacks until it has finished, then the controller adopts the fused model (or keeps the callbacks after a failure).
+    The compile itself is replaced by a stub here (no hipcc, no GPU)."""
+    import threading
+    import time
+    from pytorch_mppi_amd import jit
+    f = lambda s, a: s + 0.1 * a
+    q = lambda s, a: (s ** 2).sum(-1)
+    c = pm.MPPI(f, q, 2, torch.eye(2, dtype=torch.double), num_samples=8, horizon=3, auto_jit=False)
+    assert c._model is None and c._jit_pending is None
+    gate = threading.Event()
+
+    class Dummy:
+        nx = nu = 2
+        traced_ops, name, process_noise = 7, "traced_dummy", None
+
+    def slow_compile(code, *a, **k):
+        assert "x[0]" in code["step"]
+        gate.wait(5.0)
+        return Dummy()
+    monkeypatch.setattr(jit, "compile_traced", slow_compile)
+    monkeypatch.setattr(jit, "traced_is_cached", lambda *a, **k: False)
+    assert c._try_trace(f, q, None, False, background=True) is None
+    assert c._jit_pending is not None and c.jit_note.startswith("generic path for now")
+    assert c._needs_generic() and c._model is None             # still compiling: callbacks
+    gate.set()
+    assert c.wait_for_jit(5.0) and isinstance(c._model, Dummy) and c._jit_pending is None
+    assert c.jit_note.startswith("fused") and "background" in c.jit_note
+    # a cached object is adopted at once, also in the background mode
+    monkeypatch.setattr(jit, "traced_is_cached", lambda *a, **k: True)
+    c2 = pm.MPPI(f, q, 2, torch.eye(2, dtype=torch.double), num_samples=8, horizon=3, auto_jit=False)
+    assert isinstance(c2._try_trace(f, q, None, False, background=True), Dummy) and c2._jit_pending is None
+    # a failed hipcc run leaves the controller on the callbacks, with the reason in jit_note
+    monkeypatch.setattr(jit, "traced_is_cached", lambda *a, **k: False)
+    monkeypatch.setattr(jit, "compile_traced", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("hipcc failed")))
+    c3 = pm.MPPI(f, q, 2, torch.eye(2, dtype=torch.double), num_samples=8, horizon=3, auto_jit=False)
+    assert c3._try_trace(f, q, None, False, background=True) is None
+    assert not c3.wait_for_jit(5.0) and c3._model is None and "hipcc failed" in c3.jit_note
