@@ -198,6 +198,11 @@ def zoo_callables(seed=3):
     return dynamics, cost, net
 
 
+def approx_terminal_cost(states, actions):
+    """terminal cost used with the learned pendulum in tests/test_gpu_from_torch.py (its traced form is built by build())"""
+    return 3.0 * (states[..., -1, :] ** 2).sum(-1)
+
+
 def train_a_little(net, steps=3, seed=0):
     """a few optimizer steps on random targets: what happens to the network between two commands"""
     g = torch.Generator().manual_seed(seed)
@@ -227,7 +232,7 @@ def traced_models():
     af, aq, _ = approx_pendulum_callables()
     zf, zq, _ = zoo_callables()
     jobs = dict(pendulum=(f, q, 2, 1), linear=(lf, lq, 2, 2, lt), mlp=(mf, mq, 4, 2), watched=(wf, wq, 2, 2), approx=(af, aq, 2, 1),
-                zoo=(zf, zq, 4, 2))
-    with cf.ThreadPoolExecutor(max_workers=6) as ex:      # each ends in its own hipcc subprocess
+                zoo=(zf, zq, 4, 2), approx_terminal=(af, aq, 2, 1, approx_terminal_cost))
+    with cf.ThreadPoolExecutor(max_workers=7) as ex:      # each ends in its own hipcc subprocess
         futs = {k: ex.submit(jit.from_torch, *v) for k, v in jobs.items()}
         return {k: v.result() for k, v in futs.items()}

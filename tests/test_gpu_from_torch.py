@@ -231,3 +231,44 @@ def test_wider_operator_vocabulary_runs_fused():
     b.inject_noise(z)
     ua, ub = a.command(x0.cuda()), b.command(x0.cuda())
     assert float((ua - ub).abs().max()) <= 1e-9 and float((a.cost_total - b.cost_total).abs().max()) <= 1e-9 * float(b.cost_total.abs().max())
+
+
+@pytest.mark.parametrize("variant", ["kmppi", "smppi", "states_null_action_terminal"])
+def test_heavy_traced_model_under_the_other_controllers(variant):
+    """the one-copy-of-the-step stream (`rollout_stream_heavy`) behind everything that reaches K1: KMPPI (two-launch form: the
+    interpolated actions arrive as rows), SMPPI (base sequence, smoothness cost), the `states` output, the null-action row and
+    a terminal cost -- against the callback loop on the same draw, fp64."""
+    import pytorch_mppi_amd as pm
+    f, q, net = jf.approx_pendulum_callables()
+    net.cuda()
+    K, T = 600, 20
+    sigma = torch.tensor(0.8, dtype=torch.float64)
+    kw = dict(num_samples=K, horizon=T, device="cuda", lambda_=1.0, U_init=torch.zeros(T, 1, dtype=torch.float64))
+    shape = (K, T, 1)
+    if variant == "kmppi":
+        mk = lambda auto: pm.KMPPI(f, q, 2, sigma, num_support_pts=6, u_min=torch.tensor(-2.0, dtype=torch.float64),
+                                   u_max=torch.tensor(2.0, dtype=torch.float64), auto_jit=auto, **kw)
+        shape = (K, 6, 1)
+        keys = ("U", "theta", "cost_total")
+    elif variant == "smppi":
+        mk = lambda auto: pm.SMPPI(f, q, 2, sigma, action_max=torch.tensor([1.5], dtype=torch.float64), w_action_seq_cost=0.7,
+                                   delta_t=0.1, auto_jit=auto, **kw)
+        keys = ("U", "action_sequence", "cost_total")
+    else:
+        mk = lambda auto: pm.MPPI(f, q, 2, sigma, terminal_state_cost=jf.approx_terminal_cost, sample_null_action=True, auto_jit=auto, **kw)
+        keys = ("U", "cost_total", "states")       # (the visited states are kept when a terminal cost is set, mppi.py:307-310)
+    a, b = mk(True), mk(False)
+    assert a.jit_note.startswith("fused") and a._model.heavy and not a._needs_generic(), a.jit_note
+    assert b._needs_generic()
+    x0 = torch.tensor([2.0, -0.5], dtype=torch.float64).cuda()
+    gen = torch.Generator().manual_seed(31)
+    for step in range(2):
+        z = torch.randn(*shape, generator=gen, dtype=torch.float64)
+        for c in (a, b):
+            c.inject_noise(z)
+        ua, ub = a.command(x0), b.command(x0)
+        assert float((ua - ub).abs().max()) <= 1e-9 * max(1.0, float(ub.abs().max())), (variant, step)
+        for k in keys:
+            ga, gb = getattr(a, k), getattr(b, k)
+            assert ga.shape == gb.shape, (variant, k, ga.shape, gb.shape)
+            assert float((ga - gb).abs().max()) <= 1e-9 * max(1.0, float(gb.abs().max())), (variant, step, k)
