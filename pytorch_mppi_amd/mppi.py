@@ -639,6 +639,8 @@ class MPPI:
         """mppi.py:240-252: returns the (nu,) / (u_per_command,nu) action as a device tensor,
         without synchronising."""
         self.info = info
+        if self._jit_pending is not None:
+            self._adopt_background_model()         # only HERE, between two commands: a command never changes path half-way
         return self._command(state, bool(shift_nominal_trajectory))
 
     def capture_command(self, state, shift_nominal_trajectory=True, warmup=3):
@@ -720,8 +722,6 @@ class MPPI:
         return self._model is not None
 
     def _needs_generic(self):
-        if self._model is None and self._jit_pending is not None:
-            self._adopt_background_model()
         if self._model is None:
             return True
         if getattr(self._model, "_param_tensors", None):
@@ -1399,6 +1399,8 @@ class MPPI_Batched:
         """states (N,nx) -> actions (N,nu) or (N,u_per_command,nu)   (mppi.py:811-873)"""
         lib = N.lib()
         c = self._c
+        if c._jit_pending is not None:
+            c._adopt_background_model()
         if not torch.is_tensor(states):
             states = torch.tensor(states)
         states = states.to(dtype=self.dtype, device=self.d)

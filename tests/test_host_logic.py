@@ -245,6 +245,8 @@ def test_background_jit_state_machine(monkeypatch):
     assert c._try_trace(f, q, None, False, background=True) is None
     assert c._jit_pending is not None and c.jit_note.startswith("generic path for now")
     assert c._needs_generic() and c._model is None             # still compiling: callbacks
+    c._adopt_background_model()                                # (what command() does first: nothing to adopt yet)
+    assert c._model is None and c._jit_pending is not None
     gate.set()
     assert c.wait_for_jit(5.0) and isinstance(c._model, Dummy) and c._jit_pending is None
     assert c.jit_note.startswith("fused") and "background" in c.jit_note
