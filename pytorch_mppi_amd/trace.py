@@ -756,6 +756,10 @@ class SymS:
     def __truediv__(self, o): return self._b("div", o)
     def __rtruediv__(self, o): return self._b("div", o, True)
     def __pow__(self, o): return self._b("pow", o)
+    def __mod__(self, o): return self._b("floormod", o)
+    def __floordiv__(self, o):
+        r = self._b("div", o)
+        return SymS(self.g, self.g.un("floor", r.i)) if isinstance(r, SymS) else r.floor()
     def __neg__(self): return SymS(self.g, self.g.un("neg", self.i))
     def __bool__(self): raise TraceUnsupported("control flow on the timestep")
     def __index__(self): raise TraceUnsupported("indexing by the timestep")
@@ -974,13 +978,13 @@ def _call(g, name, args, kwargs):
         if name == "softsign":
             return a0 / (a0.abs() + 1.0)
         if name == "mish":
-            return a0 * (a0.exp().log1p()).tanh()
+            return a0 * _where(g, a0 > 20.0, a0, a0.minimum(20.0).exp().log1p()).tanh()     # x tanh(softplus(x))
         if name == "hardswish":
             return a0 * (a0 + 3.0).clamp(0.0, 6.0) * (1.0 / 6.0)
         if name == "hardsigmoid":
             return (a0 + 3.0).clamp(0.0, 6.0) * (1.0 / 6.0)
         if name == "logsigmoid":
-            return -((-a0).exp().log1p())
+            return a0.minimum(0.0) - (-a0.abs()).exp().log1p()         # stable on both sides
         if name == "threshold":
             th, val = kwargs.get("threshold", rest[0] if rest else None), kwargs.get("value", rest[1] if len(rest) > 1 else None)
             return _where(g, a0 > float(th), a0, _as_sym(g, float(val)))
@@ -989,8 +993,11 @@ def _call(g, name, args, kwargs):
             return _where(g, a0 > lam, a0 - lam, _where(g, a0 < -lam, a0 + lam, _as_sym(g, 0.0)))
         return _where(g, a0.abs() > lam, a0, _as_sym(g, 0.0))                      # hardshrink
     if name in ("softplus",):
-        beta = kwargs.get("beta", 1.0)
-        return ((a0 * beta).exp() + 1.0).log() / beta
+        # F.softplus(input, beta=1, threshold=20): linear above the threshold (and no overflow of the exponential there)
+        beta = float(kwargs.get("beta", rest[0] if rest else 1.0))
+        th = float(kwargs.get("threshold", rest[1] if len(rest) > 1 else 20.0))
+        bx = a0 * beta
+        return _where(g, bx > th, a0, bx.minimum(th).exp().log1p() / beta)
     if name in ("dropout", "alpha_dropout", "feature_alpha_dropout"):
         if kwargs.get("training", rest[1] if len(rest) > 1 else False):
             raise TraceUnsupported("dropout in training mode")
@@ -998,7 +1005,20 @@ def _call(g, name, args, kwargs):
     if name in ("leaky_relu",):
         slope = kwargs.get("negative_slope", rest[0] if rest else 0.01)
         return _where(g, a0 > 0.0, a0, a0 * slope)
-    if name in ("batch_norm", "group_norm", "instance_norm", "embedding", "conv1d", "conv2d"):
+    if name == "batch_norm":                           # F.batch_norm(input, running_mean, running_var, weight, bias, training, momentum, eps)
+        if kwargs.get("training", rest[4] if len(rest) > 4 else False):
+            raise TraceUnsupported("batch_norm in training mode (statistics over the batch)")
+        rm, rv = rest[0], rest[1]
+        w = kwargs.get("weight", rest[2] if len(rest) > 2 else None)
+        b = kwargs.get("bias", rest[3] if len(rest) > 3 else None)
+        eps = kwargs.get("eps", rest[6] if len(rest) > 6 else 1e-5)
+        if rm is None or rv is None:
+            raise TraceUnsupported("batch_norm without running statistics")
+        y = (a0 - rm) / (_as_sym(g, rv) + eps).sqrt()
+        if w is not None:
+            y = y * w
+        return y + b if b is not None else y
+    if name in ("group_norm", "instance_norm", "embedding", "conv1d", "conv2d"):
         raise TraceUnsupported(f"torch.nn.functional.{name}")
     if name in ("__getitem__",):
         return a0[rest[0]]
@@ -1267,6 +1287,27 @@ extern "C" void run(int B, const double* X, const double* U, int t, double* Xn, 
   }
 }
 '''
+
+
+def evaluate_on_host(code, X, U, nx, nu, t=0):
+    """The generated bodies, compiled for the host, on a batch: (next states (B,nx), running costs (B,), terminal costs (B,))
+    in fp64 -- what the device functor computes, for tests and for looking at a translation by hand."""
+    src = _HOST % dict(nx=nx, nu=nu, step=code["step"], cost=code["cost"], terminal=code["terminal"] or "return T(0);")
+    X, U = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, nx), np.ascontiguousarray(U, dtype=np.float64).reshape(-1, nu)
+    B = X.shape[0]
+    with tempfile.TemporaryDirectory() as d:
+        cpp, so = os.path.join(d, "v.cpp"), os.path.join(d, "v.so")
+        open(cpp, "w").write(src)
+        r = subprocess.run(["g++", "-O1", "-shared", "-fPIC", "-o", so, cpp], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise TraceUnsupported("generated code does not compile: " + r.stderr[-400:])
+        lib = C.CDLL(so)
+        P = gather_params(code.get("param_tensors"), code.get("n_params", 0))
+        Pa = np.ascontiguousarray(P.cpu().numpy()) if P is not None else np.zeros(1)
+        Xn, Cc, Tc = np.zeros((B, nx)), np.zeros(B), np.zeros(B)
+        p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        lib.run(B, p(X), p(U), int(t), p(Xn), p(Cc), p(Tc), p(Pa))
+    return Xn, Cc, Tc
 
 
 def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, B=24, rtol=1e-9):

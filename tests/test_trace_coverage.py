@@ -146,3 +146,43 @@ def test_random_draws_and_data_dependent_selections_are_refused():
         trace.generate(lambda s, a: s + 0.1 * torch.randn(s.shape[0], NX, dtype=s.dtype), Q, NX, NU)
     with pytest.raises(trace.TraceUnsupported, match="masked selection"):
         trace.generate(lambda s, a: s + s[s > 0].sum(), Q, NX, NU)
+
+
+def test_saturating_activations_do_not_overflow_far_from_the_origin():
+    """softplus / mish / logsigmoid are written through exp(): the traced forms must follow torch's own guards (softplus is
+    linear above its threshold, logsigmoid is evaluated on -|x|), or states far from the origin would come back inf / nan --
+    far beyond the range the random verification batches visit"""
+    import ctypes as C
+    import numpy as np
+
+    def f(s, a):
+        return torch.cat((F.softplus(s[:, :1] * 40.0, beta=2.0), F.mish(s[:, 1:2] * 50.0), F.logsigmoid(s[:, 2:3] * 400.0)), 1) + a[:, :1] * 0.0
+
+    code = trace.generate(f, Q, NX, NU)
+    assert trace.verify_on_host(code, f, Q, NX, NU)
+    # evaluate the traced step far out through the same host build the verification uses
+    x = torch.tensor([[30.0, 25.0, -20.0], [-30.0, -25.0, 20.0]], dtype=torch.float64)
+    want = f(x, torch.zeros(2, NU, dtype=torch.float64))
+    assert torch.isfinite(want).all()
+    got = trace.evaluate_on_host(code, x.numpy(), np.zeros((2, NU)), NX, NU)[0]
+    assert np.isfinite(got).all() and np.allclose(got, want.numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_batch_norm_in_eval_mode_and_timestep_arithmetic():
+    torch.manual_seed(4)
+    bn = nn.BatchNorm1d(NX).double().eval()
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.tensor([0.1, -0.2, 0.3]))
+        bn.running_var.copy_(torch.tensor([1.5, 0.7, 2.0]))
+        bn.weight.mul_(1.2)
+    f = lambda s, a: s + 0.1 * bn(s) * a[:, :1]
+    code = trace.generate(f, Q, NX, NU)
+    assert trace.verify_on_host(code, f, Q, NX, NU)
+    bn.train()
+    with pytest.raises(trace.TraceUnsupported, match="training"):
+        trace.generate(f, Q, NX, NU)
+    # the timestep: t % period, t // k
+    ft = lambda s, a, t: s + a[:, :1] * (1.0 + 0.1 * (t % 4)) + 0.01 * (t // 3)
+    qt = lambda s, a, t: (s ** 2).sum(-1) * (1.0 + 0.05 * t)
+    code = trace.generate(ft, qt, NX, NU, None, True)
+    assert trace.verify_on_host(code, ft, qt, NX, NU, None, True)
