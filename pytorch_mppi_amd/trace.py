@@ -396,6 +396,24 @@ class SymT:
     def is_cuda(self): return False
     def size(self, d=None): return self.shape if d is None else self.a.shape[d]
     def dim(self): return self.a.ndim
+    ndimension = dim
+    def nelement(self): return self.a.size
+    def is_floating_point(self): return not self.boolean
+    def is_contiguous(self, *a, **k): return True
+    @property
+    def data(self): return self
+    @property
+    def grad_fn(self): return None
+    def numpy(self, *a, **k): raise TraceUnsupported("tensor converted to a numpy array")
+    def tolist(self): raise TraceUnsupported("tensor converted to a Python list")
+    def item(self): raise TraceUnsupported("tensor converted to a Python number (.item())")
+    def type(self, *a, **k): return self if a or k else "torch.DoubleTensor"
+    def _new(self, shape, v): return SymT(self.g, np.full(self._shape_args(shape), self.g.const(v), dtype=np.int64))
+    def new_zeros(self, *shape, **k): return self._new(shape, 0.0)
+    def new_ones(self, *shape, **k): return self._new(shape, 1.0)
+    def new_empty(self, *shape, **k): return self._new(shape, 0.0)
+    def new_full(self, shape, fill_value, **k): return self._new((shape,), float(fill_value))
+    def new_tensor(self, data, **k): return self._lift(torch.as_tensor(data, dtype=torch.float64))
     def numel(self): return self.a.size
     def t(self): return self.T
 
@@ -445,6 +463,10 @@ class SymT:
     def expand_as(self, o): return self.expand(*o.shape)
     def repeat(self, *s): return SymT(self.g, np.tile(self.a, self._shape_args(s)), self.boolean)
     def transpose(self, d0, d1): return SymT(self.g, np.swapaxes(self.a, d0, d1), self.boolean)
+    swapaxes = swapdims = transpose
+    def movedim(self, src, dst): return SymT(self.g, np.moveaxis(self.a, src, dst), self.boolean)
+    moveaxis = movedim
+    def tile(self, *s): return self.repeat(*s)
     def permute(self, *d): return SymT(self.g, np.transpose(self.a, self._shape_args(d)), self.boolean)
     def unbind(self, dim=0): return tuple(SymT(self.g, np.take(self.a, i, axis=dim)) for i in range(self.a.shape[dim]))
     def chunk(self, n, dim=0): return tuple(SymT(self.g, p) for p in np.array_split(self.a, n, axis=dim))
@@ -564,6 +586,21 @@ class SymT:
     def atan2(self, o): return self._ew2("atan2", o)
     def maximum(self, o): return self._ew2("max", o)
     def minimum(self, o): return self._ew2("min", o)
+    fmax, fmin = maximum, minimum
+    def mv(self, o): return self.matmul(o)
+    def inner(self, o): return (self * o).sum(-1) if self.a.ndim == 1 else self.matmul(self._lift(o).mT if self._lift(o).a.ndim > 1 else o)
+    def any(self, dim=None, keepdim=False):
+        if not self.boolean:
+            raise TraceUnsupported("any() of a tensor that is not a traced comparison")
+        r, _ = self._reduce_with(lambda i, j: self.g.logic("or", i, j), dim, keepdim)
+        r.boolean = True
+        return r
+    def all(self, dim=None, keepdim=False):
+        if not self.boolean:
+            raise TraceUnsupported("all() of a tensor that is not a traced comparison")
+        r, _ = self._reduce_with(lambda i, j: self.g.logic("and", i, j), dim, keepdim)
+        r.boolean = True
+        return r
     def lt(self, o): return self < o
     def le(self, o): return self <= o
     def gt(self, o): return self > o
@@ -594,6 +631,9 @@ class SymT:
 
     # -- reductions ---------------------------------------------------------------------------------------------
     def _reduce(self, op, dim, keepdim):
+        return self._reduce_with(lambda i, j: self.g.bin(op, i, j), dim, keepdim)
+
+    def _reduce_with(self, f, dim, keepdim):
         a = self.a
         if dim is None:
             dims = tuple(range(a.ndim))
@@ -605,7 +645,7 @@ class SymT:
         for r in range(1, flat.shape[0]):                       # index order, like a sequential sum
             fo, fr = out.reshape(-1), flat[r].reshape(-1)
             for i in range(fo.size):
-                fo[i] = self.g.bin(op, int(fo[i]), int(fr[i]))
+                fo[i] = f(int(fo[i]), int(fr[i]))
         if keepdim:
             for d in sorted(dims):
                 out = np.expand_dims(out, d)
@@ -903,6 +943,13 @@ def _call(g, name, args, kwargs):
         p_ = kwargs.get("ord", kwargs.get("p", rest[0] if rest else 2))
         dim = kwargs.get("dim", rest[1] if len(rest) > 1 else None)
         return a0.norm(2 if p_ is None else p_, dim, kwargs.get("keepdim", rest[2] if len(rest) > 2 else False))
+    if name in ("tensor", "as_tensor", "asarray"):     # `if not torch.is_tensor(x): x = torch.tensor(x)` on a traced input
+        return a0
+    if name == "cdist":                                # torch.cdist(x1 (..,P,M), x2 (..,R,M), p=2) -> (..,P,R)
+        x2 = _as_sym(g, rest[0])
+        p_ = float(kwargs.get("p", rest[1] if len(rest) > 1 else 2.0))
+        d = a0.unsqueeze(-2) - x2.unsqueeze(-3)
+        return d.norm(p_ if p_ != 2.0 else 2, -1)
     if name == "normalize":                            # F.normalize(input, p=2, dim=1, eps=1e-12)
         p_ = kwargs.get("p", rest[0] if rest else 2.0)
         dim = kwargs.get("dim", rest[1] if len(rest) > 1 else 1)
@@ -1023,7 +1070,7 @@ def _call(g, name, args, kwargs):
     if name in ("__getitem__",):
         return a0[rest[0]]
     meth = {"absolute": "abs", "negative": "neg", "true_divide": "div", "divide": "div", "multiply": "mul", "subtract": "sub",
-            "clip": "clamp", "arctan2": "atan2", "linalg_cross": "cross", "bitwise_and": "logical_and",
+            "clip": "clamp", "arctan2": "atan2", "linalg_cross": "cross", "linalg_matmul": "matmul", "bitwise_and": "logical_and",
             "bitwise_or": "logical_or", "bitwise_not": "logical_not", "bitwise_xor": "logical_xor"}.get(name, name)
     if a0 is not None and hasattr(SymT, meth) and (not meth.startswith("_") or meth in _DUNDERS):
         f = getattr(a0, meth)

@@ -186,3 +186,26 @@ def test_batch_norm_in_eval_mode_and_timestep_arithmetic():
     qt = lambda s, a, t: (s ** 2).sum(-1) * (1.0 + 0.05 * t)
     code = trace.generate(ft, qt, NX, NU, None, True)
     assert trace.verify_on_host(code, ft, qt, NX, NU, None, True)
+
+
+def test_obstacle_costs_and_constructor_idioms():
+    """distance-to-obstacle costs (cdist, any() of a mask), state.new_zeros(...), the `if not torch.is_tensor(x)` guard"""
+    obstacles = torch.tensor([[0.5, 0.5], [-1.0, 0.3], [0.2, -0.8]], dtype=torch.float64)
+
+    def f(s, a):
+        if not torch.is_tensor(s):
+            s = torch.tensor(s)
+        nxt = s.new_zeros(s.shape[0], NX)
+        nxt[:, :2] = s[:, :2] + 0.1 * a
+        nxt[:, 2] = torch.fmax(s[:, 2], torch.mv(a, torch.tensor([0.3, -0.2], dtype=s.dtype)))
+        return nxt
+
+    def q(s, a):
+        d = torch.cdist(s[:, None, :2], obstacles.to(s.device)).squeeze(1)               # (B, 3)
+        hit = (d < 0.4).any(dim=1)
+        return torch.exp(-d ** 2 / 0.1).sum(1) + 100.0 * hit + (d > 5.0).all(1) * 3.0 + torch.cdist(s[:, None, :2], obstacles, p=1.0).amin((1, 2))
+
+    code = trace.generate(f, q, NX, NU)
+    assert trace.verify_on_host(code, f, q, NX, NU)
+    with pytest.raises(trace.TraceUnsupported, match="item"):
+        trace.generate(lambda s, a: s * s[0, 0].item(), Q, NX, NU)
