@@ -152,6 +152,13 @@ class Graph:
     def cmp(self, op, a, b):
         return self._mk((op, a, b))
 
+    def table(self, values, idx):
+        """("tab", values, idx): element [idx] of a constant table -- a reference / schedule indexed by the timestep"""
+        ci = self.cval(idx)
+        if ci is not None and ci == int(ci) and 0 <= int(ci) < len(values):
+            return self.const(values[int(ci)])
+        return self._mk(("tab", tuple(float(v) for v in values), idx))
+
     def logic(self, op, a, b=None):
         """boolean nodes: ("and" | "or" | "xor", a, b), ("not", a)"""
         if op == "not":
@@ -286,6 +293,21 @@ class SymT:
             # traced (as a select under the mask): the result is a placeholder that takes scalar arithmetic and goes back into
             # `x[mask] = ...` with the SAME mask
             return _Masked(self.clone(), idx)
+        first = idx[0] if isinstance(idx, tuple) else idx
+        if isinstance(first, SymT) and first.a.ndim == 0 and not first.boolean:
+            first = SymS(self.g, int(first.a))                     # (the timestep after a trip through a torch function)
+        if isinstance(first, SymS):
+            # table[t] (or table[t, ...]): a constant reference / schedule looked up by the timestep -> one small constant
+            # array per selected element in the functor, read at index clamp(t, 0, len - 1)
+            rest = idx[1:] if isinstance(idx, tuple) else ()
+            cols = np.moveaxis(self.a, 0, -1)                      # (..., N)
+            if any(self.g.cval(int(v)) is None for v in cols.reshape(-1)):
+                raise TraceUnsupported("indexing a traced (non-constant) tensor by the timestep")
+            out = np.empty(cols.shape[:-1], dtype=np.int64)
+            for pos in np.ndindex(*out.shape):
+                out[pos] = self.g.table([self.g.cval(int(v)) for v in cols[pos]], first.i)
+            r = SymT(self.g, out)
+            return r[rest] if rest else r
         def chk(i):
             if isinstance(i, (SymT, SymS)):
                 raise TraceUnsupported("indexing by a traced value")
@@ -1165,7 +1187,9 @@ def _reaches(g, roots, kinds):
         n = g.nodes[i]
         if n[0] in kinds:
             return True
-        if n[0] not in ("c", "x", "u", "t", "y", "w", "p"):
+        if n[0] == "tab":
+            stack.append(n[2])
+        elif n[0] not in ("c", "x", "u", "t", "y", "w", "p"):
             stack.extend(n[1:])
     return False
 
@@ -1210,7 +1234,9 @@ def emit(g, roots, assign=None, ret=False):
             seen.add(i)
             stack.append((i, True))
             n = g.nodes[i]
-            if n[0] not in ("c", "x", "u", "t", "y", "w", "p"):
+            if n[0] == "tab":
+                stack.append((n[2], False))
+            elif n[0] not in ("c", "x", "u", "t", "y", "w", "p"):
                 for a in n[1:]:
                     stack.append((a, False))
     name = {}
@@ -1230,6 +1256,12 @@ def emit(g, roots, assign=None, ret=False):
             name[i] = f"p[{n[1]}]"
         elif k in ("y", "w"):
             raise TraceUnsupported("internal: terminal leaf in a step / cost body")
+        elif k == "tab":
+            vals, N = n[1], len(n[1])
+            lines.append(f"const T tab{i}[{N}] = {{{', '.join(_lit(v) for v in vals)}}};")
+            lines.append(f"const int ix{i} = (int)({name[n[2]]});")
+            lines.append(f"const T v{i} = tab{i}[ix{i} < 0 ? 0 : (ix{i} > {N - 1} ? {N - 1} : ix{i})];")
+            name[i] = f"v{i}"
         else:
             ops = [name[a] for a in n[1:]]
             if k in _FMT1:
@@ -1357,7 +1389,7 @@ def evaluate_on_host(code, X, U, nx, nu, t=0):
     return Xn, Cc, Tc
 
 
-def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, B=24, rtol=1e-9):
+def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, B=24, rtol=1e-9, horizon=None):
     """Compile the generated bodies for the host and compare with the callables on random batches (fp64).
     Raises TraceUnsupported on any disagreement (the caller keeps the generic path)."""
     src = _HOST % dict(nx=nx, nu=nu, step=code["step"], cost=code["cost"], terminal=code["terminal"] or "return T(0);")
@@ -1380,6 +1412,8 @@ def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=Non
         for scale, t in ((1.0, 0), (3.0, 5), (0.1, 11), (40.0, 2)):
             if scale > 10.0 and form is not None and form[1] != torch.float64:
                 continue
+            if horizon is not None:
+                t = min(t, int(horizon) - 1)           # (a schedule indexed by the timestep is only as long as the horizon)
             X = torch.randn(B, nx, generator=gen, dtype=torch.float64) * scale
             U = torch.randn(B, nu, generator=gen, dtype=torch.float64) * scale
             Xn, Cc, Tc = np.zeros((B, nx)), np.zeros(B), np.zeros(B)

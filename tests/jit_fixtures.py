@@ -198,6 +198,22 @@ def zoo_callables(seed=3):
     return dynamics, cost, net
 
 
+def tracking_callables(T=24):
+    """time-varying reference (step_dependent_dynamics=True): a schedule tensor indexed by the timestep, `ref[t]` / `ref[t + 1]`
+    -- one small constant table per looked-up element in the traced functor"""
+    ref = torch.stack((torch.sin(torch.linspace(0, 3, T + 1)), torch.cos(torch.linspace(0, 2, T + 1))), 1).double()     # (T + 1, 2)
+    gain = torch.linspace(1.0, 0.5, T).double()
+
+    def dynamics(state, action, t):
+        return state + 0.1 * action * gain.to(state.device)[t]
+
+    def cost(state, action, t):
+        r = ref.to(state.device)
+        return ((state - r[t]) ** 2).sum(-1) + 0.1 * (state[:, 0] - r[t + 1, 0]) ** 2 + 0.01 * (action ** 2).sum(-1)
+
+    return dynamics, cost
+
+
 def approx_terminal_cost(states, actions):
     """terminal cost used with the learned pendulum in tests/test_gpu_from_torch.py (its traced form is built by build())"""
     return 3.0 * (states[..., -1, :] ** 2).sum(-1)
@@ -233,6 +249,8 @@ def traced_models():
     zf, zq, _ = zoo_callables()
     jobs = dict(pendulum=(f, q, 2, 1), linear=(lf, lq, 2, 2, lt), mlp=(mf, mq, 4, 2), watched=(wf, wq, 2, 2), approx=(af, aq, 2, 1),
                 zoo=(zf, zq, 4, 2), approx_terminal=(af, aq, 2, 1, approx_terminal_cost))
-    with cf.ThreadPoolExecutor(max_workers=7) as ex:      # each ends in its own hipcc subprocess
+    tf, tq = tracking_callables()
+    with cf.ThreadPoolExecutor(max_workers=8) as ex:      # each ends in its own hipcc subprocess
         futs = {k: ex.submit(jit.from_torch, *v) for k, v in jobs.items()}
+        futs["tracking"] = ex.submit(jit.from_torch, tf, tq, 2, 2, step_dependent=True, horizon=24)
         return {k: v.result() for k, v in futs.items()}

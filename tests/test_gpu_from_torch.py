@@ -275,3 +275,24 @@ def test_heavy_traced_model_under_the_other_controllers(variant):
             ga, gb = getattr(a, k), getattr(b, k)
             assert ga.shape == gb.shape, (variant, k, ga.shape, gb.shape)
             assert float((ga - gb).abs().max()) <= 1e-9 * max(1.0, float(gb.abs().max())), (variant, step, k)
+
+
+def test_reference_schedule_indexed_by_the_timestep_runs_fused():
+    """trajectory tracking under step_dependent_dynamics=True: `ref[t]` / `gain[t]` lookups of constant tensors are constant
+    tables in the functor (read with the wave-uniform timestep); against the callback loop on the same draw, fp64"""
+    import pytorch_mppi_amd as pm
+    f, q = jf.tracking_callables()
+    K, T = 700, 24
+    kw = dict(num_samples=K, horizon=T, device="cuda", lambda_=1.0, step_dependent_dynamics=True,
+              U_init=torch.zeros(T, 2, dtype=torch.float64))
+    a = pm.MPPI(f, q, 2, torch.eye(2, dtype=torch.float64) * 0.6, auto_jit=True, **kw)
+    b = pm.MPPI(f, q, 2, torch.eye(2, dtype=torch.float64) * 0.6, auto_jit=False, **kw)
+    assert a.jit_note.startswith("fused") and not a._needs_generic(), a.jit_note
+    x0 = torch.tensor([0.3, 0.8], dtype=torch.float64).cuda()
+    gen = torch.Generator().manual_seed(41)
+    for step in range(2):
+        z = torch.randn(K, T, 2, generator=gen, dtype=torch.float64)
+        for c in (a, b):
+            c.inject_noise(z)
+        ua, ub = a.command(x0), b.command(x0)
+        assert float((ua - ub).abs().max()) <= 1e-9 and float((a.cost_total - b.cost_total).abs().max()) <= 1e-9 * float(b.cost_total.abs().max())

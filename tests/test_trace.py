@@ -147,3 +147,20 @@ def test_verification_catches_a_wrong_translation():
     code["step"] = code["step"].replace("T(0.05)", "T(0.06)")
     with pytest.raises(trace.TraceUnsupported):
         trace.verify_on_host(code, f, q, 2, 1)
+
+
+def test_schedule_indexed_by_the_timestep():
+    """`ref[t]`, `ref[t + 1, 0]`, `gain[t]` on constant tensors (trajectory tracking under step_dependent_dynamics): constant
+    tables in the functor; the verification stays inside the horizon"""
+    f, q = jf.tracking_callables(T=24)
+    code = trace.generate(f, q, 2, 2, None, True)
+    assert "tab" in code["cost"] and "tab" in code["step"]
+    assert trace.verify_on_host(code, f, q, 2, 2, None, True, horizon=24)
+    short_f, short_q = jf.tracking_callables(T=8)                  # tables of 8 / 9 entries: t = 11 would be out of range
+    code = trace.generate(short_f, short_q, 2, 2, None, True)
+    assert trace.verify_on_host(code, short_f, short_q, 2, 2, None, True, horizon=8)
+    with pytest.raises(IndexError):
+        trace.verify_on_host(code, short_f, short_q, 2, 2, None, True)
+    # a table of traced values cannot be looked up (its entries are not constants)
+    with pytest.raises(trace.TraceUnsupported):
+        trace.generate(lambda s, a, t: s + torch.stack((s[0], a[0]))[t], lambda s, a, t: (s ** 2).sum(-1), 2, 2, None, True)
