@@ -247,7 +247,8 @@ class MPPI:
         from . import jit, trace
         log = logging.getLogger("pytorch_mppi_amd")
         try:
-            code = jit.trace_and_verify(dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent, horizon=self.T)
+            code = jit.trace_and_verify(dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent, horizon=self.T,
+                                        device=self.d, dtype=self.dtype)
             if background and not jit.traced_is_cached(code, self.nx, self.nu):
                 # the hipcc run (30 s - 2 min) happens beside the control loop: callbacks until it has finished
                 import threading

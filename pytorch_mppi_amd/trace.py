@@ -49,10 +49,17 @@ _CMP = {"lt": lambda a, b: a < b, "le": lambda a, b: a <= b, "gt": lambda a, b: 
 
 
 class Graph:
-    def __init__(self, max_nodes=60000):
+    def __init__(self, max_nodes=60000, device=None, dtype=None):
+        # what the symbolic inputs report as .device / .dtype: the controller's own, so that `net.to(state.device, state.dtype)`
+        # or `if state.is_cuda:` inside the callables behave as they will at run time (and a module is not dragged to the host)
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.dtype = dtype if dtype is not None else torch.float64
         self.nodes = []          # tuples: ("c", float) | ("x", i) | ("u", n) | ("t",) | ("y", i) | (op, ids...)
         self.index = {}
         self.captured = []       # (tensor, version at trace time) of every torch tensor whose VALUES went into constants
+        self.derived = {}        # id(tensor made INSIDE the callables from real tensors) -> (tensor, [the tensors it came from]):
+        #                          B.to(state.device), W @ W.T, ... are constants of the functor too; the version watch must sit
+        #                          on what they were made from (the copy itself is never written again)
         self.param_tensors = []  # (tensor, base): TRAINABLE tensors -- element i is the leaf ("p", base + i), read from the
         self._param_base = {}    # model's parameter vector at run time (re-gathered when the tensor's version moves)
         self.n_params = 0
@@ -86,6 +93,19 @@ class Graph:
             self.param_tensors.append((t, base))         # (keeps t alive: id(t) stays unique)
             self.n_params += t.numel()
         return np.array([self.leaf("p", base + i) for i in range(t.numel())], dtype=np.int64).reshape(tuple(t.shape))
+
+    def roots_of(self, t):
+        d = self.derived.get(id(t))
+        return d[1] if d is not None and d[0] is t else [t]
+
+    def note_derived(self, out, srcs):
+        roots = []
+        for s_ in srcs:
+            for r in self.roots_of(s_):
+                if not any(r is q for q in roots):
+                    roots.append(r)
+        if roots and len(self.derived) < 4096 and not any(out is r for r in roots):
+            self.derived[id(out)] = (out, roots)               # (holding `out` keeps its id unique)
 
     def cval(self, i):
         n = self.nodes[i]
@@ -204,7 +224,9 @@ class SymT:
                 # with the first optimizer step.  Its elements become reads of the model's parameter vector p[]: the
                 # functor stays valid, the vector is re-gathered when the tensor's version counter moves.
                 return SymT(self.g, self.g.param_leaves(v))
-            self.g.captured.append((v, v._version))      # captured BY VALUE: the controller watches the version counter
+            for r in self.g.roots_of(v):                 # captured BY VALUE: the controller watches the version counters of
+                if not any(r is c for c, _ in self.g.captured):     # the tensor -- or of what it was made from inside the callable
+                    self.g.captured.append((r, r._version))
             v = v.detach().cpu().double().numpy()
         if isinstance(v, np.ndarray):
             if v.size > 65536:
@@ -405,9 +427,9 @@ class SymT:
     @property
     def ndim(self): return self.a.ndim
     @property
-    def dtype(self): return torch.float64
+    def dtype(self): return self.g.dtype
     @property
-    def device(self): return torch.device("cpu")
+    def device(self): return self.g.device
     @property
     def T(self): return SymT(self.g, self.a.T)
     @property
@@ -415,7 +437,7 @@ class SymT:
     @property
     def requires_grad(self): return False
     @property
-    def is_cuda(self): return False
+    def is_cuda(self): return self.g.device.type == "cuda"
     def size(self, d=None): return self.shape if d is None else self.a.shape[d]
     def dim(self): return self.a.ndim
     ndimension = dim
@@ -1145,15 +1167,22 @@ class _TraceMode(torch.overrides.TorchFunctionMode):
             args = tuple(SymT(a.g, np.array(a.i)) if isinstance(a, SymS) else a for a in args)
             return _call(self.g, name, args, kwargs)
         out = func(*args, **kwargs)
-        if name in _FACTORIES and isinstance(out, torch.Tensor) and out.is_floating_point() and out.numel() <= 65536 and not out.requires_grad:
+        srcs = [v for v in list(args) + list(kwargs.values()) if isinstance(v, torch.Tensor)]
+        srcs += [e for v in args if isinstance(v, (tuple, list)) for e in v if isinstance(e, torch.Tensor)]
+        if srcs:
+            for o in (out if isinstance(out, (tuple, list)) else (out,)):
+                if isinstance(o, torch.Tensor):
+                    self.g.note_derived(o, srcs)
+        if name in _FACTORIES and not srcs and isinstance(out, torch.Tensor) and out.is_floating_point() and out.numel() <= 65536 \
+                and not out.requires_grad:
             vals = out.detach().cpu().double().numpy()
             return SymT(self.g, np.vectorize(self.g.const, otypes=[np.int64])(vals))
         return out
 
 
-def trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False):
+def trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, device=None, dtype=None):
     """-> (Graph, step outputs [nx node ids], cost output id, terminal output id or None)"""
-    g = Graph()
+    g = Graph(device=device, dtype=dtype)
 
     def xs(kind, n, shape):
         return SymT(g, np.array([g.leaf(kind, i) for i in range(n)], dtype=np.int64).reshape(shape))
@@ -1297,9 +1326,10 @@ def emit(g, roots, assign=None, ret=False):
     return " ".join(lines)
 
 
-def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False):
-    """-> dict(step=..., cost=..., terminal=... or None, n_ops=...): the C++ bodies for jit.compile_model."""
-    g, so, co, to = trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost, step_dependent)
+def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, device=None, dtype=None):
+    """-> dict(step=..., cost=..., terminal=... or None, n_ops=...): the C++ bodies for jit.compile_model.
+    device / dtype: what the symbolic inputs report (the controller's; default cpu / float64)."""
+    g, so, co, to = trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost, step_dependent, device, dtype)
     step = emit(g, so, assign=[f"x[{i}]" for i in range(nx)])
     cost = emit(g, [co], ret=True)
     term = emit(g, [to], ret=True) if to is not None else None

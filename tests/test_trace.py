@@ -164,3 +164,38 @@ def test_schedule_indexed_by_the_timestep():
     # a table of traced values cannot be looked up (its entries are not constants)
     with pytest.raises(trace.TraceUnsupported):
         trace.generate(lambda s, a, t: s + torch.stack((s[0], a[0]))[t], lambda s, a, t: (s ** 2).sum(-1), 2, 2, None, True)
+
+
+def test_symbolic_inputs_report_the_controllers_device_and_dtype():
+    """`net.to(state.device, state.dtype)` inside a callable must not move the user's module while it is being traced"""
+    seen = []
+
+    def f(s, a):
+        seen.append((s.device, s.dtype, s.is_cuda))
+        return s + a
+
+    q = lambda s, a: (s ** 2).sum(-1)
+    trace.generate(f, q, 2, 2, device="cuda:0", dtype=torch.float32)
+    assert seen[-1] == (torch.device("cuda:0"), torch.float32, True)
+    trace.generate(f, q, 2, 2)
+    assert seen[-1] == (torch.device("cpu"), torch.float64, False)
+    # a float32 constant created from state.dtype enters the functor with its float32 value
+    g = lambda s, a: s + a * torch.tensor(0.1, dtype=s.dtype)
+    c32 = trace.generate(g, q, 2, 2, dtype=torch.float32)["step"]
+    assert repr(float(torch.tensor(0.1, dtype=torch.float32))) in c32 and "T(0.1)" in trace.generate(g, q, 2, 2)["step"]
+
+
+def test_constants_derived_inside_the_callable_are_watched_at_their_source():
+    """`B.to(state.device)`, `W @ W.T`, `torch.diag(q)`: the functor holds the VALUES of the derived tensor; the version watch must
+    sit on B / W / q -- the copies are never written again"""
+    B = torch.tensor([[1.0, 0.0], [0.5, -1.0]], dtype=torch.float32)          # (another dtype: .to() makes a copy)
+    W = torch.tensor([[1.0, 0.2], [0.0, 1.0]], dtype=torch.float64)
+    qd = torch.tensor([1.0, 3.0], dtype=torch.float64)
+    f = lambda s, a: s + a @ B.to(s.device, s.dtype).T
+    q = lambda s, a: ((s @ (W @ W.T)) * s).sum(-1) + (s @ torch.diag(qd) * s).sum(-1)
+    code = _roundtrip(f, q, 2, 2)
+    roots = [t for t, _ in code["captured"]]
+    assert any(t is B for t in roots) and any(t is W for t in roots) and any(t is qd for t in roots)
+    assert all(t._version == v for t, v in code["captured"])
+    B[0, 1] = 2.0
+    assert any(t._version != v for t, v in code["captured"])
