@@ -260,3 +260,30 @@ def test_background_jit_state_machine(monkeypatch):
     c3 = pm.MPPI(f, q, 2, torch.eye(2, dtype=torch.double), num_samples=8, horizon=3, auto_jit=False)
     assert c3._try_trace(f, q, None, False, background=True) is None
     assert not c3.wait_for_jit(5.0) and c3._model is None and "hipcc failed" in c3.jit_note
+
+
+def test_traced_model_follows_its_trainable_tensors_without_recompiling():
+    """jit.from_torch on the learned-pendulum fixture (its object is built by __graft_entry__.build(): a cache hit here): the
+    network's parameters are the model's parameter vector; optimizer steps, load_state_dict and a storage swap are picked up
+    by refresh_params() -- version counters and data pointers -- and bump the model's parameter version (new device blob)."""
+    import jit_fixtures as jf
+    from pytorch_mppi_amd import jit
+    f, q, net = jf.approx_pendulum_callables()
+    m = jit.from_torch(f, q, 2, 1)
+    assert m.heavy and m._n_params == 1250 and not m._captured and not m.stale()
+    flat = lambda: torch.cat([p_.detach().reshape(-1) for p_ in net.parameters()])
+    # the order of the vector is the order in which the callables first read the tensors
+    assert sorted(m.params.tolist()) == sorted(flat().tolist())
+    v0 = m._param_version
+    assert not m.refresh_params() and m._param_version == v0
+    jf.train_a_little(net, steps=2)
+    assert m.refresh_params() and m._param_version == v0 + 1
+    assert sorted(m.params.tolist()) == sorted(flat().tolist())
+    assert not m.refresh_params()
+    net.load_state_dict({k: v * 0.5 for k, v in net.state_dict().items()})
+    assert m.refresh_params() and m._param_version == v0 + 2
+    for p_ in net.parameters():                       # a storage swap without a version bump (what module.to() does)
+        p_.data = p_.data.clone() + 1.0
+    assert m.refresh_params() and sorted(m.params.tolist()) == sorted(flat().tolist())
+    blob = m.param_blob("cpu", torch.float32)
+    assert blob.dtype == torch.float32 and blob.numel() == 1250
