@@ -1311,10 +1311,12 @@ def emit(g, roots, assign=None, ret=False):
     if assign is not None:
         # x[] entries that are read by later assignments are protected by the temporaries above only when every output is a
         # temporary or a leaf other than x[j], j != i: copy leaves first
-        outs = []
+        outs, copied = [], set()
         for tgt, r in zip(assign, roots):
             if g.nodes[r][0] == "x" and name[r] != tgt:
-                lines.append(f"const T c{r} = {name[r]};")
+                if r not in copied:                     # (two outputs may be the same input component: one copy)
+                    lines.append(f"const T c{r} = {name[r]};")
+                    copied.add(r)
                 outs.append((tgt, f"c{r}"))
             else:
                 outs.append((tgt, name[r]))

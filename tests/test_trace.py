@@ -199,3 +199,9 @@ def test_constants_derived_inside_the_callable_are_watched_at_their_source():
     assert all(t._version == v for t, v in code["captured"])
     B[0, 1] = 2.0
     assert any(t._version != v for t, v in code["captured"])
+
+
+def test_two_outputs_from_the_same_input_component():
+    """x'[0] = x'[1] = x[2] (found by differential fuzzing: the protective copy of x[2] was declared twice)"""
+    f = lambda s, a: torch.stack((s[:, 2], s[:, 2], s[:, 0] + a[:, 0]), 1)
+    _roundtrip(f, lambda s, a: (s ** 2).sum(-1), 3, 1)
