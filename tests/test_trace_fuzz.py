@@ -56,3 +56,79 @@ def test_random_programs_translate_or_are_refused_for_numerical_reasons():
             assert "differs from the callable" in str(e) or "which results are finite" in str(e), (seed, str(e)[:300])
             refused += 1
     assert ok >= 40, (ok, refused)
+
+
+# ---- the same for the STRUCTURAL operations: slicing, cat / stack / unbind / flip, views and transposes, reductions with
+# keepdim, constant matmul / einsum, in-place updates through views, masked updates, cumsum / roll, max / min with a dim,
+# outer products / diagonals, split, norms -- chained on tensors of changing width
+def structural_program(seed, nx=3, nu=2):
+    rng = random.Random(seed)
+    gen = torch.Generator().manual_seed(seed)
+    consts = {}
+    def cmat(r, c):
+        key = (r, c, len(consts))
+        consts[key] = torch.randn(r, c, generator=gen, dtype=torch.float64) * 0.5
+        return consts[key]
+    nsteps = rng.randint(3, 7)
+    plan = []
+    for _ in range(nsteps):
+        plan.append((rng.randrange(14), rng.random(), rng.random(), rng.randrange(1 << 30)))
+    mats = {}
+    def getm(key, r, c, sd):
+        if key not in mats:
+            mats[key] = torch.randn(r, c, generator=torch.Generator().manual_seed(sd), dtype=torch.float64) * 0.4
+        return mats[key]
+    def f(s, a):
+        x = torch.cat((s, a), dim=1)                      # (B, 5)
+        for k, (op, r1, r2, sd) in enumerate(plan):
+            w = x.shape[1]
+            if op == 0:                                   # slice columns
+                lo = int(r1 * (w - 1)); hi = lo + 1 + int(r2 * (w - lo - 1))
+                x = torch.cat((x[:, lo:hi], x[:, :1] * 0.5), 1)
+            elif op == 1:                                 # constant matmul to a new width
+                nw = 2 + int(r1 * 3)
+                M = getm((k, w, nw), w, nw, sd)
+                x = torch.tanh(x @ M)
+            elif op == 2:                                 # reduction keepdim + broadcast
+                x = x - x.mean(dim=1, keepdim=True) + x.sum(1, keepdim=True) * 0.1
+            elif op == 3:                                 # stack / unbind / flip
+                x = torch.stack(x.unbind(1)[::-1], dim=1) + torch.flip(x, dims=(1,)) * 0.3
+            elif op == 4:                                 # view to 3-d and back
+                x = torch.cat((x, x), 1).view(x.shape[0], 2, w).transpose(1, 2).reshape(x.shape[0], -1)[:, :w + 1]
+            elif op == 5:                                 # in-place on a view
+                x = x.clone(); v = x[:, : max(1, w // 2)]; v += 0.25; v.mul_(1.1); x[:, -1] = x[:, 0] * x[:, -1]
+            elif op == 6:                                 # masked update
+                x = x.clone(); m = x > 0.3; x[m] -= 0.6; x[x < -1.0] = -1.0
+            elif op == 7:                                 # cumsum / roll
+                x = torch.cumsum(x, dim=1) * 0.5 + torch.roll(x, 1, dims=1)
+            elif op == 8:                                 # where with broadcasted column
+                x = torch.where(x[:, :1] > 0, x, -x * 0.5)
+            elif op == 9:                                 # max / min with dim, amax
+                x = torch.cat((x, x.max(dim=1, keepdim=True).values, x.min(dim=1, keepdim=True)[0], x.amax(1, keepdim=True)), 1)
+            elif op == 10:                                # expand + outer product + diagonal
+                o = x.unsqueeze(-1) * x.unsqueeze(-2)
+                x = o.diagonal(dim1=-2, dim2=-1) + o.sum(-1) * 0.1
+            elif op == 11:                                # chunk / split recombine
+                parts = x.split(1, dim=1)
+                x = torch.cat([p_ * (i + 1) * 0.3 for i, p_ in enumerate(parts)], 1)
+            elif op == 12:                                # norm / normalize
+                x = x / (1.0 + x.norm(dim=1, keepdim=True)) + torch.linalg.norm(x, ord=1, dim=1, keepdim=True) * 0.05
+            else:                                         # einsum with a constant
+                nw = 2 + int(r1 * 2)
+                M = getm((k, w, nw, 'e'), w, nw, sd)
+                x = torch.einsum('bi,ij->bj', x, M)
+            if x.shape[1] > 8:
+                x = x[:, :8]
+        P = getm(('P', x.shape[1]), x.shape[1], nx, seed + 7)
+        return s * 0.5 + x @ P
+    q = lambda s, a: (f(s, a) ** 2).sum(1) + a.abs().sum(1)
+    f(torch.zeros(2, nx, dtype=torch.float64), torch.zeros(2, nu, dtype=torch.float64))      # (creates the constant matrices: not inside the trace)
+    return f, q
+
+
+
+def test_random_structural_programs_translate():
+    for seed in range(40):
+        f, q = structural_program(seed)
+        code = trace.generate(f, q, 3, 2)
+        assert trace.verify_on_host(code, f, q, 3, 2), seed
