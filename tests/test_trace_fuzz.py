@@ -8,6 +8,7 @@ import random
 
 import pytest
 import torch
+import torch.nn as nn
 
 from pytorch_mppi_amd import trace
 
@@ -131,4 +132,36 @@ def test_random_structural_programs_translate():
     for seed in range(40):
         f, q = structural_program(seed)
         code = trace.generate(f, q, 3, 2)
+        assert trace.verify_on_host(code, f, q, 3, 2), seed
+
+
+# ---- random nn.Sequential networks (1-3 hidden layers, random widths, 12 activations, optional LayerNorm / missing biases,
+# sometimes a layer shared with the cost): traced with their weights as run-time parameters, verified, then verified AGAIN
+# with the same code after every parameter was changed in place (200 networks offline without a failure)
+MODULE_ACTS = [nn.Tanh, nn.ReLU, nn.GELU, nn.ELU, nn.SiLU, nn.Sigmoid, nn.Softplus, lambda: nn.LeakyReLU(0.2), nn.Hardtanh, nn.Mish, nn.SELU, nn.Identity]
+def module_program(seed, nx=3, nu=2):
+    rng = random.Random(seed); torch.manual_seed(seed)
+    widths = [nx + nu] + [rng.randint(2, 9) for _ in range(rng.randint(1, 3))] + [nx]
+    layers = []
+    for i in range(len(widths) - 1):
+        layers.append(nn.Linear(widths[i], widths[i + 1], bias=rng.random() < 0.8))
+        if i < len(widths) - 2:
+            layers.append(rng.choice(MODULE_ACTS)())
+            if rng.random() < 0.3: layers.append(nn.LayerNorm(widths[i + 1]))
+    net = nn.Sequential(*layers).double()
+    share = rng.random() < 0.3                      # the cost reads a layer of the same network (shared parameters)
+    f = lambda s, a: s + 0.3 * net(torch.cat((s, a), 1))
+    q = (lambda s, a: (net[0](torch.cat((s, a), 1)) ** 2).sum(1)) if share else (lambda s, a: (s ** 2).sum(1))
+    return f, q, net
+
+
+def test_random_networks_keep_following_their_parameters():
+    for seed in range(24):
+        f, q, net = module_program(seed)
+        code = trace.generate(f, q, 3, 2)
+        assert trace.verify_on_host(code, f, q, 3, 2), seed
+        assert code["n_params"] == sum(p_.numel() for p_ in net.parameters()), seed
+        with torch.no_grad():
+            for p_ in net.parameters():
+                p_.add_(torch.randn_like(p_) * 0.3)
         assert trace.verify_on_host(code, f, q, 3, 2), seed
