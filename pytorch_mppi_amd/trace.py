@@ -43,7 +43,7 @@ _UNARY = {"neg": lambda a: -a, "sin": math.sin, "cos": math.cos, "tan": math.tan
           "trunc": math.trunc}
 _BINARY = {"add": lambda a, b: a + b, "sub": lambda a, b: a - b, "mul": lambda a, b: a * b, "div": lambda a, b: a / b,
            "min": min, "max": max, "pow": lambda a, b: a ** b, "atan2": math.atan2,
-           "floormod": lambda a, b: a - math.floor(a / b) * b, "fmod": math.fmod}
+           "floormod": lambda a, b: a % b, "fmod": math.fmod}        # (Python's float % is torch.remainder: exact, sign of b)
 _CMP = {"lt": lambda a, b: a < b, "le": lambda a, b: a <= b, "gt": lambda a, b: a > b, "ge": lambda a, b: a >= b,
         "eq": lambda a, b: a == b, "ne": lambda a, b: a != b}
 
@@ -1295,6 +1295,10 @@ def emit(g, roots, assign=None, ret=False):
             ops = [name[a] for a in n[1:]]
             if k in _FMT1:
                 e = _FMT1[k].format(*ops)
+            elif k == "floormod" and (g.cval(n[2]) or 0.0) > 0.0:
+                # a positive constant modulus (angle wrapping): the exact remainder -- k = floor(a / b) from the rounded quotient
+                # is off by one at exact multiples of b, where torch's remainder (fmod + sign fix-up) is not
+                e = f"m_floormod({ops[0]}, {ops[1]})"
             elif k in _FMT2:
                 e = _FMT2[k].format(*ops)
             elif k == "clamp":
@@ -1368,6 +1372,7 @@ static inline T m_max(T a, T b) { return a > b ? a : b; }
 static inline T m_pow(T a, T b) { return std::pow(a, b); }
 static inline T m_atan2(T a, T b) { return std::atan2(a, b); }
 static inline T m_fmod(T a, T b) { return std::fmod(a, b); }
+static inline T m_floormod(T a, T b) { T r = std::fmod(a, b); return r < 0 ? r + b : r; }        // b > 0
 static inline T m_erf(T x) { return std::erf(x); }
 static inline T m_atan(T x) { return std::atan(x); }
 static inline T m_asin(T x) { return std::asin(x); }

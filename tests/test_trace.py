@@ -205,3 +205,17 @@ def test_two_outputs_from_the_same_input_component():
     """x'[0] = x'[1] = x[2] (found by differential fuzzing: the protective copy of x[2] was declared twice)"""
     f = lambda s, a: torch.stack((s[:, 2], s[:, 2], s[:, 0] + a[:, 0]), 1)
     _roundtrip(f, lambda s, a: (s ** 2).sum(-1), 3, 1)
+
+
+def test_python_modulo_is_exact_at_multiples_of_the_modulus():
+    """`floor(u) % 0.7` (found by differential fuzzing): k = floor(a / b) from the rounded quotient is off by one at exact
+    multiples of b; torch's remainder is fmod + a sign fix-up.  A positive constant modulus goes through m_floormod."""
+    f = lambda s, a: torch.stack((torch.floor(a[:, 0] * 3) % 0.7, (s[:, 1] * 4).round() % 0.1, s[:, 0] % (2 * math.pi)), 1)
+    code = _roundtrip(f, lambda s, a: (s ** 2).sum(-1), 3, 1)
+    assert code["step"].count("m_floormod") == 3
+    import numpy as np
+    X = np.array([[7.0, 0.25, 0.0], [0.7 * 3, 0.5, 0.0], [-1.4, -0.75, 0.0]])
+    U = np.array([[7.0 / 3], [1.0], [-2.0]])
+    got = trace.evaluate_on_host(code, X, U, 3, 1)[0]
+    want = f(torch.tensor(X), torch.tensor(U)).numpy()
+    assert np.array_equal(got, want), (got, want)
