@@ -1328,7 +1328,7 @@ class MPPI_Batched:
                  u_per_command=1,
                  step_dependent_dynamics=False,
                  noise_abs_cost=False,
-                 *, rng="torch", seed=None, shard=None):
+                 *, rng="torch", seed=None, shard=None, auto_jit=None):
         # shard = (rank, world_size[, group]): the ENVIRONMENT axis is split contiguously over the ranks
         # ("the better fit for filling 8 GPUs"); every environment is a complete,
         # independent controller, so a sharded command needs no collective at all -- only the ONE noise
@@ -1352,7 +1352,7 @@ class MPPI_Batched:
                        U_init=torch.zeros(horizon, 1 if len(noise_sigma.shape) == 0 else noise_sigma.shape[0],
                                           dtype=noise_sigma.dtype),
                        u_scale=u_scale, u_per_command=u_per_command, step_dependent_dynamics=step_dependent_dynamics,
-                       noise_abs_cost=noise_abs_cost, rng=rng, seed=seed)
+                       noise_abs_cost=noise_abs_cost, rng=rng, seed=seed, auto_jit=auto_jit)
         c = self._c
         self.d, self.dtype = c.d, c.dtype
         self.N, self.K, self.T, self.nx, self.nu = num_envs, c.K, c.T, c.nx, c.nu
