@@ -1375,6 +1375,12 @@ class MPPI_Batched:
         return U[self.env_offset:self.env_offset + self.N].contiguous()
 
     # attribute surface shared with the inner parameter block
+    jit_note = property(lambda self: self._c.jit_note)
+
+    def wait_for_jit(self, timeout=None):
+        """see MPPI.wait_for_jit (plain callables traced into fused kernels by a background hipcc run)"""
+        return self._c.wait_for_jit(timeout)
+
     lambda_ = property(lambda self: self._c.lambda_, lambda self, v: setattr(self._c, "lambda_", v))
     u_scale = property(lambda self: self._c.u_scale, lambda self, v: setattr(self._c, "u_scale", v))
     u_min = property(lambda self: self._c.u_min, lambda self, v: setattr(self._c, "u_min", v))
