@@ -206,7 +206,11 @@ __host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned
     unsigned long long p0 = (unsigned long long)M0 * c.x;
     unsigned long long p1 = (unsigned long long)M1 * c.z;
     U4 n;
-    n.x = xor3((unsigned)(p1 >> 32), c.y, k0);
+    // round 0: c.z (the command number), c.y (the row) and the key are wave-uniform in every kernel whose lane is a sample,
+    // so this word is scalar work (s_mul_hi / s_xor) when spelled with ^ -- v_bitop3_b32 has no scalar form: as a builtin it
+    // put the word into a VGPR, and the KMPPI-fused K1, which hoists these row constants out of its chunk loop, spilled
+    // 131 of them to scratch (94 us instead of 70.7)
+    n.x = r == 0 ? ((unsigned)(p1 >> 32) ^ c.y ^ k0) : xor3((unsigned)(p1 >> 32), c.y, k0);
     n.y = (unsigned)p1;
     n.z = xor3((unsigned)(p0 >> 32), c.w, k1);
     n.w = (unsigned)p0;

@@ -54,6 +54,17 @@ class SpecificActionSampler:
         self.slice = slice(start_idx, end_idx)
 
 
+def _auto_jit_mode(v):
+    """auto_jit / MPPI_AUTO_JIT -> "sync" | "async" | "0" (anything else is an error: `MPPI_AUTO_JIT=false` must not mean on)"""
+    if isinstance(v, str):
+        v = v.strip().lower()
+    m = {True: "sync", "1": "sync", "sync": "sync", "true": "sync", "on": "sync", "yes": "sync", "async": "async",
+         False: "0", "": "0", "0": "0", "off": "0", "false": "0", "no": "0", "none": "0"}.get(v)
+    if m is None:
+        raise ValueError(f"auto_jit / MPPI_AUTO_JIT = {v!r}: expected 'sync', 'async' or '0' (aliases: True/1/on, False/0/off/false/no)")
+    return m
+
+
 def _ptr(t):
     # a plain int is what a ctypes c_void_p field wants; no wrapper object per pointer per command
     return None if t is None else t.data_ptr()
@@ -217,8 +228,17 @@ class MPPI:
         # auto_jit: True / "sync" = trace and compile now (construction blocks for the hipcc run unless the object is cached);
         # "async" = trace now, compile in a background thread -- commands run the callbacks until the fused kernels are
         # there; False / "0" = off.  None: the environment's MPPI_AUTO_JIT (default "async")
-        mode = auto_jit if auto_jit is not None else os.environ.get("MPPI_AUTO_JIT", "async")
-        mode = {True: "sync", "1": "sync", False: "0", "": "0"}.get(mode, mode)
+        mode = _auto_jit_mode(auto_jit if auto_jit is not None else os.environ.get("MPPI_AUTO_JIT", "async"))
+        # traced callables are re-checked against the live ones: a flat watch of the places they can read from on every
+        # command (watch.StateWatch), and functor-against-callables on a small random batch on the device at adoption and
+        # every MPPI_JIT_CHECK_EVERY commands (default 256; 0 = never) -- _check_traced / _spot_check below
+        self._jit_mode = mode
+        self._jit_check_every = int(os.environ.get("MPPI_JIT_CHECK_EVERY", "256"))
+        self._jit_cmds = 0             # fused commands since the current traced model was adopted
+        self._jit_retraces = 0         # times the callables' state moved in a way that changed the functor
+        self._jit_benign = 0           # ... in a way that did not
+        self._jit_spot_checks = 0
+        self._jit_dynamic = []         # places (watch.Path) whose tensors were seen to change: run-time parameters from then on
         if m is None and self.d.type == "cuda" and self.M == 1 and mode != "0":
             # plain torch callables (the reference's plugin API): try to trace them into a device functor
             # (pytorch_mppi_amd/trace.py -> jit.compile_model); outside the traceable subset the generic path stays
@@ -242,29 +262,41 @@ class MPPI:
         self._dev_index = (self.d.index if self.d.index is not None else
                            (torch.cuda.current_device() if self.d.type == "cuda" and torch.cuda.is_available() else 0))
 
-    def _try_trace(self, dynamics, running_cost, terminal_state_cost, step_dependent, background=False):
+    def _try_trace(self, dynamics, running_cost, terminal_state_cost, step_dependent, background=False, dynamic=(),
+                   verify_in_background=False):
+        """Plain torch callables -> fused model, or None (generic path; `jit_note` says why).  background: the hipcc run
+        happens in a thread unless the object is cached; verify_in_background: so does the host check of the trace (a
+        RE-trace in the middle of a control loop must not stall it for the second g++ takes)."""
         import logging
-        from . import jit, trace
+        from . import jit, trace, watch
         log = logging.getLogger("pytorch_mppi_amd")
         try:
+            # the places the callables can read from, snapshotted BEFORE they run on symbols: whatever they write there
+            # themselves (call counters, `self.last = state`) shows up as a difference and is dropped in _settle_watch
+            w = watch.StateWatch([dynamics, running_cost, terminal_state_cost])
             code = jit.trace_and_verify(dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent, horizon=self.T,
-                                        device=self.d, dtype=self.dtype)
-            if background and not jit.traced_is_cached(code, self.nx, self.nu):
+                                        device=self.d, dtype=self.dtype, dynamic=dynamic, verify=not verify_in_background)
+            w.forget([src.path for src, _ in code["param_tensors"] if isinstance(src, trace.PathParam)])
+            cached = jit.traced_is_cached(code, self.nx, self.nu)
+            if verify_in_background or (background and not cached):
                 # the hipcc run (30 s - 2 min) happens beside the control loop: callbacks until it has finished
                 import threading
-                box = {}
+                box = {"watch": w}
 
                 def work():
                     try:
+                        if verify_in_background:
+                            jit.verify_traced(code, dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent, self.T)
                         box["model"] = jit.compile_traced(code, dynamics, running_cost, self.nx, self.nu, terminal_state_cost,
                                                           step_dependent=step_dependent)
-                    except Exception as e:                      # a failed hipcc run: stay on the callbacks
+                    except Exception as e:                      # a failed check / hipcc run: stay on the callbacks
                         box["error"] = e
                 th = threading.Thread(target=work, name="pytorch_mppi_amd-jit", daemon=True)
                 self._jit_pending = (th, box)
                 th.start()
-                self.jit_note = "generic path for now: the fused kernels of the traced callables are being compiled in the background"
-                log.warning("pytorch_mppi_amd: %s (auto_jit='sync' / MPPI_AUTO_JIT=sync waits for them instead)", self.jit_note)
+                if not (verify_in_background and cached):
+                    self.jit_note = "generic path for now: the fused kernels of the traced callables are being compiled in the background"
+                    log.warning("pytorch_mppi_amd: %s (auto_jit='sync' / MPPI_AUTO_JIT=sync waits for them instead)", self.jit_note)
                 return None
             m = jit.compile_traced(code, dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent=step_dependent)
         except trace.TraceUnsupported as e:
@@ -275,9 +307,194 @@ class MPPI:
             self.jit_note = f"generic path: {type(e).__name__}: {e}"
             log.info("pytorch_mppi_amd: dynamics / running_cost stay on the generic (callback) path: %s: %s", type(e).__name__, e)
             return None
+        m.watch = w
+        self._settle_watch(m)            # (what the callables wrote to their own state while they were traced and checked)
+        self._jit_cmds = 0
         self.jit_note = f"fused: traced {m.traced_ops} operations per sample into {m.name}"
         log.info("pytorch_mppi_amd: %s", self.jit_note)
         return m
+
+    # -- traced callables against the live ones ---------------------------------------------------------------------------
+    def _callables(self):
+        return self.F, self.running_cost, self.terminal_state_cost, bool(self.step_dependency)
+
+    def _drop_traced(self, note):
+        import logging
+        self.jit_note = note
+        logging.getLogger("pytorch_mppi_amd").warning("pytorch_mppi_amd: %s", note)
+        self._model = None
+        self._problem_cache.clear()
+
+    def _check_traced(self, state=None):
+        """Once per command, before anything is launched (mppi.py:314,318 call the user's callables on every command: a
+        traced functor has to notice when they would now compute something else).  Cheap part, every command: the
+        parameter tensors' version counters (`refresh_params`), the version counters of tensors that became constants,
+        and the watch over every place the callables can read from (watch.StateWatch.changed, ~0.1 us per place).
+        Every `_jit_check_every` commands and on the first command of a newly adopted model: `_spot_check`."""
+        m = self._model
+        w = getattr(m, "watch", None)
+        if w is None:
+            return
+        from . import trace
+        try:
+            if m._param_tensors:
+                m.refresh_params()
+            moved = w.changed()
+        except trace.StaleTrace as e:
+            moved, w = None, None
+            self._traced_state_moved([], str(e))
+            return
+        if moved or (m._captured and m.stale()):
+            self._traced_state_moved(moved, None)
+            return
+        n = self._jit_cmds
+        self._jit_cmds = n + 1
+        if self._jit_check_every > 0 and n % self._jit_check_every == 0 and state is not None \
+                and not torch.cuda.is_current_stream_capturing():
+            if not self._spot_check(state):
+                self._traced_state_moved([], "the fused functor and the callables disagree on a random batch")
+
+    def _traced_state_moved(self, moved, why):
+        """Something the traced callables can read is not what it was.  Re-trace (symbolic: milliseconds) and compare:
+        the same functor source and parameter sources -> irrelevant (forget the places); the same source, parameters read
+        from other tensors (a sub-module replaced by one of the same architecture) -> re-bind, no compile; anything else
+        -> the fused kernels are out of date: back to the callables NOW (the reference's behaviour), new functor compiled
+        beside the loop with the tensors that moved as run-time parameters."""
+        from . import jit, trace
+        m, w = self._model, self._model.watch
+        dyn, rc, term, sd = self._callables()
+        what = why or ("changed: " + w.describe(moved) if moved else "a tensor the traced callables read was modified in place")
+        try:
+            code = jit.trace_and_verify(dyn, rc, self.nx, self.nu, term, sd, verify=False, horizon=self.T, device=self.d,
+                                        dtype=self.dtype, dynamic=self._jit_dynamic)
+        except Exception as e:
+            self._drop_traced(f"generic path: the callables' state changed ({what}) and they can no longer be traced: {type(e).__name__}: {e}")
+            return
+        if trace.same_functor(code, m._code) and why is None:
+            self._jit_benign += 1
+            if trace.same_param_sources(code, m._code):
+                w.drop(moved)
+            else:
+                m.rebind_params(code)
+                w.resnap(moved)
+                self._problem_cache.clear()
+            m._code = code
+            return
+        if why is not None and trace.same_functor(code, m._code) and trace.same_param_sources(code, m._code):
+            # a spot-check mismatch that a fresh trace does not explain (a discontinuous cost on a boundary sample, state
+            # behind a C extension): the parameters were re-gathered by the spot-check; nothing else can be done from here
+            self._jit_benign += 1
+            return
+        self._jit_retraces += 1
+        for path in w.tensors_at(moved or []):
+            if not any(q.holder is path.holder and q.key == path.key for q in self._jit_dynamic):
+                self._jit_dynamic.append(path)
+        self._drop_traced(f"generic path for now: the callables' state changed ({what}); tracing them again")
+        if self._jit_retraces > 16:
+            self.jit_note = (f"generic path: the callables' state changed {self._jit_retraces} times in ways that change the functor; "
+                             f"ctrl.retrace() tries again")
+            return
+        self._model = self._try_trace(dyn, rc, term, sd, background=True, dynamic=self._jit_dynamic, verify_in_background=True)
+
+    def retrace(self, wait=True):
+        """Trace the callables again now (what the controller does by itself when it sees their state move); wait=True
+        blocks for the host check and the hipcc run unless the kernels are cached.  True when the controller runs fused."""
+        if self._jit_pending is not None:
+            self._jit_pending[0].join()
+            self._jit_pending = None
+        dyn, rc, term, sd = self._callables()
+        if native_model_of(dyn, rc, term) is not None:
+            return self._model is not None
+        self._model = None
+        self._problem_cache.clear()
+        self._jit_retraces = 0
+        self._model = self._try_trace(dyn, rc, term, sd, background=not wait, dynamic=self._jit_dynamic)
+        if self._model is not None:
+            self._settle_watch(self._model)
+        return self._model is not None
+
+    def _settle_watch(self, m):
+        """A traced model is about to serve commands: places that moved since its watch was taken are either the callables'
+        own doing (they ran on symbols and on the verification batches since) or a real change during the compile."""
+        w = m.watch
+        moved = w.changed()
+        if not moved:
+            return True
+        from . import jit, trace
+        dyn, rc, term, sd = self._callables()
+        try:
+            code = jit.trace_and_verify(dyn, rc, self.nx, self.nu, term, sd, verify=False, horizon=self.T, device=self.d,
+                                        dtype=self.dtype, dynamic=m._code.get("dynamic", ()))
+        except Exception:
+            return False
+        if not trace.same_functor(code, m._code):
+            return False
+        if trace.same_param_sources(code, m._code):
+            w.drop(moved)
+        else:
+            m.rebind_params(code)
+            w.resnap(moved)
+        m._code = code
+        return True
+
+    def _spot_check(self, state, samples=64, steps=4):
+        """The fused functor against the user's callables on a small random batch ON THE DEVICE (`samples` states around the
+        current one, `steps` timesteps of random bounded actions): total costs and visited states of a tiny fused rollout
+        against the reference's own loop (mppi.py:297-332) over the same actions.  What the watch cannot see ends here:
+        writes through `.data`, state behind C extensions, a tracer bug the host check did not meet.  One device sync."""
+        m = self._model
+        self._jit_spot_checks += 1
+        try:
+            m.refresh_params(force=True)              # (a write through .data moves no version counter)
+        except Exception:
+            return False
+        Tp = max(1, min(int(steps), self.T))
+        pr = getattr(m, "_probe", None)
+        if pr is None or pr.T != Tp:
+            term = m.terminal_state_cost if self.terminal_state_cost is not None else None
+            pr = MPPI(m.dynamics, m.running_cost, self.nx, self.noise_sigma.reshape(self.nu, self.nu), num_samples=samples, horizon=Tp,
+                      device=self.d, terminal_state_cost=term, lambda_=1.0, u_min=self.u_min, u_max=self.u_max, u_scale=self.u_scale,
+                      step_dependent_dynamics=bool(self.step_dependency), U_init=torch.zeros(Tp, self.nu, dtype=self.dtype),
+                      rng="torch", auto_jit=False)
+            pr._want_states = True
+            m._probe = pr
+        if pr._needs_generic():
+            return True                                # no fused kernel for this model at the probe's shape: nothing to compare
+        gen = getattr(self, "_spot_gen", None)
+        if gen is None:
+            gen = self._spot_gen = torch.Generator(device=self.d)
+            gen.manual_seed(0x5EED)
+        x = self._to_state(state).reshape(-1)
+        x = x[:self.nx] if x.numel() >= self.nx else torch.zeros(self.nx, device=self.d, dtype=self.dtype)
+        X0 = x + torch.randn(samples, self.nx, device=self.d, dtype=self.dtype, generator=gen) * (0.5 * x.abs() + 1.0)
+        z = torch.randn(samples, Tp, self.nu, device=self.d, dtype=self.dtype, generator=gen)
+        with torch.no_grad():
+            pr.U = torch.zeros(Tp, self.nu, device=self.d, dtype=self.dtype)     # U = 0: no action cost, cost_total is the rollout's
+            pr.inject_noise(z)
+            pr.command(X0, shift_nominal_trajectory=False)
+            fused_c, fused_x, pa = pr.cost_total, pr.states, pr.perturbed_action
+            state, ref_c = X0.clone(), torch.zeros(samples, device=self.d, dtype=self.dtype)
+            states = torch.empty(1, samples, Tp, self.nx, device=self.d, dtype=self.dtype)
+            actions = torch.empty(1, samples, Tp, self.nu, device=self.d, dtype=self.dtype)
+            for t in range(Tp):
+                u = self.u_scale * pa[:, t]
+                state = self._dynamics_fn(state, u, t)
+                ref_c = ref_c + self._running_cost_fn(state, u, t).reshape(samples)
+                states[0, :, t] = state[:, :self.nx]
+                actions[0, :, t] = u
+            if self.terminal_state_cost is not None:
+                c = self._terminal_state_cost_fn(states, actions)
+                ref_c = ref_c + (c.squeeze(0) if torch.is_tensor(c) and c.dim() > 1 else c)
+            tol = 2e-3 if self.dtype == torch.float32 else 1e-7
+            bad = torch.zeros(samples, dtype=torch.bool, device=self.d)
+            for got, ref in ((fused_c, ref_c), (fused_x[0].reshape(samples, -1), states[0].reshape(samples, -1))):
+                got, ref = got.reshape(samples, -1), ref.reshape(samples, -1).to(got.dtype)
+                fin = torch.isfinite(ref)
+                scale = torch.where(fin, ref.abs(), torch.zeros_like(ref)).amax().clamp_min(1.0)
+                d = torch.where(fin, (got - ref).abs(), torch.zeros_like(ref))
+                bad |= ((d > tol * scale) | (fin != torch.isfinite(got))).any(dim=1)
+            # more than a few samples off: not a boundary case of a discontinuous cost
+            return int(bad.sum().item()) <= samples // 16
 
     # ------------------------------------------------------------------------------------------
     # parameter resolution (host, once per change)
@@ -642,6 +859,8 @@ class MPPI:
         self.info = info
         if self._jit_pending is not None:
             self._adopt_background_model()         # only HERE, between two commands: a command never changes path half-way
+        if getattr(self._model, "watch", None) is not None:
+            self._check_traced(state)              # traced callables: do they still say what the functor computes?
         return self._command(state, bool(shift_nominal_trajectory))
 
     def capture_command(self, state, shift_nominal_trajectory=True, warmup=3):
@@ -710,7 +929,19 @@ class MPPI:
             self.jit_note = f"generic path: {type(box.get('error')).__name__}: {box.get('error')}"
             log.warning("pytorch_mppi_amd: dynamics / running_cost stay on the generic (callback) path: %s", self.jit_note)
             return
+        m.watch = box["watch"]
+        if not self._settle_watch(m):
+            # the callables' state moved again while these kernels were being compiled: they are already out of date
+            self._jit_retraces += 1
+            if self._jit_retraces <= 16:
+                for path in m.watch.tensors_at(m.watch.changed()):
+                    if not any(q.holder is path.holder and q.key == path.key for q in self._jit_dynamic):
+                        self._jit_dynamic.append(path)
+                dyn, rc, term, sd = self._callables()
+                self._model = self._try_trace(dyn, rc, term, sd, background=True, dynamic=self._jit_dynamic, verify_in_background=True)
+            return
         self._model = m
+        self._jit_cmds = 0
         self._problem_cache.clear()
         self.jit_note = f"fused: traced {m.traced_ops} operations per sample into {m.name} (compiled in the background)"
         log.warning("pytorch_mppi_amd: %s", self.jit_note)
@@ -724,15 +955,6 @@ class MPPI:
 
     def _needs_generic(self):
         if self._model is None:
-            return True
-        if getattr(self._model, "_param_tensors", None):
-            self._model.refresh_params()           # trainable tensors of a traced model: new values, same functor
-        if getattr(self._model, "_captured", None) and self._model.stale():
-            import logging
-            self.jit_note = "generic path: a tensor the traced callables read was modified in place after tracing"
-            logging.getLogger("pytorch_mppi_amd").warning("pytorch_mppi_amd: %s", self.jit_note)
-            self._model = None
-            self._problem_cache.clear()
             return True
         if self.M != 1 and not self._fused_multi_ok():
             return True
@@ -1059,7 +1281,7 @@ class MPPI:
         """Visited states: (1,K,T,nx), like the reference only kept when a terminal cost is set
         (mppi.py:307-310, :329-331) -- or (M,K,T,nx) for M > 1 rollouts, where the reference always
         stores them (:349-350, :366)."""
-        want = self.terminal_state_cost is not None or self.M > 1
+        want = self.terminal_state_cost is not None or self.M > 1 or getattr(self, "_want_states", False)
         if self._states is None and self._last is not None and want and not self._needs_generic():
             lib = N.lib()
             p = self._last
@@ -1411,6 +1633,8 @@ class MPPI_Batched:
         if not torch.is_tensor(states):
             states = torch.tensor(states)
         states = states.to(dtype=self.dtype, device=self.d)
+        if getattr(c._model, "watch", None) is not None:
+            c._check_traced(states.reshape(-1, self.nx)[0])
         if self.N != self.N_global and states.numel() == self.N_global * self.nx:
             states = states.reshape(self.N_global, self.nx)[self.env_offset:self.env_offset + self.N]   # this rank's environments
         states = states.reshape(self.N, self.nx).contiguous()

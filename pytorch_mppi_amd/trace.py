@@ -32,6 +32,30 @@ class TraceUnsupported(Exception):
     pass
 
 
+class StaleTrace(Exception):
+    """a run-time parameter of a traced functor is no longer what the trace saw (another shape, not a tensor any more)"""
+
+
+class PathParam:
+    """A NON-trainable tensor the callables read from a fixed place (watch.Path: an attribute, a closure cell, a global)
+    whose values the functor reads from its parameter vector instead of carrying them as constants: the controller promotes
+    a tensor to this once it has SEEN it change (`cost.goal = new_goal`; mppi.MPPI._traced_state_moved), so that the next
+    change is one small copy, not a compile.  `tensor()` is whatever sits at the place now."""
+    def __init__(self, path, t):
+        self.path, self.shape = path, tuple(t.shape)
+
+    def tensor(self):
+        v = self.path.get()
+        if not isinstance(v, torch.Tensor) or tuple(v.shape) != self.shape or not v.is_floating_point():
+            raise StaleTrace(f"{self.path!r} no longer holds a floating tensor of shape {self.shape}")
+        return v
+
+
+def param_tensor(src):
+    """the tensor behind an entry of `param_tensors` (a trainable tensor itself, or what a PathParam's place holds now)"""
+    return src.tensor() if isinstance(src, PathParam) else src
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # expression graph (hash-consed, constants folded)
 # ---------------------------------------------------------------------------------------------------------------
@@ -49,7 +73,13 @@ _CMP = {"lt": lambda a, b: a < b, "le": lambda a, b: a <= b, "gt": lambda a, b: 
 
 
 class Graph:
-    def __init__(self, max_nodes=60000, device=None, dtype=None):
+    def __init__(self, max_nodes=60000, device=None, dtype=None, dynamic=()):
+        # dynamic: watch.Path places whose (non-trainable) tensors are run-time parameters of this trace (PathParam)
+        self.dynamic = {}
+        for path in dynamic:
+            v = path.get()
+            if isinstance(v, torch.Tensor) and v.is_floating_point() and v.numel() > 0:
+                self.dynamic[id(v)] = (v, path)
         # what the symbolic inputs report as .device / .dtype: the controller's own, so that `net.to(state.device, state.dtype)`
         # or `if state.is_cuda:` inside the callables behave as they will at run time (and a module is not dragged to the host)
         self.device = torch.device(device) if device is not None else torch.device("cpu")
@@ -83,14 +113,16 @@ class Graph:
         return self._mk((kind,) if i is None else (kind, int(i)))
 
     def param_leaves(self, t, max_params=32768):
-        """node ids (shape of t) of the run-time parameter leaves of a trainable tensor"""
+        """node ids (shape of t) of the run-time parameter leaves of a trainable tensor (or of a promoted one: `dynamic`)"""
         base = self._param_base.get(id(t))
         if base is None:
             if self.n_params + t.numel() > max_params:
                 raise TraceUnsupported(f"more than {max_params} trainable parameters")
             base = self.n_params
             self._param_base[id(t)] = base
-            self.param_tensors.append((t, base))         # (keeps t alive: id(t) stays unique)
+            dyn = self.dynamic.get(id(t))
+            # (the entry keeps t alive, directly or through `dynamic`: id(t) stays unique)
+            self.param_tensors.append((PathParam(dyn[1], t) if dyn is not None and dyn[0] is t else t, base))
             self.n_params += t.numel()
         return np.array([self.leaf("p", base + i) for i in range(t.numel())], dtype=np.int64).reshape(tuple(t.shape))
 
@@ -218,11 +250,12 @@ class SymT:
         if isinstance(v, torch.Tensor):
             if v.dtype == torch.bool:
                 raise TraceUnsupported("boolean constant tensors")
-            if isinstance(v, torch.nn.Parameter) or v.requires_grad:
+            if isinstance(v, torch.nn.Parameter) or v.requires_grad or id(v) in self.g.dynamic:
                 # a TRAINABLE tensor: its values are expected to change (online learning of the dynamics, as in the
                 # reference's tests/pendulum_approximate.py:47-67,140-170) -- baking them into the functor would go stale
                 # with the first optimizer step.  Its elements become reads of the model's parameter vector p[]: the
-                # functor stays valid, the vector is re-gathered when the tensor's version counter moves.
+                # functor stays valid, the vector is re-gathered when the tensor's version counter moves.  (Same for a
+                # tensor the controller has seen change at its place: Graph.dynamic, PathParam.)
                 return SymT(self.g, self.g.param_leaves(v))
             for r in self.g.roots_of(v):                 # captured BY VALUE: the controller watches the version counters of
                 if not any(r is c for c, _ in self.g.captured):     # the tensor -- or of what it was made from inside the callable
@@ -850,7 +883,10 @@ class SymS:
     __int__ = __index__
     def __float__(self): raise TraceUnsupported("the timestep converted to a Python float")
     def __lt__(self, o): raise TraceUnsupported("comparison on the timestep")
-    __le__ = __gt__ = __ge__ = __lt__
+    # == / != / hashing must fail as loudly as < does: left at the object defaults, `if t == T - 1:` would evaluate to a plain
+    # False while tracing and the branch would be dropped without a word (`t in (...)`, dict lookups by t: the same)
+    __le__ = __gt__ = __ge__ = __eq__ = __ne__ = __lt__
+    def __hash__(self): raise TraceUnsupported("the timestep used as a dictionary key / set member")
     __array_priority__ = 1000
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -1140,6 +1176,8 @@ def _flatten_result(r, want, what):
 
 _FACTORIES = {"zeros", "ones", "empty", "full", "tensor", "as_tensor", "eye", "from_numpy", "linspace", "diag", "diag_embed",
               "zeros_like", "ones_like", "full_like", "empty_like", "scalar_tensor", "asarray"}
+_META = {"size", "dim", "numel", "nelement", "stride", "is_floating_point", "is_contiguous", "data_ptr", "element_size", "get_device",
+         "is_complex", "storage_offset", "__len__", "ndimension", "type", "is_pinned", "__format__", "__repr__", "__str__"}
 _RANDOM = {"randn", "rand", "randn_like", "rand_like", "normal", "randint", "bernoulli", "multinomial", "randperm", "poisson"}
 
 
@@ -1155,8 +1193,18 @@ class _TraceMode(torch.overrides.TorchFunctionMode):
         kwargs = kwargs or {}
         name = getattr(func, "__name__", str(func))
 
+        dyn = self.g.dynamic
+
         def has_sym(v):
-            return isinstance(v, (SymT, SymS, _Masked)) or (isinstance(v, (tuple, list)) and any(has_sym(e) for e in v))
+            return isinstance(v, (SymT, SymS, _Masked)) or (isinstance(v, (tuple, list)) and any(has_sym(e) for e in v)) \
+                or (dyn and isinstance(v, torch.Tensor) and id(v) in dyn)
+
+        def sym_dyn(v):          # a promoted tensor met by a torch function on its own (`self.goal.to(device)`, `goal[None]`)
+            if isinstance(v, torch.Tensor) and id(v) in dyn:
+                return SymT(self.g, self.g.param_leaves(v))
+            if isinstance(v, (tuple, list)) and any(isinstance(e, torch.Tensor) and id(e) in dyn for e in v):
+                return type(v)(sym_dyn(e) for e in v)
+            return v
         if name in _RANDOM:
             raise TraceUnsupported(f"torch.{name} inside the callable (random draws are not a function of state, action and timestep)")
         if any(has_sym(v) for v in args) or any(has_sym(v) for v in kwargs.values()):
@@ -1165,6 +1213,17 @@ class _TraceMode(torch.overrides.TorchFunctionMode):
             if name == "__setitem__" and isinstance(args[0], torch.Tensor):
                 raise TraceUnsupported("item assignment of a traced value into a tensor created outside the traced callables")
             args = tuple(SymT(a.g, np.array(a.i)) if isinstance(a, SymS) else a for a in args)
+            if dyn:
+                if name == "__get__" and isinstance(args[0], torch.Tensor):
+                    # a property of a promoted tensor: views become symbolic, metadata (shape, device, dtype, ...) stays real
+                    prop = getattr(getattr(func, "__self__", None), "__name__", "")
+                    if prop not in ("T", "mT", "H", "mH", "data", "real"):
+                        return func(*args, **kwargs)
+                    return getattr(sym_dyn(args[0]), {"H": "T", "mH": "mT", "real": "data"}.get(prop, prop))
+                if name in _META and not any(isinstance(a, (SymT, _Masked)) for a in args):
+                    return func(*args, **kwargs)
+                args = tuple(sym_dyn(a) for a in args)
+                kwargs = {k: sym_dyn(v) for k, v in kwargs.items()}
             return _call(self.g, name, args, kwargs)
         out = func(*args, **kwargs)
         srcs = [v for v in list(args) + list(kwargs.values()) if isinstance(v, torch.Tensor)]
@@ -1180,9 +1239,10 @@ class _TraceMode(torch.overrides.TorchFunctionMode):
         return out
 
 
-def trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, device=None, dtype=None):
+def trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, device=None, dtype=None,
+                    dynamic=()):
     """-> (Graph, step outputs [nx node ids], cost output id, terminal output id or None)"""
-    g = Graph(device=device, dtype=dtype)
+    g = Graph(device=device, dtype=dtype, dynamic=dynamic)
 
     def xs(kind, n, shape):
         return SymT(g, np.array([g.leaf(kind, i) for i in range(n)], dtype=np.int64).reshape(shape))
@@ -1332,15 +1392,37 @@ def emit(g, roots, assign=None, ret=False):
     return " ".join(lines)
 
 
-def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, device=None, dtype=None):
+def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, device=None, dtype=None, dynamic=()):
     """-> dict(step=..., cost=..., terminal=... or None, n_ops=...): the C++ bodies for jit.compile_model.
-    device / dtype: what the symbolic inputs report (the controller's; default cpu / float64)."""
-    g, so, co, to = trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost, step_dependent, device, dtype)
+    device / dtype: what the symbolic inputs report (the controller's; default cpu / float64).
+    dynamic: places (watch.Path) whose tensors become run-time parameters instead of constants."""
+    g, so, co, to = trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost, step_dependent, device, dtype, dynamic)
     step = emit(g, so, assign=[f"x[{i}]" for i in range(nx)])
     cost = emit(g, [co], ret=True)
     term = emit(g, [to], ret=True) if to is not None else None
     return dict(step=step, cost=cost, terminal=term, n_ops=len(g.nodes), captured=g.captured, param_tensors=g.param_tensors,
-                n_params=g.n_params)
+                n_params=g.n_params, dynamic=list(dynamic))
+
+
+def same_functor(a, b):
+    """two traces print the same device functor (same bodies: same constants folded in, same parameter reads)"""
+    return all(a[k] == b[k] for k in ("step", "cost", "terminal", "n_params"))
+
+
+def same_param_sources(a, b):
+    """... and read their run-time parameters from the same tensors / places"""
+    pa, pb = a["param_tensors"], b["param_tensors"]
+    if len(pa) != len(pb):
+        return False
+    for (sa, ba), (sb, bb) in zip(pa, pb):
+        if ba != bb or isinstance(sa, PathParam) != isinstance(sb, PathParam):
+            return False
+        if isinstance(sa, PathParam):
+            if sa.path.holder is not sb.path.holder or sa.path.key != sb.path.key or sa.shape != sb.shape:
+                return False
+        elif sa is not sb:
+            return False
+    return True
 
 
 def gather_params(param_tensors, n_params):
@@ -1348,7 +1430,9 @@ def gather_params(param_tensors, n_params):
     if not param_tensors:
         return None
     with torch.no_grad():
-        return torch.cat([t.detach().reshape(-1).double() for t, _ in param_tensors])
+        ts = [param_tensor(src).detach().reshape(-1).double() for src, _ in param_tensors]
+        dev = next((t.device for t in ts if t.device.type != "cpu"), ts[0].device)     # (a goal kept on the host beside device weights)
+        return torch.cat([t.to(dev) for t in ts])
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1446,7 +1530,13 @@ def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=Non
         form = None                                    # (device, dtype) the callables accept: found on the first batch
         # three batches around the origin and one far out (fp64 callables only): rewrites that are only equal where nothing
         # overflows -- log(1 + exp(x)) for softplus -- show up there, matching inf / nan patterns count as agreement
-        for scale, t in ((1.0, 0), (3.0, 5), (0.1, 11), (40.0, 2)):
+        batches = [(1.0, 0), (3.0, 5), (0.1, 11), (40.0, 2)]
+        if step_dependent and horizon is not None:
+            # a step-dependent callable is checked at EVERY timestep of the horizon (the last one first: terminal-style terms
+            # `c + (t == T - 1) * ...` live there); the host check costs a fraction of a millisecond per batch
+            H = int(horizon)
+            batches += [(1.0, t) for t in [H - 1] + [t for t in range(H - 1) if t not in (0, 2, 5, 11)][:1023]]
+        for scale, t in batches:
             if scale > 10.0 and form is not None and form[1] != torch.float64:
                 continue
             if horizon is not None:

@@ -238,6 +238,65 @@ def watched_linear_callables():
     return (lambda s, a: s + a @ B.to(s.device).T), (lambda s, a: (s ** 2).sum(-1)), B
 
 
+class RetargetedCost:
+    """state the reference reads live on every call (/root/reference/tests/smooth_mppi.py:54-58: `dx = self.goal - state`):
+    a goal TENSOR the user rebinds between commands and a Python float gain"""
+    def __init__(self):
+        self.goal = torch.tensor([1.5, -0.5], dtype=torch.float64)
+        self.gain = 2.0
+        self.calls = 0
+
+    def __call__(self, state, action):
+        self.calls += 1
+        dx = self.goal.to(state.device, state.dtype) - state
+        return self.gain * (dx ** 2).sum(-1) + 0.01 * (action ** 2).sum(-1)
+
+
+def retargeted_callables():
+    """(dynamics, cost object, holder): linear dynamics through a matrix in a holder dict, the cost above"""
+    holder = {"B": torch.tensor([[0.2, 0.0], [0.05, -0.2]], dtype=torch.float64)}
+    cost = RetargetedCost()
+
+    def dynamics(state, action):
+        return state + action @ holder["B"].to(state.device, state.dtype).T
+
+    return dynamics, cost, holder
+
+
+RETARGET_GOAL_2, RETARGET_GAIN_2 = [-1.0, 0.75], 3.0
+
+
+def swappable_net_callables(seed=11, hidden=6):
+    """an nn.Module the user REPLACES between commands (same architecture, other weights): holder['net'] = new_net"""
+    mk = lambda s_: _frozen_mlp(s_, hidden)
+    holder = {"net": mk(seed)}
+
+    def dynamics(state, action):
+        return state + 0.1 * holder["net"](torch.cat((state, action), dim=1).to(torch.float64)).to(state.dtype)
+
+    def cost(state, action):
+        return (state ** 2).sum(dim=1) + 0.05 * (action ** 2).sum(dim=1)
+
+    return dynamics, cost, holder, mk
+
+
+def _frozen_mlp(seed, hidden):
+    g = torch.Generator().manual_seed(seed)
+    net = torch.nn.Sequential(torch.nn.Linear(3, hidden), torch.nn.Tanh(), torch.nn.Linear(hidden, 2)).double()
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g, dtype=torch.float64) * 0.4)
+    return net
+
+
+def promoted_paths(callables, tensors):
+    """the places (watch.Path) at which `callables` read the given tensors: what the controller promotes to run-time
+    parameters once it has seen them change (build() compiles those variants ahead, so that the GPU tests find them cached)"""
+    from pytorch_mppi_amd import watch
+    w = watch.StateWatch(list(callables))
+    return [p_ for p_, kind, ref in w.places if kind == "t" and any(ref[0] is t for t in tensors)]
+
+
 def traced_models():
     """the traced + compiled forms of the callables above (built by __graft_entry__.build() so that the objects travel)"""
     import concurrent.futures as cf
@@ -250,7 +309,23 @@ def traced_models():
     jobs = dict(pendulum=(f, q, 2, 1), linear=(lf, lq, 2, 2, lt), mlp=(mf, mq, 4, 2), watched=(wf, wq, 2, 2), approx=(af, aq, 2, 1),
                 zoo=(zf, zq, 4, 2), approx_terminal=(af, aq, 2, 1, approx_terminal_cost))
     tf, tq = tracking_callables()
+    # callables whose state the user changes between commands (tests/test_gpu_from_torch.py): the functor of the first trace,
+    # and the one the controller compiles after it has seen the state move (the tensors that moved as run-time parameters)
+    rf, rq, rh = retargeted_callables()
+    jobs["retarget"] = (rf, rq, 2, 2)
+    rf2, rq2, rh2 = retargeted_callables()
+    rq2.gain = RETARGET_GAIN_2
+    wf2, wq2, wB2 = watched_linear_callables()
+    sf, sq, sh, _ = swappable_net_callables()
+    jobs["swappable"] = (sf, sq, 2, 1)
     with cf.ThreadPoolExecutor(max_workers=8) as ex:      # each ends in its own hipcc subprocess
         futs = {k: ex.submit(jit.from_torch, *v) for k, v in jobs.items()}
         futs["tracking"] = ex.submit(jit.from_torch, tf, tq, 2, 2, step_dependent=True, horizon=24)
+        futs["retarget_goal_promoted"] = ex.submit(jit.from_torch, rf2, rq2, 2, 2, dynamic=promoted_paths((rf2, rq2), [rq2.goal]))
+        futs["retarget_goal_and_B_promoted"] = ex.submit(jit.from_torch, rf2, rq2, 2, 2,
+                                                         dynamic=promoted_paths((rf2, rq2), [rq2.goal, rh2["B"]]))
+        wf3, wq3, wB3 = watched_linear_callables()
+        wB3.data[1, 0] = 0.75                             # (a write the version counters do not see: re-traced with the new constant)
+        futs["watched_data_write"] = ex.submit(jit.from_torch, wf3, wq3, 2, 2)
+        futs["watched_promoted"] = ex.submit(jit.from_torch, wf2, wq2, 2, 2, dynamic=promoted_paths((wf2, wq2), [wB2]))
         return {k: v.result() for k, v in futs.items()}

@@ -157,6 +157,13 @@ def test_in_place_update_of_a_captured_tensor_sends_the_controller_back_to_the_c
     ua, ub = a.command(x0), b.command(x0)
     assert a._needs_generic() and a.jit_note.startswith("generic path")
     assert float((ua - ub).abs().max()) <= 1e-9
+    # ... while the functor is traced again beside the loop, the matrix as run-time parameters this time
+    assert a.wait_for_jit(300.0) and not a._needs_generic() and a._model._n_params == 4, a.jit_note
+    B[1, 1] = -0.25
+    for c in (a, b):
+        c.U = torch.zeros(6, 2, dtype=torch.float64, device="cuda")
+        c.inject_noise(z)
+    assert float((a.command(x0) - b.command(x0)).abs().max()) <= 1e-9 and not a._needs_generic()
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
@@ -296,3 +303,126 @@ def test_reference_schedule_indexed_by_the_timestep_runs_fused():
             c.inject_noise(z)
         ua, ub = a.command(x0), b.command(x0)
         assert float((ua - ub).abs().max()) <= 1e-9 and float((a.cost_total - b.cost_total).abs().max()) <= 1e-9 * float(b.cost_total.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# traced callables against the live ones: the reference calls the callables on every command
+# (mppi.py:314, :318; tests/smooth_mppi.py:54-58 reads `self.goal` live), so state changed between commands must
+# reach a controller that runs a traced functor -- on the very next command
+# ---------------------------------------------------------------------------------------------------------------------
+def _retarget_oracle(f, q, K, T, U, x0, z):
+    from oracle import mppi_oracle as orc
+    p = orc.Problem(dynamics=f, running_cost=q, nx=2, noise_sigma=torch.eye(2, dtype=torch.float64), K=K, T=T, lambda_=1.0)
+    return orc.command(p, U, x0, z, True)
+
+
+def test_rebound_goal_changed_gain_and_rewritten_matrix_reach_the_fused_controller():
+    import pytorch_mppi_amd as pm
+    f, q, holder = jf.retargeted_callables()
+    K, T = 512, 8
+    U0 = torch.zeros(T, 2, dtype=torch.float64)
+    a = pm.MPPI(f, q, 2, torch.eye(2, dtype=torch.float64), num_samples=K, horizon=T, device="cuda", U_init=U0.clone(), auto_jit=True)
+    assert a.jit_note.startswith("fused") and not a._needs_generic(), a.jit_note
+    x0 = torch.tensor([0.3, -0.2], dtype=torch.float64)
+    gen = torch.Generator().manual_seed(21)
+
+    def step(tag):
+        """one command on a fresh draw, checked against the oracle that calls the LIVE callables (fp64, 1e-9)"""
+        z = torch.randn(K, T, 2, generator=gen, dtype=torch.float64)
+        U_before = a.U.detach().cpu().clone()
+        a.inject_noise(z)
+        ua = a.command(x0.cuda())
+        r = _retarget_oracle(f, q, K, T, U_before, x0, z)
+        for name, got in (("action", ua), ("U", a.U), ("cost_total", a.cost_total)):
+            s = max(1.0, float(r[name].abs().max()))
+            assert float((got.cpu() - r[name]).abs().max()) <= 1e-9 * s, (tag, name)
+
+    step("as traced")
+    step("as traced, again")
+    m0 = a._model
+    assert a._jit_spot_checks >= 1 and a._jit_retraces == 0 and not a._needs_generic()
+    # 1. the goal tensor is REBOUND and a Python float changed: the very next command follows the new cost
+    q.goal = torch.tensor(jf.RETARGET_GOAL_2, dtype=torch.float64)
+    q.gain = jf.RETARGET_GAIN_2
+    step("goal rebound + gain changed")
+    assert a._jit_retraces == 1 and "RetargetedCost.goal" in " ".join(repr(p_) for p_ in a._jit_dynamic)
+    assert a.wait_for_jit(300.0) and a._model is not m0 and not a._needs_generic(), a.jit_note
+    m1 = a._model
+    assert m1._n_params == 2 and "p[0]" in m1._code["cost"]        # the goal is a run-time parameter now
+    step("new functor")
+    # 2. the next goals cost one small copy each: same kernels
+    for goal in ([0.25, 0.5], [2.0, -2.0]):
+        q.goal = torch.tensor(goal, dtype=torch.float64)
+        step(f"goal {goal}")
+        assert a._model is m1 and not a._needs_generic()
+    q.goal[1] = 0.125                                                # ... written in place too
+    step("goal written in place")
+    assert a._model is m1 and a._jit_retraces == 1
+    # 3. a matrix the dynamics read is written IN PLACE (version counter): promoted as well
+    holder["B"][0, 1] = 0.15
+    step("B written in place")
+    assert a._jit_retraces == 2 and a.wait_for_jit(300.0) and a._model._n_params == 6
+    step("B as parameters")
+    holder["B"] = holder["B"] * 0.5                                  # rebound this time
+    m2 = a._model
+    step("B rebound")
+    assert a._model is m2 and not a._needs_generic()
+
+
+def test_writes_the_watch_cannot_see_are_caught_by_the_spot_check():
+    """`tensor.data[...] = v` moves no version counter and no pointer: the periodic functor-against-callables check on the
+    device (MPPI._spot_check) is what notices"""
+    import pytorch_mppi_amd as pm
+    f, q, B = jf.watched_linear_callables()
+    mk = lambda auto: pm.MPPI(f, q, 2, torch.eye(2, dtype=torch.float64), num_samples=256, horizon=6, device="cuda",
+                              U_init=torch.zeros(6, 2, dtype=torch.float64), auto_jit=auto)
+    a, b = mk(True), mk(False)
+    assert not a._needs_generic()
+    a._jit_check_every = 4
+    x0 = torch.ones(2, dtype=torch.float64).cuda()
+    gen = torch.Generator().manual_seed(5)
+
+    def both():
+        z = torch.randn(256, 6, 2, generator=gen, dtype=torch.float64)
+        a.U = b.U.clone()
+        for c in (a, b):
+            c.inject_noise(z)
+        return float((a.command(x0) - b.command(x0)).abs().max())
+    for _ in range(6):
+        assert both() <= 1e-9
+    n0 = a._jit_spot_checks
+    assert n0 >= 2 and not a._needs_generic()
+    B.data[1, 0] = 0.75                               # invisible to version counters
+    worst = [both() for _ in range(4)]                # at most three commands until the next check ...
+    assert a._jit_spot_checks > n0 and a._jit_retraces == 1
+    assert both() <= 1e-9                             # ... then the callables again, and the new functor later
+    assert max(worst) > 1e-6                          # (the window the spot-check interval leaves: documented in DESIGN.md 2b)
+    assert a.wait_for_jit(300.0)
+    assert both() <= 1e-9 and not a._needs_generic()
+
+
+def test_replaced_module_keeps_the_kernels():
+    import pytorch_mppi_amd as pm
+    f, q, holder, mk_net = jf.swappable_net_callables()
+    mk = lambda auto: pm.MPPI(f, q, 2, torch.tensor(0.5, dtype=torch.float64), num_samples=300, horizon=7, device="cuda",
+                              U_init=torch.zeros(7, 1, dtype=torch.float64), auto_jit=auto)
+    holder["net"].cuda()
+    a, b = mk(True), mk(False)
+    assert not a._needs_generic(), a.jit_note
+    m = a._model
+    x0 = torch.tensor([0.4, -0.1], dtype=torch.float64).cuda()
+    gen = torch.Generator().manual_seed(6)
+
+    def both():
+        z = torch.randn(300, 7, 1, generator=gen, dtype=torch.float64)
+        a.U = b.U.clone()
+        for c in (a, b):
+            c.inject_noise(z)
+        return float((a.command(x0) - b.command(x0)).abs().max())
+    assert both() <= 1e-9
+    holder["net"] = mk_net(99).cuda()                 # same architecture, other weights
+    assert both() <= 1e-9 and a._model is m and not a._needs_generic() and a._jit_retraces == 0
+    with torch.no_grad():
+        holder["net"][0].weight.data.mul_(0.5)        # a write through .data: re-gathered by the spot-check
+    a._jit_check_every = 1
+    assert both() <= 1e-9 and a._model is m
