@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 18
+#define MPPI_ABI_VERSION 19
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -284,6 +284,13 @@ int64_t mppi_stat_single_launch_commands(void);
  * when given).  Problems outside that scope with p->z == NULL run K1 + K3 with the rows generated twice, as before.
  * MPPI_ONCHIP=0 in the environment disables the form (A/B runs).  Count of commands that took it: */
 int64_t mppi_stat_onchip_commands(void);
+/* ABI 19: the form the CALLING THREAD's last mppi_command took (thread-local; the two counters above are process-wide and
+ * cannot answer "did my command run on chip" once two controllers command from two threads). */
+#define MPPI_FORM_NONE 0           /* no command yet on this thread, or the last one failed before its first launch */
+#define MPPI_FORM_STREAMING 1      /* K1 + K3 + K4 */
+#define MPPI_FORM_SINGLE_LAUNCH 2  /* small problems: one launch */
+#define MPPI_FORM_ONCHIP 3         /* on-chip K1 + finalize_blocks */
+int mppi_last_command_form(void);
 
 /* K5 -- multi-GPU: combine `n_shards` records (all-gathered, rank order) exactly the same way
  * on every rank: beta = min beta_g; s_g = exp(-(beta_g-beta)/lambda); eta = sum s_g eta_g;

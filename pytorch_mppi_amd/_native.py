@@ -9,11 +9,12 @@ import os
 
 from . import _build
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
 E_UNSUPPORTED = -2
+FORM_NONE, FORM_STREAMING, FORM_SINGLE_LAUNCH, FORM_ONCHIP = 0, 1, 2, 3      # mppi_last_command_form()
 E_DIST = -4
 MODEL_NONE, MODEL_PENDULUM, MODEL_INTEGRATOR, MODEL_LINEAR_GOAL, MODEL_MLP = 0, 1, 2, 3, 4
 MODEL_CUSTOM_BASE = 100
@@ -76,6 +77,7 @@ SYMBOLS = {
     "mppi_command": (C.c_int, [_PP, C.c_int, _vp]),
     "mppi_stat_single_launch_commands": (C.c_int64, []),
     "mppi_stat_onchip_commands": (C.c_int64, []),
+    "mppi_last_command_form": (C.c_int, []),
     "mppi_stat_kmppi_fused_rollouts": (C.c_int64, []),
     "mppi_combine": (C.c_int, [_PP, _vp, C.c_int32, _vp]),
     "mppi_register_model": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),

@@ -544,6 +544,10 @@ static std::atomic<long long> g_single_launch_commands{0};
 extern "C" int64_t mppi_stat_single_launch_commands(void) { return g_single_launch_commands.load(); }
 static std::atomic<long long> g_onchip_commands{0};
 extern "C" int64_t mppi_stat_onchip_commands(void) { return g_onchip_commands.load(); }
+// which form the calling THREAD's last mppi_command took (the counters above are process-wide: with two controllers
+// commanding from two threads, "did MY command run on chip" cannot be read off a shared count -- ADVICE r03)
+static thread_local int t_last_form = MPPI_FORM_NONE;
+extern "C" int mppi_last_command_form(void) { return t_last_form; }
 
 template <typename T>
 static int do_finalize_blocks(const MppiProblem* p, int apply, hipStream_t st) {
@@ -560,8 +564,10 @@ extern "C" int mppi_command(const MppiProblem* p, int apply, void* stream) {
   // cost_total_non_zero NULL (they are functions of cost_total and the record: see the header)
   const int e1 = BY_DTYPE(p, do_rollout<float>(p, (hipStream_t)stream, apply ? 1 : 0),
                           do_rollout<double>(p, (hipStream_t)stream, apply ? 1 : 0));
-  if (e1 == MPPI_OK_FUSED) { ++g_single_launch_commands; return 0; }
+  t_last_form = MPPI_FORM_NONE;
+  if (e1 == MPPI_OK_FUSED) { ++g_single_launch_commands; t_last_form = MPPI_FORM_SINGLE_LAUNCH; return 0; }
   if (e1 == MPPI_OK_ONCHIP) {
+    t_last_form = MPPI_FORM_ONCHIP;
     // rng = engine generator, no row array (p->z == NULL): K1 generated, rolled out, kept the bounded noise on
     // chip and left one partial record per workgroup (csrc/rollout_onchip.hpp); this launch combines them
     ++g_onchip_commands;
@@ -571,6 +577,7 @@ extern "C" int mppi_command(const MppiProblem* p, int apply, void* stream) {
   MppiProblem q = *p;
   // "generate once": K1 stored the Philox rows it generated, K3 re-reads them
   if (q.noise_src == MPPI_NOISE_PHILOX && q.z != nullptr) q.noise_src = MPPI_NOISE_TNK4;
+  t_last_form = MPPI_FORM_STREAMING;
   if (int e = mppi_weights_partial(&q, stream)) return e;
   return mppi_finalize(&q, apply, stream);
 }

@@ -31,7 +31,10 @@ namespace mppi {
 template <int NU>
 struct OnChip {
   static constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
-  static constexpr int PB = (12 / P4) > 0 ? (12 / P4) : 1;       // super-steps generated together (~12 rows: the Philox chains interleave)
+#ifndef MPPI_ONCHIP_PBROWS
+#define MPPI_ONCHIP_PBROWS 12
+#endif
+  static constexpr int PB = (MPPI_ONCHIP_PBROWS / P4) > 0 ? (MPPI_ONCHIP_PBROWS / P4) : 1;   // super-steps generated together (~12 rows: the Philox chains interleave)
   static constexpr int SW = (16 / P4) > 0 ? (16 / P4) : 1;       // super-steps per weighting tile
   static constexpr int TRW = SW * P4;                            // rows per tile (15 for nu = 12, else <= 16)
   static constexpr int TC = TRW * 4;                             // columns per tile (<= 64)

@@ -209,7 +209,6 @@ class MPPI:
         # (a full Sigma is coloured in the lane: L z + mu per timestep out of LDS)
         self.philox_onchip = None
         self._onchip_refused = False
-        self._onchip_seen = 0
         self.ktn_direct = os.environ.get("MPPI_KTN_DIRECT", "1") != "0"   # rng="torch": read (K,T,nu) in place when possible
         self._force_collective = False
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
@@ -760,7 +759,6 @@ class MPPI:
             p.z = None
             if self.philox_store and self._onchip_wanted(K, Tn, nu):
                 self.last_draw = "philox-onchip"
-                self._onchip_seen = int(lib.mppi_stat_onchip_commands())
                 return
             if self.philox_store:
                 # generate once, keep the rows for K3 to re-read: Philox + Box-Muller costs more per
@@ -1083,7 +1081,7 @@ class MPPI:
                 self._convert_noise(p)
                 rc = launch()
             N.check(rc, "mppi_command")
-            if self.last_draw == "philox-onchip" and int(lib.mppi_stat_onchip_commands()) == self._onchip_seen:
+            if self.last_draw == "philox-onchip" and int(lib.mppi_last_command_form()) != N.FORM_ONCHIP:
                 # the engine ran K1 + K3 with the rows generated twice instead (a model without the on-chip kernel, ...):
                 # correct, slower -- store the rows from the next command on
                 self._onchip_refused = True

@@ -265,6 +265,14 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert ex["us_per_exchange"] > 0 and ex["calls"] > 0
     if torch.cuda.device_count() < 2:
         assert "TEST RIG" in d["config"]["backend"]
+    # what the first multi-GPU run has to put on record (VERDICT r03 missing #1): weak scaling against this box's own
+    # single-GPU time of the same workload, the collective alone, and BASELINE configs[4] (C5: the MLP at K = 65536 x N)
+    for key, kper in (("weak_scaling", d["config"]["K_per_gpu"]), ("c5", 65536)):
+        w = d[key]
+        assert w["n_gpus"] == 2 and w["K_per_gpu"] == kper and w["K_global"] == 2 * kper
+        assert w["sharded_ms_per_step"] > 0 and w["single_gpu_ms_per_step"] > 0 and w["collective_us"] > 0
+        assert abs(w["weak_scaling_speedup"] - 2 * w["single_gpu_ms_per_step"] / w["sharded_ms_per_step"]) < 1e-9
+    assert "MLP" in d["c5"]["workload"] and abs(d["weak_scaling"]["sharded_ms_per_step"] - d["ms_per_step"]) < 1e-9
 
 
 def test_sharded_kmppi_with_the_interpolation_inside_k1_rolls_out_its_own_global_rows():
