@@ -173,6 +173,31 @@ def cpu_baseline(wl, budget_s=15.0):
     return out
 
 
+CLOCK_WARMUP_S = 0.03
+
+
+def clock_warmup(ctrl, x0, seconds=CLOCK_WARMUP_S):
+    """Untimed commands until the GPU has been busy for `seconds`: the chip clocks to its load, and a region timed right
+    behind set-up work (allocations, a probe controller, a host copy: milliseconds of idle GPU) starts at idle clocks --
+    measured with tools/edge_overhead.py: the same 20 C3 commands take 81.6 us each on a busy chip and 86-94 us behind a
+    1-2 ms pause.  The driver's --warmup (5 commands = 0.4 ms of C3 work) is issued first and is far too short for that; what
+    this adds is reported as `clock_warmup_commands`.  Returns the number of commands issued."""
+    n = 0
+    if ctrl._sharded():
+        # every rank must issue the SAME number of sharded commands (each carries a collective): a fixed count, not a clock
+        for _ in range(120):
+            ctrl.command(x0)
+        torch.cuda.synchronize()
+        return 120
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            ctrl.command(x0)
+        n += 10
+        torch.cuda.synchronize()
+    return n
+
+
 def _stats(xs):
     xs = sorted(x for x in xs if x is not None and x > 0)
     if not xs:
@@ -374,6 +399,7 @@ def main():
     lib = N.lib()
     for _ in range(args.warmup):
         ctrl.command(x0)
+    n_clock_warmup = clock_warmup(ctrl, x0)
     # device-clock stamps on every K1 launch of the timed region: no extra packets, no events (see the docstring)
     lib.mppi_profile_enable(STAMPS_ONLY)
     barrier()
@@ -439,6 +465,7 @@ def main():
         cs.lambda_ = ctrl.lambda_
         for _ in range(args.warmup):
             cs.command(xs)
+        clock_warmup(cs, xs)
         lib.mppi_profile_enable(STAMPS_ONLY)
         barrier()
         t1 = time.perf_counter()
@@ -582,6 +609,7 @@ def main():
         "metric": "rollouts/sec (K x T state evals) per .command() call",
         "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "clock_warmup_commands": n_clock_warmup,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "K_per_gpu": Kper, "K_global": Kglobal, "T": T, "nx": nx, "nu": nu,
                    "rng": args.rng, "draw": ctrl.last_draw or "torch.randn", "lambda": float(ctrl.lambda_), "n_eff": n_eff,
@@ -610,6 +638,7 @@ def main():
         def timed(c_, x_, steps, warmup):
             for _ in range(warmup):
                 c_.command(x_)
+            clock_warmup(c_, x_)
             barrier()
             t_ = time.perf_counter()
             for _ in range(steps):
@@ -674,7 +703,7 @@ def main():
             c2.lambda_ = ctrl.lambda_
             for _ in range(3):
                 c2.command(x2)
-            torch.cuda.synchronize()
+            clock_warmup(c2, x2)
             t1 = time.perf_counter()
             n = max(5, args.steps // 5)
             for _ in range(n):
@@ -700,6 +729,7 @@ def main():
             nw = 100 if wl == "c2" else 8
             for _ in range(3):
                 cw.command(xw)
+            clock_warmup(cw, xw)
             lib.mppi_profile_enable(STAMPS_ONLY)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -736,7 +766,7 @@ def main():
                 cf_ = mk()
                 for _ in range(5):
                     cf_.command(x0)
-                torch.cuda.synchronize()
+                clock_warmup(cf_, x0)
                 t1 = time.perf_counter()
                 for _ in range(30):
                     cf_.command(x0)

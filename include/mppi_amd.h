@@ -235,6 +235,19 @@ int mppi_rollout_cost(const MppiProblem* p, void* stream);
 int mppi_rollout_cost_kmppi(const MppiProblem* p, void* stream);
 /* process-wide count of mppi_rollout_cost_kmppi calls that launched (tests, bench) */
 int64_t mppi_stat_kmppi_fused_rollouts(void);
+/* ABI 19 -- one KMPPI command (mppi.py:672-688) from one call: K1 with the interpolation inside (`p`, as above) and the
+ * control-point update theta += sum_k omega_k noise_theta_k (mppi.py:679-681) on `theta_problem` -- the (K, S, nu) problem whose
+ * "nominal sequence" U is theta, U_out the new theta, `record` / cost_total (== p's) / lambda as for mppi_weights_partial +
+ * mppi_finalize, on THE SAME workspace as `p`.  Where the kernel can (LDS room for the column sums; no sampler rows) it reduces
+ * its workgroups' part of the update from the bounded control points the lanes STILL HOLD -- weights relative to the
+ * workgroup's own minimum, one partial record per 256 samples, the algebra of the on-chip mppi_command -- and a small launch
+ * combines the records: the stand-alone K3 that re-creates every sample's S*nu control-point rows is gone.  Elsewhere:
+ * mppi_rollout_cost_kmppi + mppi_weights_partial + mppi_finalize on the two problems.  MPPI_E_UNSUPPORTED (before any launch)
+ * where the fused-interpolation kernel does not exist: run the two-launch form.  omega / cost_total_non_zero of the theta
+ * problem are written when given (they are functions of cost_total and the record otherwise). */
+int mppi_command_kmppi(const MppiProblem* p, const MppiProblem* theta_problem, int apply, void* stream);
+/* process-wide count of mppi_command_kmppi calls whose theta update was reduced inside K1 */
+int64_t mppi_stat_kmppi_onchip_updates(void);
 
 /* generic path (user callbacks stay Python callables, mppi.py:63-64): everything of
  * _compute_total_cost_batch except the rollout loop: writes perturbed_action, noise (K,T,nu)

@@ -79,6 +79,8 @@ SYMBOLS = {
     "mppi_stat_onchip_commands": (C.c_int64, []),
     "mppi_last_command_form": (C.c_int, []),
     "mppi_stat_kmppi_fused_rollouts": (C.c_int64, []),
+    "mppi_command_kmppi": (C.c_int, [_PP, _PP, C.c_int, _vp]),
+    "mppi_stat_kmppi_onchip_updates": (C.c_int64, []),
     "mppi_combine": (C.c_int, [_PP, _vp, C.c_int32, _vp]),
     "mppi_register_model": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "mppi_dist_available": (C.c_int, []),

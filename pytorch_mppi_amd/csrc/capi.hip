@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <vector>
 #include <cstring>
 #include <hip/hip_ext.h>
 #include "dispatch.hpp"
@@ -64,13 +65,14 @@ extern "C" int64_t mppi_noise_pitch(int32_t K, int32_t dtype) {
 //    longer than the same kernel launched plainly.  Kept because HIP events are the conventional clock;
 //    bench.py takes it in a separate pass behind the timed region.
 namespace {
-constexpr int PROF_MAX = 8192;
+constexpr int PROF_MAX = 2048;             // launches per mppi_profile_enable .. mppi_profile_read_launches window
 int g_prof_every = 0;                      // 0 = off; N = HIP events on every N-th K1 launch
 int g_prof_n = 0;                          // launches stamped since the last read
 hipEvent_t g_prof_ev[PROF_MAX][2];         // event pairs, created on first use
 bool g_prof_has_ev[PROF_MAX];              // does launch i carry events?
 int g_prof_created = 0;
-unsigned long long* g_prof_ts = nullptr;   // device: PROF_MAX x {min entry, max exit}
+unsigned long long* g_prof_ts = nullptr;   // device: PROF_MAX launches x STAMP_SLOTS x {min entry, max exit} (common.hpp stamp_entry)
+constexpr size_t PROF_TS_WORDS = (size_t)2 * mppi::STAMP_SLOTS * PROF_MAX;
 double prof_dispatch_ms(int i) {           // < 0: launch i carried no events
   if (!g_prof_has_ev[i]) return -1.0;
   float ms = 0;
@@ -85,9 +87,9 @@ bool profile_next_events(hipEvent_t* start, hipEvent_t* stop, unsigned long long
   *start = *stop = nullptr;
   if (g_prof_every <= 0 || g_prof_n >= PROF_MAX) return false;
   const int i = g_prof_n++;
-  if (tstamp && g_prof_ts) *tstamp = g_prof_ts + 2 * (size_t)i;
+  if (tstamp && g_prof_ts) *tstamp = g_prof_ts + (size_t)2 * STAMP_SLOTS * i;
   g_prof_has_ev[i] = false;
-  if (i % g_prof_every != 0) return false;
+  if (g_prof_every >= (1 << 30) || i % g_prof_every != 0) return false;     // (1 << 30: stamps only, no launch carries events)
   if (i >= g_prof_created) {
     // pairs are created densely up to i so that index == launch number
     for (int j = g_prof_created; j <= i; ++j) {
@@ -107,11 +109,11 @@ extern "C" int mppi_profile_enable(int every) {
   if (every > 0) {
     g_prof_n = 0;
     // measurement set-up (outside any timed region): stamp slots {min = ~0, max = 0}
-    if (!g_prof_ts && hipMalloc((void**)&g_prof_ts, sizeof(unsigned long long) * 2 * PROF_MAX) != hipSuccess) g_prof_ts = nullptr;
-    if (g_prof_ts) {
-      static unsigned long long init[2 * PROF_MAX];
-      for (int i = 0; i < PROF_MAX; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
-      if (hipMemcpy(g_prof_ts, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(g_prof_ts); g_prof_ts = nullptr; }
+    if (!g_prof_ts && hipMalloc((void**)&g_prof_ts, sizeof(unsigned long long) * PROF_TS_WORDS) != hipSuccess) g_prof_ts = nullptr;
+    // arm the window: every slot {0, 0} (stamp_entry / stamp_exit are both atomicMax)
+    if (g_prof_ts && hipMemset(g_prof_ts, 0, sizeof(unsigned long long) * PROF_TS_WORDS) != hipSuccess) {
+      (void)hipFree(g_prof_ts);
+      g_prof_ts = nullptr;
     }
   }
   return 0;
@@ -119,12 +121,24 @@ extern "C" int mppi_profile_enable(int every) {
 extern "C" int mppi_profile_read_launches(double* device_us, double* dispatch_us, int64_t capacity, int64_t* count) {
   const int n = g_prof_n;
   if (count) *count = n;
-  static unsigned long long host[2 * PROF_MAX];
+  static std::vector<unsigned long long> slots, host;
+  host.resize((size_t)2 * PROF_MAX);
   bool have_dev = false;
   if (g_prof_ts && n > 0) {
+    slots.resize(PROF_TS_WORDS);
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(host, g_prof_ts, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(slots.data(), g_prof_ts, sizeof(unsigned long long) * 2 * mppi::STAMP_SLOTS * n, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return hipfail((int)e, "mppi_profile_read_launches");
+    for (int i = 0; i < n; ++i) {              // the launch's span: earliest entry .. latest exit over its workgroups' slots
+      unsigned long long nlo = 0ull, hi = 0ull;     // slot[0] = max of ~entry over the slot's workgroups, slot[1] = max of exit
+      for (int q = 0; q < mppi::STAMP_SLOTS; ++q) {
+        const unsigned long long a = slots[((size_t)i * mppi::STAMP_SLOTS + q) * 2], b = slots[((size_t)i * mppi::STAMP_SLOTS + q) * 2 + 1];
+        nlo = a > nlo ? a : nlo;
+        hi = b > hi ? b : hi;
+      }
+      host[2 * i] = nlo != 0ull ? ~nlo : ~0ull;     // (no stamp at all: an empty span)
+      host[2 * i + 1] = hi;
+    }
     have_dev = true;
   }
   int dev_id = 0, khz = 100000;
@@ -231,7 +245,7 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.var_cost = (T)p->rollout_var_cost; a.var_disc = (T)p->rollout_var_discount;
   a.proc_sd = (const T*)p->process_noise_sd;
   a.fuse = -1;
-  a.W = a.theta = nullptr; a.S = 0;
+  a.W = a.theta = nullptr; a.S = 0; a.kw = 0; a.kw_jpad = 0;
   // The arrival ticket of the single-launch command sits in the LAST 4 elements of the caller's buffer
   // (workspace + workspace_elems - 4): a place that does not depend on (K, T, nu, num_envs), so that
   // problems of different shapes may share one zero-filled workspace -- at `carve().total - 4` a smaller
@@ -261,7 +275,7 @@ int need_noise(const KArgs<T>& a) {
 }
 
 template <typename T>
-int do_rollout(const MppiProblem* p, hipStream_t st, int fuse = -1, bool kmppi = false) {
+int do_rollout(const MppiProblem* p, hipStream_t st, int fuse = -1, bool kmppi = false, const MppiProblem* theta_problem = nullptr) {
   KArgs<T> a;
   if (int e = make_args<T>(p, a)) return e;
   if (int e = need_noise(a)) return e;
@@ -273,6 +287,16 @@ int do_rollout(const MppiProblem* p, hipStream_t st, int fuse = -1, bool kmppi =
     if (a.noise_src != MPPI_NOISE_TNK4 && a.noise_src != MPPI_NOISE_PHILOX)
       return fail(MPPI_E_UNSUPPORTED, "mppi_rollout_cost_kmppi: support points come from MPPI_NOISE_TNK4 or MPPI_NOISE_PHILOX");
     a.W = (const T*)p->W; a.theta = (const T*)p->theta; a.S = p->S;
+    if (theta_problem != nullptr) {
+      // mppi_command_kmppi: the kernel may leave the theta update's partial records (one per 256 samples) in the workspace
+      // the two problems share, laid out for finalize_blocks on the theta problem
+      const MppiProblem* q = theta_problem;
+      if (q->K != p->K || q->T != p->S || q->nu != p->nu || q->workspace != p->workspace || q->workspace_elems != p->workspace_elems ||
+          q->dtype != p->dtype || q->num_envs > 1)
+        return fail(MPPI_E_BADARG, "mppi_command_kmppi: the theta problem must be (K, S, nu) on the trajectory problem's workspace");
+      a.kw = 1;
+      a.kw_jpad = carve(q).Jpad;
+    }
   }
   int r;
   switch (p->model_id) {
@@ -290,7 +314,7 @@ int do_rollout(const MppiProblem* p, hipStream_t st, int fuse = -1, bool kmppi =
       r = fn((const void*)&a, (void*)st);
     }
   }
-  if (r == MPPI_OK_FUSED || r == MPPI_OK_ONCHIP) return r;
+  if (r == MPPI_OK_FUSED || r == MPPI_OK_ONCHIP || r == MPPI_OK_KMPPI_W) return r;
   return hipfail(r, "mppi_rollout_cost");
 }
 }  // namespace
@@ -543,6 +567,7 @@ extern "C" int mppi_finalize(const MppiProblem* p, int apply, void* stream) {
 static std::atomic<long long> g_single_launch_commands{0};
 extern "C" int64_t mppi_stat_single_launch_commands(void) { return g_single_launch_commands.load(); }
 static std::atomic<long long> g_onchip_commands{0};
+static std::atomic<long long> g_kmppi_onchip_updates{0};
 extern "C" int64_t mppi_stat_onchip_commands(void) { return g_onchip_commands.load(); }
 // which form the calling THREAD's last mppi_command took (the counters above are process-wide: with two controllers
 // commanding from two threads, "did MY command run on chip" cannot be read off a shared count -- ADVICE r03)
@@ -558,6 +583,25 @@ static int do_finalize_blocks(const MppiProblem* p, int apply, hipStream_t st) {
   onchip_carve(a);                       // one partial record per 256-sample workgroup of the on-chip K1
   return hipfail(launch_finalize_blocks<T>(a, apply, st), "mppi_command (on-chip finalize)");
 }
+
+extern "C" int mppi_command_kmppi(const MppiProblem* p, const MppiProblem* theta_problem, int apply, void* stream) {
+  if (theta_problem == nullptr) return fail(MPPI_E_BADARG, "mppi_command_kmppi: null theta problem");
+  const int r = BY_DTYPE(p, do_rollout<float>(p, (hipStream_t)stream, -1, true, theta_problem),
+                         do_rollout<double>(p, (hipStream_t)stream, -1, true, theta_problem));
+  if (r == MPPI_OK_KMPPI_W) {
+    // K1 interpolated, rolled out and reduced its workgroups' part of the theta update from the control points it
+    // still held: this launch combines the K/256 partial records in workgroup order and applies the update
+    ++g_kmppi_fused_rollouts;
+    ++g_kmppi_onchip_updates;
+    return BY_DTYPE(theta_problem, do_finalize_blocks<float>(theta_problem, apply, (hipStream_t)stream),
+                    do_finalize_blocks<double>(theta_problem, apply, (hipStream_t)stream));
+  }
+  if (r != 0) return r;               // MPPI_E_UNSUPPORTED: no fused-interpolation kernel here -- the caller's two-launch form
+  ++g_kmppi_fused_rollouts;
+  if (int e = mppi_weights_partial(theta_problem, stream)) return e;
+  return mppi_finalize(theta_problem, apply, stream);
+}
+extern "C" int64_t mppi_stat_kmppi_onchip_updates(void) { return g_kmppi_onchip_updates.load(); }
 
 extern "C" int mppi_command(const MppiProblem* p, int apply, void* stream) {
   // small problems: K1's launch carries K3 and K4 as well when the caller left omega and

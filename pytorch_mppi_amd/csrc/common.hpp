@@ -11,6 +11,7 @@ namespace mppi {
 constexpr int MPPI_OK_FUSED = -100;
 // ... or K1 + the workgroups' partial records (rollout_onchip.hpp): finalize_blocks_kernel completes the command
 constexpr int MPPI_OK_ONCHIP = -101;
+constexpr int MPPI_OK_KMPPI_W = -102;  // rollout_kmppi_kernel left partial records of the theta update: finalize_blocks on the theta problem
 
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;            // threads per workgroup of the per-sample kernels
@@ -44,8 +45,29 @@ struct KArgs {
   unsigned* ticket;             // arrival counter of the single-launch command (workspace tail, kept at 0)
   const T *W, *theta;           // KMPPI inside K1 (rollout_kmppi.hpp): (T,S) operator, (S,nu) control points; else null
   int S;                        //   number of support points; z / seed / call then describe the SUPPORT-point stream
+  int kw;                       //   1: the kernel also reduces its workgroups' part of the theta update (mppi.py:679): one partial
+                                //   record {beta_b, eta_b, P_b[S*nu]} per 256 samples, on-chip carve with row stride kw_jpad
+  int kw_jpad;
   int model_flags;              // MPPI_MODEL_FLAG_* (include/mppi_amd.h)
 };
+
+// Measurement hook (mppi_profile_enable, capi.hip): every workgroup stamps its entry and its exit on the device's wall clock
+// into ONE OF STAMP_SLOTS {min entry, max exit} pairs of the launch (slot = workgroup index mod STAMP_SLOTS), the host takes
+// the minimum / maximum over the slots.  One pair per launch -- what this was until round 4 -- put 2 x 256 atomics on one
+// address: ~12 ns apiece at the memory side, 6-7 us added to every launch of an 80 us kernel (tools/edge_overhead.py:
+// 87.8 us per C3 command with the stamps, 81.7 without).  With a slot per workgroup the atomics do not meet.
+constexpr int STAMP_SLOTS = 256;
+// slot = {max over the workgroups of ~entry, max of exit}: both stamps are atomicMax, so a window of slots is armed by zero-filling
+// it (one memset; the {~0, 0} pattern of the min / max form needed an 8 MB host copy per window -- a millisecond in which the GPU
+// idled and clocked down right in front of the region to be timed)
+__device__ __forceinline__ void stamp_entry(unsigned long long* ts) {
+  if (ts != nullptr && threadIdx.x == 0)
+    atomicMax(&ts[2 * ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & (STAMP_SLOTS - 1))], ~(unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void stamp_exit(unsigned long long* ts) {      // call behind a block barrier: the last wave's exit
+  if (ts != nullptr && threadIdx.x == 0)
+    atomicMax(&ts[2 * ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & (STAMP_SLOTS - 1)) + 1], (unsigned long long)wall_clock64());
+}
 
 // the workspace of an on-chip command: one partial record per 256-sample workgroup
 //   block_min[0 .. nchunks)  beta_b | eta_part[0 .. nchunks)  eta_b | P_part[nchunks][Jpad]

@@ -638,7 +638,7 @@ template <class Model, typename T, int NOISE, bool DIAG, int DMA_ROWS = 0, bool 
 __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a_in) {
   constexpr int NX = Model::NX, NU = Model::NU;
   const KArgs<T> a = env_view(a_in);        // MPPI_Batched: environment = blockIdx.z
-  if (a.tstamp != nullptr && threadIdx.x == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
+  stamp_entry(a.tstamp);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ue = reinterpret_cast<T*>(smem_raw);   // [J] nominal sequence, shift applied
   T* Um = Ue + a.J;                         // [J] Ue + mu
@@ -977,7 +977,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
     // exit stamp AFTER every wave of the workgroup is done (the stamp is the kernel's span on the
     // device clock; without the barrier it missed the three other waves of the last workgroup)
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
+    stamp_exit(a.tstamp);
   }
 }
 

@@ -55,6 +55,15 @@ __device__ __forceinline__ float to_agpr(float v) {
   return r;
 }
 
+// ... and read it back for the VALU through an explicit copy: the value the matrix instructions read stays in the accumulation
+// class for its whole life (left to the allocator, ONE live range that ends in a VALU use is given a VGPR from the start -- and
+// 256 control points no longer fit beside the rollout: 250 spilled registers around the horizon loop)
+__device__ __forceinline__ float from_agpr(float a) {
+  float r;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(a));
+  return r;
+}
+
 // the four timesteps of one accumulator tile (D[n][i] = raw action n of timestep t0 + i)
 template <class Model, int MODE>
 __device__ __forceinline__ void kmppi_steps4(const KArgs<float>& a, const ActionConsts<float, Model::NU>& ac, const Model& model,
@@ -84,7 +93,7 @@ template <class Model, int NOISE>
 __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<float> a) {
   constexpr int NX = Model::NX, NU = Model::NU, P4 = NU / 4, SMAX = KmppiFuse<NU>::SMAX;
   constexpr int NA = KmppiRegs<NU>::NA;
-  if (a.tstamp != nullptr && threadIdx.x == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
+  stamp_entry(a.tstamp);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int S = a.S, Thor = a.Tn;
   const int T4 = (Thor + 3) & ~3, S4 = (S + 3) & ~3;        // support points beyond S only ever meet zero columns of W
@@ -93,13 +102,22 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<flo
   float* G = Ue + ((a.J + 3) & ~3);                     // [J] lambda * U / sigma^2
   float* thl = G + ((a.J + 3) & ~3);                    // [S*NU] control points theta + noise mean
   float* Wl = thl + ((S * NU + 3) & ~3);                // [T4][SPW], zero outside (T, S)
-  float* thx = Wl + T4 * SPW;                           // [NL/4][K1_BLOCK][4] bounded control points beyond the AGPRs
+  // in-kernel theta update (a.kw): theta itself (the noise is measured from it: mppi.py:664), block reduction scratch and the
+  // four waves' column sums; the bounded control points beyond the AGPRs come last
+  constexpr int NWT = (SMAX * NU + 63) / 64;            // 64-column tiles of the control-point sequence
+  float* th0 = Wl + T4 * SPW;                           // [S*NU]
+  float* red = th0 + (a.kw ? NWT * 64 : 0);             // [4]   (th0 is read in whole tiles)
+  float* exw = red + (a.kw ? 4 : 0);                    // [4 waves][NWT][64]
+  float* thx = exw + (a.kw ? 4 * NWT * 64 : 0);         // [NL/4][K1_BLOCK][4] bounded control points beyond the AGPRs
   for (int j = threadIdx.x; j < a.J; j += K1_BLOCK) {
     const int n = j % NU;
     Ue[j] = u_base(a, j);
     G[j] = a.lambda_ * (u_eff(a, j) * a.sinv[n * NU + n]);
   }
-  for (int i = threadIdx.x; i < S * NU; i += K1_BLOCK) thl[i] = a.theta[i] + (a.coloured ? 0.f : a.mu[i % NU]);   // theta + mu
+  for (int i = threadIdx.x; i < S * NU; i += K1_BLOCK) {
+    thl[i] = a.theta[i] + (a.coloured ? 0.f : a.mu[i % NU]);   // theta + mu
+    if (a.kw) th0[i] = a.theta[i];
+  }
   for (int i = threadIdx.x; i < T4 * SPW; i += K1_BLOCK) {
     const int t = i / SPW, s = i - t * SPW;
     Wl[i] = (t < Thor && s < S) ? a.W[(long long)t * S + s] : 0.f;
@@ -275,12 +293,63 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<flo
       a.cost[k] = total;
       if (a.pert != nullptr) a.pert[k] = pert;
     }
-    const float bm = wave_min<float>(active ? total : inf_v<float>());   // one minimum per 64 samples
-    if (lane == 0 && kraw < a.K) a.block_min[kraw / WAVE] = bm;
+    if (!a.kw) {
+      const float bm = wave_min<float>(active ? total : inf_v<float>());   // one minimum per 64 samples
+      if (lane == 0 && kraw < a.K) a.block_min[kraw / WAVE] = bm;
+    } else {
+      // ---- this workgroup's part of the theta update (mppi.py:254-259, :679), as the on-chip MPPI command does it for U:
+      // weights relative to the WORKGROUP's minimum, eta_b, P_b[i] = sum_k w_k (theta'_k[i] - theta[i]) over its 256 samples.
+      // The lane still holds its bounded control points (AGPRs + LDS): nothing is re-read or generated again -- the
+      // stand-alone K3 re-created all S*nu rows per sample (18 us + a launch at C3-sized work).
+      const float inv_lambda = 1.f / a.lambda_;
+      const float beta_b = block_min<float>(active ? total : inf_v<float>(), red);
+      const float wk = active ? weight_of<float>(total, beta_b, inv_lambda) : 0.f;
+      const float eta_b = block_sum<float>(wk, red);
+      const bool live = __ballot(wk != 0.f) != 0ull;      // a wave of exactly-zero weights adds exactly nothing
+      const int wv = threadIdx.x / WAVE;
+      const int ncol = S * NU;
+      static_for<0, NWT>([&](auto tc) {
+        constexpr int TI = decltype(tc)::value;
+        __builtin_amdgcn_sched_barrier(0);     // one tile at a time: six tiles' operands in flight at once do not fit the file
+        if (TI * 64 < ncol) {
+          float acc[64];
+          if (live) {
+#pragma unroll
+            for (int q4 = 0; q4 < 16; ++q4) {
+              const int i0 = TI * 64 + 4 * q4;             // (compile-time: TI and q4 are)
+              kf32x4_t v;
+              if (TI * 64 + 4 * q4 < NA) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = from_agpr(tha[(TI * 64 + 4 * q4 + c) < NA ? (TI * 64 + 4 * q4 + c) : 0]);
+              } else if (TI * 64 + 4 * q4 < SMAX * NU) {
+                v = thx_me[((TI * 64 + 4 * q4 - NA) >> 2) * K1_BLOCK];
+              } else {
+                v = kf32x4_t{0.f, 0.f, 0.f, 0.f};
+              }
+              // (columns beyond S*nu hold leftovers of the padding: every column is reduced on its own and those are never
+              // stored -- no select, whose 384 wave-uniform conditions cost 700 spilled SGPRs)
+              const kf32x4_t t4 = *reinterpret_cast<const kf32x4_t*>(th0 + i0);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[4 * q4 + c] = wk * (v[c] - t4[c]);
+            }
+            exw[(wv * NWT + TI) * 64 + lane] = wave_reduce_transpose64<float>(acc);
+          } else {
+            exw[(wv * NWT + TI) * 64 + lane] = 0.f;
+          }
+        }
+      });
+      __syncthreads();
+      for (int i = threadIdx.x; i < ncol; i += K1_BLOCK)      // one combine over the four waves, in wave order
+        a.P_part[(long long)chunk * a.kw_jpad + i] = (exw[i] + exw[NWT * 64 + i]) + (exw[2 * NWT * 64 + i] + exw[3 * NWT * 64 + i]);
+      if (threadIdx.x == 0) {
+        a.eta_part[chunk] = eta_b;
+        a.block_min[chunk] = beta_b;
+      }
+    }
   }
   if (a.tstamp != nullptr) {
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
+    stamp_exit(a.tstamp);
   }
 }
 
@@ -296,8 +365,14 @@ static int launch_rollout_kmppi(const KArgs<T>& a, hipStream_t st) {
     if (a.noise_src != MPPI_NOISE_TNK4 && a.noise_src != MPPI_NOISE_PHILOX) return MPPI_E_UNSUPPORTED;
     const int S4 = (a.S + 3) & ~3, T4 = (a.Tn + 3) & ~3;
     const int in_lds = S4 * NU > KmppiRegs<NU>::NA ? S4 * NU - KmppiRegs<NU>::NA : 0;     // control points per lane beyond the AGPRs
-    const size_t smem = (size_t)(2 * ((a.J + 3) & ~3) + ((a.S * NU + 3) & ~3) + T4 * (S4 + 4) + in_lds * K1_BLOCK) * sizeof(float);
-    if (smem > 160 * 1024) return MPPI_E_UNSUPPORTED;
+    const size_t smem0 = (size_t)(2 * ((a.J + 3) & ~3) + ((a.S * NU + 3) & ~3) + T4 * (S4 + 4) + in_lds * K1_BLOCK) * sizeof(float);
+    if (smem0 > 160 * 1024) return MPPI_E_UNSUPPORTED;
+    // the theta update inside the launch (a.kw asked for by mppi_command_kmppi): needs theta, the reduction scratch and the four
+    // waves' column sums in LDS as well; where that does not fit the kernel leaves the per-wave minima for K3 as before
+    constexpr int NWT = (KmppiFuse<NU>::SMAX * NU + 63) / 64;
+    const size_t smem_w = smem0 + (size_t)(NWT * 64 + 4 + 4 * NWT * 64) * sizeof(float);
+    const bool kw = a.kw != 0 && smem_w <= 160 * 1024 && a.n_sampler == 0 && (a.K + K1_BLOCK - 1) / K1_BLOCK <= 8192;
+    const size_t smem = kw ? smem_w : smem0;
     const int nchunks = (a.K + K1_BLOCK - 1) / K1_BLOCK;
     static const int n_cu = [] {
       int dev = 0, n = 256;
@@ -306,6 +381,8 @@ static int launch_rollout_kmppi(const KArgs<T>& a, hipStream_t st) {
     }();
     const dim3 grid(nchunks < n_cu ? nchunks : n_cu), block(K1_BLOCK);
     KArgs<float> b = a;
+    b.kw = kw ? 1 : 0;
+    if (kw) onchip_carve(b);               // one partial record per 256 samples: block_min / eta_part / P_part[.][kw_jpad]
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     profile_next_events(&ev0, &ev1, &b.tstamp);
 #define MPPI_LAUNCHK(KERNEL)                                                                                 \
@@ -318,7 +395,8 @@ static int launch_rollout_kmppi(const KArgs<T>& a, hipStream_t st) {
     if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCHK((rollout_kmppi_kernel<Model, MPPI_NOISE_PHILOX>));
     else MPPI_LAUNCHK((rollout_kmppi_kernel<Model, MPPI_NOISE_TNK4>));
 #undef MPPI_LAUNCHK
-    return (int)hipGetLastError();
+    const int e = (int)hipGetLastError();
+    return e != 0 ? e : (kw ? MPPI_OK_KMPPI_W : 0);
   }
 }
 

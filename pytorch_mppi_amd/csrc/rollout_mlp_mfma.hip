@@ -61,7 +61,7 @@ template <int HT /* hidden / 16 */, int NOISE, bool DIAG>
 __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KArgs<float> a_in) {
   constexpr int NU = MLP_NU, NX = MLP_NX, NT = MLP_NT, H = HT * 16;
   const KArgs<float> a = env_view(a_in);
-  if (a.tstamp != nullptr && threadIdx.x == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
+  stamp_entry(a.tstamp);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* Ue = reinterpret_cast<float*>(smem_raw);   // [J]
   float* Um = Ue + a.J;                             // [J]
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if ((int)blockIdx.x * 4 + q < a.nb1) a.block_min[blockIdx.x * 4 + q] = r;
-    if (a.tstamp != nullptr) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
+    stamp_exit(a.tstamp);
   }
 }
 

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
   static_assert(HT % 2 == 0, "layer 2 consumes hidden tiles in pairs");
   constexpr int NU = B3_NU, NX = B3_NX, NT = B3_NT, H = HT * 16, HP = HT / 2;
   const KArgs<float> a = env_view(a_in);
-  if (a.tstamp != nullptr && threadIdx.x == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
+  stamp_entry(a.tstamp);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* Ue = reinterpret_cast<float*>(smem_raw);   // [J]
   float* Um = Ue + a.J;                             // [J]
@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
   }
   if (a.tstamp != nullptr) {
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
+    stamp_exit(a.tstamp);
   }
 }
 

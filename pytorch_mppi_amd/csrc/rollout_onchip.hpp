@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
   constexpr int P4 = OC::P4, TT = OC::TT, PB = OC::PB, SW = OC::SW, TRW = OC::TRW, TC = OC::TC, NTA = OC::NTA, AG_SS = OC::AG_SS,
                 RG = OC::RG;
   static_assert(K1_BLOCK == 256 && K1_BLOCK == BLOCK, "four waves per workgroup; onchip_carve (common.hpp) counts BLOCK-sample records");
-  if (a.tstamp != nullptr && threadIdx.x == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
+  stamp_entry(a.tstamp);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int nss = (a.Tn + TT - 1) / TT;
   const int ntiles = (nss + SW - 1) / SW;
@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
   }
   if (a.tstamp != nullptr) {
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
+    stamp_exit(a.tstamp);
   }
 }
 

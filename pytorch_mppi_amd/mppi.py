@@ -456,8 +456,9 @@ class MPPI:
                       step_dependent_dynamics=bool(self.step_dependency), U_init=torch.zeros(Tp, self.nu, dtype=self.dtype),
                       rng="torch", auto_jit=False)
             pr._want_states = True
+            pr._jit_check_every = 0                    # (the probe runs the model under test: it does not check itself)
             m._probe = pr
-        if pr._needs_generic():
+        if pr._needs_generic() or getattr(m, "_spot_unavailable", False):
             return True                                # no fused kernel for this model at the probe's shape: nothing to compare
         gen = getattr(self, "_spot_gen", None)
         if gen is None:
@@ -472,18 +473,36 @@ class MPPI:
             pr.inject_noise(z)
             pr.command(X0, shift_nominal_trajectory=False)
             fused_c, fused_x, pa = pr.cost_total, pr.states, pr.perturbed_action
-            state, ref_c = X0.clone(), torch.zeros(samples, device=self.d, dtype=self.dtype)
-            states = torch.empty(1, samples, Tp, self.nx, device=self.d, dtype=self.dtype)
-            actions = torch.empty(1, samples, Tp, self.nu, device=self.d, dtype=self.dtype)
-            for t in range(Tp):
-                u = self.u_scale * pa[:, t]
-                state = self._dynamics_fn(state, u, t)
-                ref_c = ref_c + self._running_cost_fn(state, u, t).reshape(samples)
-                states[0, :, t] = state[:, :self.nx]
-                actions[0, :, t] = u
-            if self.terminal_state_cost is not None:
-                c = self._terminal_state_cost_fn(states, actions)
-                ref_c = ref_c + (c.squeeze(0) if torch.is_tensor(c) and c.dim() > 1 else c)
+
+            def reference(dev):
+                """the reference's own loop (mppi.py:297-332) over the same actions, its tensors on `dev`"""
+                state, ref_c = X0.to(dev).clone(), torch.zeros(samples, device=dev, dtype=self.dtype)
+                states = torch.empty(1, samples, Tp, self.nx, device=dev, dtype=self.dtype)
+                actions = torch.empty(1, samples, Tp, self.nu, device=dev, dtype=self.dtype)
+                pad = pa.to(dev)
+                for t in range(Tp):
+                    u = self.u_scale * pad[:, t]
+                    state = self._dynamics_fn(state, u, t)
+                    ref_c = ref_c + self._running_cost_fn(state, u, t).reshape(samples)
+                    states[0, :, t] = state[:, :self.nx]
+                    actions[0, :, t] = u
+                if self.terminal_state_cost is not None:
+                    c = self._terminal_state_cost_fn(states, actions)
+                    ref_c = ref_c + (c.squeeze(0) if torch.is_tensor(c) and c.dim() > 1 else c)
+                return ref_c.to(self.d), states.to(self.d)
+            ref = None
+            for dev in (self.d, torch.device("cpu")):
+                # callables that only work on host tensors (numpy ufuncs on tensors: the reference's own pendulum,
+                # tests/pendulum.py:45-46) are checked there; ones that work on neither cannot be checked at all
+                try:
+                    ref = reference(dev)
+                    break
+                except Exception:
+                    continue
+            if ref is None:
+                m._spot_unavailable = True
+                return True
+            ref_c, states = ref
             tol = 2e-3 if self.dtype == torch.float32 else 1e-7
             bad = torch.zeros(samples, dtype=torch.bool, device=self.d)
             for got, ref in ((fused_c, ref_c), (fused_x[0].reshape(samples, -1), states[0].reshape(samples, -1))):
@@ -1726,6 +1745,7 @@ class KMPPI(MPPI):
         self.ktn_direct = False        # the support-point draw always goes through the layout conversion
         self.coloured_fill = False     # the interpolation kernel colours the support points itself
         self.fuse_interpolation = True  # K1 interpolates in-kernel where it can (mppi_rollout_cost_kmppi)
+        self.onchip_update = True       # ... and reduces its part of the theta update from the control points it holds (mppi_command_kmppi)
         self._noise_theta = None
         self._last_theta = None
         self.prepare_vmap_interpolation()
@@ -1847,6 +1867,19 @@ class KMPPI(MPPI):
         per_sample = tuple(self.state.shape) == (K, self.nx)
         self._states = self._actions = self._noise = self._perturbed_action = None
         self._noise_theta = None
+        # --- theta update: K3/K4 on the support-point stream (mppi.py:679-681) ---
+        sharded = self._sharded()
+        # omega = (1/eta) exp(-(c - beta)/lambda) and cost_total_non_zero are functions of cost_total and the record: a
+        # single-shard command leaves them to their first read (MPPI.omega); a sharded one has K5 rescale them
+        lazy = not sharded
+        omega = None if lazy else torch.empty(K, device=self.d, dtype=self.dtype)
+        wnz = None if lazy else torch.empty(K, device=self.d, dtype=self.dtype)
+        theta_new = torch.empty(S, self.nu, device=self.d, dtype=self.dtype)
+        record = torch.empty(2 + S * self.nu, device=self.d, dtype=self.dtype)
+        pt.cost_total = p.cost_total
+        pt.omega, pt.cost_total_non_zero, pt.U_out, pt.record = _ptr(omega), _ptr(wnz), _ptr(theta_new), _ptr(record)
+        pt.u_per_command = 0
+        updated = False
         if not self._needs_generic():
             s0 = self._fused_state(per_sample)
             p.state = _ptr(s0)
@@ -1854,36 +1887,37 @@ class KMPPI(MPPI):
             p.state_per_sample = int(per_sample)
             p.use_terminal = int(self.terminal_state_cost is not None)
             # interpolation inside K1 where that kernel exists (fp32, diagonal Sigma, nu % 4 == 0, S*nu <= 384):
-            # the (K,T,nu) raw actions are never written; lazy attributes build them on demand (_raw_actions)
-            rc = lib.mppi_rollout_cost_kmppi(C.byref(p), st) if self.fuse_interpolation else N.E_UNSUPPORTED
+            # the (K,T,nu) raw actions are never written; lazy attributes build them on demand (_raw_actions).
+            # ONE call for the command (mppi_command_kmppi): where it can, that kernel also reduces its workgroups' part of
+            # the theta update from the control points the lanes still hold, and the stand-alone K3 -- which re-creates all
+            # S*nu control-point rows per sample -- is replaced by the small combine launch of the on-chip MPPI command
+            if not self.fuse_interpolation:
+                rc = N.E_UNSUPPORTED
+            elif self.onchip_update:
+                rc = lib.mppi_command_kmppi(C.byref(p), C.byref(pt), 0 if sharded else 1, st)
+                updated = rc == 0
+            else:
+                rc = lib.mppi_rollout_cost_kmppi(C.byref(p), st)      # (A/B seam: K1 here, the stand-alone K3 / K4 below)
             if rc == N.E_UNSUPPORTED:
                 self._raw_actions(p)
                 N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
             else:
-                N.check(rc, "mppi_rollout_cost_kmppi")
+                N.check(rc, "mppi_command_kmppi")
         else:
             self._raw_actions(p)
             self._generic_total_cost(p, cost_total, st)
         self.cost_total = cost_total
-        # --- theta update: K3/K4 on the support-point stream (mppi.py:679-681) ---
-        omega = torch.empty(K, device=self.d, dtype=self.dtype)
-        wnz = torch.empty(K, device=self.d, dtype=self.dtype)
-        theta_new = torch.empty(S, self.nu, device=self.d, dtype=self.dtype)
-        record = torch.empty(2 + S * self.nu, device=self.d, dtype=self.dtype)
-        pt.cost_total = p.cost_total
-        pt.omega, pt.cost_total_non_zero, pt.U_out, pt.record = _ptr(omega), _ptr(wnz), _ptr(theta_new), _ptr(record)
-        pt.u_per_command = 0
-        N.check(lib.mppi_weights_partial(C.byref(pt), st), "mppi_weights_partial")
-        if not self._sharded():
-            N.check(lib.mppi_finalize(C.byref(pt), 1, st), "mppi_finalize")
-        else:
-            N.check(lib.mppi_finalize(C.byref(pt), 0, st), "mppi_finalize")
+        if not updated:
+            N.check(lib.mppi_weights_partial(C.byref(pt), st), "mppi_weights_partial")
+            N.check(lib.mppi_finalize(C.byref(pt), 0 if sharded else 1, st), "mppi_finalize")
+        if sharded:
             comm = self._shard.native_comm(self.d)
             if comm is not None:
                 self._exchange_native(pt, comm)
             else:
                 self._combine(pt, self._shard.all_gather(record))
-        self.omega, self.cost_total_non_zero = omega, wnz
+        self._omega, self._wnz = omega, wnz
+        self._lazy_w = (float(self.lambda_), record) if lazy else None
         self._record = record
         self._last, self._last_theta = p, pt
         self.theta = theta_new

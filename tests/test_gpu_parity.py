@@ -571,6 +571,59 @@ def test_kmppi_interpolation_inside_k1_matches_the_two_launch_form_and_the_oracl
         # lazy attributes of the fused form: built on demand from the same control points
         assert float((a.perturbed_action - b.perturbed_action).abs().max()) == 0.0
         assert float((a.noise - b.noise).abs().max()) == 0.0
+        # (the fused form reduces its theta update inside K1, the two-launch form in the stand-alone K3: the same update in
+        # another summation order -- keep the two controllers on ONE sequence so that the bitwise checks above stay meaningful)
+        b.theta, b.U = a.theta.clone(), a.U.clone()
+
+
+@pytest.mark.parametrize("nx,nu,K,T,S,lam", [
+    (16, 12, 4096, 64, 32, 12.0),         # C3-shaped: 256 control points in accumulation registers, 128 in LDS, six column tiles
+    (16, 12, 1000, 64, 32, 1e-3),         # ragged K, a peaked softmax (waves of exactly-zero weights are skipped)
+    (16, 12, 777, 30, 15, 5.0),           # S not a multiple of 4: the padded support points never reach the update
+    (6, 4, 2048, 24, 12, 3.0),            # nu = 4: one column tile, everything in the accumulation registers
+    (8, 4, 70000, 50, 25, 20.0),          # more chunks than CUs: several partial records per workgroup
+])
+def test_kmppi_theta_update_inside_k1_matches_the_standalone_k3(nx, nu, K, T, S, lam):
+    """mppi_command_kmppi: the control-point update theta += sum_k omega_k noise_theta_k (mppi.py:679-681) reduced INSIDE K1
+    from the bounded control points the lanes still hold (one partial record per 256 samples + finalize_blocks) against the
+    stand-alone K3 / K4 on the same Philox stream: theta, U, action, the record {beta, eta, P} and the lazily derived
+    omega / cost_total_non_zero against the eagerly written ones."""
+    import pytorch_mppi_amd as pm
+    g = torch.Generator().manual_seed(K + S)
+    sigma = torch.diag(torch.rand(nu, generator=g) * 0.5 + 0.3)
+    umax = torch.rand(nu, generator=g) * 0.8 + 0.6
+    x0 = torch.randn(nx, generator=g).cuda()
+    m = pm.models.Integrator(nx, nu)
+
+    def make(onchip):
+        c = pm.KMPPI(m.dynamics, m.running_cost, nx, sigma, num_samples=K, horizon=T, device="cuda", num_support_pts=S,
+                     kernel=pm.RBFKernel(sigma=1.5), U_init=torch.zeros(T, nu), rng="philox", seed=5, lambda_=lam, u_max=umax,
+                     noise_mu=torch.full((nu,), 0.03), sample_null_action=True)
+        c.onchip_update = onchip
+        assert not c._needs_generic() and c._fused_interp_expected()
+        return c
+    a, b = make(True), make(False)
+    lib = pm._native.lib()
+    for call in range(3):
+        n0, f0 = lib.mppi_stat_kmppi_onchip_updates(), lib.mppi_stat_kmppi_fused_rollouts()
+        ua = a.command(x0)
+        assert lib.mppi_stat_kmppi_onchip_updates() == n0 + 1 and lib.mppi_stat_kmppi_fused_rollouts() == f0 + 1
+        ub = b.command(x0)
+        assert lib.mppi_stat_kmppi_onchip_updates() == n0 + 1 and lib.mppi_stat_kmppi_fused_rollouts() == f0 + 2
+        assert torch.equal(a.cost_total, b.cost_total)                    # the same K1 arithmetic either way
+        ra, rb = a._record, b._record
+        assert float(ra[0]) == float(rb[0])                               # beta: a minimum, exact
+        assert abs(float(ra[1]) - float(rb[1])) <= 2e-6 * float(rb[1])   # eta: another (equally fixed) summation order
+        sc = max(1e-6, float(rb[2:].abs().max()))
+        margins.record(_test_id(), f"call {call} P", float((ra[2:] - rb[2:]).abs().max()) / sc, None, 1e-4, "in-kernel vs stand-alone K3")
+        assert float((ra[2:] - rb[2:]).abs().max()) <= 1e-4 * sc          # K1 forms theta' with one fma, K3 with two roundings; P averages out
+        for name, x, y in (("theta", a.theta, b.theta), ("U", a.U, b.U), ("action", ua, ub)):
+            assert float((x - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max())), (name, call)
+        # lazily derived weights (functions of cost_total and the record) against the ones K3 / K4 wrote
+        assert float((a.omega - b.omega).abs().max()) <= 2e-6 * float(b.omega.max())
+        assert float((a.cost_total_non_zero - b.cost_total_non_zero).abs().max()) <= 1e-6
+        assert abs(float(a.omega.sum()) - 1.0) < 1e-4
+        b.theta, b.U = a.theta.clone(), a.U.clone()                       # keep the two on the same sequence
 
 
 def test_kmppi_interpolation_inside_k1_with_sampler_rows_per_sample_states_and_terminal_cost():

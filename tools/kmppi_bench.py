@@ -15,10 +15,11 @@ m = pm.models.Integrator(nx, nu)
 torch.manual_seed(0)
 x0 = torch.randn(nx, device="cuda")
 lib = N.lib()
-for fuse, fill in ((True, None), (True, False), (False, None)):
+for fuse, fill, upd in ((True, None, True), (True, None, False), (True, False, True), (False, None, False)):
     c = pm.KMPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), num_support_pts=S, kernel=pm.RBFKernel(sigma=2.0),
                  rng=rng, num_samples=K, horizon=T, device="cuda", lambda_=50.0)
     c.fuse_interpolation = fuse
+    c.onchip_update = upd            # theta update reduced inside K1 (mppi_command_kmppi) / by the stand-alone K3
     c.philox_fill = fill          # None: generator launch for the support-point rows; False: K1 / K3 generate them in-kernel
     for _ in range(5):
         c.command(x0)
@@ -38,6 +39,6 @@ for fuse, fill in ((True, None), (True, False), (False, None)):
     lib.mppi_profile_enable(0)
     k1 = b.value / max(1, cn.value) * 1e3
     macs = K * T * S * nu
-    print(f"KMPPI S={S} K={K} rng={rng} {'interpolation inside K1' if fuse else 'two launches         '}{' rows generated in-kernel' if fill is False else ''}: {dt * 1e3:.4f} ms/command, "
+    print(f"KMPPI S={S} K={K} rng={rng} {'interpolation inside K1' if fuse else 'two launches         '}{' rows generated in-kernel' if fill is False else ''}{' theta update inside K1' if upd else ' stand-alone K3'}: {dt * 1e3:.4f} ms/command, "
           f"K1 device clock {k1:.1f} us" + (f" = {2 * macs / k1 / 1e6:.1f} TFLOP/s of interpolation (fp32 MFMA peak 157.3)" if fuse else ""),
           flush=True)

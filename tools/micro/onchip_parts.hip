@@ -8,7 +8,8 @@
 #include "dispatch.hpp"
 #include "rollout.hpp"
 namespace mppi {
-bool profile_next_events(hipEvent_t* a, hipEvent_t* b, unsigned long long** t) { *a = *b = nullptr; if (t) *t = nullptr; return false; }
+static unsigned long long* g_ts = nullptr;     // MPPI_MICRO_STAMPS=1: the measurement hook's stamp slots (what do they cost?)
+bool profile_next_events(hipEvent_t* a, hipEvent_t* b, unsigned long long** t) { *a = *b = nullptr; if (t) *t = g_ts; return false; }
 }
 using namespace mppi;
 #ifndef MPPI_ONCHIP_EXP
@@ -30,6 +31,7 @@ int main(int argc, char** argv) {
   a.cost = dev(K, 0.f); a.block_min = dev(K / 64 + 4, 0.f); a.record = dev(2 + J, 0.f); a.U_out = dev(J, 0.f);
   const int nb = (K + 255) / 256;
   a.eta_part = dev((size_t)nb + (size_t)nb * J, 0.f); a.nkc = nb; a.R = 1;
+  if (getenv("MPPI_MICRO_STAMPS")) { (void)hipMalloc(&mppi::g_ts, 16 * STAMP_SLOTS); (void)hipMemset(mppi::g_ts, 0, 16 * STAMP_SLOTS); }
   hipStream_t st; (void)hipStreamCreate(&st);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int n = 200;
@@ -42,7 +44,7 @@ int main(int argc, char** argv) {
   (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   float c0; (void)hipMemcpy(&c0, a.cost, 4, hipMemcpyDeviceToHost);
-  printf("on-chip K1, K = %d, lambda %g, %s, knocked out = %2d (1 weighting | 2 second generation | 4 keeping | 8 rollout): %.1f us per launch (back to back)  cost[0] = %g\n",
-         K, a.lambda_, argc > 3 ? "no bounds" : "bounds +-2.5", MPPI_ONCHIP_EXP, ms / n * 1e3, c0);
+  printf("%son-chip K1, K = %d, lambda %g, %s, knocked out = %2d (1 weighting | 2 second generation | 4 keeping | 8 rollout): %.1f us per launch (back to back)  cost[0] = %g\n",
+         mppi::g_ts ? "[stamps] " : "", K, a.lambda_, argc > 3 ? "no bounds" : "bounds +-2.5", MPPI_ONCHIP_EXP, ms / n * 1e3, c0);
   return 0;
 }
