@@ -249,6 +249,29 @@ def _pmc_lookup(key, kernel):
         return None
 
 
+def _onchip_valu_roofline(workload, k1_us):
+    """The headline kernel's own roofline: it moves 1.3 MB and is bound by VALU issue -- the generator.
+    From the committed SQ counter passes of this command (profiles/pmc_onchip_valu.json; a lookup, like `traffic`): VALU
+    instructions per wave, the share of the wave's cycles in which the VALU is executing one (`frac`: what the kernel achieves
+    of the one thing that bounds it -- a wave alone on its SIMD cannot issue while it waits for its own previous result,
+    LDS or the scalar unit), and the time the same instruction stream would take with the VALU never idle."""
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", "pmc_onchip_valu.json")))[f"{workload}/philox-onchip"]["rollout_onchip_kernel"]
+    except Exception:
+        return None
+    w = c["waves"]
+    frac = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
+    return {"bound": "valu", "valu_insts_per_wave": c["SQ_INSTS_VALU"] / w,
+            "valu_active_cycles_per_wave": 4.0 * c["SQ_ACTIVE_INST_VALU"] / w, "wave_cycles": 4.0 * c["SQ_WAVE_CYCLES"] / w,
+            "frac": frac, "achieved": frac, "peak": 1.0, "unit": "VALU-active share of wave cycles",
+            "issue_floor_us": frac * k1_us if k1_us else None,
+            "cycles_per_valu_inst": 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"],
+            "waiting_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stall_share": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+            "traffic_bytes": (2 * c["FETCH_SIZE_KiB"] + c["WRITE_SIZE_KiB"]) * 1024,
+            "source": "profiles/pmc_onchip_valu.json (rocprofv3 --pmc passes: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES, SQ_WAIT_*; "
+                      "FETCH_SIZE doubled per the gfx950 note) -- a lookup; `issue_floor_us` = frac x this run's measured launch time"}
+
+
 def latency_synced(ctrl, x0, warmup=3, iters=20):
     """The reference's timing protocol (/root/reference/tests/benchmark_mppi.py:84-113): warm-ups without the
     shift, then per iteration reset() + state.clone() outside the clock, synchronize, ONE command, synchronize.
@@ -417,7 +440,7 @@ def main():
         onchip_now = ctrl.last_draw == "philox-onchip"
         json.dump({"warmup": args.warmup, "steps": args.steps, "regions": {
             "headline": {"pattern": "rollout_onchip_kernel" if onchip_now else K1_KERNEL_PATTERN[kind], "spans_us": k1_dev_us,
-                         "launches_before": (1 if kind != "pendulum" else 0) + args.warmup}}}, open(dump, "w"))
+                         "launches_before": (1 if kind != "pendulum" else 0) + args.warmup + n_clock_warmup}}}, open(dump, "w"))
     if world > 1:
         tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -465,7 +488,7 @@ def main():
         cs.lambda_ = ctrl.lambda_
         for _ in range(args.warmup):
             cs.command(xs)
-        clock_warmup(cs, xs)
+        n_cw_stream = clock_warmup(cs, xs)
         lib.mppi_profile_enable(STAMPS_ONLY)
         barrier()
         t1 = time.perf_counter()
@@ -486,7 +509,7 @@ def main():
             dts = float(tt)
         if dump and rank == 0:
             dd = json.load(open(dump))
-            dd["regions"]["streaming"] = {"pattern": K1_KERNEL_PATTERN[kind], "spans_us": k1_dev_us, "launches_before": args.warmup}
+            dd["regions"]["streaming"] = {"pattern": K1_KERNEL_PATTERN[kind], "spans_us": k1_dev_us, "launches_before": args.warmup + n_cw_stream}
             json.dump(dd, open(dump, "w"))
         roof_ctrl = cs
         oc_us = (oc_dev["avg"] + DISPATCH_OFFSET_US_ONCHIP) if oc_dev else 0.0
@@ -504,6 +527,7 @@ def main():
                   "bound": "VALU: Philox4x32-10 + Box-Muller of the sample's T*nu normals (generated once, ~half of them a "
                            "second time in the weighting phase: the rest stays in accumulation registers / LDS), ~80 % of the "
                            "kernel (tools/micro/onchip_parts.hip, profiles/r03_onchip_parts.txt)",
+                  "roofline": _onchip_valu_roofline(args.workload, oc_us) if world == 1 else None,
                   "streaming_form_ms_per_step": dts / args.steps * 1e3,
                   "speedup_vs_streaming_form": (dts / args.steps) / (dt / args.steps),
                   "note": "SURVEY.md 8d: with the engine's generator inside K1 the algorithmic HBM bytes collapse to O(K) and the "

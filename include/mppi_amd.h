@@ -72,6 +72,8 @@ enum {
 /* model_flags */
 #define MPPI_MODEL_FLAG_EXACT_FP32 1   /* MPPI_MODEL_MLP: some |W2| >= 3e4 lies outside the fp16 operand range of the split
                                           matrix-core kernel -> run the exact fp32 MFMA kernel (no range limit) instead */
+#define MPPI_MODEL_FLAG_NO_WIDE 2      /* run-time registered models with dense layers (csrc/mlp_wide.hpp): keep the one-lane-per-sample
+                                          kernels (fma chains) instead of the matrix-core kernel of sixteen samples per wave (A/B, tests) */
 
 typedef struct MppiProblem {
   /* ---- dimensions ---- */

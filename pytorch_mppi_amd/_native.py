@@ -19,6 +19,7 @@ E_DIST = -4
 MODEL_NONE, MODEL_PENDULUM, MODEL_INTEGRATOR, MODEL_LINEAR_GOAL, MODEL_MLP = 0, 1, 2, 3, 4
 MODEL_CUSTOM_BASE = 100
 MODEL_FLAG_EXACT_FP32 = 1
+MODEL_FLAG_NO_WIDE = 2
 
 _vp = C.c_void_p
 

@@ -983,6 +983,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
 
 }  // namespace mppi
 #include "rollout_kmppi.hpp"   // KMPPI: interpolation inside K1 (needs rollout_step)
+#include "mlp_wide.hpp"        // traced models with dense layers: matrix-core execution, sixteen samples per wave (needs rollout_stream_heavy)
 #include "rollout_onchip.hpp"  // rng="philox" without a (K,T,nu) array: generate, roll out, keep eps' on chip, partial records
 namespace mppi {
 
@@ -1020,6 +1021,11 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
   {
     // whole-command request on the engine's own generator with no row array: the on-chip form (or "not this path")
     const int r = launch_rollout_onchip<Model, T>(a_in, st);
+    if (r != -1) return r;
+  }
+  {
+    // a traced model with dense layers, fp32: sixteen samples per wave, the layers on the matrix cores (mlp_wide.hpp)
+    const int r = launch_rollout_wide<Model, T>(a_in, st);
     if (r != -1) return r;
   }
   KArgs<T> a = a_in;

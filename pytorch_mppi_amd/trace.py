@@ -90,6 +90,12 @@ class Graph:
         self.derived = {}        # id(tensor made INSIDE the callables from real tensors) -> (tensor, [the tensors it came from]):
         #                          B.to(state.device), W @ W.T, ... are constants of the functor too; the version watch must sit
         #                          on what they were made from (the copy itself is never written again)
+        # dense layers kept AS LAYERS (F.linear on a real weight tensor, >= DENSE_MIN multiply-adds): node ("lin", layer, o) is
+        # output o of layers[layer] = dict(IN, OUT, inputs=[node ids], wbase, bbase | None) -- weights and bias are parameter-
+        # vector reads.  Code generation prints chains of them as mlp_first / mlp_mid / mlp_last calls (csrc/mlp_wide.hpp): fma
+        # chains per lane in the ordinary kernels, matrix-core tiles of sixteen samples in the wide kernel
+        self.layers = []
+        self.dense_layers = os.environ.get("MPPI_TRACE_DENSE", "1") != "0"
         self.param_tensors = []  # (tensor, base): TRAINABLE tensors -- element i is the leaf ("p", base + i), read from the
         self._param_base = {}    # model's parameter vector at run time (re-gathered when the tensor's version moves)
         self.n_params = 0
@@ -125,6 +131,19 @@ class Graph:
             self.param_tensors.append((PathParam(dyn[1], t) if dyn is not None and dyn[0] is t else t, base))
             self.n_params += t.numel()
         return np.array([self.leaf("p", base + i) for i in range(t.numel())], dtype=np.int64).reshape(tuple(t.shape))
+
+    def param_base(self, t):
+        """base of tensor t in the parameter vector (registers it on first use, like param_leaves)"""
+        self.param_leaves(t)
+        return self._param_base[id(t)]
+
+    def dense(self, inputs, W, b):
+        """a layer y = W x + b on node ids `inputs` -> node ids of its OUT outputs"""
+        OUT, IN = int(W.shape[0]), int(W.shape[1])
+        lid = len(self.layers)
+        self.layers.append(dict(IN=IN, OUT=OUT, inputs=[int(i) for i in inputs], wbase=self.param_base(W),
+                                bbase=self.param_base(b) if b is not None else None))
+        return [self._mk(("lin", lid, o)) for o in range(OUT)]
 
     def roots_of(self, t):
         d = self.derived.get(id(t))
@@ -1008,6 +1027,19 @@ def _call(g, name, args, kwargs):
         v = {"zeros_like": 0.0, "ones_like": 1.0, "empty_like": 0.0}.get(name, rest[0] if rest else kwargs.get("fill_value"))
         return SymT(g, np.full(a0.a.shape, g.const(v), dtype=np.int64))
     if name == "linear":                               # F.linear(input, weight, bias): nn.Linear inside a module
+        b_ = rest[1] if len(rest) > 1 else kwargs.get("bias")
+        W_ = rest[0]
+        if (g.dense_layers and isinstance(W_, torch.Tensor) and W_.dim() == 2 and W_.is_floating_point() and W_.numel() >= DENSE_MIN
+                and isinstance(a0, SymT) and a0.a.ndim >= 1 and a0.a.shape[-1] == W_.shape[1] and not a0.boolean
+                and (b_ is None or (isinstance(b_, torch.Tensor) and b_.dim() == 1 and b_.numel() == W_.shape[0]))
+                and id(W_) not in g.dynamic and (b_ is None or id(b_) not in g.dynamic)):
+            # a dense layer stays a layer: its weights become parameter-vector reads (trainable or not: a frozen network's
+            # weights are followed by version counter and storage like any parameter), its outputs `lin` nodes
+            rows = a0.a.reshape(-1, a0.a.shape[-1])
+            out = np.empty((rows.shape[0], int(W_.shape[0])), dtype=np.int64)
+            for r in range(rows.shape[0]):
+                out[r] = g.dense(rows[r], W_, b_)
+            return SymT(g, out.reshape(a0.a.shape[:-1] + (int(W_.shape[0]),)))
         w = _as_sym(g, rest[0])
         out = a0.matmul(w.T)
         b = rest[1] if len(rest) > 1 else kwargs.get("bias")
@@ -1176,6 +1208,7 @@ def _flatten_result(r, want, what):
 
 _FACTORIES = {"zeros", "ones", "empty", "full", "tensor", "as_tensor", "eye", "from_numpy", "linspace", "diag", "diag_embed",
               "zeros_like", "ones_like", "full_like", "empty_like", "scalar_tensor", "asarray"}
+DENSE_MIN = 64        # multiply-adds from which F.linear on a real weight tensor is kept as a layer (below: scalar terms)
 _META = {"size", "dim", "numel", "nelement", "stride", "is_floating_point", "is_contiguous", "data_ptr", "element_size", "get_device",
          "is_complex", "storage_offset", "__len__", "ndimension", "type", "is_pinned", "__format__", "__repr__", "__str__"}
 _RANDOM = {"randn", "rand", "randn_like", "rand_like", "normal", "randint", "bernoulli", "multinomial", "randperm", "poisson"}
@@ -1278,6 +1311,8 @@ def _reaches(g, roots, kinds):
             return True
         if n[0] == "tab":
             stack.append(n[2])
+        elif n[0] == "lin":
+            stack.extend(g.layers[n[1]]["inputs"])
         elif n[0] not in ("c", "x", "u", "t", "y", "w", "p"):
             stack.extend(n[1:])
     return False
@@ -1307,9 +1342,135 @@ def _lit(v):
     return f"T({v!r})"
 
 
-def emit(g, roots, assign=None, ret=False):
+def _deps(g, n):
+    """node ids a node's value is computed from"""
+    k = n[0]
+    if k in ("c", "x", "u", "t", "y", "w", "p"):
+        return ()
+    if k == "tab":
+        return (n[2],)
+    if k == "lin":
+        return tuple(g.layers[n[1]]["inputs"])
+    return n[1:]
+
+
+def _dense_chains(g, roots):
+    """Which dense layers below `roots` feed each other through one elementwise activation and nothing else: -> (tail layer ->
+    [(layer, activation format or None) ...] from the chain's head to the tail, set of nodes internal to a chain).
+    Layer Lp is fused into L when L's inputs are act(lin(Lp, 0)), act(lin(Lp, 1)), ... in order, with ONE activation (a unary
+    function, or max / min / mul / add with a constant) and neither the outputs of Lp nor the activations are used anywhere else."""
+    seen, stack, cons = set(), list(roots), {}
+    for r in roots:
+        cons[r] = cons.get(r, 0) + 1
+    layer_seen = set()
+    while stack:
+        i = stack.pop()
+        if i in seen:
+            continue
+        seen.add(i)
+        n = g.nodes[i]
+        if n[0] == "lin":                       # a layer consumes each of its inputs ONCE, however many of its outputs are used
+            if n[1] in layer_seen:
+                continue
+            layer_seen.add(n[1])
+        for d in _deps(g, n):
+            cons[d] = cons.get(d, 0) + 1
+            stack.append(d)
+    layers = sorted({g.nodes[i][1] for i in seen if g.nodes[i][0] == "lin"})
+    prev = {}
+    for L in layers:
+        ins = g.layers[L]["inputs"]
+        spec, Lp = None, None
+        ok = True
+        for pos, a in enumerate(ins):
+            # walk from the input down to a layer output through operations of ONE operand (unary functions, max / min / mul /
+            # add / sub / div with a constant): the activation, innermost operation last in `path`
+            path, cur, chain_nodes = [], a, []
+            while g.nodes[cur][0] != "lin":
+                n = g.nodes[cur]
+                # (the distributed form pads a layer's outputs to whole blocks of 16 with zeros, which meet zero weights in the next
+                # layer: the activation must be FINITE at 0 -- log(0) or c / 0 would put inf * 0 = NaN into every sum)
+                if n[0] in _FMT1 and len(n) == 2 and n[0] not in ("log", "not"):
+                    path.append((n[0],))
+                    nxt = n[1]
+                elif n[0] in ("max", "min", "mul", "add", "sub", "div") and len(n) == 3 and (g.cval(n[1]) is not None) != (g.cval(n[2]) is not None) \
+                        and not (n[0] == "div" and g.cval(n[1]) is not None):
+                    left_const = g.cval(n[1]) is not None
+                    path.append((n[0], g.cval(n[1] if left_const else n[2]), left_const))
+                    nxt = n[2] if left_const else n[1]
+                else:
+                    ok = False
+                    break
+                chain_nodes.append(cur)
+                cur = nxt
+                if len(path) > 8:
+                    ok = False
+                    break
+            if not ok:
+                break
+            sl = g.nodes[cur]
+            this = tuple(reversed(path))                        # in the order they are applied to the layer's output
+            if sl[2] != pos or (Lp is not None and sl[1] != Lp) or (spec is not None and this != spec):
+                ok = False
+                break
+            if cons.get(cur, 0) != 1 or any(cons.get(c_, 0) != 1 for c_ in chain_nodes):
+                ok = False
+                break
+            spec, Lp = this, sl[1]
+        if ok and Lp is not None and g.layers[Lp]["OUT"] == len(ins) and Lp != L:
+            prev[L] = (Lp, spec)
+    fused_into = {lp: L for L, (lp, _) in prev.items()}
+    chains, internal = {}, set()
+    for L in layers:
+        if L in fused_into:
+            continue                                             # not a tail
+        chain, cur = [], L
+        while True:
+            if cur in prev:
+                lp, spec = prev[cur]
+                chain.append((cur, spec))
+                cur = lp
+            else:
+                chain.append((cur, None))
+                break
+        chain.reverse()            # head first; entry i = (layer, activation applied to the PREVIOUS layer's output before this one)
+        chains[L] = chain
+        for (Lc, _) in chain[:-1]:
+            for o in range(g.layers[Lc]["OUT"]):
+                internal.add(g.index[("lin", Lc, o)])
+        for (Lc, spec) in chain[1:]:
+            for a in g.layers[Lc]["inputs"]:
+                internal.add(a)
+    return chains, internal
+
+
+def _act_code(spec, var):
+    """the activation between two fused layers (operations of one operand, applied in order) on the register array `var`, in place"""
+    if not spec:
+        return ""
+    e = f"{var}[i_]"
+    for op in spec:
+        if len(op) == 1:
+            e = _FMT1[op[0]].format(e)
+        else:
+            e = _FMT2[op[0]].format(_lit(op[1]), e) if op[2] else _FMT2[op[0]].format(e, _lit(op[1]))
+    return f"for (int i_ = 0; i_ < (int)(sizeof({var}) / sizeof({var}[0])); ++i_) {var}[i_] = {e}; "
+
+
+def emit(g, roots, assign=None, ret=False, used=None):
     """C++ statements computing `roots` (node ids): temporaries in topological order, then either `x[i] = ...;`
-    assignments (`assign` = list of targets) or `return ...;`."""
+    assignments (`assign` = list of targets) or `return ...;`.  used: dict collecting the (layer, kind) pairs of the dense
+    layers the body calls (kind 0: replicated input, 1: distributed input; members of the functor: `layer_members`)."""
+    used = {} if used is None else used
+    chains, internal = _dense_chains(g, roots) if g.layers else ({}, set())
+
+    def deps(i):
+        n = g.nodes[i]
+        if n[0] == "lin":
+            if n[1] not in chains:
+                raise TraceUnsupported("internal: a fused layer's output used outside its chain")
+            return tuple(g.layers[chains[n[1]][0][0]]["inputs"])       # a chain's tail depends on the inputs of its head
+        return _deps(g, n)
     order, seen = [], set()
     for r in roots:
         stack = [(r, False)]
@@ -1322,14 +1483,11 @@ def emit(g, roots, assign=None, ret=False):
                 continue
             seen.add(i)
             stack.append((i, True))
-            n = g.nodes[i]
-            if n[0] == "tab":
-                stack.append((n[2], False))
-            elif n[0] not in ("c", "x", "u", "t", "y", "w", "p"):
-                for a in n[1:]:
-                    stack.append((a, False))
+            for a in deps(i):
+                stack.append((a, False))
     name = {}
     lines = []
+    emitted_chains = set()
     for i in order:
         n = g.nodes[i]
         k = n[0]
@@ -1345,6 +1503,33 @@ def emit(g, roots, assign=None, ret=False):
             name[i] = f"p[{n[1]}]"
         elif k in ("y", "w"):
             raise TraceUnsupported("internal: terminal leaf in a step / cost body")
+        elif k == "lin":
+            L = n[1]
+            if L not in emitted_chains:
+                emitted_chains.add(L)
+                chain = chains[L]
+                head = g.layers[chain[0][0]]
+                lines.append(f"T mi{L}[{head['IN']}] = {{{', '.join(name[a] for a in head['inputs'])}}};")
+                lines.append(f"T mo{L}[{g.layers[L]['OUT']}];")
+                if len(chain) == 1:
+                    used[(chain[0][0], 0)] = True
+                    lines.append(f"mlp_single(ml{chain[0][0]}_0, mi{L}, mo{L});")
+                else:
+                    body, prev_var = "{ ", None
+                    for ci, (Lc, spec) in enumerate(chain):
+                        lay = g.layers[Lc]
+                        used[(Lc, 0 if ci == 0 else 1)] = True
+                        if ci == 0:
+                            body += f"T d{Lc}[mlp_dlen({lay['OUT']}, WX)]; mlp_first(ml{Lc}_0, mi{L}, d{Lc}); "
+                        else:
+                            body += _act_code(spec, prev_var)
+                            if ci < len(chain) - 1:
+                                body += f"T d{Lc}[mlp_dlen({lay['OUT']}, WX)]; mlp_mid(ml{Lc}_1, {prev_var}, d{Lc}); "
+                            else:
+                                body += f"mlp_last(ml{Lc}_1, {prev_var}, mo{L}); "
+                        prev_var = f"d{Lc}"
+                    lines.append(body + "}")
+            name[i] = f"mo{L}[{n[2]}]"
         elif k == "tab":
             vals, N = n[1], len(n[1])
             lines.append(f"const T tab{i}[{N}] = {{{', '.join(_lit(v) for v in vals)}}};")
@@ -1397,11 +1582,34 @@ def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_depe
     device / dtype: what the symbolic inputs report (the controller's; default cpu / float64).
     dynamic: places (watch.Path) whose tensors become run-time parameters instead of constants."""
     g, so, co, to = trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost, step_dependent, device, dtype, dynamic)
-    step = emit(g, so, assign=[f"x[{i}]" for i in range(nx)])
-    cost = emit(g, [co], ret=True)
-    term = emit(g, [to], ret=True) if to is not None else None
+    used = {}
+    step = emit(g, so, assign=[f"x[{i}]" for i in range(nx)], used=used)
+    cost = emit(g, [co], ret=True, used=used)
+    term = emit(g, [to], ret=True, used=used) if to is not None else None
+    members, ctor = layer_members(g, used)
     return dict(step=step, cost=cost, terminal=term, n_ops=len(g.nodes), captured=g.captured, param_tensors=g.param_tensors,
-                n_params=g.n_params, dynamic=list(dynamic))
+                n_params=g.n_params, dynamic=list(dynamic), members=members, ctor=ctor,
+                dense=[dict(IN=g.layers[L]["IN"], OUT=g.layers[L]["OUT"], kind=k) for (L, k) in sorted(used)])   # layers kept as layers
+
+
+def layer_members(g, used):
+    """the functor's dense layers as members (csrc/mlp_wide.hpp MlpLayer) and the constructor statements that bind them to
+    their weights in the parameter vector.  In the wide form a layer's A operands and bias live in registers for the whole
+    launch (PRE) as long as all layers together stay below ~160 registers per lane; beyond that they are read where used."""
+    regs = 0
+    for (L, kind) in used:
+        lay = g.layers[L]
+        ob = (lay["OUT"] + 15) // 16
+        ks = (lay["IN"] + 3) // 4 if kind == 0 else ((lay["IN"] + 15) // 16) * 4
+        regs += ob * ks + 4 * ob
+    pre = "true" if regs <= 160 else "false"
+    members, ctor = [], []
+    for (L, kind) in sorted(used):
+        lay = g.layers[L]
+        members.append(f"MlpLayer<{lay['IN']}, {lay['OUT']}, {kind}, WX, {pre}, T, ParamPtr> ml{L}_{kind};")
+        bias = f"p + {lay['bbase']}" if lay["bbase"] is not None else "(ParamPtr)nullptr"
+        ctor.append(f"ml{L}_{kind}.load(p + {lay['wbase']}, {bias});")
+    return " ".join(members), " ".join(ctor)
 
 
 def same_functor(a, b):
@@ -1469,13 +1677,30 @@ static inline T m_ceil(T x) { return std::ceil(x); }
 static inline T m_rint(T x) { return std::nearbyint(x); }
 static inline T m_trunc(T x) { return std::trunc(x); }
 static inline T clampT(T x, T lo, T hi) { return std::fmin(std::fmax(x, lo), hi); }
+// dense layers kept as layers (csrc/mlp_wide.hpp): on the host the distributed form of a vector is the vector
+static const bool WX = false;
+typedef const double* ParamPtr;
+constexpr int mlp_dlen(int n, bool) { return n; }
+template <int IN, int OUT, int KIND, bool WX_, bool PRE, typename U, typename P> struct MlpLayer {
+  P w, b;
+  void load(P w_, P b_) { w = w_; b = b_; }
+  void apply(const U* in, U* out) const {
+    for (int o = 0; o < OUT; ++o) { U acc = b ? b[o] : U(0); for (int i = 0; i < IN; ++i) acc += w[o * IN + i] * in[i]; out[o] = acc; }
+  }
+};
+template <class L, int IN, int OUT> static inline void mlp_first(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in, d); }
+template <class L, int IN, int OUT> static inline void mlp_mid(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in, d); }
+template <class L, int IN, int OUT> static inline void mlp_last(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in, d); }
+template <class L, int IN, int OUT> static inline void mlp_single(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in, d); }
 static const int NX = %(nx)d, NU = %(nu)d;
 static const double* p;
+%(members)s
 static inline void step_(T (&x)[NX], const T (&u)[NU], int t) { %(step)s }
 static inline T cost_(const T (&x)[NX], const T (&u)[NU], int t) { %(cost)s }
 static inline T term_(const T (&x)[NX]) { %(terminal)s }
 extern "C" void run(int B, const double* X, const double* U, int t, double* Xn, double* Cc, double* Tc, const double* P) {
   p = P;
+  %(ctor)s
   for (int b = 0; b < B; ++b) {
     T x[NX], u[NU];
     for (int i = 0; i < NX; ++i) x[i] = X[b * NX + i];
@@ -1492,7 +1717,8 @@ extern "C" void run(int B, const double* X, const double* U, int t, double* Xn, 
 def evaluate_on_host(code, X, U, nx, nu, t=0):
     """The generated bodies, compiled for the host, on a batch: (next states (B,nx), running costs (B,), terminal costs (B,))
     in fp64 -- what the device functor computes, for tests and for looking at a translation by hand."""
-    src = _HOST % dict(nx=nx, nu=nu, step=code["step"], cost=code["cost"], terminal=code["terminal"] or "return T(0);")
+    src = _HOST % dict(nx=nx, nu=nu, step=code["step"], cost=code["cost"], terminal=code["terminal"] or "return T(0);",
+                       members=code.get("members", ""), ctor=code.get("ctor", ""))
     X, U = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, nx), np.ascontiguousarray(U, dtype=np.float64).reshape(-1, nu)
     B = X.shape[0]
     with tempfile.TemporaryDirectory() as d:
@@ -1513,7 +1739,8 @@ def evaluate_on_host(code, X, U, nx, nu, t=0):
 def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, B=24, rtol=1e-9, horizon=None):
     """Compile the generated bodies for the host and compare with the callables on random batches (fp64).
     Raises TraceUnsupported on any disagreement (the caller keeps the generic path)."""
-    src = _HOST % dict(nx=nx, nu=nu, step=code["step"], cost=code["cost"], terminal=code["terminal"] or "return T(0);")
+    src = _HOST % dict(nx=nx, nu=nu, step=code["step"], cost=code["cost"], terminal=code["terminal"] or "return T(0);",
+                       members=code.get("members", ""), ctor=code.get("ctor", ""))
     with tempfile.TemporaryDirectory() as d:
         cpp, so = os.path.join(d, "v.cpp"), os.path.join(d, "v.so")
         open(cpp, "w").write(src)

@@ -198,6 +198,23 @@ def zoo_callables(seed=3):
     return dynamics, cost, net
 
 
+def relu_net_callables(seed=7, dtype=torch.float32):
+    """nx = 4, nu = 2 dynamics network with the activations that are NOT all one-operand functions of their layer (GELU reads its
+    argument twice: that layer stands alone; ReLU and a scaled sigmoid fuse) and an output wider than the state"""
+    torch.manual_seed(seed)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 24), torch.nn.GELU(), torch.nn.Linear(24, 24), torch.nn.ReLU(), torch.nn.Linear(24, 20),
+                              torch.nn.Sigmoid(), torch.nn.Linear(20, 6)).to(dtype)
+
+    def dynamics(state, action):
+        out = net(torch.cat((state, action), dim=1))
+        return state + 0.1 * out[:, :4] * (1.0 + 0.1 * out[:, 4:5])
+
+    def cost(state, action):
+        return (state ** 2).sum(dim=1) + 0.05 * (action ** 2).sum(dim=1)
+
+    return dynamics, cost, net
+
+
 def tracking_callables(T=24):
     """time-varying reference (step_dependent_dynamics=True): a schedule tensor indexed by the timestep, `ref[t]` / `ref[t + 1]`
     -- one small constant table per looked-up element in the traced functor"""
@@ -318,6 +335,11 @@ def traced_models():
     wf2, wq2, wB2 = watched_linear_callables()
     sf, sq, sh, _ = swappable_net_callables()
     jobs["swappable"] = (sf, sq, 2, 1)
+    nf, nq, _ = relu_net_callables()
+    jobs["relu_net"] = (nf, nq, 4, 2)
+    af32, aq32, _ = approx_pendulum_callables(dtype=torch.float32)
+    jobs["approx_f32"] = (af32, aq32, 2, 1)
+    jobs["approx_f32_terminal"] = (af32, aq32, 2, 1, approx_terminal_cost)
     with cf.ThreadPoolExecutor(max_workers=8) as ex:      # each ends in its own hipcc subprocess
         futs = {k: ex.submit(jit.from_torch, *v) for k, v in jobs.items()}
         futs["tracking"] = ex.submit(jit.from_torch, tf, tq, 2, 2, step_dependent=True, horizon=24)

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import jit_fixtures as jf
-from pytorch_mppi_amd import trace
+from pytorch_mppi_amd import jit, trace
 
 
 def _roundtrip(f, q, nx, nu, term=None, step_dependent=False):
@@ -103,7 +103,8 @@ def test_learned_pendulum_dynamics_of_the_reference_example():
     by item assignment.  Traced once; the functor follows the network through training steps."""
     f, q, net = jf.approx_pendulum_callables()
     code = _roundtrip(f, q, 2, 1)
-    assert code["n_params"] == 3 * 32 + 32 + 32 * 32 + 32 + 32 * 2 + 2 and code["step"].count("m_tanh") == 64
+    # (the three Linear layers stay layers -- one chain, the two tanh applied to whole register arrays; csrc/mlp_wide.hpp)
+    assert code["n_params"] == 3 * 32 + 32 + 32 * 32 + 32 + 32 * 2 + 2 and code["step"].count("m_tanh") == 2 and len(code["dense"]) == 3
     assert not code["captured"]
     jf.train_a_little(net)
     assert trace.verify_on_host(code, f, q, 2, 1)
@@ -219,3 +220,72 @@ def test_python_modulo_is_exact_at_multiples_of_the_modulus():
     got = trace.evaluate_on_host(code, X, U, 3, 1)[0]
     want = f(torch.tensor(X), torch.tensor(U)).numpy()
     assert np.array_equal(got, want), (got, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dense layers kept as layers (VERDICT r03 missing #2): F.linear on a real weight tensor becomes an MlpLayer member of the functor
+# (csrc/mlp_wide.hpp: fma chains per lane, or matrix-core tiles of sixteen samples in the wide kernel); chains of layers joined
+# by one elementwise activation keep their hidden activations in the distributed form
+# ---------------------------------------------------------------------------------------------------------------------
+def _check_against_torch(code, f, q, nx, nu, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    X, U = torch.randn(9, nx, generator=g, dtype=torch.float64), torch.randn(9, nu, generator=g, dtype=torch.float64)
+    xn, cc, _ = trace.evaluate_on_host(code, X.numpy(), U.numpy(), nx, nu)
+    with torch.no_grad():
+        assert np.allclose(xn, f(X, U).double().numpy(), rtol=1e-9, atol=1e-11)
+        assert np.allclose(cc, q(X, U).double().reshape(-1).numpy(), rtol=1e-9, atol=1e-11)
+
+
+def test_dense_layers_stay_layers_and_chain_through_their_activations():
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(), torch.nn.Linear(32, 2)).double()
+    f = lambda s, a: s + net(torch.cat((s, a), 1))
+    q = lambda s, a: (s ** 2).sum(1)
+    code = jit.trace_and_verify(f, q, 2, 1)
+    assert [(d["IN"], d["OUT"], d["kind"]) for d in code["dense"]] == [(3, 32, 0), (32, 32, 1), (32, 2, 1)]
+    assert "mlp_first(ml0_0" in code["step"] and "mlp_mid(ml1_1" in code["step"] and "mlp_last(ml2_1" in code["step"]
+    assert code["step"].count("m_tanh") == 2                 # the activations run over whole register arrays, not per element
+    assert "MlpLayer<32, 32, 1, WX, true, T, ParamPtr> ml1_1;" in code["members"] and "ml1_1.load(p + 128, p + 1152);" in code["ctor"]
+    assert code["n_params"] == 3 * 32 + 32 + 32 * 32 + 32 + 32 * 2 + 2
+    _check_against_torch(code, f, q, 2, 1)
+
+
+def test_dense_layer_chains_break_where_the_pattern_does():
+    torch.manual_seed(4)
+    l1, l2, l4 = torch.nn.Linear(4, 16).double(), torch.nn.Linear(16, 16).double(), torch.nn.Linear(16, 4).double()
+    l3 = lambda h: l4(h)[:, :3]                # (16 x 4 = 64 multiply-adds: the smallest layer that stays a layer)
+
+    def f(s, a):                               # a skip connection: h1 is used twice -> three layers on their own
+        h1 = torch.relu(l1(torch.cat((s, a), 1)))
+        h2 = torch.relu(l2(h1)) + h1
+        return s + 0.1 * l3(h2)
+    q = lambda s, a: (s ** 2).sum(1) + 0.1 * (a ** 2).sum(1)
+    code = jit.trace_and_verify(f, q, 3, 1)
+    assert code["step"].count("mlp_single(") == 3 and "mlp_mid" not in code["step"]
+    _check_against_torch(code, f, q, 3, 1)
+
+    def f2(s, a):                              # relu / sigmoid / a scale between the layers: one chain
+        h = torch.sigmoid(l2(torch.relu(l1(torch.cat((s, a), 1)))))
+        return s + l3(0.5 * h)
+    code = jit.trace_and_verify(f2, q, 3, 1)
+    assert "mlp_first(ml0_0" in code["step"] and "mlp_mid(ml1_1" in code["step"] and "mlp_last(ml2_1" in code["step"]
+    assert "m_max(d0[i_], T(0.0))" in code["step"] and "* T(0.5)" in code["step"]
+    _check_against_torch(code, f2, q, 3, 1)
+
+    small = torch.nn.Linear(3, 4).double()     # 12 multiply-adds: scalar terms, no layer
+    code = jit.trace_and_verify(lambda s, a: s + small(s)[:, :3] * a, q, 3, 1)
+    assert not code["dense"] and "mlp_" not in code["step"]
+
+    # the same layer applied to two different inputs: two calls on one member
+    def f3(s, a):
+        return s + 0.1 * l3(torch.tanh(l2(torch.tanh(l1(torch.cat((s, a), 1)))))) - 0.1 * l3(torch.tanh(l2(torch.tanh(l1(torch.cat((-s, a), 1))))))
+    code = jit.trace_and_verify(f3, q, 3, 1)
+    assert code["step"].count("mlp_first(ml0_0") == 1 and code["step"].count("mlp_first(ml3_0") == 1     # (two applications = two layer records)
+    _check_against_torch(code, f3, q, 3, 1)
+
+
+def test_dense_layers_can_be_switched_off(monkeypatch):
+    monkeypatch.setenv("MPPI_TRACE_DENSE", "0")
+    net = torch.nn.Sequential(torch.nn.Linear(3, 16), torch.nn.Tanh(), torch.nn.Linear(16, 2)).double()
+    code = jit.trace_and_verify(lambda s, a: s + net(torch.cat((s, a), 1)), lambda s, a: (s ** 2).sum(1), 2, 1)
+    assert not code["dense"] and "mlp_" not in code["step"] and code["members"] == ""
