@@ -89,9 +89,11 @@ struct OnChipRow {
 // Gaussian noise via a Cholesky-factored noise_sigma", applied in the lane that owns the sample (mppi.py:204-206).
 // ESC: the bounded noise is rescaled (SMPPI: eps' = (v - B) / dt, mppi.py:544)
 // `null_in_wave` (wave-uniform): some lane of the wave is the sample_null_action row
-template <int NU, bool DIAG, bool ESC = false>
+// esc (wave-uniform, in fact launch-uniform): the rescale, applied IN PLACE behind the common code -- two instantiations chosen by
+// a branch per super-step left 24-66 register moves at every merge (339 v_mov_b32 in the batch loop of round 3's kernel)
+template <int NU, bool DIAG>
 __device__ __forceinline__ void onchip_actions(const ActionConsts<float, NU>& ac, const OnChipRow<NU>& row, int orow, bool null_in_wave,
-                                               float (&z)[Stream<NU>::P4 * 4], float (&v)[Stream<NU>::P4 * 4]) {
+                                               float (&z)[Stream<NU>::P4 * 4], float (&v)[Stream<NU>::P4 * 4], bool esc) {
   if constexpr (DIAG) {
 #pragma unroll
     for (int f = 0; f < Stream<NU>::P4 * 4; ++f) v[f] = fmaf(z[f], ac.sd[f % NU], row.um[f]);   // mppi.py:201-206, :380
@@ -119,39 +121,52 @@ __device__ __forceinline__ void onchip_actions(const ActionConsts<float, NU>& ac
     float w = v[f];
     w = clampT(w, ac.lo[n], ac.hi[n]);                                  // :383
     v[f] = w;
-    z[f] = ESC ? (w - row.ue[f]) * ac.e_scale : w - row.ue[f];          // :385 (SMPPI :544)
+    z[f] = w - row.ue[f];                                               // :385
+  }
+  if (esc) {
+#pragma unroll
+    for (int f = 0; f < Stream<NU>::P4 * 4; ++f) z[f] *= ac.e_scale;    // SMPPI :544
   }
 }
 
-// PLAIN: no |noise| cost, u_scale == 1, no SMPPI terms (the common case, wave-uniform): no select and no multiply per control
-template <class Model, bool PLAIN>
+// plain (wave-uniform): no |noise| cost, u_scale == 1, no SMPPI terms -- the common case; the extras are applied in place under
+// the flag (one code path: no merge copies)
+template <class Model>
 __device__ __forceinline__ void onchip_steps(const KArgs<float>& a, const ActionConsts<float, Model::NU>& ac, const Model& model,
                                              const OnChipRow<Model::NU>& row, int ss, const float (&e)[Stream<Model::NU>::P4 * 4],
                                              const float (&v)[Stream<Model::NU>::P4 * 4], float (&x)[Model::NX], float (&vprev)[Model::NU],
-                                             float& rollout, float& pert) {
+                                             float& rollout, float& pert, bool plain) {
   constexpr int NU = Model::NU, TT = Stream<NU>::TT;
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     const int t = ss * TT + tt;
     if (t < a.Tn) {
-      if (!PLAIN && a.smooth_w != 0.f) {
-        // SMPPI smoothness cost w * |u_scale * (v[t] - v[t-1])|^2 (mppi.py:559-562), as rollout_step has it
-        float d2 = 0.f;
-#pragma unroll
-        for (int n = 0; n < NU; ++n) {
-          const float d = v[tt * NU + n] - vprev[n];
-          d2 = fmaf(d, d, d2);
-          vprev[n] = v[tt * NU + n];
-        }
-        if (t > 0) rollout = fmaf(a.smooth_w, d2, rollout);
-      }
-      float u[NU];
+      float u[NU], en[NU];
 #pragma unroll
       for (int n = 0; n < NU; ++n) {
-        const float en = e[tt * NU + n];
-        pert = fmaf(row.g[tt * NU + n], (!PLAIN && ac.abs_cost) ? fabsf(en) : en, pert);   // :409, :415
-        u[n] = PLAIN ? v[tt * NU + n] : a.u_scale * v[tt * NU + n];     // :313
+        u[n] = v[tt * NU + n];
+        en[n] = e[tt * NU + n];
       }
+      if (!plain) {
+        if (a.smooth_w != 0.f) {
+          // SMPPI smoothness cost w * |u_scale * (v[t] - v[t-1])|^2 (mppi.py:559-562), as rollout_step has it
+          float d2 = 0.f;
+#pragma unroll
+          for (int n = 0; n < NU; ++n) {
+            const float d = u[n] - vprev[n];
+            d2 = fmaf(d, d, d2);
+            vprev[n] = u[n];
+          }
+          if (t > 0) rollout = fmaf(a.smooth_w, d2, rollout);
+        }
+#pragma unroll
+        for (int n = 0; n < NU; ++n) {
+          en[n] = ac.abs_cost ? fabsf(en[n]) : en[n];
+          u[n] *= a.u_scale;                                             // :313
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NU; ++n) pert = fmaf(row.g[tt * NU + n], en[n], pert);   // :409, :415
       model.step(x, u, t);                                              // :314
       rollout += model.cost(x, u, t);                                   // :318-319
     }
@@ -258,13 +273,8 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
 #endif
       OnChipRow<NU> row;
       row.load(tb, ss < nss ? ss : nss - 1, true);
-      if (plain) {
-        onchip_actions<NU, DIAG>(ac, row, orow, null_in_wave, zb[b], vb[b]);
-        onchip_steps<Model, true>(a, ac, model, row, ss, zb[b], vb[b], x, vprev, rollout, pert);
-      } else {
-        onchip_actions<NU, DIAG, true>(ac, row, orow, null_in_wave, zb[b], vb[b]);
-        onchip_steps<Model, false>(a, ac, model, row, ss, zb[b], vb[b], x, vprev, rollout, pert);
-      }
+      onchip_actions<NU, DIAG>(ac, row, orow, null_in_wave, zb[b], vb[b], !plain);
+      onchip_steps<Model>(a, ac, model, row, ss, zb[b], vb[b], x, vprev, rollout, pert, plain);
     }
 #if defined(MPPI_ONCHIP_EXP) && (MPPI_ONCHIP_EXP & 4)      // experiment: nothing kept
     continue;
@@ -358,8 +368,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
           for (int s = 0; s < RG; ++s) {
             OnChipRow<NU> row;
             row.load(tb, (ss0 + s) < nss ? ss0 + s : nss - 1, false);
-            if (plain) onchip_actions<NU, DIAG>(ac, row, orow, null_in_wave, zg[s], vg);
-            else onchip_actions<NU, DIAG, true>(ac, row, orow, null_in_wave, zg[s], vg);
+            onchip_actions<NU, DIAG>(ac, row, orow, null_in_wave, zg[s], vg, !plain);
 #pragma unroll
             for (int i = 0; i < P4; ++i)
 #pragma unroll
