@@ -181,6 +181,17 @@ int mppi_noise_fill_philox(const MppiProblem* p, void* z_tnk4, void* stream);
  * HBM-bound kernels).  MPPI_E_UNSUPPORTED for control widths without a compiled instantiation. */
 int mppi_noise_fill_philox_coloured(const MppiProblem* p, void* eps_tnk4, void* stream);
 
+/* rng = "torch" (the reference's own draw, mppi.py:203 `torch.randn(K, T, nu)` on the controller's device, fp32): the VALUES
+ * that call would produce from generator state (seed, philox_offset), written straight into a TNK4 array of row pitch
+ * `pitch` (>= K, in rows-of-4) -- bit for bit what ATen's normal_ kernel computes (Philox4x32-10 keyed `seed`, subsequence
+ * = thread index, rocrand's Box-Muller; thread idx of 256 * grid_blocks threads gives element idx + 256 grid_blocks (4 m +
+ * i) component i of its m-th block), enumerated by destination.  `grid_blocks` is ATen's launch grid for that call:
+ * min(multiProcessorCount * (maxThreadsPerMultiProcessor / 256), ceil(K T nu / 256)); the CALLER advances the generator by
+ * ((K T nu - 1) / (1024 grid_blocks) + 1) * 4 like ATen does, so that every later draw of the process is unchanged.
+ * Needs (T nu) % 4 == 0; MPPI_E_UNSUPPORTED otherwise (draw with torch.randn and use MPPI_NOISE_KTN / mppi_noise_from_ktn). */
+int mppi_noise_fill_torch(void* z_tnk4, int64_t K, int32_t T, int32_t nu, int64_t pitch, uint64_t seed, uint64_t philox_offset,
+                          int32_t grid_blocks, void* stream);
+
 /* Test / debug seam: the process-noise normals the fused multi-rollout K1 (rollout_samples M in 2..4, p->process_noise_sd
  * set) draws in-kernel for command p->call -- its own Philox key (seed ^ tag), counter (sample, (t*4 + m)*ceil(nx/4) +
  * block, call) -- written to `out` as (M,K,T,nx) row-major.  Generated by the same device function the kernel calls, so a

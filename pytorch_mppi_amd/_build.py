@@ -17,7 +17,7 @@ SUFFIX = os.environ.get("MPPI_LIB_SUFFIX", "")
 LIB = os.path.join(HERE, f"libmppi_amd{SUFFIX}.so")
 OBJ_DIR = os.path.join(CSRC, "build" + SUFFIX)
 SOURCES = ["capi.hip", "dist.hip", "update.hip", "rollout_pendulum.hip", "rollout_integrator.hip",
-           "rollout_linear_goal.hip", "rollout_mlp.hip", "rollout_mlp_mfma.hip", "rollout_mlp_split.hip"]
+           "rollout_linear_goal.hip", "rollout_mlp.hip", "rollout_mlp_mfma.hip", "rollout_mlp_split.hip", "noise_torch.hip"]
 # translation units: (source, object name, extra flags).  The two heaviest sources are compiled as several units each
 # (groups of model dimensions selected with a define) so that the parallel build is not one long compile
 _GROUPS = {"rollout_integrator.hip": ("MPPI_INTEGRATOR_GROUP", 4), "rollout_linear_goal.hip": ("MPPI_LINEAR_GROUP", 3),
@@ -56,7 +56,10 @@ EXTRA = {"update.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
          # the KMPPI-fused K1 (rollout_kmppi.hpp) pins 256 control points in the AGPRs and reads its 4 x nu
          # accumulator tile with the VALU: same flag for every unit that instantiates it (jit.py passes it too)
          "rollout_integrator.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-         "rollout_linear_goal.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+         "rollout_linear_goal.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+         # the torch.randn stream, bit for bit: rocrand's Box-Muller with the contraction rule the library itself is built
+         # with (a later -ffp-contract wins; with =fast one value in ~10^5 differs from torch's in its last bit)
+         "noise_torch.hip": ["-ffp-contract=on"]}
 K1_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]     # for translation units built around csrc/rollout.hpp (jit.py)
 # heavy user models (jit.py) only: the SLP vectorizer pairs the products of a traced network into v_pk_mul_f32 before fp
 # contraction sees them (570 mul + add pairs instead of fmas in a 3700-operation step); packed fp32 arithmetic is no faster

@@ -62,6 +62,7 @@ SYMBOLS = {
     "mppi_model_supported": (C.c_int, [C.c_int32] * 5),
     "mppi_noise_fill_philox": (C.c_int, [_PP, _vp, _vp]),
     "mppi_noise_fill_philox_coloured": (C.c_int, [_PP, _vp, _vp]),
+    "mppi_noise_fill_torch": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _vp]),
     "mppi_noise_from_ktn": (C.c_int, [_PP, _vp, _vp, _vp]),
     "mppi_process_noise_export": (C.c_int, [_PP, _vp, _vp]),
     "mppi_kmppi_interp": (C.c_int, [_PP, _vp, _vp]),

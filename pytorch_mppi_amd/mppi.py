@@ -32,6 +32,7 @@ from .models import MLPResidual, NativeModel, native_model_of
 logger = logging.getLogger(__name__)
 
 _DT = {torch.float32: N.F32, torch.float64: N.F64}
+_TORCH_ROWS = {}     # rng="torch": (device, K, T, nu) -> did csrc/noise_torch.hip reproduce torch.randn bit for bit (MPPI._torch_stream_fill)
 
 
 class SpecificActionSampler:
@@ -210,6 +211,10 @@ class MPPI:
         self.philox_onchip = None
         self._onchip_refused = False
         self.ktn_direct = os.environ.get("MPPI_KTN_DIRECT", "1") != "0"   # rng="torch": read (K,T,nu) in place when possible
+        # rng="torch": compute torch.randn's values straight into the engine's rows (see _torch_stream_fill); off: call
+        # torch.randn and read / convert its (K,T,nu) array
+        self.torch_rows = os.environ.get("MPPI_TORCH_ROWS", "1") != "0"
+        self._in_capture = False
         self._force_collective = False
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self._call = 0
@@ -762,6 +767,8 @@ class MPPI:
                 raise ValueError(f"injected noise has shape {tuple(z.shape)}, expected {(K, Tn, nu)}")
             z = z.contiguous()
         elif self.rng == "torch":
+            if self.torch_rows and self._torch_stream_fill(p, K, Tn, nu):
+                return                                                    # the same values, already in the engine's rows
             z = self._randn(K, Tn, nu)                                    # mppi.py:203
         elif self.rng == "torch-native":
             # same generator, drawn straight into the engine's sample-minor layout: no conversion
@@ -826,6 +833,60 @@ class MPPI:
             p.z = _ptr(z)
             return
         self._convert_noise(p)
+
+    def _torch_stream_fill(self, p, K, Tn, nu):
+        """rng="torch": the values `torch.randn(K, Tn, nu)` would produce from the generator's present state, written by
+        the engine's own launch straight into the rows K1 / K3 stream (csrc/noise_torch.hip, `mppi_noise_fill_torch`),
+        and the generator advanced exactly as that call advances it -- every draw of the process, before and after, is
+        what it would have been.  The first draw of every shape is compared with torch.randn itself, bit for bit, and
+        the generator's offset with ATen's rule; a disagreement (another torch, another rocrand) switches this off for
+        the process and the command draws with torch.randn as before.  False: not applicable here."""
+        if (self.dtype != torch.float32 or (Tn * nu) % 4 or self.d.type != "cuda" or self._in_capture
+                or _TORCH_ROWS.get("off")):
+            return False
+        gen = self._shard_gen if self._shard_gen is not None else torch.cuda.default_generators[self._dev_index]
+        numel = K * Tn * nu
+        cap = _TORCH_ROWS.get(("cap", self._dev_index))
+        if cap is None:
+            props = torch.cuda.get_device_properties(self._dev_index)
+            cap = _TORCH_ROWS[("cap", self._dev_index)] = props.multi_processor_count * (props.max_threads_per_multi_processor // 256)
+        grid = min(cap, (numel + 255) // 256)
+        inc = ((numel - 1) // (1024 * grid) + 1) * 4
+        lib = N.lib()
+        zn = self._row_buffer(self._zelems(Tn))
+        pitch = self._zpitch()
+        key = (self._dev_index, K, Tn, nu)
+        if key not in _TORCH_ROWS:
+            # once per shape and process: is this what torch.randn does here?
+            state = gen.get_state()
+            seed, off = gen.initial_seed(), gen.get_offset()
+            ref = torch.randn(K, Tn, nu, device=self.d, dtype=self.dtype, generator=gen)
+            moved = gen.get_offset() - off
+            gen.set_state(state)
+            rc = lib.mppi_noise_fill_torch(_ptr(zn), K, Tn, nu, pitch, seed, off, grid, self._stream())
+            ok = rc == 0 and moved == inc
+            if ok:
+                rows = zn.view(-1, pitch, 4)[:, :K, :].permute(1, 0, 2).reshape(K, Tn, nu)
+                ok = torch.equal(rows, ref)
+            _TORCH_ROWS[key] = ok
+            if not ok:
+                import logging
+                _TORCH_ROWS["off"] = True
+                logging.getLogger("pytorch_mppi_amd").warning(
+                    "pytorch_mppi_amd: torch.randn(%d, %d, %d) is not the stream csrc/noise_torch.hip reproduces (rc %d, generator "
+                    "offset +%d against +%d expected): rng='torch' keeps drawing with torch.randn", K, Tn, nu, rc, moved, inc)
+                return False
+        elif not _TORCH_ROWS[key]:
+            return False
+        off = gen.get_offset()
+        N.check(lib.mppi_noise_fill_torch(_ptr(zn), K, Tn, nu, pitch, gen.initial_seed(), off, grid, self._stream()),
+                "mppi_noise_fill_torch")
+        gen.set_offset(off + inc)
+        p.noise_src = N.NOISE_TNK4
+        p.z = _ptr(zn)
+        p._keep["z"] = zn
+        self.last_draw = "torch-rows"
+        return True
 
     def _onchip_wanted(self, K, Tn, nu):
         """rng="philox": does this command go without a row array (include/mppi_amd.h, ABI 18; scope as checked again by
@@ -1362,6 +1423,15 @@ class GraphedCommand:
 
     def __init__(self, ctrl, state, shift, warmup):
         self.ctrl = ctrl
+        # rng="torch": torch.randn registers its generator with the graph and replays advance it; the engine's own launch of
+        # the same values (MPPI._torch_stream_fill) takes the generator's offset as an argument, which a graph would freeze
+        ctrl._in_capture = True
+        try:
+            self._capture(ctrl, state, shift, warmup)
+        finally:
+            ctrl._in_capture = False
+
+    def _capture(self, ctrl, state, shift, warmup):
         self.state = ctrl._to_state(state).clone()
         self.U = ctrl.U.detach().to(device=ctrl.d, dtype=ctrl.dtype).clone().contiguous()
         ctrl.U = self.U

@@ -42,12 +42,13 @@ def device_process_normals(ctrl, call):
     return out.cpu()
 
 
-def consumed_normals(ctrl, p=None):
+def consumed_normals(ctrl, p=None, Tn=None):
     """The standard normals the last command's kernels read from memory, as a (K_local,T,nu) host tensor: the torch draw
-    (read in place or converted) or the engine's stored Philox rows."""
+    (read in place, converted, or computed straight into the rows) or the engine's stored Philox rows.  Tn: the length of
+    the sampled sequence when it is not the horizon (KMPPI's support points)."""
     from pytorch_mppi_amd import _native as N
     p = p or ctrl._last
-    K, T, nu = ctrl.K_local, ctrl.T, ctrl.nu
+    K, T, nu = ctrl.K_local, int(Tn or ctrl.T), ctrl.nu
     if "z_ktn" in p._keep and int(p.noise_src) == N.NOISE_KTN:
         return p._keep["z_ktn"].cpu()
     assert not int(p.noise_coloured)

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 import pytorch_mppi_amd as pm
+import gpu_util
 
 pytestmark = pytest.mark.gpu
 
@@ -83,12 +84,18 @@ def test_sharded_torch_modes_draw_rank_distinct_samples_without_a_process_group(
     x = torch.ones(6, device="cuda")
     torch.manual_seed(0)
     ps = [c._begin(x, True) for c in cs]
-    assert not torch.equal(ps[0]._keep["z_ktn"], ps[1]._keep["z_ktn"])
+    assert all(c.last_draw == "torch-rows" for c in cs)           # the shard's generator, the engine's launch
+    draw = lambda c, p: gpu_util.consumed_normals(c, p)
+    assert not torch.equal(draw(cs[0], ps[0]), draw(cs[1], ps[1]))
     # and the draw is reproducible for a given (seed, rank)
     c0 = pm.MPPI(m.dynamics, m.running_cost, 6, torch.eye(4), num_samples=512, horizon=8, device="cuda", lambda_=10.0,
                  U_init=torch.zeros(8, 4), rng="torch", seed=7, shard=(0, 2))
     p0 = c0._begin(x, True)
-    assert torch.equal(p0._keep["z_ktn"], ps[0]._keep["z_ktn"])
+    assert torch.equal(draw(c0, p0), draw(cs[0], ps[0]))
+    # ... and it is the draw torch.randn makes from that generator
+    g = torch.Generator(device="cuda")
+    g.manual_seed(c0._shard_gen.initial_seed())
+    assert torch.equal(draw(c0, p0), torch.randn(256, 8, 4, device="cuda", generator=g).cpu())
 
 
 @pytest.mark.parametrize("path", ["fused", "generic"])

@@ -59,6 +59,7 @@ def _setup(cfg):
     return model, mk, sigma, kw, x0, U0
 
 
+TORCH_ROWS = True   # rng="torch": the engine computes torch.randn's values into its rows | False = torch.randn's own (K,T,nu) array
 ONCHIP = None      # rng="philox": None = the controller's own choice | False = the streaming command (rows in memory)
 
 
@@ -67,6 +68,7 @@ def _controller(cfg, model, sigma, kw, U0, lam, rng, shard=None, K=None):
     c = pm.MPPI(model.dynamics, model.running_cost, cfg["nx"], sigma, num_samples=K or cfg["K"], horizon=cfg["T"],
                 device="cuda", lambda_=lam, U_init=U0.clone(), rng=rng, seed=4321, shard=shard, **kw)
     c.philox_onchip = ONCHIP
+    c.torch_rows = TORCH_ROWS
     return c
 
 
@@ -194,13 +196,33 @@ def test_c3_quadtoy_65536x64_philox_on_chip(regime):
 
 @pytest.mark.parametrize("regime", ["healthy", "peaked"])
 def test_c3_quadtoy_65536x64_torch_draw_read_in_place(regime):
+    """torch.randn's own (K,T,nu) array (what injected noise runs, and rng="torch" where the engine's launch does not apply)"""
     import pytorch_mppi_amd  # noqa: F401
     from pytorch_mppi_amd import _native as N
+    global TORCH_ROWS
+    TORCH_ROWS = False
+    try:
+        model, mk, sigma, kw, x0, U0 = _setup(C3)
+        probe = _controller(C3, model, sigma, kw, U0, 1.0, "torch")
+        probe.command(x0.cuda())
+        assert int(probe._last.noise_src) == N.NOISE_KTN, "torch.randn's array at C3 must take the in-place (K,T,nu) kernels"
+        _run_case(C3, "torch", regime, None)
+    finally:
+        TORCH_ROWS = True
+
+
+@pytest.mark.parametrize("regime", ["healthy", "peaked"])
+def test_c3_quadtoy_65536x64_torch_stream_in_the_engines_rows(regime):
+    """the drop-in default since round 4: torch.randn's values computed by the engine's launch (csrc/noise_torch.hip) straight
+    into the rows, K1 / K3 as the row kernels; the consumed draw IS torch.randn(K, T, nu) of the seed (bit for bit)"""
+    torch.manual_seed(31)
+    ref = torch.randn(C3["K"], C3["T"], C3["nu"], device="cuda")
     model, mk, sigma, kw, x0, U0 = _setup(C3)
-    probe = _controller(C3, model, sigma, kw, U0, 1.0, "torch")
-    probe.command(x0.cuda())
-    assert int(probe._last.noise_src) == N.NOISE_KTN, "rng='torch' at C3 must take the in-place (K,T,nu) kernels"
-    _run_case(C3, "torch", regime, None)
+    c = _controller(C3, model, sigma, kw, U0, 1.0, "torch")
+    torch.manual_seed(31)
+    c.command(x0.cuda())
+    assert c.last_draw == "torch-rows" and torch.equal(_consumed_normals(c), ref.cpu())
+    _run_case(C3, "torch", regime, "torch-rows")
 
 
 @pytest.mark.parametrize("regime", ["healthy", "peaked"])
@@ -354,7 +376,8 @@ def test_c3_shape_kmppi_65536x64_s32_interpolation_inside_k1(rng, regime):
     act = ctrl.command(x0.cuda())
     assert lib.mppi_stat_kmppi_fused_rollouts() == n0 + 1, "the interpolation did not run inside K1"
     if rng == "torch":
-        z = ctrl._last_theta._keep["z_ktn"].cpu()
+        assert ctrl.last_draw == "torch-rows"
+        z = gpu_util.consumed_normals(ctrl, ctrl._last_theta, Tn=S)
     else:
         z = gpu_util.device_philox_normals(ctrl, int(ctrl._last.call), Tn=S)     # the support-point draw, as consumed
         assert float((z - torch.from_numpy(oph.normals_ktn(4321, int(ctrl._last.call), K, S, nu))).abs().max()) <= 4e-6

@@ -1,0 +1,142 @@
+"""rng="torch" (the drop-in default): the values of the reference's own draw (mppi.py:203 `torch.randn(K, T, nu)`) are computed
+by the engine's own launch straight into its sample-minor rows (csrc/noise_torch.hip, `mppi_noise_fill_torch`; MPPI._torch_stream_fill).
+What has to hold, bit for bit because it is the SAME arithmetic:
+  * the rows are torch.randn's values for the same generator state, for shapes on both sides of ATen's grid cap, ragged K, every
+    control width with (T nu) % 4 == 0;
+  * the generator ends where torch.randn would have left it: every later draw of the process is unchanged;
+  * a controller on this path reports the reference's noise (`ctrl.noise`) for the seed, and commands the same actions as the same
+    controller reading torch.randn's own array (torch_rows = False);
+  * where it does not apply ((T nu) % 4 != 0, fp64, graph capture) the command draws with torch.randn as before."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(65536, 64, 12), (8192, 32, 4), (1000, 30, 4), (77, 9, 4), (100000, 16, 8), (4096, 32, 12), (3, 1, 4), (50000, 15, 12),
+          (513, 10, 2), (2049, 4, 1), (30011, 20, 6)]
+
+
+def _grid(numel):
+    props = torch.cuda.get_device_properties(0)
+    return min(props.multi_processor_count * (props.max_threads_per_multi_processor // 256), (numel + 255) // 256)
+
+
+@pytest.mark.parametrize("K,T,nu", SHAPES)
+def test_rows_are_torch_randn_bit_for_bit(K, T, nu):
+    from pytorch_mppi_amd import _native as N
+    dev = torch.device("cuda", 0)
+    torch.cuda.init()
+    gen = torch.cuda.default_generators[0]
+    torch.manual_seed(1234 + K)
+    torch.randn(7, device=dev)                               # the generator is somewhere in its stream
+    seed, off = gen.initial_seed(), gen.get_offset()
+    ref = torch.randn(K, T, nu, device=dev)
+    moved = gen.get_offset() - off
+    numel = K * T * nu
+    grid = _grid(numel)
+    assert moved == ((numel - 1) // (1024 * grid) + 1) * 4    # ATen's increment: what the caller of the C entry must add
+    pitch = N.noise_pitch(K, N.F32)
+    z = torch.full((T * nu // 4, pitch, 4), float("nan"), device=dev)
+    rc = N.lib().mppi_noise_fill_torch(z.data_ptr(), K, T, nu, pitch, seed, off, grid, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    got = z[:, :K, :].permute(1, 0, 2).reshape(K, T, nu)
+    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {numel} values differ"
+
+
+def test_unsupported_shapes_are_refused():
+    from pytorch_mppi_amd import _native as N
+    z = torch.empty(4096, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert N.lib().mppi_noise_fill_torch(z.data_ptr(), 10, 3, 3, 64, 1, 0, 1, st) == N.E_UNSUPPORTED      # (T nu) % 4 != 0
+    assert N.lib().mppi_noise_fill_torch(z.data_ptr(), 100, 2, 2, 64, 1, 0, 1, st) == N.E_UNSUPPORTED     # pitch < K
+    assert N.lib().mppi_noise_fill_torch(None, 10, 2, 2, 64, 1, 0, 1, st) == -1            # MPPI_E_BADARG
+
+
+def _ctrl(cls, K, T, nx, nu, rows, sigma=None, **kw):
+    import pytorch_mppi_amd as pm
+    model = pm.models.Integrator(nx, nu)
+    g = torch.Generator().manual_seed(3)
+    sigma = torch.eye(nu) * 0.6 if sigma is None else sigma
+    extra = dict(U_init=torch.randn(T, nu, generator=g) * 0.1) if cls == "MPPI" else {}
+    if cls == "KMPPI":
+        extra = dict(num_support_pts=kw.pop("num_support_pts", 8))
+    c = getattr(pm, cls)(model.dynamics, model.running_cost, nx, sigma, num_samples=K, horizon=T, device="cuda", lambda_=2.0,
+                         **extra, **kw)
+    c.torch_rows = rows
+    return c
+
+
+@pytest.mark.parametrize("cls,K,T,nx,nu,kw", [
+    ("MPPI", 65536, 64, 16, 12, {}),
+    ("MPPI", 3000, 20, 8, 4, dict(sample_null_action=True, u_min=torch.tensor([-0.4] * 4), u_max=torch.tensor([0.5] * 4))),
+    ("MPPI", 5000, 16, 8, 4, dict(noise_sigma_full=True)),
+    ("SMPPI", 4000, 24, 8, 4, {}),
+    ("KMPPI", 4000, 32, 8, 4, {}),
+])
+def test_controller_on_the_engines_rows_is_the_controller_on_torch_randn(cls, K, T, nx, nu, kw):
+    kw = dict(kw)
+    if kw.pop("noise_sigma_full", False):
+        A = torch.randn(nu, nu, generator=torch.Generator().manual_seed(8)) * 0.2
+        kw["sigma"] = A @ A.T + 0.3 * torch.eye(nu)
+    x = torch.linspace(-1, 1, nx, device="cuda")
+    out = {}
+    for rows in (True, False):
+        c = _ctrl(cls, K, T, nx, nu, rows, **kw)
+        torch.manual_seed(77)
+        acts = []
+        for _ in range(3):
+            acts.append(c.command(x).clone())
+            if rows:
+                assert c.last_draw == "torch-rows", c.last_draw
+            else:
+                assert c.last_draw is None
+        tail = torch.randn(9, device="cuda")                 # where did the command leave the generator?
+        out[rows] = (torch.stack(acts), c.noise.clone(), c.cost_total.clone(), tail)
+    a, b = out[True], out[False]
+    assert torch.equal(a[3], b[3]), "the generator must end where torch.randn leaves it"
+    # the same standard normals; with bounds `noise` is clamp(U + eps) - U, evaluated by two different kernels (one rounding apart)
+    assert float((a[1] - b[1]).abs().max()) <= (1e-6 if "u_min" in kw else 0.0), "ctrl.noise must be the colouring of the same standard normals"
+    scale = float(b[2].abs().max())
+    assert float((a[2] - b[2]).abs().max()) <= 1e-5 * scale
+    assert float((a[0] - b[0]).abs().max()) <= 1e-5 * max(1.0, float(b[0].abs().max()))
+
+
+def test_the_draw_is_the_references_draw_for_the_seed():
+    """mppi.py:203 through the reference's own distribution object is torch.randn(K, T, nu) @ chol + mu: for a diagonal
+    Sigma, `ctrl.noise` / sigma must be torch.randn(K, T, nu) of the same seed."""
+    K, T, nx, nu = 2048, 12, 8, 4
+    c = _ctrl("MPPI", K, T, nx, nu, True)
+    torch.manual_seed(2024)
+    c.command(torch.zeros(nx, device="cuda"))
+    assert c.last_draw == "torch-rows"
+    torch.manual_seed(2024)
+    ref = torch.randn(K, T, nu, device="cuda") * (0.6 ** 0.5)
+    assert float((c.noise - ref).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("why", ["shape", "fp64", "capture"])
+def test_where_it_does_not_apply_the_command_draws_with_torch_randn(why):
+    import pytorch_mppi_amd as pm
+    nx, nu, T = 6, (3 if why == "shape" else 4), (5 if why == "shape" else 8)
+    model = pm.models.Integrator(nx, nu)
+    dt = torch.float64 if why == "fp64" else torch.float32
+    c = pm.MPPI(model.dynamics, model.running_cost, nx, torch.eye(nu, dtype=dt) * 0.5, num_samples=1024, horizon=T, device="cuda")
+    x = torch.zeros(nx, device="cuda", dtype=dt)
+    if why == "capture":
+        g = c.capture_command(x)
+        torch.manual_seed(4)
+        a = g(x).clone()
+        b = g(x).clone()
+        assert not torch.equal(a, b), "replays must advance the generator"
+        assert c.last_draw is None
+        c.command(x)
+        assert c.last_draw == "torch-rows"                   # outside the graph the controller is back on its rows
+        return
+    torch.manual_seed(4)
+    c.command(x)
+    assert c.last_draw is None
+    torch.manual_seed(4)
+    ref = torch.randn(1024, T, nu, device="cuda", dtype=dt) * (0.5 ** 0.5)
+    assert float((c.noise - ref).abs().max()) <= 1e-6
