@@ -842,7 +842,10 @@ class MPPI:
         the generator's offset with ATen's rule; a disagreement (another torch, another rocrand) switches this off for
         the process and the command draws with torch.randn as before.  False: not applicable here."""
         if (self.dtype != torch.float32 or (Tn * nu) % 4 or self.d.type != "cuda" or self._in_capture
-                or _TORCH_ROWS.get("off")):
+                or _TORCH_ROWS.get("off") or torch.cuda.is_current_stream_capturing()):
+            # (a capture: torch.randn registers its generator with the graph and replays advance it; the offset this launch
+            # takes as an argument would be frozen -- capture_command() says so itself, a user's own torch.cuda.graph() is
+            # caught by the query)
             return False
         gen = self._shard_gen if self._shard_gen is not None else torch.cuda.default_generators[self._dev_index]
         numel = K * Tn * nu
@@ -864,6 +867,9 @@ class MPPI:
             moved = gen.get_offset() - off
             gen.set_state(state)
             rc = lib.mppi_noise_fill_torch(_ptr(zn), K, Tn, nu, pitch, seed, off, grid, self._stream())
+            if rc == N.E_UNSUPPORTED:
+                _TORCH_ROWS[key] = False           # a shape the launch does not take (more than 65535 rows-of-4): torch.randn
+                return False
             ok = rc == 0 and moved == inc
             if ok:
                 rows = zn.view(-1, pitch, 4)[:, :K, :].permute(1, 0, 2).reshape(K, Tn, nu)

@@ -140,3 +140,19 @@ def test_where_it_does_not_apply_the_command_draws_with_torch_randn(why):
     torch.manual_seed(4)
     ref = torch.randn(1024, T, nu, device="cuda", dtype=dt) * (0.5 ** 0.5)
     assert float((c.noise - ref).abs().max()) <= 1e-6
+
+
+def test_a_users_own_graph_capture_is_noticed():
+    """`with torch.cuda.graph(g): ctrl.command(x)` written by the user: the offset argument of the engine's launch would be frozen
+    in the graph, torch.randn's registered generator is not -- the path must step aside by itself."""
+    c = _ctrl("MPPI", 1024, 8, 6, 4, True)
+    x = torch.zeros(6, device="cuda")
+    c.command(x)
+    assert c.last_draw == "torch-rows"
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            took = c._torch_stream_fill(c._problem(), 1024, 8, 4)
+    assert took is False
