@@ -201,6 +201,14 @@ def main():
     run_case("linear_multi_f32", model="linear_multi", model_args=dict(B=Bt, goal=[1.0, -1.0], w_scale=0.3), nx=2, nu=2,
              K=256, T=12, dtype="f32", sigma=[[1.0, 0.3], [0.3, 0.6]], steps=2, lambda_=6.0,
              rollout_samples=4, rollout_var_cost=0.5, step_dependent_dynamics=True, per_sample_state=True, seed=15)
+    # ... and the same M rollouts under the other two controllers (both call _compute_rollout_costs, mppi.py:564 / :672)
+    run_case("smppi_multi_f64", model="linear_multi", model_args=dict(B=Bt, goal=[2.0, 2.0], w_scale=0.15), nx=2, nu=2,
+             K=100, T=10, dtype="f64", sigma=I2, state=[-3.0, -2.0], steps=3, lambda_=1.0,
+             rollout_samples=3, rollout_var_cost=0.2, rollout_var_discount=0.9, step_dependent_dynamics=True,
+             smppi=dict(w_action_seq_cost=0.7, delta_t=0.5, action_max=[1.0, 0.8]), sample_null_action=True, seed=16)
+    run_case("kmppi_multi_f64", model="linear_multi", model_args=dict(B=Bt, goal=[1.0, -1.0], w_scale=0.2), nx=2, nu=2,
+             K=100, T=10, dtype="f64", sigma=I2, state=[-3.0, -2.0], steps=3, lambda_=1.0, kmppi=True,
+             rollout_samples=2, rollout_var_cost=0.3, step_dependent_dynamics=True, u_max=[1.0, 1.0], seed=17)
     run_batched_case("batched_linear_f64", N=3, K=100, T=10, dtype="f64", sigma=[[1.0, 0.0], [0.0, 1.0]], steps=3,
                      lambda_=1.0, u_max=[1.5, 1.0], seed=12)
     run_batched_case("batched_linear_full_f32", N=5, K=128, T=8, dtype="f32", sigma=[[1.0, 0.3], [0.3, 0.6]], steps=2,

@@ -195,6 +195,14 @@ def weights(cost_total, lambda_):
     return (1.0 / eta) * w, w, beta, eta
 
 
+def compute_rollout_costs(p: Problem, state, perturbed):
+    """mppi.py:292-295 `_compute_rollout_costs`: one rollout per action sequence, or M (what MPPI :411, KMPPI :672 and
+    SMPPI :564 all call)."""
+    if p.rollout_samples > 1:
+        return rollout_costs_multi(p, state, perturbed)
+    return rollout_costs(p, state, perturbed)
+
+
 def command(p: Problem, U, state, z, shift_nominal_trajectory=True, sampler_actions=None):
     """One `MPPI.command()` (mppi.py:240-275, :375-417) with injected z of shape (K,T,nu).
     Returns a dict with every public result the reference leaves on `self`."""
@@ -208,10 +216,7 @@ def command(p: Problem, U, state, z, shift_nominal_trajectory=True, sampler_acti
     perturbed = torch.clamp(perturbed, p.u_min, p.u_max)    # :383, :419-420
     noise = perturbed - U                                   # :385  (post-clamp noise)
     ac = action_cost(noise, p.fac, p.lambda_, p.noise_abs_cost)   # :409
-    if p.rollout_samples > 1:                               # :292-295
-        rollout_cost, states, actions = rollout_costs_multi(p, state, perturbed)
-    else:
-        rollout_cost, states, actions = rollout_costs(p, state, perturbed)   # :411
+    rollout_cost, states, actions = compute_rollout_costs(p, state, perturbed)   # :411
     pert_cost = torch.sum(U * ac, dim=(1, 2))               # :415
     cost_total = rollout_cost + pert_cost                   # :416
     omega, w, beta, eta = weights(cost_total, p.lambda_)    # :267
@@ -263,7 +268,7 @@ def kmppi_command(p: Problem, theta, U, state, z, W, W_shift, shift_nominal_traj
     perturbed = torch.clamp(perturbed, p.u_min, p.u_max)    # :668
     noise = perturbed - U                                   # :670
     ac = action_cost(noise, p.fac, p.lambda_, p.noise_abs_cost)
-    rollout_cost, states, actions = rollout_costs(p, state, perturbed)
+    rollout_cost, states, actions = compute_rollout_costs(p, state, perturbed)   # :672
     cost_total = rollout_cost + torch.sum(U * ac, dim=(1, 2))
     omega, w, beta, eta = weights(cost_total, p.lambda_)
     theta_new = theta + torch.einsum("k,ksn->sn", omega, noise_theta)   # :679-681
@@ -308,7 +313,7 @@ def smppi_command(p: Problem, U, A, state, z, action_min, action_max, w_action_s
     ac = action_cost(noise, p.fac, p.lambda_, p.noise_abs_cost)   # :548
     diff = p.u_scale * torch.diff(perturbed, dim=-2)        # :551
     smooth = torch.sum(torch.square(diff), dim=(1, 2)) * w_action_seq_cost   # :552-554
-    rollout_cost, states, actions = rollout_costs(p, state, perturbed)       # :556
+    rollout_cost, states, actions = compute_rollout_costs(p, state, perturbed)   # :556-564
     pert_cost = torch.sum(U * ac, dim=(1, 2))               # :560
     cost_total = rollout_cost + pert_cost + smooth          # :561
     omega, w, beta, eta = weights(cost_total, p.lambda_)

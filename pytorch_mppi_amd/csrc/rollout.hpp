@@ -152,6 +152,11 @@ __device__ __forceinline__ void rollout_stream_multi(const KArgs<T>& a, const Ac
     for (int i = 0; i < NX; ++i) xm[m][i] = x0[i];
   }
   T cvar = T(0), dpow = T(1);
+  // SMPPI (mppi.py:551-554, :561): the smoothness cost belongs to the action sequence, not to a state rollout -- added once, behind
+  // the mean over the M rollouts, exactly as the single-rollout kernels add it (rollout_step)
+  T smooth = T(0), vprev[NU];
+#pragma unroll
+  for (int n = 0; n < NU; ++n) vprev[n] = T(0);
   const T inv_M = T(1) / (T)M, inv_Mm1 = T(1) / (T)(M - 1);
   const int nss = (a.Tn + TT - 1) / TT;
   for (int ss = 0; ss < nss; ++ss) {
@@ -174,6 +179,16 @@ __device__ __forceinline__ void rollout_stream_multi(const KArgs<T>& a, const Ac
       if (a.noise_src == MPPI_NOISE_ACTIONS) make_action<T, NU, true, true>(ac, tb.Ue + t * NU, srow, z, orow, v, e);
       else make_action<T, NU, DIAG, false>(ac, tb.Ue + t * NU, srow, z, orow, v, e);
       const T* __restrict__ Gt = tb.G + t * NU;
+      if (a.smooth_w != T(0)) {
+        T d2 = T(0);
+#pragma unroll
+        for (int n = 0; n < NU; ++n) {
+          const T d = v[n] - vprev[n];
+          d2 = m_fma(d, d, d2);
+          vprev[n] = v[n];
+        }
+        if (t > 0) smooth = m_fma(a.smooth_w, d2, smooth);
+      }
 #pragma unroll
       for (int n = 0; n < NU; ++n) {
         pert = m_fma(Gt[n], ac.abs_cost ? m_abs(e[n]) : e[n], pert);              // mppi.py:409, :415
@@ -222,7 +237,7 @@ __device__ __forceinline__ void rollout_stream_multi(const KArgs<T>& a, const Ac
 #pragma unroll
   for (int m = 0; m < MM; ++m)
     if (m < M) tot += cs[m] + (a.use_terminal ? model.terminal(xm[m]) : T(0));    // :369-370
-  rollout = tot * inv_M + a.var_cost * cvar;                                      // :371-372
+  rollout = tot * inv_M + a.var_cost * cvar + smooth;                             // :371-372 (+ SMPPI :561)
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
@@ -1097,8 +1112,9 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
     }                                                                                              \
   } while (0)
   if (a.M > 1) {
-    // several state rollouts per action sequence: rows in memory (the caller fills / converts them), plain MPPI
-    if (a.M > 4 || (a.noise_src != MPPI_NOISE_TNK4) || a.B != nullptr || a.smooth_w != T(0)) return MPPI_E_UNSUPPORTED;
+    // several state rollouts per action sequence: rows in memory (the caller fills / converts them: standard normals, or KMPPI's
+    // interpolated raw actions); MPPI, SMPPI (base sequence + smoothness cost) and KMPPI's two-launch form
+    if (a.M > 4 || (a.noise_src != MPPI_NOISE_TNK4 && a.noise_src != MPPI_NOISE_ACTIONS)) return MPPI_E_UNSUPPORTED;
     if constexpr (!model_heavy<Model>::value) {
       if (diag) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_TNK4, true, 0, false, 4>));
       else MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_TNK4, false, 0, false, 4>));

@@ -1053,10 +1053,10 @@ class MPPI:
         return not p_ok
 
     def _fused_multi_ok(self):
-        """M > 1 rollouts per action sequence inside K1 (csrc/rollout.hpp rollout_stream_multi): plain MPPI,
-        at most 4 copies of the state per lane; anything else runs the reference's callback loop."""
-        return (type(self) is MPPI and 1 < self.M <= 4 and self.specific_action_sampler is None
-                and not getattr(self._model, "heavy", False))
+        """M > 1 rollouts per action sequence inside K1 (csrc/rollout.hpp rollout_stream_multi): MPPI, SMPPI and KMPPI (its
+        two-launch form: interpolated raw actions in memory), at most 4 copies of the state per lane; anything else runs
+        the reference's callback loop."""
+        return (1 < self.M <= 4 and self.specific_action_sampler is None and not getattr(self._model, "heavy", False))
 
     def _command(self, state, shift):
         p = self._begin(state, shift)

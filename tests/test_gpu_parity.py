@@ -502,6 +502,62 @@ def test_fused_multi_rollout_matches_oracle(case):
         c.U = U.to(dt).cuda()
 
 
+@pytest.mark.parametrize("cls,dtname,M", [("SMPPI", "f32", 3), ("SMPPI", "f64", 2), ("KMPPI", "f32", 3), ("KMPPI", "f64", 4)])
+def test_fused_multi_rollout_smppi_and_kmppi_match_oracle(cls, dtname, M):
+    """rollout_samples M > 1 inside K1 for the other two controllers (round 4; VERDICT r03 missing #5): SMPPI -- base sequence A + U dt,
+    bounded noise rescaled by 1/dt, the smoothness cost added once behind the mean over the M rollouts (mppi.py:540-561 around
+    :334-373) -- and KMPPI in its two-launch form (interpolated raw actions in memory, mppi.py:657-688).  Against the fp64 / fp32
+    oracle fed the SAME action draws and the SAME process-noise draws, two commands in a row."""
+    import pytorch_mppi_amd as pm
+    from oracle import mppi_oracle as orc, dynamics as dyn
+    dt = torch.float64 if dtname == "f64" else torch.float32
+    g = torch.Generator().manual_seed(7 * M + len(cls))
+    nx, nu, K, T, S = 6, 4, 1300, 16, 8
+    m = pm.models.Integrator(nx, nu)
+    base, q2 = dyn.make_quadtoy(nx, nu)
+    sd = torch.linspace(0.05, 0.2, nx, dtype=torch.float64)
+    m.with_process_noise(sd)
+    sigma = torch.diag(torch.linspace(0.5, 1.2, nu, dtype=torch.float64))
+    x0 = torch.randn(nx, generator=g, dtype=torch.float64)
+    kw = dict(lambda_=7.0, sample_null_action=True, rollout_samples=M, rollout_var_cost=0.4, rollout_var_discount=0.85)
+    if cls == "SMPPI":
+        amax = torch.full((nu,), 0.9, dtype=torch.float64)
+        w_, dt_ = 0.6, 0.5
+        c = pm.SMPPI(m.dynamics, m.running_cost, nx, sigma.to(dt), num_samples=K, horizon=T, device="cuda", rng="philox", seed=41,
+                     action_min=-amax.to(dt), action_max=amax.to(dt), w_action_seq_cost=w_, delta_t=dt_, **kw)
+    else:
+        kw["u_max"] = torch.full((nu,), 1.1, dtype=torch.float64)
+        c = pm.KMPPI(m.dynamics, m.running_cost, nx, sigma.to(dt), num_samples=K, horizon=T, device="cuda", rng="philox", seed=41,
+                     num_support_pts=S, kernel=pm.RBFKernel(sigma=1.5), U_init=torch.zeros(T, nu, dtype=dt),
+                     **{k: (v.to(dt) if torch.is_tensor(v) else v) for k, v in kw.items()})
+        W, W_shift, _, _ = orc.kmppi_matrices(T, S, torch.float64, kernel=lambda t, tk: orc.rbf_kernel(t, tk, sigma=1.5))
+    assert not c._needs_generic(), "M > 1 with a native model must take the fused kernel"
+    U = torch.zeros(T, nu, dtype=torch.float64)
+    A = torch.zeros(T, nu, dtype=torch.float64)
+    theta = torch.zeros(S, nu, dtype=torch.float64)
+    tol = 1e-9 if dt == torch.float64 else 1e-5
+    for call in (1, 2):
+        z = gpu_util.device_philox_normals(c, call, Tn=(S if cls == "KMPPI" else None)).double()
+        w = gpu_util.device_process_normals(c, call).double()
+        f64 = dyn.with_injected_process_noise(base, w, sd)
+        p = orc.Problem(dynamics=f64, running_cost=lambda s_, a_, t_: q2(s_, a_), nx=nx, noise_sigma=sigma, K=K, T=T,
+                        step_dependent_dynamics=True, **kw)
+        a = c.command(x0.to(dt).cuda())
+        assert not c._needs_generic()
+        if cls == "SMPPI":
+            r = orc.smppi_command(p, U, A, x0, z, -amax, amax, w_, dt_, True)
+            U, A = r["U"], r["action_sequence"]
+            _assert_close(c.action_sequence, A.numpy(), tol, f"{cls} call {call} action_sequence")
+            c.U, c.action_sequence = U.to(dt).cuda(), A.to(dt).cuda()
+        else:
+            r = orc.kmppi_command(p, theta, U, x0, z, W, W_shift, True)
+            theta, U = r["theta"], r["U"]
+            _assert_close(c.theta, theta.numpy(), tol, f"{cls} call {call} theta")
+            c.theta, c.U = theta.to(dt).cuda(), U.to(dt).cuda()
+        _assert_close(c.cost_total, r["cost_total"].numpy(), tol, f"{cls} call {call} cost_total")
+        _assert_close(a, r["action"].numpy(), tol, f"{cls} call {call} action")
+
+
 @pytest.mark.parametrize("nx,nu,K,T,S,rng", [
     (16, 12, 4096, 64, 32, "philox"),     # the C3-shaped case: every support point present, 128 control points per lane in LDS
     (16, 12, 1000, 64, 32, "torch"),      # ragged K, rows from memory
