@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 19
+#define MPPI_ABI_VERSION 20
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -150,6 +150,12 @@ typedef struct MppiProblem {
   /* ---- scratch ---- */
   void* workspace;            /* >= mppi_workspace_elems() elements of dtype               */
   int64_t workspace_elems;
+  void* onchip_spill;         /* the on-chip form of mppi_command (noise_src = PHILOX, z = NULL), ABI 20: where the bounded noise
+                                 that fits neither registers nor LDS waits for its sample's weight -- stored once behind the
+                                 rollout, fetched once in the weighting phase -- instead of being GENERATED a second time;
+                                 mppi_onchip_spill_elems() elements, contents meaningless between commands.  NULL: generate twice
+                                 (the ABI 18 behaviour)                                                              [opt] */
+  int64_t onchip_spill_elems;
 } MppiProblem;
 
 int mppi_abi_version(void);
@@ -167,6 +173,11 @@ int64_t mppi_noise_pitch(int32_t K, int32_t dtype);
 
 /* elements of dtype the workspace must hold for this problem */
 int64_t mppi_workspace_elems(const MppiProblem* p);
+
+/* elements of dtype p->onchip_spill needs for the on-chip command to generate nothing twice (0: fp64, or everything fits on chip);
+ * at C3 (K = 65536, T = 64, nu = 12): 87 of the sample's 192 rows-of-4 wait there (105 stay in registers and LDS), in whole
+ * weighting tiles: 90 rows x K x 16 B = 94 MB */
+int64_t mppi_onchip_spill_elems(const MppiProblem* p);
 
 /* 1 if a fused rollout kernel exists for (model_id, nx, nu, dtype, hidden), else 0 */
 int mppi_model_supported(int32_t model_id, int32_t nx, int32_t nu, int32_t dtype, int32_t hidden);

@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
@@ -46,6 +46,7 @@ class MppiProblem(C.Structure):
         ("action_out", _vp), ("perturbed_action", _vp), ("noise", _vp), ("pert_cost", _vp),
         ("states", _vp), ("record", _vp),
         ("workspace", _vp), ("workspace_elems", C.c_int64),
+        ("onchip_spill", _vp), ("onchip_spill_elems", C.c_int64),
     ]
 
 
@@ -59,6 +60,7 @@ SYMBOLS = {
     "mppi_noise_rows4": (C.c_int64, [C.c_int32, C.c_int32]),
     "mppi_noise_pitch": (C.c_int64, [C.c_int32, C.c_int32]),
     "mppi_workspace_elems": (C.c_int64, [_PP]),
+    "mppi_onchip_spill_elems": (C.c_int64, [_PP]),
     "mppi_model_supported": (C.c_int, [C.c_int32] * 5),
     "mppi_noise_fill_philox": (C.c_int, [_PP, _vp, _vp]),
     "mppi_noise_fill_philox_coloured": (C.c_int, [_PP, _vp, _vp]),

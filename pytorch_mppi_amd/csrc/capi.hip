@@ -228,6 +228,8 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.noise_src = p->noise_src; a.u_per_command = p->u_per_command; a.hidden = p->hidden;
   a.coloured = p->noise_coloured != 0;
   a.model_flags = p->model_flags;
+  a.spill = (T*)p->onchip_spill;
+  a.spill_cap = p->onchip_spill != nullptr ? p->onchip_spill_elems : 0;
   a.lambda_ = (T)p->lambda_; a.u_scale = (T)p->u_scale;
   a.e_scale = (T)(p->noise_rescale == 0.0 ? 1.0 : p->noise_rescale); a.smooth_w = (T)p->smooth_weight;
   a.seed = p->seed; a.call = p->call;
@@ -602,6 +604,14 @@ extern "C" int mppi_command_kmppi(const MppiProblem* p, const MppiProblem* theta
   return mppi_finalize(theta_problem, apply, stream);
 }
 extern "C" int64_t mppi_stat_kmppi_onchip_updates(void) { return g_kmppi_onchip_updates.load(); }
+
+extern "C" int64_t mppi_onchip_spill_elems(const MppiProblem* p) {
+  if (p == nullptr || p->dtype != MPPI_F32 || p->K <= 0 || p->T <= 0 || p->nu <= 0) return 0;
+  const mppi::OnChipGeometry g = mppi::onchip_geometry(p->nu, p->T, p->sigma_diagonal != 0);
+  if (!g.ok || g.nsm <= 0) return 0;
+  const int64_t nkc = (p->K + mppi::BLOCK - 1) / mppi::BLOCK;
+  return (int64_t)g.nsm * g.P4 * nkc * mppi::BLOCK * 4;
+}
 
 extern "C" int mppi_command(const MppiProblem* p, int apply, void* stream) {
   // small problems: K1's launch carries K3 and K4 as well when the caller left omega and

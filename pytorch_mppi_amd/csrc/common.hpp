@@ -49,6 +49,8 @@ struct KArgs {
                                 //   record {beta_b, eta_b, P_b[S*nu]} per 256 samples, on-chip carve with row stride kw_jpad
   int kw_jpad;
   int model_flags;              // MPPI_MODEL_FLAG_* (include/mppi_amd.h)
+  T* spill;                     // on-chip command (rollout_onchip.hpp): where bounded noise that fits neither registers nor LDS waits for
+  long long spill_cap;          //   its sample's weight, [row][padded sample][4], spill_cap elements; null / 0: generated a second time
 };
 
 // Measurement hook (mppi_profile_enable, capi.hip): every workgroup stamps its entry and its exit on the device's wall clock
@@ -67,6 +69,52 @@ __device__ __forceinline__ void stamp_entry(unsigned long long* ts) {
 __device__ __forceinline__ void stamp_exit(unsigned long long* ts) {      // call behind a block barrier: the last wave's exit
   if (ts != nullptr && threadIdx.x == 0)
     atomicMax(&ts[2 * ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & (STAMP_SLOTS - 1)) + 1], (unsigned long long)wall_clock64());
+}
+
+#ifndef MPPI_ONCHIP_NTA
+#define MPPI_ONCHIP_NTA 5   // weighting tiles the on-chip command keeps in registers (csrc/rollout_onchip.hpp OnChip<NU>::NTA)
+#endif
+// LDS carve of the kernel (floats): Ue[Jp] Um[Jp] G[Jp] | red[4] | ex[4][ntiles*64] | keepL[nsl*P4][256][4],
+// Jp = the horizon padded to whole super-steps (a multiple of 4: every part starts on a 16-byte boundary)
+struct OnChipLds {
+  int Jp, ntiles, nsl, P4, nfac;     // nfac: 2 * nu * nu (chol(Sigma) | Sigma^-1) for a full Sigma, else 0
+  __host__ __device__ int tables() const { return 3 * Jp + 4 + ((nfac + 3) & ~3); }
+  __host__ __device__ int ex() const { return 4 * ntiles * 64; }
+  __host__ __device__ size_t bytes() const { return ((size_t)tables() + ex()) * 4 + (size_t)nsl * P4 * 256 * 16; }
+};
+
+// Where the rows of a sample wait for its weight, as a function of (nu, horizon): the first AG_SS super-steps in registers, the next
+// `nsl` (whole weighting tiles, as many as fit the 160 KB beside the tables) in LDS, the remaining `nsm` (whole tiles, the horizon's
+// last partial one included) in the caller's spill array if there is one -- else they are generated a second time.  One function for
+// the launcher and for mppi_onchip_spill_elems (the size a caller allocates); the constants are OnChip<NU>'s, restated at run time.
+struct OnChipGeometry {
+  int P4, TT, SW, AG_SS, nss, ntiles, nsl, nsm;
+  size_t smem;
+  bool ok;
+};
+static inline OnChipGeometry onchip_geometry(int nu, int Tn, bool diag) {
+  OnChipGeometry g{};
+  const int G = (nu % 4 == 0) ? 4 : ((nu % 2 == 0) ? 2 : 1);
+  g.P4 = nu / G;
+  g.TT = 4 / G;
+  g.SW = (16 / g.P4) > 0 ? (16 / g.P4) : 1;
+  g.AG_SS = MPPI_ONCHIP_NTA * g.SW;
+  const int RG = g.P4 >= 3 ? 1 : (g.P4 == 2 ? 2 : 4);
+  g.nss = (Tn + g.TT - 1) / g.TT;
+  g.ntiles = (g.nss + g.SW - 1) / g.SW;
+  OnChipLds L{g.nss * g.P4 * 4, g.ntiles, 0, g.P4, diag ? 0 : 2 * nu * nu};
+  g.ok = g.P4 <= 16 && (g.SW % RG) == 0 && L.bytes() <= 160 * 1024;
+  if (!g.ok) return g;
+  const long long room = (160 * 1024 - (long long)L.bytes()) / ((long long)g.P4 * 256 * 16);
+  int nsl = g.nss - g.AG_SS;
+  if (nsl < 0) nsl = 0;
+  if (nsl > room) nsl = (int)room;
+  nsl -= nsl % g.SW;
+  L.nsl = g.nsl = nsl;
+  g.nsm = g.ntiles * g.SW - g.AG_SS - nsl;
+  if (g.nsm < 0) g.nsm = 0;
+  g.smem = L.bytes();
+  return g;
 }
 
 // the workspace of an on-chip command: one partial record per 256-sample workgroup

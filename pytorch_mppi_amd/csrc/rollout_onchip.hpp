@@ -38,9 +38,7 @@ struct OnChip {
   static constexpr int SW = (16 / P4) > 0 ? (16 / P4) : 1;       // super-steps per weighting tile
   static constexpr int TRW = SW * P4;                            // rows per tile (15 for nu = 12, else <= 16)
   static constexpr int TC = TRW * 4;                             // columns per tile (<= 64)
-#ifndef MPPI_ONCHIP_NTA
-#define MPPI_ONCHIP_NTA 5   // measured at C3: 4 tiles 82.8 us | 5 tiles 81.1 (214 VGPRs) | 6 tiles 80.9 with scratch (profiles/r03_onchip_parts.txt)
-#endif
+  // (MPPI_ONCHIP_NTA: common.hpp -- measured at C3: 4 tiles 82.8 us | 5 tiles 81.1 (214 VGPRs) | 6 tiles 80.9 with scratch, profiles/r03_onchip_parts.txt)
   static constexpr int NTA = MPPI_ONCHIP_NTA;                    // tiles kept in registers (the first 256 values: accumulation registers)
   static constexpr int AG_SS = NTA * SW, AG_ROWS = AG_SS * P4;   // 75 or 80 rows: 256 values in accumulation registers, the rest in VGPRs
   static constexpr int RG = P4 >= 3 ? 1 : (P4 == 2 ? 2 : 4);     // super-steps regenerated together (>= 3 interleaved chains)
@@ -173,17 +171,8 @@ __device__ __forceinline__ void onchip_steps(const KArgs<float>& a, const Action
   }
 }
 
-// LDS carve of the kernel (floats): Ue[Jp] Um[Jp] G[Jp] | red[4] | ex[4][ntiles*64] | keepL[nsl*P4][256][4],
-// Jp = the horizon padded to whole super-steps (a multiple of 4: every part starts on a 16-byte boundary)
-struct OnChipLds {
-  int Jp, ntiles, nsl, P4, nfac;     // nfac: 2 * nu * nu (chol(Sigma) | Sigma^-1) for a full Sigma, else 0
-  __host__ __device__ int tables() const { return 3 * Jp + 4 + ((nfac + 3) & ~3); }
-  __host__ __device__ int ex() const { return 4 * ntiles * 64; }
-  __host__ __device__ size_t bytes() const { return ((size_t)tables() + ex()) * 4 + (size_t)nsl * P4 * 256 * 16; }
-};
-
 template <class Model, bool DIAG>
-__global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<float> a, const int nsl) {
+__global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<float> a, const int nsl, const int nsm) {
   using T = float;
   constexpr int NX = Model::NX, NU = Model::NU;
   using OC = OnChip<NU>;
@@ -243,6 +232,10 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
   }
   const StepTables<T> tb{Ue, Um, G, nullptr, kraw - lane};
   const long long kg = a.k_offset + k;
+  // super-steps [M0, M1) wait in memory (a.spill: [row][padded sample][4], one coalesced 16-byte store / load per lane and row)
+  const int M0 = AG_SS + nsl, M1 = M0 + nsm;
+  float4* __restrict__ spill4 = reinterpret_cast<float4*>(a.spill) + kraw;
+  const long long Kp = (long long)gridDim.x * K1_BLOCK;
   const bool null_in_wave = __any(orow == -1);
   const bool plain = !a.abs_cost && a.u_scale == 1.f && a.e_scale == 1.f && a.smooth_w == 0.f;
   T vprev[NU];
@@ -282,10 +275,18 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
     // keep eps': accumulation registers (static index -> a chain of uniform compares over the batch), then LDS
     auto keep_lds = [&](int b) {
       const int ss = bi * PB + b;
-      if (ss >= AG_SS && ss < AG_SS + nsl) {
-#pragma unroll
+      if (ss >= AG_SS && ss < M0) {
+        asm volatile("; keep in LDS");          // (distinct markers: merged into one store through a generic pointer the two branches
+#pragma unroll                                  //  become flat_store instructions, which wait on both memory counters)
         for (int i = 0; i < P4; ++i)
           keepL[((ss - AG_SS) * P4 + i) * K1_BLOCK + threadIdx.x] = make_float4(zb[b][4 * i], zb[b][4 * i + 1], zb[b][4 * i + 2], zb[b][4 * i + 3]);
+        asm volatile("; kept in LDS" ::: "memory");
+      } else if (ss >= M0 && ss < M1) {
+        asm volatile("; keep in memory");
+#pragma unroll
+        for (int i = 0; i < P4; ++i)
+          spill4[(long long)((ss - M0) * P4 + i) * Kp] = make_float4(zb[b][4 * i], zb[b][4 * i + 1], zb[b][4 * i + 2], zb[b][4 * i + 3]);
+        asm volatile("; kept in memory" ::: "memory");
       }
     };
     bool done = false;
@@ -326,34 +327,92 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
   const T eta_b = block_sum<T>(wk, red);
   // a wave whose weights are all EXACTLY zero (fp32 exp underflow: a peaked softmax) adds exactly nothing
   const bool live = __ballot(wk != T(0)) != 0ull;
-  for (int tile = 0; tile < ntiles; ++tile) {
-    if (!live) { ex[(wv * ntiles + tile) * 64 + lane] = T(0); continue; }
+  // Tiles by where their rows waited, each kind in its own loop (what is live in one -- the kept registers, the generator's
+  // constants -- is dead in the others; one loop over all tiles with the source chosen inside spilled 26 VGPRs):
+  //   A  [0, tA)      kept in registers; the tile that holds the VGPR-kept values goes first (its registers take the fetched rows)
+  //   B  [tA, tB)     kept in LDS                          (nsl is a whole number of tiles)
+  //   C  [tB, tC)     waited in memory                     (nsm is a whole number of tiles; rows past the horizon read as zero)
+  //   D  [tC, ntiles) generated a second time              (the rest: memory and the generator work side by side)
+  // The memory tiles are not a loop of their own: ONE of them is in flight at any time, fetched into `pf`, and it is consumed --
+  // and the next one fetched -- between the tiles of A, B and D once ~3 us of their arithmetic has gone by (`work`: a tile of
+  // column sums counts 1, a tile generated again 3; a fetch of 15.7 MB chip-wide takes ~3.3 us).  Measured at C3: everything
+  // beyond LDS generated again 76 us, everything fetched behind a loop of its own 77 us (the chip idles on HBM for 20 us), interleaved
+  // see profiles/r04_onchip_spill.txt.
+  const int tA = ntiles < NTA ? ntiles : NTA;
+  const int tB = tA + nsl / SW < ntiles ? tA + nsl / SW : ntiles;
+  const int tC = tB + nsm / SW < ntiles ? tB + nsm / SW : ntiles;
+  auto column_sums = [&](int tile, const T (&e)[TRW][4]) __attribute__((always_inline)) {
+    T acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = i < TC ? wk * e[(i < TC ? i : 0) / 4][i % 4] : T(0);
+    ex[(wv * ntiles + tile) * 64 + lane] = wave_reduce_transpose64<float>(acc);
+  };
+  float4 pf[TRW];
+  int mt = tB, work = 0;                                                 // the memory tile in flight (mt < tC), arithmetic since its fetch
+  auto fetch = [&](int tile) __attribute__((always_inline)) {                                           // tile in [tB, tC): super-steps M0 + (tile - tB) SW ...
+#pragma unroll
+    for (int i = 0; i < TRW; ++i) pf[i] = spill4[(long long)((tile - tB) * TRW + i) * Kp];
+  };
+  auto consume = [&]() __attribute__((always_inline)) {                                                 // the tile in flight -> column sums; the next one takes off
+    T acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int r = (i < TC ? i : 0) / 4, q = i % 4;
+      const float v = q == 0 ? pf[r].x : q == 1 ? pf[r].y : q == 2 ? pf[r].z : pf[r].w;
+      acc[i] = i < TC ? (mt * SW + r / P4 < nss ? wk * v : T(0)) : T(0);
+    }
+    const int tile = mt++;
+    if (mt < tC) fetch(mt);
+    ex[(wv * ntiles + tile) * 64 + lane] = wave_reduce_transpose64<float>(acc);
+    work = 0;
+  };
+  auto from_registers = [&](int tile) __attribute__((always_inline)) {
     T e[TRW][4];
-    bool got = false;
     static_for<0, NTA>([&](auto tt) {
       constexpr int TI = decltype(tt)::value;
       if (tile == TI) {
-#pragma unroll
+        asm volatile("; register tile %0" ::"n"(TI));                    // (distinct per branch: the branches must not be merged into
+#pragma unroll                                                           //  one copy indexed by `tile` -- that puts keepA in scratch)
         for (int i = 0; i < TRW; ++i)
 #pragma unroll
           for (int q = 0; q < 4; ++q) e[i][q] = keepA[(TI * TRW + i) * 4 + q];
-        got = true;
       }
     });
-    if (!got) {
+    column_sums(tile, e);
+  };
+  if (!live) {
+    for (int tile = 0; tile < ntiles; ++tile) ex[(wv * ntiles + tile) * 64 + lane] = T(0);
+  } else {
+    if (tA == NTA) from_registers(NTA - 1);                              // A: the tile with the VGPR-kept values
+    if (mt < tC) fetch(mt);
+    for (int tile = 0; tile < (tA == NTA ? NTA - 1 : tA); ++tile) {      // A: the rest
+      from_registers(tile);
+      if (++work >= 3 && mt < tC) consume();
+    }
+    for (int tile = tA; tile < tB; ++tile) {                             // B
+      T e[TRW][4];
+#pragma unroll
+      for (int i = 0; i < TRW; ++i) {
+        const float4 q4 = keepL[((tile - tA) * TRW + i) * K1_BLOCK + threadIdx.x];
+        e[i][0] = q4.x; e[i][1] = q4.y; e[i][2] = q4.z; e[i][3] = q4.w;
+      }
+      column_sums(tile, e);
+      if (++work >= 3 && mt < tC) consume();
+    }
+    // (the generator's sample index is made up again here instead of living in two registers through the whole kernel: the
+    //  LinearGoal<12,4> instantiation spilled exactly those two)
+    int kd = blockIdx.x * K1_BLOCK + threadIdx.x;
+    asm volatile("" : "+v"(kd));
+    const long long kgd = a.k_offset + (kd < a.K ? kd : a.K - 1);
+    for (int tile = tC; tile < ntiles; ++tile) {                         // D
+      T e[TRW][4];
 #pragma unroll
       for (int g = 0; g < SW / RG; ++g) {
         const int ss0 = tile * SW + g * RG;
-        if (ss0 < AG_SS + nsl) {                                         // kept in LDS (nsl is a multiple of RG)
-#pragma unroll
-          for (int i = 0; i < RG * P4; ++i) {
-            const float4 q4 = keepL[((ss0 - AG_SS) * P4 + i) * K1_BLOCK + threadIdx.x];
-            e[g * RG * P4 + i][0] = q4.x; e[g * RG * P4 + i][1] = q4.y; e[g * RG * P4 + i][2] = q4.z; e[g * RG * P4 + i][3] = q4.w;
-          }
 #if defined(MPPI_ONCHIP_EXP) && (MPPI_ONCHIP_EXP & 2)      // experiment: no second generation (zeros instead)
-        } else if (ss0 < 0) {
+        if (ss0 < 0) {
 #else
-        } else if (ss0 < nss) {                                          // generated a second time
+        if (ss0 < nss) {
 #endif
           T zg[RG][P4 * 4], vg[P4 * 4];
 #pragma unroll
@@ -361,7 +420,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
 #pragma unroll
             for (int i = 0; i < P4; ++i) {
               T r[4];
-              philox_normal4<T>(a.seed, a.call, kg, (long long)(ss0 + s) * P4 + i, r);
+              philox_normal4<T>(a.seed, a.call, kgd, (long long)(ss0 + s) * P4 + i, r);
               zg[s][4 * i + 0] = r[0]; zg[s][4 * i + 1] = r[1]; zg[s][4 * i + 2] = r[2]; zg[s][4 * i + 3] = r[3];
             }
 #pragma unroll
@@ -379,11 +438,11 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
           for (int i = 0; i < RG * P4; ++i) e[g * RG * P4 + i][0] = e[g * RG * P4 + i][1] = e[g * RG * P4 + i][2] = e[g * RG * P4 + i][3] = T(0);
         }
       }
+      column_sums(tile, e);
+      work += 3;
+      if (mt < tC) consume();
     }
-    T acc[64];
-#pragma unroll
-    for (int i = 0; i < 64; ++i) acc[i] = i < TC ? wk * e[(i < TC ? i : 0) / 4][i % 4] : T(0);
-    ex[(wv * ntiles + tile) * 64 + lane] = wave_reduce_transpose64<float>(acc);
+    while (mt < tC) consume();                                           // C: what the other tiles' arithmetic did not cover
   }
   __syncthreads();
   // one combine over the four waves, in wave order; column j = tile * TC + c
@@ -431,26 +490,30 @@ static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
     using OC = OnChip<NU>;
     KArgs<T> a = a_in;
     onchip_carve(a);
-    const int nss = (a.Tn + OC::TT - 1) / OC::TT;
-    const int ntiles = (nss + OC::SW - 1) / OC::SW;
     const bool diag = a.diag != 0;
-    OnChipLds L{nss * OC::P4 * 4, ntiles, 0, OC::P4, diag ? 0 : 2 * NU * NU};
-    if (L.bytes() > 160 * 1024) return -1;
-    const long long room = (160 * 1024 - (long long)L.bytes()) / ((long long)OC::P4 * 256 * 16);
-    int nsl = nss - OC::AG_SS;
-    if (nsl < 0) nsl = 0;
-    if (nsl > room) nsl = (int)room;
-    nsl -= nsl % OC::RG;
-    L.nsl = nsl;
-    const size_t smem = L.bytes();
+    const OnChipGeometry g = onchip_geometry(NU, a.Tn, diag);
+    static_assert(OC::OK, "onchip_model_ok");
+    if (!g.ok || g.P4 != OC::P4 || g.TT != OC::TT || g.SW != OC::SW || g.AG_SS != OC::AG_SS) return -1;
+    const int nsl = g.nsl;
+    // what fits neither registers nor LDS waits in a.spill when the caller provides one (else it is generated a second time)
+    static const int spill_max = [] { const char* e = getenv("MPPI_ONCHIP_SPILL_SS"); return e ? atoi(e) : 1 << 30; }();
+    int nsm = 0;
+    if (a.spill != nullptr && spill_max > 0) {
+      const long long rows = a.spill_cap / ((long long)a.nkc * K1_BLOCK * 4);
+      nsm = g.nsm;
+      if (nsm > rows / OC::P4) nsm = (int)(rows / OC::P4);
+      if (nsm > spill_max) nsm = spill_max;
+      nsm -= nsm % OC::SW;
+    }
+    const size_t smem = g.smem;
     const dim3 grid(a.nkc), block(K1_BLOCK);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     profile_next_events(&ev0, &ev1, &a.tstamp);
 #define MPPI_ONCHIP_LAUNCH(KERNEL)                                                                                  \
   do {                                                                                                              \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    if (ev1 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a, nsl);                  \
-    else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, a, nsl);                                                 \
+    if (ev1 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a, nsl, nsm);             \
+    else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, a, nsl, nsm);                                            \
   } while (0)
     if (diag) MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, true>));
 #ifdef MPPI_ONCHIP_FULL_SIGMA

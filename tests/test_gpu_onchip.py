@@ -113,6 +113,47 @@ def test_onchip_command_matches_streaming_command_and_fp64_oracle(case):
     assert _onchip_count() - n0 == 3, "every command of the first controller ran in the on-chip form"
 
 
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-nx{c[1]}-nu{c[2]}-K{c[3]}-T{c[4]}" for c in CASES])
+def test_rows_waiting_in_memory_change_no_bit(case):
+    """ABI 20: the rows that fit neither registers nor LDS WAIT in `onchip_spill` (stored behind the rollout, fetched in the
+    weighting phase) instead of being generated a second time.  The same values enter the same column sums in the same order:
+    every output is bit for bit what the twice-generating form gives, over every storage class of the kernel, bounds, the
+    null-action row, short horizons (nothing to spill: no array), shift on / off."""
+    from pytorch_mppi_amd import _native as N
+    kind, nx, nu, K, T, kw = case
+    kw = dict(kw)
+    sig = kw.pop("sigma", None)
+    a, _, _, _ = _make(kind, nx, nu, K, T, True, lam=25.0, sigma=sig, **kw)
+    b, _, _, _ = _make(kind, nx, nu, K, T, True, lam=25.0, sigma=sig, **kw)
+    a.onchip_spill, b.onchip_spill = True, False
+    x0 = torch.randn(nx, generator=torch.Generator().manual_seed(3)).cuda()
+    for shift in (True, False, True):
+        ua, ub = a.command(x0, shift_nominal_trajectory=shift), b.command(x0, shift_nominal_trajectory=shift)
+        assert a.last_draw == b.last_draw == "philox-onchip"
+        assert int(N.lib().mppi_last_command_form()) == N.FORM_ONCHIP
+        for name, xa, xb in (("action", ua, ub), ("U", a.U, b.U), ("cost_total", a.cost_total, b.cost_total), ("omega", a.omega, b.omega)):
+            assert torch.equal(xa, xb), (name, shift, float((xa - xb).abs().max()))
+    want = int(N.lib().mppi_onchip_spill_elems(a._last))
+    assert (a._spill[1] is None) == (want == 0) and b._spill is None
+    if want:
+        assert a._spill[1].numel() == want and int(a._last.onchip_spill) == a._spill[1].data_ptr()
+
+
+def test_spill_array_size_at_c3():
+    """87 of a sample's 192 rows-of-4 wait in memory at C3: 25 super-steps in registers, 10 in LDS, the other 29 -- as 6 whole
+    weighting tiles = 30 super-steps of 3 rows each, the horizon's last, partial tile included -- in the array: 90 rows x 65536
+    samples x 16 B."""
+    import ctypes as C
+    from pytorch_mppi_amd import _native as N
+    p = N.MppiProblem()
+    p.K, p.T, p.nx, p.nu, p.dtype, p.sigma_diagonal = 65536, 64, 16, 12, N.F32, 1
+    assert int(N.lib().mppi_onchip_spill_elems(C.byref(p))) == 90 * 65536 * 4
+    p.T = 20                                       # 20 super-steps: everything fits the registers
+    assert int(N.lib().mppi_onchip_spill_elems(C.byref(p))) == 0
+    p.T, p.dtype = 64, N.F64
+    assert int(N.lib().mppi_onchip_spill_elems(C.byref(p))) == 0
+
+
 def test_onchip_per_sample_states_and_terminal_cost():
     import pytorch_mppi_amd as pm
     nx, nu, K, T = 12, 4, 20000, 30

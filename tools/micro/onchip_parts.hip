@@ -31,6 +31,10 @@ int main(int argc, char** argv) {
   a.cost = dev(K, 0.f); a.block_min = dev(K / 64 + 4, 0.f); a.record = dev(2 + J, 0.f); a.U_out = dev(J, 0.f);
   const int nb = (K + 255) / 256;
   a.eta_part = dev((size_t)nb + (size_t)nb * J, 0.f); a.nkc = nb; a.R = 1;
+  if (getenv("MPPI_MICRO_SPILL")) {           // rows that fit neither registers nor LDS wait in memory instead of being generated twice
+    const long long cap = (long long)nb * 256 * 4 * 192;
+    (void)hipMalloc(&a.spill, cap * 4); a.spill_cap = cap;
+  }
   if (getenv("MPPI_MICRO_STAMPS")) { (void)hipMalloc(&mppi::g_ts, 16 * STAMP_SLOTS); (void)hipMemset(mppi::g_ts, 0, 16 * STAMP_SLOTS); }
   hipStream_t st; (void)hipStreamCreate(&st);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -44,7 +48,7 @@ int main(int argc, char** argv) {
   (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   float c0; (void)hipMemcpy(&c0, a.cost, 4, hipMemcpyDeviceToHost);
-  printf("%son-chip K1, K = %d, lambda %g, %s, knocked out = %2d (1 weighting | 2 second generation | 4 keeping | 8 rollout): %.1f us per launch (back to back)  cost[0] = %g\n",
-         mppi::g_ts ? "[stamps] " : "", K, a.lambda_, argc > 3 ? "no bounds" : "bounds +-2.5", MPPI_ONCHIP_EXP, ms / n * 1e3, c0);
+  printf("%s%son-chip K1, K = %d, lambda %g, %s, knocked out = %2d (1 weighting | 2 second generation | 4 keeping | 8 rollout): %.1f us per launch (back to back)  cost[0] = %g\n",
+         mppi::g_ts ? "[stamps] " : "", a.spill ? "[spill] " : "", K, a.lambda_, argc > 3 ? "no bounds" : "bounds +-2.5", MPPI_ONCHIP_EXP, ms / n * 1e3, c0);
   return 0;
 }
