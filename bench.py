@@ -250,7 +250,8 @@ def _pmc_lookup(key, kernel):
 
 
 def _onchip_valu_roofline(workload, k1_us):
-    """The headline kernel's own roofline: it moves 1.3 MB and is bound by VALU issue -- the generator.
+    """The headline kernel's own roofline: it is bound by VALU issue -- the generator -- and moves 187 MB
+    (the rows that wait in memory for their sample's weight: a third of what HBM could move in its time).
     From the committed SQ counter passes of this command (profiles/pmc_onchip_valu.json; a lookup, like `traffic`): VALU
     instructions per wave, the share of the wave's cycles in which the VALU is executing one (`frac`: what the kernel achieves
     of the one thing that bounds it -- a wave alone on its SIMD cannot issue while it waits for its own previous result,
@@ -268,6 +269,7 @@ def _onchip_valu_roofline(workload, k1_us):
             "cycles_per_valu_inst": 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"],
             "waiting_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stall_share": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
             "traffic_bytes": (2 * c["FETCH_SIZE_KiB"] + c["WRITE_SIZE_KiB"]) * 1024,
+            "hbm_share_of_8TBs": (2 * c["FETCH_SIZE_KiB"] + c["WRITE_SIZE_KiB"]) * 1024 / (k1_us * 1e-6) / 8e12 if k1_us else None,
             "source": "profiles/pmc_onchip_valu.json (rocprofv3 --pmc passes: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES, SQ_WAIT_*; "
                       "FETCH_SIZE doubled per the gfx950 note) -- a lookup; `issue_floor_us` = frac x this run's measured launch time"}
 
@@ -514,25 +516,28 @@ def main():
         roof_ctrl = cs
         oc_us = (oc_dev["avg"] + DISPATCH_OFFSET_US_ONCHIP) if oc_dev else 0.0
         ext_bytes = 4 * ctrl.K_local * T * nu + 4 * ctrl.K_local
+        spill_bytes = 4 * ctrl._spill[1].numel() if getattr(ctrl, "_spill", None) and ctrl._spill[1] is not None else 0
         onchip = {"kernel": "rollout_onchip_kernel (csrc/rollout_onchip.hpp) + finalize_blocks_kernel",
-                  "no_hbm_mode": True,
+                  "no_hbm_mode": spill_bytes == 0,
+                  "spill_array_bytes": spill_bytes,
                   "avg_launch_us": oc_us, "avg_launch_us_device_span": oc_dev["avg"] if oc_dev else None,
                   "launch_us_device_span": oc_dev, "avg_launch_us_hip_events": oc_ev["avg"] if oc_ev else None,
                   "dispatch_offset_us": DISPATCH_OFFSET_US_ONCHIP,
-                  "hbm_bytes_algorithmic": 4 * ctrl.K_local + 4 * (ctrl.K_local // 256 + 1) * (T * nu + 2),
+                  "hbm_bytes_algorithmic": 4 * ctrl.K_local + 4 * (ctrl.K_local // 256 + 1) * (T * nu + 2) + 2 * spill_bytes,
                   "traffic": _pmc_lookup(f"{args.workload}/philox-onchip", "rollout_onchip_kernel") if world == 1 else None,
                   "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                                    "profiles/r03_pmc_onchip_*.txt; a lookup, not measured in this run)",
+                                    "profiles/r04_spill_pmc_c3_fetch.txt / _write.txt; a lookup, not measured in this run)",
                   "external_z_equivalent_GBs": ext_bytes / (oc_us * 1e-6) / 1e9 if oc_us else None,
-                  "bound": "VALU: Philox4x32-10 + Box-Muller of the sample's T*nu normals (generated once, ~half of them a "
-                           "second time in the weighting phase: the rest stays in accumulation registers / LDS), ~80 % of the "
-                           "kernel (tools/micro/onchip_parts.hip, profiles/r03_onchip_parts.txt)",
+                  "bound": "VALU: Philox4x32-10 + Box-Muller of the sample's T*nu normals, generated ONCE; the bounded noise waits for "
+                           "its sample's weight in accumulation registers / LDS (105 of 192 rows at C3) and, since ABI 20, in the "
+                           "spill array (87 rows: stored once, fetched once, 2 x 94 MB against the streaming command's 604 MB) "
+                           "instead of being generated a second time (tools/micro/onchip_parts.hip, profiles/r04_onchip_spill.txt)",
                   "roofline": _onchip_valu_roofline(args.workload, oc_us) if world == 1 else None,
                   "streaming_form_ms_per_step": dts / args.steps * 1e3,
                   "speedup_vs_streaming_form": (dts / args.steps) / (dt / args.steps),
-                  "note": "SURVEY.md 8d: with the engine's generator inside K1 the algorithmic HBM bytes collapse to O(K) and the "
-                          "kernel is RNG-bound -- no bandwidth fraction is claimed for it; `roofline` below is the HBM-bound K1 "
-                          "of the streaming form of the SAME command, measured in this run"}
+                  "note": "SURVEY.md 8d: with the engine's generator inside K1 the kernel is RNG-bound (its own `roofline`: VALU-active "
+                          "share of the wave cycles) -- no bandwidth fraction is claimed for it; the top-level `roofline` is the "
+                          "HBM-bound K1 of the streaming form of the SAME command, measured in this run"}
 
     # ---- roofline of K1 ----
     dev_st = _stats(k1_dev_us)

@@ -1,4 +1,5 @@
-// rollout_onchip.hpp -- the rng="philox" command that moves NO (K,T,nu) array.
+// rollout_onchip.hpp -- the rng="philox" command that generates its normals where it uses them: no (K,T,nu)
+// array of normals exists; since round 4 the part of the bounded noise that does not fit the chip waits in a spill array.
 //
 // The streaming command writes the draw once and reads it twice (generator -> K1 -> K3: 604 MB for 201.6 MB
 // of algorithmic input at C3).  With the engine's own generator the normals are a pure function of
@@ -10,7 +11,10 @@
 //          kernel runs one wave per SIMD anyway (K = 65536 is one wave per SIMD of work), the AGPR half of the
 //          unified 512-entry register file is otherwise idle;
 //        * the next `nsl` super-steps in LDS ([row][thread][4], one conflict-free ds_write/read_b128 per row);
-//        * what does not fit is generated a second time in W (the generator is ~60 % of this kernel's time);
+//        * what does not fit waits in the caller's spill array (ABI 20, `a.spill`: [row][padded sample][4], one coalesced
+//          16-byte store per lane and row behind the rollout, fetched back a weighting tile ahead in W, between the tiles that
+//          come out of registers and LDS) -- or, without that array, is generated a second time in W (round 3's form;
+//          13 us of generator work at C3 against ~5 us of stores + ~5 us of exposed fetches);
 //   W  the workgroup's own part of K3 (mppi.py:254-259, :268): weights relative to the WORKGROUP's minimum
 //      beta_b, eta_b, P_b[j] = sum_k w_k eps'_k[j] over its 256 samples -- the algebra of the single-launch
 //      command (rollout.hpp FUSE block) and of the multi-GPU combine.  Column sums by a transposing wave reduction
@@ -19,7 +23,9 @@
 // block order and applies K4.  Measured at C3 (tools/micro/onchip_parts.hip on THIS kernel, profiles/r03_onchip_parts.txt,
 // r03_final_*; prototypes: tools/micro/k1ret_micro.hip): G alone 33.9 us (the chip-wide generator floor), + R 15, + keeping 3,
 // W 29 (second generation 17.5, reduction 11.5): 81-83 us back to back, 88-90 us inside the command, against 34 + 33 + 36 us for
-// generator + K1 + K3; 1.6 MB of HBM traffic per launch by PMC against 604 MB.
+// generator + K1 + K3; 1.6 MB of HBM traffic per launch by PMC against 604 MB.  Round 4 (profiles/r04_onchip_spill.txt, r04_spill_*):
+// 75.8 -> 70.9 us inside the command with the spill array (2 x 94 MB of traffic: 87 of the sample's 192 rows), 74.4 without it
+// (the weighting phase in per-source loops).
 // Scope: fp32, diagonal Sigma (a full-Sigma form -- L z + mu per timestep in the lane -- is below, behind MPPI_ONCHIP_FULL_SIGMA:
 // tested, slower than generator-coloured rows), MPPI and SMPPI (base sequence, 1/dt rescaling, smoothness cost) but not KMPPI,
 // M = 1, no sampler rows (the sample_null_action row is handled), no `states` output, one environment.
