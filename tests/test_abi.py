@@ -62,6 +62,40 @@ def test_noise_row_pitch(K, dtype, pitch):
     assert N.noise_pitch(K, dtype) == pitch
 
 
+def _spill_rows(nu, T, nta=5):
+    """where the rows of a sample wait in the on-chip command (csrc/common.hpp onchip_geometry), restated: registers hold the first
+    nta weighting tiles, LDS whole tiles as far as 160 KB go beside the tables, the spill array the rest -- in rows-of-4"""
+    g = 4 if nu % 4 == 0 else (2 if nu % 2 == 0 else 1)
+    p4, tt = nu // g, 4 // g
+    sw = max(16 // p4, 1)
+    rg = 1 if p4 >= 3 else (2 if p4 == 2 else 4)
+    ag = nta * sw
+    nss = -(-T // tt)
+    ntiles = -(-nss // sw)
+    tables = 3 * nss * p4 * 4 + 4
+    base = (tables + 4 * ntiles * 64) * 4
+    if p4 > 16 or sw % rg or base > 160 * 1024:
+        return 0
+    room = (160 * 1024 - base) // (p4 * 256 * 16)
+    nsl = max(0, min(nss - ag, room))
+    nsl -= nsl % sw
+    return max(0, ntiles * sw - ag - nsl) * p4
+
+
+@pytest.mark.parametrize("nu,T", [(12, 64), (12, 20), (12, 200), (4, 100), (4, 30), (6, 40), (2, 130), (1, 48), (3, 33), (8, 256), (16, 64)])
+def test_onchip_spill_size_is_the_geometry_restated(nu, T):
+    """ABI 20 `mppi_onchip_spill_elems`: rows-of-4 that fit neither registers nor LDS x padded samples x 4; 0 for fp64"""
+    for K in (65536, 1000):
+        p = N.MppiProblem()
+        p.K, p.T, p.nx, p.nu, p.dtype, p.sigma_diagonal = K, T, 4, nu, N.F32, 1
+        kpad = -(-K // 256) * 256
+        assert int(N.lib().mppi_onchip_spill_elems(C.byref(p))) == _spill_rows(nu, T) * kpad * 4, (nu, T, K)
+        p.dtype = N.F64
+        assert int(N.lib().mppi_onchip_spill_elems(C.byref(p))) == 0
+    if (nu, T) == (12, 64):
+        assert _spill_rows(nu, T) == 90           # C3: 25 super-steps in registers, 10 in LDS, 6 tiles = 30 super-steps x 3 rows wait
+
+
 def test_model_support_table():
     assert N.model_supported(N.MODEL_PENDULUM, 2, 1, N.F32)
     assert N.model_supported(N.MODEL_PENDULUM, 2, 1, N.F64)
