@@ -136,6 +136,18 @@ def test_rows_waiting_in_memory_change_no_bit(case):
     want = int(N.lib().mppi_onchip_spill_elems(a._last))
     assert (a._spill[1] is None) == (want == 0) and b._spill is None
     if want:
+        # an array that holds only part of the rows: those wait in memory, the rest is generated a second time, memory tiles
+        # consumed between the regenerated ones -- still the same bits
+        c, _, _, _ = _make(kind, nx, nu, K, T, True, lam=25.0, sigma=sig, **kw)
+        c._spill = ((c.K_local, T, nu), torch.empty(max(want * 2 // 5, 4), device="cuda"))
+        d, _, _, _ = _make(kind, nx, nu, K, T, True, lam=25.0, sigma=sig, **kw)
+        d.onchip_spill = False
+        for shift in (True, False):
+            uc, ud = c.command(x0, shift_nominal_trajectory=shift), d.command(x0, shift_nominal_trajectory=shift)
+            assert int(c._last.onchip_spill_elems) == c._spill[1].numel() < want
+            for name, xa, xb in (("action", uc, ud), ("U", c.U, d.U), ("cost_total", c.cost_total, d.cost_total)):
+                assert torch.equal(xa, xb), ("partial array", name, shift)
+    if want:
         assert a._spill[1].numel() == want and int(a._last.onchip_spill) == a._spill[1].data_ptr()
 
 
