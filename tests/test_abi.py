@@ -156,3 +156,15 @@ def test_plain_c_client_links_and_agrees_on_the_struct(tmp_path):
     ver, size_lib, size_c, rc1, rc2 = (int(x) for x in out.stdout.split())
     assert ver == N.ABI_VERSION and size_lib == size_c == C.sizeof(N.MppiProblem)
     assert rc1 == -1 and rc2 == -1             # MPPI_E_BADARG
+
+
+def test_integration_md_stub_mirrors_the_struct():
+    """the ctypes stub INTEGRATION.md shows a reference maintainer is the struct the library was compiled with"""
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    i, j = src.index("class MppiProblem(C.Structure):"), src.index("assert _lib.mppi_abi_version()")
+    ns = {}
+    exec("import ctypes as C\n" + src[i:j], ns)
+    stub = ns["MppiProblem"]
+    assert C.sizeof(stub) == int(N.lib().mppi_problem_size())
+    assert [(n, t) for n, t in stub._fields_] == [(n, t) for n, t in N.MppiProblem._fields_]
+    assert f"mppi_abi_version() == {N.ABI_VERSION}" in src
