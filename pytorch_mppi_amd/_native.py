@@ -159,8 +159,15 @@ def profile_read_launches(capacity=8192):
     return [dev[i] for i in range(m)], [disp[i] if disp[i] >= 0 else None for i in range(m)]
 
 
+_PURE = {}      # results of the pure geometry / capability queries (a ctypes call costs ~1 us; these sit on every command's path)
+
+
 def noise_rows4(T, nu):
-    return int(lib().mppi_noise_rows4(int(T), int(nu)))
+    k = ("r4", T, nu)
+    v = _PURE.get(k)
+    if v is None:
+        v = _PURE[k] = int(lib().mppi_noise_rows4(int(T), int(nu)))
+    return v
 
 
 def noise_pitch(K, dtype_code):
@@ -169,4 +176,10 @@ def noise_pitch(K, dtype_code):
 
 
 def model_supported(model_id, nx, nu, dtype_code, hidden=0):
-    return bool(lib().mppi_model_supported(int(model_id), int(nx), int(nu), int(dtype_code), int(hidden)))
+    k = ("ms", model_id, nx, nu, dtype_code, hidden)
+    v = _PURE.get(k)
+    if v is None:
+        v = bool(lib().mppi_model_supported(int(model_id), int(nx), int(nu), int(dtype_code), int(hidden)))
+        if model_id < MODEL_CUSTOM_BASE:
+            _PURE[k] = v            # (run-time registered models come and go: not cached)
+    return v

@@ -66,6 +66,17 @@ def _auto_jit_mode(v):
     return m
 
 
+_TRACE = []
+
+
+def _trace_module():
+    """pytorch_mppi_amd.trace, imported on first use (an `import` statement per command costs a microsecond of a 15 us budget)"""
+    if not _TRACE:
+        from . import trace
+        _TRACE.append(trace)
+    return _TRACE[0]
+
+
 def _ptr(t):
     # a plain int is what a ctypes c_void_p field wants; no wrapper object per pointer per command
     return None if t is None else t.data_ptr()
@@ -218,6 +229,7 @@ class MPPI:
         # rng="torch": compute torch.randn's values straight into the engine's rows (see _torch_stream_fill); off: call
         # torch.randn and read / convert its (K,T,nu) array
         self.torch_rows = os.environ.get("MPPI_TORCH_ROWS", "1") != "0"
+        self._generic_memo = None
         self._in_capture = False
         self._force_collective = False
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
@@ -243,6 +255,11 @@ class MPPI:
         self._jit_mode = mode
         self._jit_check_every = int(os.environ.get("MPPI_JIT_CHECK_EVERY", "256"))
         self._jit_cmds = 0             # fused commands since the current traced model was adopted
+        # share of the issuing time the spot-checks may take: the interval is stretched beyond `_jit_check_every` where a check
+        # (~1 ms) would cost more than this (0: never stretched)
+        self._jit_check_share = float(os.environ.get("MPPI_JIT_CHECK_SHARE", "0.01"))
+        self._jit_next_check = 0       # ... and the command at which the next on-device spot-check is due
+        self._jit_last_check = None    # (command number, time) of the previous one
         self._jit_retraces = 0         # times the callables' state moved in a way that changed the functor
         self._jit_benign = 0           # ... in a way that did not
         self._jit_spot_checks = 0
@@ -318,6 +335,7 @@ class MPPI:
         m.watch = w
         self._settle_watch(m)            # (what the callables wrote to their own state while they were traced and checked)
         self._jit_cmds = 0
+        self._jit_next_check, self._jit_last_check = 0, None
         self.jit_note = f"fused: traced {m.traced_ops} operations per sample into {m.name}"
         log.info("pytorch_mppi_amd: %s", self.jit_note)
         return m
@@ -343,7 +361,7 @@ class MPPI:
         w = getattr(m, "watch", None)
         if w is None:
             return
-        from . import trace
+        trace = _trace_module()
         try:
             if m._param_tensors:
                 m.refresh_params()
@@ -357,9 +375,24 @@ class MPPI:
             return
         n = self._jit_cmds
         self._jit_cmds = n + 1
-        if self._jit_check_every > 0 and n % self._jit_check_every == 0 and state is not None \
+        if self._jit_check_every > 0 and n >= self._jit_next_check and state is not None \
                 and not torch.cuda.is_current_stream_capturing():
-            if not self._spot_check(state):
+            # every `_jit_check_every` commands -- stretched, for problems so small that a check (a millisecond: the user's
+            # callables on a batch, a tiny fused rollout, one device sync) would cost more than `_jit_check_share` (1 %) of the
+            # time between two of them, to that many commands: a 20 us command is checked every ~6000 commands = 0.12 s
+            import time
+            t0 = time.perf_counter()
+            ok = self._spot_check(state)
+            t1 = time.perf_counter()
+            last = self._jit_last_check
+            every = self._jit_check_every
+            if last is not None and n > last[0]:
+                period = (t0 - last[1]) / (n - last[0])                 # seconds per command since the previous check
+                if period > 0 and self._jit_check_share > 0:
+                    every = max(every, min(65536, int((t1 - t0) / (self._jit_check_share * period))))
+            self._jit_last_check = (n, t1)
+            self._jit_next_check = n + every
+            if not ok:
                 self._traced_state_moved([], "the fused functor and the callables disagree on a random batch")
 
     def _traced_state_moved(self, moved, why):
@@ -645,13 +678,17 @@ class MPPI:
         """Identity + in-place version of everything the static part of the problem block is built
         from: a steady-state command() re-uses the cached block and parameter tensors, while
         attribute assignments / in-place edits by the caller (autotune, tests) are picked up."""
-        tv = lambda t: (id(t), t._version) if torch.is_tensor(t) else t
+        # (this runs on every command: small problems are bound by the host's ~15 us per command, not by the device)
         m = self._model
+        a, b, c, d, e, f = self.u_init, self.noise_mu, self._sigma_inv_kernel, self._noise_L, self.u_min, self.u_max
+        T_ = torch.Tensor
         return (Tn, self.K_local, self.nx, self.nu, self.k_offset, id(m), m.hidden if m is not None else 0,
                 bool(self.noise_abs_cost), bool(self.sample_null_action), int(self.u_per_command),
                 float(self.lambda_), float(self.u_scale), int(self.M), float(self.rollout_var_cost),
-                float(self.rollout_var_discount), self.seed, tv(self.u_init), tv(self.noise_mu),
-                tv(self._sigma_inv_kernel), tv(self._noise_L), tv(self.u_min), tv(self.u_max),
+                float(self.rollout_var_discount), self.seed,
+                (id(a), a._version) if isinstance(a, T_) else a, (id(b), b._version) if isinstance(b, T_) else b,
+                (id(c), c._version) if isinstance(c, T_) else c, (id(d), d._version) if isinstance(d, T_) else d,
+                (id(e), e._version) if isinstance(e, T_) else e, (id(f), f._version) if isinstance(f, T_) else f,
                 m._param_version if m is not None else 0)
 
     def _problem(self, Tn=None, U=None):
@@ -1041,6 +1078,7 @@ class MPPI:
             return
         self._model = m
         self._jit_cmds = 0
+        self._jit_next_check, self._jit_last_check = 0, None
         self._problem_cache.clear()
         self.jit_note = f"fused: traced {m.traced_ops} operations per sample into {m.name} (compiled in the background)"
         log.warning("pytorch_mppi_amd: %s", self.jit_note)
@@ -1053,6 +1091,20 @@ class MPPI:
         return self._model is not None
 
     def _needs_generic(self):
+        # (twice per command, and the host's ~15 us per command are what bounds a small problem: memoised on what it reads)
+        m = self._model
+        if m is None:
+            return True
+        s = self.specific_action_sampler
+        key = (id(m), m.model_id, self.M, id(s), id(m.process_noise), self.nx, self.nu, self.dtype)
+        hit = self._generic_memo
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        v = self._needs_generic_now()
+        self._generic_memo = (key, v)
+        return v
+
+    def _needs_generic_now(self):
         if self._model is None:
             return True
         if self.M != 1 and not self._fused_multi_ok():

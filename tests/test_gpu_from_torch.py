@@ -379,7 +379,7 @@ def test_writes_the_watch_cannot_see_are_caught_by_the_spot_check():
                               U_init=torch.zeros(6, 2, dtype=torch.float64), auto_jit=auto)
     a, b = mk(True), mk(False)
     assert not a._needs_generic()
-    a._jit_check_every = 4
+    a._jit_check_every, a._jit_check_share = 4, 0.0      # (exactly every 4th command: no stretching for cheap commands)
     x0 = torch.ones(2, dtype=torch.float64).cuda()
     gen = torch.Generator().manual_seed(5)
 
@@ -425,7 +425,7 @@ def test_replaced_module_keeps_the_kernels():
     assert both() <= 1e-9 and a._model is m and not a._needs_generic() and a._jit_retraces == 0
     with torch.no_grad():
         holder["net"][0].weight.data.mul_(0.5)        # a write through .data: re-gathered by the spot-check
-    a._jit_check_every = 1
+    a._jit_check_every, a._jit_check_share, a._jit_next_check = 1, 0.0, 0
     assert both() <= 1e-9 and a._model is m
 
 
