@@ -247,6 +247,14 @@ __device__ __forceinline__ void rollout_stream_multi(const KArgs<T>& a, const Ac
 #define MPPI_K1_BLOCK 256   // threads per K1 workgroup (multiple of 64)
 #endif
 constexpr int K1_BLOCK = MPPI_K1_BLOCK;
+// tools/micro/fuse_parts.hip: where the single-launch command's time goes (phase stamps of every workgroup on the device clock);
+// compiled out of the product
+#ifdef MPPI_FUSE_STAMPS
+__device__ unsigned long long g_fuse_stamps[64 * 8];
+#define MPPI_FUSE_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 64) g_fuse_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define MPPI_FUSE_STAMP(i) do { } while (0)
+#endif
 
 #ifndef MPPI_K1_ROWS
 // rows-of-4 (16 B each) a lane keeps in flight; fp64 uses half.  Measured at C3 (tools/run_k1_rows.sh,
@@ -654,6 +662,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
   constexpr int NX = Model::NX, NU = Model::NU;
   const KArgs<T> a = env_view(a_in);        // MPPI_Batched: environment = blockIdx.z
   stamp_entry(a.tstamp);
+  MPPI_FUSE_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ue = reinterpret_cast<T*>(smem_raw);   // [J] nominal sequence, shift applied
   T* Um = Ue + a.J;                         // [J] Ue + mu
@@ -758,6 +767,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
 
   const int nchunks = (a.K + K1_BLOCK - 1) / K1_BLOCK;
   T fuse_total = T(0);
+  MPPI_FUSE_STAMP(1);
   for (int chunk = blockIdx.x;;) {
   T rollout = T(0), pert = T(0);
   // wave-uniform choice: does this wave own overwritten rows, or must it store the states?
@@ -848,6 +858,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     const int b = blockIdx.x, nb = gridDim.x;
     const T inv_lambda = T(1) / a.lambda_;
+    MPPI_FUSE_STAMP(2);
     const T beta_b = block_min<T>(active ? fuse_total : inf_v<T>(), f_red);
     const T wk = active ? weight_of<T>(fuse_total, beta_b, inv_lambda) : T(0);
     const T eta_b = block_sum<T>(wk, f_red);
@@ -855,6 +866,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
     const T w1[1] = {over ? T(0) : wk};
     const bool live1[1] = {__ballot(w1[0] != T(0)) != 0ull};
     const int njt = a.Jpad / UPD_TJ;
+    MPPI_FUSE_STAMP(3);
     for (int jt = 0; jt < njt; ++jt) {
       const int j0 = jt * UPD_TJ;
       __syncthreads();                       // the previous tile's constants and sums are consumed
@@ -914,6 +926,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
       __hip_atomic_store(&a.block_min[(long long)b * (K1_BLOCK / WAVE)], beta_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // every partial store of this workgroup has left the CU before its ticket is drawn
+    MPPI_FUSE_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -921,6 +934,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
       f_last = old == (unsigned)(nb - 1);
     }
     __syncthreads();
+    MPPI_FUSE_STAMP(5);
     if (f_last) {
       // ---- C: combine, in workgroup order whoever is last ----
       // All loads of the first pass are issued before anything waits for one of them: an agent-scope
@@ -986,6 +1000,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
         a.record[1] = eta;
         __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next command
       }
+      MPPI_FUSE_STAMP(6);
     }
   }
   if (a.tstamp != nullptr) {
