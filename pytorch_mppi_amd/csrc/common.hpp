@@ -161,7 +161,9 @@ __device__ __forceinline__ KArgs<T> env_view(const KArgs<T>& a) {
 // step: 8 of the single-launch command's 16 us at C2).  Cody-Waite reduction by pi/2 in three parts (exact products with k for
 // |x| < 1e5) and the usual minimax polynomials on [-pi/4, pi/4]: 22 instructions, <= 1.52 ulp against the correctly rounded
 // result on 1.6e7 random arguments in |x| < 1e5 (numpy's own float32 sin: 1.47) -- what the reference's torch.sin gives or takes.
-// Larger arguments (and non-finite ones) take the library routine.
+// Larger arguments are first reduced modulo 2 pi in fp64 (a handful of instructions; fp32-level accuracy up to |x| ~ 2^40) -- NOT
+// handed to the library routine: its Payne-Hanek path brings 400 B of scratch per lane into every kernel that could reach it.
+// NaN for NaN / inf.
 __device__ __forceinline__ void sincos_reduce(float x, float& s, float& c, int& q) {
   const float k = __builtin_rintf(x * 0.63661977236758134f);
   float r = fmaf(-k, 1.57079601287841796875f, x);
@@ -177,8 +179,16 @@ __device__ __forceinline__ void sincos_reduce(float x, float& s, float& c, int& 
   pc = fmaf(pc, r2, -0.5f);
   c = fmaf(pc, r2, 1.0f);
 }
+__device__ __forceinline__ float sincos_moderate(float x) {
+  if (__builtin_expect(!(__builtin_fabsf(x) <= 1.0e5f), 0)) {
+    const double t = (double)x;
+    const double k = __builtin_rint(t * 0.15915494309189535);            // 1 / (2 pi)
+    x = (float)__builtin_fma(-k, 6.283185307179586, t);                  // |x| <= pi  (NaN for NaN / inf)
+  }
+  return x;
+}
 __device__ __forceinline__ float m_sin(float x) {
-  if (!(__builtin_fabsf(x) <= 1.0e5f)) return sinf(x);
+  x = sincos_moderate(x);
   float s, c;
   int q;
   sincos_reduce(x, s, c, q);
@@ -187,7 +197,7 @@ __device__ __forceinline__ float m_sin(float x) {
 }
 __device__ __forceinline__ double m_sin(double x) { return sin(x); }
 __device__ __forceinline__ float m_cos(float x) {
-  if (!(__builtin_fabsf(x) <= 1.0e5f)) return cosf(x);
+  x = sincos_moderate(x);
   float s, c;
   int q;
   sincos_reduce(x, s, c, q);
