@@ -67,3 +67,24 @@ def test_no_fp32_kernel_of_the_path_spills_vector_registers(table):
 def test_resource_table_sees_the_whole_library(table):
     assert len(table) > 300
     assert R.find(table, "rollout_onchip_kernel") and R.find(table, "rollout_mlp_split_kernel") and R.find(table, "combine_kernel")
+
+
+def test_run_time_compiled_models_carry_no_scratch_to_speak_of():
+    """the functors __graft_entry__.build() compiles from the fixtures' callables (pytorch_mppi_amd/_jit): what the scalar vocabulary
+    of traced code (csrc/common.hpp m_sin, m_tanh, ...) drags into a user's kernels shows here -- a library sinf in m_sin's rare path
+    once brought 400 B of scratch per lane with it.  fp32 kernels: no VGPR spills, at most 64 B of scratch."""
+    import glob
+    import os
+    objs = sorted(glob.glob(os.path.join(os.path.dirname(R.__file__), "_jit", "user_*.so")), key=os.path.getmtime)[-24:]
+    if not objs:
+        pytest.skip("no run-time compiled models here (run __graft_entry__.build())")
+    bad = {}
+    seen = 0
+    for f in objs:
+        for k, v in R.kernels(f).items():
+            if "double" in k:
+                continue
+            seen += 1
+            if v.get("scratch", 0) > 64 or v.get("vgpr_spill", 0) > 0:
+                bad[os.path.basename(f) + " :: " + k[:90]] = v
+    assert seen > 20 and not bad, bad
