@@ -243,6 +243,9 @@ class MPPI:
         if m is not None and (getattr(m, "step_dependent", False) is None
                               or bool(step_dependent_dynamics) == bool(getattr(m, "step_dependent", False))):
             self._model = m
+        # a model that jit.from_torch traced from plain callables: re-traces (watch, spot-check) run on those callables
+        self._traced_user_callables = ((m._dyn, m._cost, m._term) if self._model is not None and getattr(m, "_code", None) is not None
+                                       and getattr(m, "watch", None) is not None else None)
         self.jit_note = None
         self._jit_pending = None
         # auto_jit: True / "sync" = trace and compile now (construction blocks for the hipcc run unless the object is cached);
@@ -342,6 +345,9 @@ class MPPI:
 
     # -- traced callables against the live ones ---------------------------------------------------------------------------
     def _callables(self):
+        raw = self._traced_user_callables
+        if raw is not None:                       # a jit.from_torch model: the user's own callables, not the model's wrappers
+            return raw[0], raw[1], raw[2], bool(self.step_dependency)
         return self.F, self.running_cost, self.terminal_state_cost, bool(self.step_dependency)
 
     def _drop_traced(self, note):
@@ -392,7 +398,9 @@ class MPPI:
                     every = max(every, min(65536, int((t1 - t0) / (self._jit_check_share * period))))
             self._jit_last_check = (n, t1)
             self._jit_next_check = n + every
-            if not ok:
+            if ok:
+                self._jit_unexplained = 0
+            else:
                 self._traced_state_moved([], "the fused functor and the callables disagree on a random batch")
 
     def _traced_state_moved(self, moved, why):
@@ -413,18 +421,26 @@ class MPPI:
             return
         if trace.same_functor(code, m._code) and why is None:
             self._jit_benign += 1
-            if trace.same_param_sources(code, m._code):
-                w.drop(moved)
-            else:
+            if not trace.same_param_sources(code, m._code):
                 m.rebind_params(code)
-                w.resnap(moved)
                 self._problem_cache.clear()
-            m._code = code
+            self._settle_moved(m, moved, code)
             return
         if why is not None and trace.same_functor(code, m._code) and trace.same_param_sources(code, m._code):
             # a spot-check mismatch that a fresh trace does not explain (a discontinuous cost on a boundary sample, state
-            # behind a C extension): the parameters were re-gathered by the spot-check; nothing else can be done from here
+            # behind a C extension, a tracer bug): the parameters were re-gathered by the spot-check.  Said aloud, and after
+            # three in a row the controller stops trusting the functor: back to the callables, the reference's behaviour
+            # (this is the case the spot-check exists for)
             self._jit_benign += 1
+            self._jit_unexplained = getattr(self, "_jit_unexplained", 0) + 1
+            import logging
+            logging.getLogger("pytorch_mppi_amd").warning(
+                "pytorch_mppi_amd: %s -- and a fresh trace of the callables prints the same functor (%d in a row)", why, self._jit_unexplained)
+            if self._jit_unexplained >= 3:
+                self._drop_traced("generic path: the fused functor disagreed with the callables on three spot-checks in a row and a fresh "
+                                  "trace does not explain it (state behind a C extension? a tracer bug?); ctrl.retrace() tries again")
+            else:
+                self.jit_note = f"fused, but a spot-check found an unexplained mismatch ({self._jit_unexplained}): {m.name}"
             return
         self._jit_retraces += 1
         for path in w.tensors_at(moved or []):
@@ -470,13 +486,68 @@ class MPPI:
             return False
         if not trace.same_functor(code, m._code):
             return False
-        if trace.same_param_sources(code, m._code):
-            w.drop(moved)
-        else:
+        if not trace.same_param_sources(code, m._code):
             m.rebind_params(code)
-            w.resnap(moved)
-        m._code = code
+        self._settle_moved(m, moved, code, adoption=True)
         return True
+
+    def _settle_moved(self, m, moved, code, adoption=False):
+        """A fresh trace prints the same functor although these watched places moved.  Which of them may be forgotten?  Only
+        those the trace did NOT read (`cost.goal = torch.tensor([2., 1.])` -- same values, a new object, what a
+        planner does every cycle -- was judged benign and `GoalCost.goal` dropped from the watch for good; the next, real
+        change of the goal then went unseen).  A place keeps being watched, with its present value as the new reference, when
+        that value is a tensor / array among the roots of the trace's constants or its parameter tensors, or a number / string
+        equal to one of the graph's numeric constants; integers, booleans and strings (what Python-level control flow reads
+        without leaving a constant behind) are forgotten only after three benign moves in a row, or at adoption (what moved
+        while the callables were being traced and verified is their own bookkeeping).  A place re-bound to a NEW container or
+        object gets the watch rebuilt over the roots, so that what hangs below the new object is watched too."""
+        import numpy as np
+        from . import trace, watch as watch_mod
+        w = m.watch
+        read = [c for c, _ in code["captured"]]
+        for src, _ in code["param_tensors"]:
+            try:
+                read.append(trace.param_tensor(src))
+            except Exception:
+                pass
+        numbers = code.get("numbers", frozenset())
+        drop, keep, rebuild = [], [], False
+        for i in moved:
+            path = w.places[i][0]
+            v = path.get()
+            key = (id(path.holder), path.key if not isinstance(path.holder, watch_mod._Len) else "#len")
+            if isinstance(v, (torch.Tensor, np.ndarray)):
+                was_read = any(v is r for r in read)
+                (keep if was_read else drop).append(i)
+                continue
+            if isinstance(v, (bool, str)) or (isinstance(v, int) and not isinstance(path.holder, watch_mod._Len)):
+                n = w.benign.get(key, 0) + 1
+                w.benign[key] = n
+                in_graph = isinstance(v, (int, bool)) and float(v) in numbers
+                (drop if (adoption or n >= 3) and not in_graph else keep).append(i)
+                continue
+            if isinstance(v, float):
+                (keep if v in numbers else drop).append(i)
+                continue
+            if v is watch_mod._MISSING or v is None or isinstance(path.holder, watch_mod._Len) or isinstance(v, watch_mod._PRIMS):
+                drop.append(i)
+                continue
+            # re-bound to another container / object: the trace may have read what hangs below it
+            keep.append(i)
+            rebuild = True
+        if keep:
+            w.resnap(keep)          # (indices stay valid: resnap replaces in place)
+        if drop:
+            w.drop(drop)
+        if rebuild:
+            dyn, rc, term, _ = self._callables()
+            nw = watch_mod.StateWatch([dyn, rc, term])
+            nw.benign = w.benign
+            nw.forget(w.dropped_paths)
+            nw.dropped, nw.dropped_paths = w.dropped, list(w.dropped_paths)
+            m.watch = nw
+        m._code = code
+        m._captured = list(code["captured"])
 
     def _spot_check(self, state, samples=64, steps=4):
         """The fused functor against the user's callables on a small random batch ON THE DEVICE (`samples` states around the

@@ -1417,6 +1417,8 @@ def _dense_chains(g, roots):
                 ok = False
                 break
             spec, Lp = this, sl[1]
+        if ok and Lp is not None and g.layers[Lp]["OUT"] % 16 != 0 and not _finite_at_zero(spec):
+            ok = False                                           # the padded lanes of the wide form would carry NaN / inf into L
         if ok and Lp is not None and g.layers[Lp]["OUT"] == len(ins) and Lp != L:
             prev[L] = (Lp, spec)
     fused_into = {lp: L for L, (lp, _) in prev.items()}
@@ -1442,6 +1444,32 @@ def _dense_chains(g, roots):
             for a in g.layers[Lc]["inputs"]:
                 internal.add(a)
     return chains, internal
+
+
+def _finite_at_zero(spec):
+    """Is the activation path (operations of one operand, in the order they are applied) finite at 0?  The wide matrix-core form
+    pads a layer's outputs to whole blocks of 16 with zeros; `sqrt(h - 1)`, `log1p(h - 1)`, `asin(h + 2)` give NaN / inf on the
+    padded lanes, and inf * 0 = NaN in the next layer's products would poison every output of the sample.
+    Evaluated on the host in fp64 with numpy's semantics (no exceptions: inf / nan are values)."""
+    import numpy as np
+    f1 = {"neg": np.negative, "sin": np.sin, "cos": np.cos, "tan": np.tan, "tanh": np.tanh, "exp": np.exp, "log": np.log, "sqrt": np.sqrt,
+          "abs": np.abs, "floor": np.floor, "sigmoid": lambda v: 1.0 / (1.0 + np.exp(-v)), "sign": np.sign, "atan": np.arctan,
+          "asin": np.arcsin, "acos": np.arccos, "sinh": np.sinh, "cosh": np.cosh, "expm1": np.expm1, "log1p": np.log1p, "ceil": np.ceil,
+          "round": np.rint, "trunc": np.trunc, "erf": lambda v: np.float64(math.erf(float(v))) if np.isfinite(v) else v}
+    f2 = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "min": np.minimum, "max": np.maximum}
+    v = np.float64(0.0)
+    with np.errstate(all="ignore"):
+        for op in spec or ():
+            if len(op) == 1:
+                if op[0] not in f1:
+                    return False
+                v = np.float64(f1[op[0]](v))
+            else:
+                if op[0] not in f2:
+                    return False
+                c = np.float64(op[1])
+                v = np.float64(f2[op[0]](c, v) if op[2] else f2[op[0]](v, c))
+    return bool(np.isfinite(v))
 
 
 def _act_code(spec, var):
@@ -1589,6 +1617,7 @@ def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_depe
     members, ctor = layer_members(g, used)
     return dict(step=step, cost=cost, terminal=term, n_ops=len(g.nodes), captured=g.captured, param_tensors=g.param_tensors,
                 n_params=g.n_params, dynamic=list(dynamic), members=members, ctor=ctor,
+                numbers=frozenset(n[1] for n in g.nodes if n[0] == "c"),     # every numeric constant of the graph (mppi.MPPI._settle_moved)
                 dense=[dict(IN=g.layers[L]["IN"], OUT=g.layers[L]["OUT"], kind=k) for (L, k) in sorted(used)])   # layers kept as layers
 
 

@@ -78,6 +78,8 @@ class StateWatch:
         self.places = []            # (Path, snapshot kind, reference object / value)
         self.truncated = False      # the walk stopped at max_places: rely on the spot-check for the rest
         self.dropped = 0
+        self.dropped_paths = []     # the places forgotten by drop(): a watch rebuilt over the same roots forgets them again
+        self.benign = {}            # (id(holder), key) -> benign moves in a row (mppi.MPPI._settle_moved)
         self._seen = set()
         self._keep = []             # objects whose id() is in _seen must stay alive for the ids to stay unique
         self._max, self._max_depth = max_places, max_depth
@@ -256,6 +258,7 @@ class StateWatch:
         """forget these places (they change without changing what the callables compute)"""
         gone = set(idx)
         self.dropped += len(gone)
+        self.dropped_paths.extend(self.places[i][0] for i in gone if i < len(self.places))
         self.places = [p for i, p in enumerate(self.places) if i not in gone]
         self._compile()
 

@@ -252,3 +252,109 @@ def test_timestep_comparisons_are_refused_not_dropped():
     code = jit.trace_and_verify(dyn, ok, 2, 2, None, True, horizon=T)
     X = np.ones((1, 2))
     assert trace.evaluate_on_host(code, X, X, 2, 2, t=T - 1)[1][0] == 102.0 and trace.evaluate_on_host(code, X, X, 2, 2, t=3)[1][0] == 2.0
+
+
+def test_same_value_rebinding_keeps_the_place_watched(monkeypatch):
+    """`cost.goal = torch.tensor([2., 1.])` -- same values, a new object, as a planner does every cycle --
+    re-traces to the SAME functor; the place used to be dropped from the watch for good and the next, real change of the goal
+    went unseen until the next spot-check.  It stays watched (the trace READ that tensor), the captured list follows the new
+    object, and the real change is seen at once."""
+    _stub_compile(monkeypatch)
+    cost = GoalCost()
+    dyn = lambda x, u: x + 0.1 * u
+    c = _controller(dyn, cost)
+    m0 = c._model
+    for _ in range(5):                                  # every cycle: same values, new object
+        cost.goal = torch.tensor([2.0, 1.0], dtype=torch.float64)
+        c._check_traced()
+        assert c._model is m0 and c._jit_retraces == 0
+        assert any(t is cost.goal for t, _ in m0._captured)         # the version watch follows the object that is there NOW
+    assert c._jit_benign == 5
+    cost.goal.mul_(2.0)                                 # in place, on the re-bound object
+    c._check_traced()
+    assert c._model is None and c._jit_retraces == 1
+    assert c.wait_for_jit(20.0)
+    m1 = c._model
+    cost.scale = 3.0                                    # a float equal to a constant of the graph, re-bound to itself: kept
+    c._check_traced()
+    cost.scale = 4.0
+    c._check_traced()
+    assert c._model is not m1 or c._model is None       # seen
+
+
+def test_flags_are_forgotten_only_after_three_benign_moves(monkeypatch):
+    """integers / booleans / strings can steer Python-level control flow without leaving a constant in the graph: a benign
+    move does not make them invisible at once"""
+    _stub_compile(monkeypatch)
+
+    class ModeCost:
+        def __init__(self):
+            self.mode = 0
+            self.ticks = 0.0
+
+        def __call__(self, x, u):
+            if self.mode >= 3:
+                return (x * x).sum(-1) * 5.0
+            return (x * x).sum(-1)
+    cost = ModeCost()
+    c = _controller(lambda x, u: x + 0.1 * u, cost)
+    m0 = c._model
+    cost.ticks = 0.125                                  # a float that is no constant of the graph: forgotten at once
+    c._check_traced()
+    cost.ticks = 0.25
+    c._check_traced()
+    assert c._jit_benign == 1 and c._model is m0
+    cost.mode = 1                                       # same branch: same functor -- but still watched
+    c._check_traced()
+    cost.mode = 2
+    c._check_traced()
+    assert c._model is m0 and c._jit_benign == 3
+    cost.mode = 3                                       # the other branch
+    c._check_traced()
+    assert c._model is None and c._jit_retraces == 1
+
+
+def test_explicit_from_torch_model_is_guarded_like_an_auto_traced_one(monkeypatch):
+    """a model from the documented jit.from_torch(...) passed as MPPI(m.dynamics, m.running_cost, ...) has
+    captured tensors but had no watch: after B.mul_(3) the controller stayed fused on the stale constants"""
+    _stub_compile(monkeypatch)
+    B = torch.tensor([[0.5, 0.0], [0.0, -0.5]], dtype=torch.float64)
+    gain = {"g": 2.0}
+    dyn = lambda x, u: x + u @ B.T
+    cost = lambda x, u: gain["g"] * (x * x).sum(-1)
+    m = jit.from_torch(dyn, cost, 2, 2, verify=False)
+    assert m.watch is not None and m._captured
+    c = pm.MPPI(m.dynamics, m.running_cost, 2, torch.eye(2, dtype=torch.float64), num_samples=8, horizon=3, auto_jit=False)
+    c._jit_check_every = 0
+    assert c._model is m and c._traced_user_callables is not None
+    c._check_traced()
+    assert c._model is m
+    B.mul_(3.0)                                         # in-place write into a captured constant
+    assert m.stale()
+    c._check_traced()
+    assert c._model is None and c._needs_generic()
+    assert c.wait_for_jit(20.0) and c._model is not m and c._model.params.tolist() == [1.5, 0.0, 0.0, -1.5]
+    # a second controller on a fresh model: a re-bound Python float
+    m2 = jit.from_torch(dyn, cost, 2, 2, verify=False)
+    c2 = pm.MPPI(m2.dynamics, m2.running_cost, 2, torch.eye(2, dtype=torch.float64), num_samples=8, horizon=3, auto_jit=False)
+    c2._jit_check_every = 0
+    gain["g"] = 5.0
+    c2._check_traced()
+    assert c2._model is None and "T(5.0)" in (c2.wait_for_jit(20.0) and c2._model._code["cost"])
+
+
+def test_unexplained_spot_check_mismatches_end_on_the_callables(monkeypatch, caplog):
+    """functor and callables disagree, a fresh trace prints the same source -- logged, and after three in a row
+    the controller returns to the callables"""
+    _stub_compile(monkeypatch)
+    cost = GoalCost()
+    c = _controller(lambda x, u: x + 0.1 * u, cost)
+    m0 = c._model
+    import logging
+    with caplog.at_level(logging.WARNING, logger="pytorch_mppi_amd"):
+        for i in range(2):
+            c._traced_state_moved([], "the fused functor and the callables disagree on a random batch")
+            assert c._model is m0 and "unexplained mismatch" in c.jit_note
+        c._traced_state_moved([], "the fused functor and the callables disagree on a random batch")
+    assert c._model is None and "three spot-checks in a row" in c.jit_note
+    assert sum("prints the same functor" in r.getMessage() for r in caplog.records) == 3
