@@ -28,9 +28,11 @@ profiles/r03_event_clock.txt): they are sampled in a short pass of their own beh
 reported as `avg_launch_us_hip_events`.
 `latency_ms_synced` is the reference's own protocol (tests/benchmark_mppi.py:84-113: reset, sync, one
 command, sync; 3 warm-ups, 20 iterations, 10 % trimmed mean) beside the pipelined `ms_per_step`.
-N > 1: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run on 127.0.0.1) when it is not
-already one of them; on a box with fewer than N GPUs the ranks share the devices and the record exchange is
-staged through gloo (a test rig for the code path, labelled as such in `config.backend`).
+N > 1: under torch.distributed.run (what the driver does) every rank is one process on one GPU, `shard=(rank, N)`, RCCL.
+`python bench.py --gpus N` outside a launcher runs ONE process on N devices -- `MPPI(..., devices=[0..N-1])`, SURVEY 8b / 8e's
+process model -- and says so in `config.process_model`; `--process-model spawn` starts N ranks itself instead
+(torch.distributed.run on 127.0.0.1).  On a box with fewer than N GPUs the shards / ranks share the devices and the record
+exchange is staged (device copies / gloo): a test rig for the code path, labelled as such.
 `cpu_baseline` times the oracle (CPU restatement of the reference path, kind "port") on the same
 workload at the full K on the host cores (at most 3 timed calls); the live reference itself, timed
 in the build container beside the port, is on record in profiles/r02_cpu_reference_vs_port.txt.
@@ -72,7 +74,7 @@ STAMPS_ONLY = 1 << 30      # mppi_profile_enable argument: device-clock stamps o
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
 
 
-def make_controller(pm, wl, device, rng, shard, K):
+def make_controller(pm, wl, device, rng, shard, K, devices=None):
     _, kind, nx, nu, _, T = WORKLOADS[wl]
     dtype = torch.float32
     torch.manual_seed(0)
@@ -95,7 +97,7 @@ def make_controller(pm, wl, device, rng, shard, K):
     # which must stay O(1) for a healthy softmax (N_eff >> 1)
     U0 = torch.randn(T, nu, dtype=dtype) * 0.02
     ctrl = pm.MPPI(model.dynamics, model.running_cost, nx, sigma, num_samples=K, horizon=T, device=device,
-                   U_init=U0, rng="philox" if rng.startswith("philox") else rng, seed=1234, shard=shard, **kw)
+                   U_init=U0, rng="philox" if rng.startswith("philox") else rng, seed=1234, shard=shard, devices=devices, **kw)
     if rng == "philox-fused":
         ctrl.philox_fill = False                  # force the generation into K1
         ctrl.philox_onchip = False
@@ -327,6 +329,74 @@ def _self_spawn(n, argv):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def main_devices(args):
+    """`python bench.py --gpus N` outside any launcher: ONE Python process commanding on N devices through
+    `MPPI(..., devices=[0..N-1])` (pytorch_mppi_amd/group.py; SURVEY.md 8b / 8e: ncclCommInitAll communicators, the record
+    all-gathers of a command in one RCCL group).  On a box with fewer than N GPUs the shards share the devices and the records are
+    staged through device copies (a rig for the code path, labelled in config.process_model).  K is per GPU (weak scaling)."""
+    import pytorch_mppi_amd as pm
+    n = args.gpus
+    have = torch.cuda.device_count()
+    devs = list(range(n)) if have >= n else [i % max(1, have) for i in range(n)]
+    desc, kind, nx, nu, Kper, T = WORKLOADS[args.workload]
+    Kglobal = Kper * n
+    dev0 = torch.device("cuda", devs[0])
+    torch.cuda.set_device(dev0)
+
+    def sync():
+        for d in sorted(set(devs)):
+            torch.cuda.synchronize(d)
+
+    ctrl, x0, _ = make_controller(pm, args.workload, dev0, args.rng, None, Kglobal, devices=devs)
+    if kind != "pendulum":
+        probe, _, _ = make_controller(pm, args.workload, dev0, args.rng, None, Kper)
+        probe.command(x0)
+        ctrl.lambda_ = float(probe.cost_total.float().std())
+        del probe
+    for _ in range(args.warmup):
+        ctrl.command(x0)
+    for _ in range(120):
+        ctrl.command(x0)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctrl.command(x0)
+    sync()
+    dt = time.perf_counter() - t0
+    identical = bool(all(torch.equal(ctrl.shards[0].U.cpu(), s_.U.cpu()) for s_ in ctrl.shards[1:]))
+    one, x1, _ = make_controller(pm, args.workload, dev0, args.rng, None, Kper)
+    one.lambda_ = float(ctrl.lambda_)
+    for _ in range(args.warmup):
+        one.command(x1)
+    clock_warmup(one, x1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        one.command(x1)
+    torch.cuda.synchronize()
+    d1 = time.perf_counter() - t1
+    out = {
+        "metric": "rollouts/sec (K x T state evals) per .command() call",
+        "value": Kglobal * args.steps / dt, "unit": "rollouts/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "K_per_gpu": Kper, "K_global": Kglobal, "T": T, "nx": nx, "nu": nu, "rng": args.rng,
+                   "draw": ctrl.last_draw or "torch.randn", "lambda": float(ctrl.lambda_), "sharding": f"samples/{n}",
+                   "devices": devs, "devices_hold_identical_U": identical,
+                   "process_model": "ONE process, MPPI(..., devices=[...]) (pytorch_mppi_amd/group.py): " + ctrl.exchange
+                                    + ("" if have >= n else f" -- {n} shards share {have} GPU(s): exercises the code path, not a measurement")},
+        "state_evals_per_s": Kglobal * T * args.steps / dt,
+        "roofline": None,
+        "weak_scaling": {"single_gpu_ms_per_step": d1 / args.steps * 1e3, "single_gpu_rollouts_per_s": Kper * args.steps / d1,
+                         "weak_scaling_speedup": n * d1 / dt, "weak_scaling_efficiency": d1 / dt,
+                         "note": "against the same workload unsharded at K_per_gpu on device 0, timed in this run with the same loop; the "
+                                 "shards' launches are issued by one Python thread, so commands shorter than N x ~40 us are host-bound "
+                                 "in this process model (the per-process model -- this script under torch.distributed.run, or "
+                                 "--process-model spawn -- is not)"},
+    }
+    print(json.dumps(out), flush=True)
+
+
 def exchange_time_us(ctrl, dist, barrier, n=30):
     """The collective part of a sharded command alone: all-gather of the (2 + T*nu)-element shard record + K5
     (rank-order combine), issued back to back `n` times on the last command's problem block; max over ranks by
@@ -361,6 +431,9 @@ def main():
     ap.add_argument("--rng", default="philox", choices=["torch", "torch-native", "philox", "philox-stream", "philox-fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--process-model", default="auto", choices=["auto", "devices", "spawn"],
+                    help="--gpus N outside torch.distributed.run: 'devices' (auto) = ONE process, MPPI(..., devices=[0..N-1]); 'spawn' = start "
+                         "N ranks (one process per GPU, shard=(rank, N)) like the driver's launcher does")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -368,7 +441,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-            _self_spawn(args.gpus, sys.argv[1:])               # does not return
+            if args.process_model == "spawn" or os.environ.get("MPPI_BENCH_SPAWN_ONLY") == "1":
+                _self_spawn(args.gpus, sys.argv[1:])           # does not return
+            return main_devices(args)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if os.environ.get("MPPI_BENCH_SPAWN_ONLY") == "1":
         # plumbing check without a GPU (tests/test_dist_gloo.py): the self-started ranks rendezvous on gloo, agree on

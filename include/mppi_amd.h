@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 20
+#define MPPI_ABI_VERSION 21
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
@@ -156,6 +156,21 @@ typedef struct MppiProblem {
                                  mppi_onchip_spill_elems() elements, contents meaningless between commands.  NULL: generate twice
                                  (the ABI 18 behaviour)                                                              [opt] */
   int64_t onchip_spill_elems;
+  /* ---- ABI 21: the NEXT command's draw, generated inside THIS command's K3 launch ---- */
+  void* next_z;               /* rng = "torch": a second TNK4 array (same pitch as z, not z itself) that mppi_weights_partial /
+                                 mppi_command fill with the values torch.randn(K, T, nu) -- (K, S, nu) on a KMPPI theta problem:
+                                 the shape of the rows this K3 reads -- WILL produce from generator state (next_seed,
+                                 next_philox_offset), while the same launch streams this command's rows: the generator is
+                                 VALU-bound, K3 is HBM-bound, four more waves per workgroup run one beside the other (reference:
+                                 mppi.py:203, :378 -- the draw of command n+1 depends on nothing command n computes).  Taken only
+                                 where the streaming diagonal K3 on fp32 TNK4 rows runs (one environment, (T nu) % 4 == 0);
+                                 anywhere else the field is ignored.  mppi_last_next_draw() says whether it was taken; the CALLER
+                                 decides at the next command whether the generator is where this assumed (mppi_noise_fill_torch
+                                 otherwise) and advances it.  NULL: nothing of the kind                                 [opt] */
+  uint64_t next_seed;
+  uint64_t next_philox_offset;
+  int32_t next_grid_blocks;   /* ATen's launch grid for that call (see mppi_noise_fill_torch) */
+  int32_t _reserved0;
 } MppiProblem;
 
 int mppi_abi_version(void);
@@ -328,6 +343,9 @@ int64_t mppi_stat_onchip_commands(void);
 #define MPPI_FORM_SINGLE_LAUNCH 2  /* small problems: one launch */
 #define MPPI_FORM_ONCHIP 3         /* on-chip K1 + finalize_blocks */
 int mppi_last_command_form(void);
+/* ABI 21: 1 when the calling thread's last mppi_weights_partial / mppi_command / mppi_command_sharded / mppi_command_kmppi
+ * also generated p->next_z (see MppiProblem.next_z), else 0 */
+int mppi_last_next_draw(void);
 
 /* K5 -- multi-GPU: combine `n_shards` records (all-gathered, rank order) exactly the same way
  * on every rank: beta = min beta_g; s_g = exp(-(beta_g-beta)/lambda); eta = sum s_g eta_g;
@@ -349,6 +367,16 @@ int mppi_dist_init(const void* id128, int32_t rank, int32_t world_size, void** c
 int mppi_dist_destroy(void* comm);
 int mppi_exchange_combine(const MppiProblem* p, void* comm, void* records, int32_t world_size, void* stream);
 int mppi_command_sharded(const MppiProblem* p, void* comm, void* records, int32_t world_size, void* stream);
+
+/* One process, N devices: communicators of all listed devices from ncclCommInitAll (comms_out[ndev]; each is
+ * destroyed with mppi_dist_destroy), and the exchange of one command on all of them from one call: the N all-gathers of the shard
+ * records (problems[g]->record -> records[g], (ndev, 2 + T nu) elements) inside ONE ncclGroupStart / ncclGroupEnd, each on
+ * streams[g] -- the stream device devs[g]'s K1 / K3 / K4 were issued on --, then mppi_combine on every device.  The calling
+ * thread's current device is left as it was.  MPPI_E_UNSUPPORTED: no RCCL, or a device listed twice (RCCL takes one rank per
+ * device: a caller that shards over ONE device for testing stages the records itself and calls mppi_combine). */
+int mppi_dist_init_all(int32_t ndev, const int32_t* devs, void** comms_out);
+int mppi_exchange_combine_all(int32_t ndev, const int32_t* devs, const MppiProblem* const* problems, void* const* comms,
+                              void* const* records, void* const* streams);
 
 /* User models.  The reference's plugin API is "any Python callable" (mppi.py:63-64); the fused
  * equivalent is a device functor {step, cost, terminal} that pytorch_mppi_amd/jit.py wraps around

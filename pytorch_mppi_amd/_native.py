@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
@@ -47,6 +47,8 @@ class MppiProblem(C.Structure):
         ("states", _vp), ("record", _vp),
         ("workspace", _vp), ("workspace_elems", C.c_int64),
         ("onchip_spill", _vp), ("onchip_spill_elems", C.c_int64),
+        # ABI 21: the next command's torch-stream draw inside this command's K3 launch
+        ("next_z", _vp), ("next_seed", C.c_uint64), ("next_philox_offset", C.c_uint64), ("next_grid_blocks", C.c_int32), ("_reserved0", C.c_int32),
     ]
 
 
@@ -82,6 +84,7 @@ SYMBOLS = {
     "mppi_stat_single_launch_commands": (C.c_int64, []),
     "mppi_stat_onchip_commands": (C.c_int64, []),
     "mppi_last_command_form": (C.c_int, []),
+    "mppi_last_next_draw": (C.c_int, []),
     "mppi_stat_kmppi_fused_rollouts": (C.c_int64, []),
     "mppi_command_kmppi": (C.c_int, [_PP, _PP, C.c_int, _vp]),
     "mppi_stat_kmppi_onchip_updates": (C.c_int64, []),
@@ -93,6 +96,9 @@ SYMBOLS = {
     "mppi_dist_destroy": (C.c_int, [_vp]),
     "mppi_exchange_combine": (C.c_int, [_PP, _vp, _vp, C.c_int32, _vp]),
     "mppi_command_sharded": (C.c_int, [_PP, _vp, _vp, C.c_int32, _vp]),
+    "mppi_dist_init_all": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
+    "mppi_exchange_combine_all": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(_PP), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p)]),
     "mppi_profile_enable": (C.c_int, [C.c_int]),
     "mppi_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mppi_profile_read2": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

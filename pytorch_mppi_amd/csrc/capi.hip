@@ -541,12 +541,32 @@ extern "C" int mppi_cost_block_min(const MppiProblem* p, void* stream) {
   return BY_DTYPE(p, do_bmin<float>(p, (hipStream_t)stream), do_bmin<double>(p, (hipStream_t)stream));
 }
 
+static thread_local int t_next_draw = 0;
+extern "C" int mppi_last_next_draw(void) { return t_next_draw; }
+// fp32 rows in the engine's layout, diagonal Sigma: ONE kernel with or without the next draw (noise_torch.hip), so that a command's
+// bits do not depend on whether its K3 launch also generated
+template <typename T>
+static int weights_rows(const KArgs<T>&, void*, const MppiProblem*, hipStream_t) { return MPPI_E_UNSUPPORTED; }
+template <>
+int weights_rows<float>(const KArgs<float>& a, void* next_z, const MppiProblem* p, hipStream_t st) {
+  return launch_weights_partial_rows_f32(a, next_z, p->next_seed, p->next_philox_offset, p->next_grid_blocks, st);
+}
 template <typename T>
 static int do_weights(const MppiProblem* p, hipStream_t st) {
   KArgs<T> a;
   if (int e = make_args<T>(p, a)) return e;
   if (int e = need_noise(a)) return e;
   if (!a.cost) return fail(MPPI_E_BADARG, "null cost_total");
+  t_next_draw = 0;
+  static const bool off = getenv("MPPI_NO_NEXT_DRAW") != nullptr;       // A/B knob for tools/, read once
+  if (p->next_z != nullptr && !off) {
+    // ABI 21: the next command's draw beside this K3 where that launch exists
+    const int e = weights_rows<T>(a, p->next_z, p, st);
+    if (e == 0) { t_next_draw = 1; return 0; }
+    if (e != MPPI_E_UNSUPPORTED) return hipfail(e, "mppi_weights_partial (with the next draw)");
+  }
+  const int e = weights_rows<T>(a, nullptr, p, st);
+  if (e != MPPI_E_UNSUPPORTED) return hipfail(e, "mppi_weights_partial");
   return hipfail(launch_weights_partial<T>(a, st), "mppi_weights_partial");
 }
 extern "C" int mppi_weights_partial(const MppiProblem* p, void* stream) {
@@ -588,6 +608,7 @@ static int do_finalize_blocks(const MppiProblem* p, int apply, hipStream_t st) {
 
 extern "C" int mppi_command_kmppi(const MppiProblem* p, const MppiProblem* theta_problem, int apply, void* stream) {
   if (theta_problem == nullptr) return fail(MPPI_E_BADARG, "mppi_command_kmppi: null theta problem");
+  t_next_draw = 0;
   const int r = BY_DTYPE(p, do_rollout<float>(p, (hipStream_t)stream, -1, true, theta_problem),
                          do_rollout<double>(p, (hipStream_t)stream, -1, true, theta_problem));
   if (r == MPPI_OK_KMPPI_W) {
@@ -614,6 +635,7 @@ extern "C" int64_t mppi_onchip_spill_elems(const MppiProblem* p) {
 }
 
 extern "C" int mppi_command(const MppiProblem* p, int apply, void* stream) {
+  t_next_draw = 0;
   // small problems: K1's launch carries K3 and K4 as well when the caller left omega and
   // cost_total_non_zero NULL (they are functions of cost_total and the record: see the header)
   const int e1 = BY_DTYPE(p, do_rollout<float>(p, (hipStream_t)stream, apply ? 1 : 0),

@@ -316,10 +316,13 @@ __host__ __device__ __forceinline__ unsigned xor3(unsigned a, unsigned b, unsign
 #endif
 }
 
+#ifndef MPPI_PHILOX_ROUNDS
+#define MPPI_PHILOX_ROUNDS 10     // measurement seam (tools/micro/onchip_parts.hip -DMPPI_PHILOX_ROUNDS=7); the product is Philox4x32-10
+#endif
 __host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
   constexpr unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < MPPI_PHILOX_ROUNDS; ++r) {
     unsigned long long p0 = (unsigned long long)M0 * c.x;
     unsigned long long p1 = (unsigned long long)M1 * c.z;
     U4 n;

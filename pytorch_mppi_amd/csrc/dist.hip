@@ -23,6 +23,8 @@ typedef int (*fn_get_unique_id)(NcclUniqueId*);
 typedef int (*fn_comm_init_rank)(NcclComm*, int, NcclUniqueId, int);
 typedef int (*fn_comm_destroy)(NcclComm);
 typedef int (*fn_all_gather)(const void*, void*, size_t, int, NcclComm, hipStream_t);
+typedef int (*fn_comm_init_all)(NcclComm*, int, const int*);
+typedef int (*fn_group)(void);
 typedef const char* (*fn_error_string)(int);
 constexpr int NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8;                // ncclDataType_t
 
@@ -31,6 +33,8 @@ struct Rccl {
   fn_comm_init_rank comm_init_rank = nullptr;
   fn_comm_destroy comm_destroy = nullptr;
   fn_all_gather all_gather = nullptr;
+  fn_comm_init_all comm_init_all = nullptr;      // single process, N devices (mppi_dist_init_all); optional
+  fn_group group_start = nullptr, group_end = nullptr;
   fn_error_string error_string = nullptr;
   bool tried = false, ok = false;
   char why[200] = "";
@@ -60,6 +64,9 @@ bool rccl_load() {
   g_rccl.comm_destroy = (fn_comm_destroy)find_symbol(&h, "ncclCommDestroy");
   g_rccl.all_gather = (fn_all_gather)find_symbol(&h, "ncclAllGather");
   g_rccl.error_string = (fn_error_string)find_symbol(&h, "ncclGetErrorString");
+  g_rccl.comm_init_all = (fn_comm_init_all)find_symbol(&h, "ncclCommInitAll");
+  g_rccl.group_start = (fn_group)find_symbol(&h, "ncclGroupStart");
+  g_rccl.group_end = (fn_group)find_symbol(&h, "ncclGroupEnd");
   g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.all_gather;
   if (!g_rccl.ok) snprintf(g_rccl.why, sizeof(g_rccl.why), "RCCL not found (set MPPI_RCCL_LIB): %s", dlerror() ? dlerror() : "symbols missing");
   return g_rccl.ok;
@@ -117,4 +124,51 @@ extern "C" int mppi_command_sharded(const MppiProblem* p, void* comm, void* reco
   MppiProblem q = *p;
   if (q.noise_src == MPPI_NOISE_PHILOX && q.z != nullptr) q.noise_src = MPPI_NOISE_TNK4;
   return mppi_exchange_combine(&q, comm, records, world_size, stream);
+}
+
+// ---- one process, N devices ("single Python process, ncclCommInitAll over visible devices, one stream per
+// device, ncclGroupStart/End -- keeps .command() a single drop-in call") ----
+extern "C" int mppi_dist_init_all(int32_t ndev, const int32_t* devs, void** comms_out) {
+  if (ndev <= 0 || devs == nullptr || comms_out == nullptr) return mppi_fail_message(MPPI_E_BADARG, "mppi_dist_init_all: bad arguments");
+  for (int i = 0; i < ndev; ++i)
+    for (int j = 0; j < i; ++j)
+      if (devs[i] == devs[j]) return mppi_fail_message(MPPI_E_UNSUPPORTED, "mppi_dist_init_all: RCCL takes one rank per device (a device is listed twice)");
+  if (!rccl_load()) return mppi_fail_message(MPPI_E_UNSUPPORTED, g_rccl.why);
+  if (!g_rccl.comm_init_all || !g_rccl.group_start || !g_rccl.group_end)
+    return mppi_fail_message(MPPI_E_UNSUPPORTED, "this RCCL has no ncclCommInitAll / ncclGroupStart / ncclGroupEnd");
+  const int r = g_rccl.comm_init_all((NcclComm*)comms_out, ndev, (const int*)devs);
+  if (r != 0) return mppi_fail_message(MPPI_E_DIST, g_rccl.error_string ? g_rccl.error_string(r) : "ncclCommInitAll failed");
+  return 0;
+}
+
+// The exchange of ONE command on all devices of the process: the N all-gathers of the shard records inside one RCCL group
+// (problems[g]->record -> records[g][ndev][2 + J], on streams[g], the stream device devs[g]'s part of the command was issued
+// on), then K5 on every device.  The calling thread's current device is restored.
+extern "C" int mppi_exchange_combine_all(int32_t ndev, const int32_t* devs, const MppiProblem* const* problems, void* const* comms,
+                                         void* const* records, void* const* streams) {
+  if (ndev <= 0 || devs == nullptr || problems == nullptr || comms == nullptr || records == nullptr || streams == nullptr)
+    return mppi_fail_message(MPPI_E_BADARG, "mppi_exchange_combine_all: bad arguments");
+  if (!rccl_load() || !g_rccl.group_start || !g_rccl.group_end) return mppi_fail_message(MPPI_E_UNSUPPORTED, g_rccl.why);
+  for (int g = 0; g < ndev; ++g)
+    if (problems[g] == nullptr || problems[g]->record == nullptr || comms[g] == nullptr || records[g] == nullptr)
+      return mppi_fail_message(MPPI_E_BADARG, "mppi_exchange_combine_all: every device needs a problem with a record, a communicator and a records buffer");
+  int dev0 = 0;
+  (void)hipGetDevice(&dev0);
+  const size_t n = 2 + (size_t)problems[0]->T * problems[0]->nu;
+  const int dt = problems[0]->dtype == MPPI_F64 ? NCCL_FLOAT64 : NCCL_FLOAT32;
+  int r = g_rccl.group_start();
+  for (int g = 0; g < ndev && r == 0; ++g) {
+    (void)hipSetDevice(devs[g]);
+    r = g_rccl.all_gather(problems[g]->record, records[g], n, dt, (NcclComm)comms[g], (hipStream_t)streams[g]);
+  }
+  const int r2 = g_rccl.group_end();
+  if (r == 0) r = r2;
+  int e = 0;
+  if (r != 0) e = mppi_fail_message(MPPI_E_DIST, g_rccl.error_string ? g_rccl.error_string(r) : "ncclAllGather (group) failed");
+  for (int g = 0; g < ndev && e == 0; ++g) {
+    (void)hipSetDevice(devs[g]);
+    e = mppi_combine(problems[g], records[g], ndev, streams[g]);
+  }
+  (void)hipSetDevice(dev0);
+  return e;
 }

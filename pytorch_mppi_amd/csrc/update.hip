@@ -404,80 +404,7 @@ __global__ void __launch_bounds__(BLOCK) cost_block_min_kernel(const KArgs<T> a_
 // =============================================================================================
 template <typename T, int NOISE, int R>
 __global__ void __launch_bounds__(BLOCK) weights_partial_diag_kernel(const KArgs<T> a_in) {
-  const KArgs<T> a = env_view(a_in);
-  __shared__ __attribute__((aligned(16))) T cU[UPD_TJ], cS[UPD_TJ], cM[UPD_TJ], cLo[UPD_TJ], cHi[UPD_TJ];
-  __shared__ T red[BLOCK / WAVE];
-  __shared__ T wsum[BLOCK / WAVE][UPD_TJ];
-  const int kc = blockIdx.x, jt = blockIdx.y;
-  const int j0 = jt * UPD_TJ;
-  if (threadIdx.x < UPD_TJ) {
-    const int j = j0 + threadIdx.x;
-    const bool ok = j < a.J;
-    const int n = ok ? j % a.nu : 0;
-    cU[threadIdx.x] = ok ? u_base(a, j) : T(0);
-    cS[threadIdx.x] = ok ? (a.coloured ? T(1) : a.L[n * a.nu + n]) : T(0);     // coloured stream: eps is in z
-    cM[threadIdx.x] = (ok && !a.coloured) ? a.mu[n] : T(0);
-    cLo[threadIdx.x] = ok ? a.umin[n] : T(0);
-    cHi[threadIdx.x] = ok ? a.umax[n] : T(0);
-  }
-  const T beta = shard_beta(a, red);   // contains the barriers that publish the constants
-  const T inv_lambda = T(1) / a.lambda_;
-  const long long n_over = (a.null_action ? 1 : 0) + (long long)a.n_sampler;
-
-  T w[R];
-  int kk[R];
-  T eta = T(0);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int k = (kc * R + r) * BLOCK + threadIdx.x;
-    const bool ok = k < a.K;
-    kk[r] = ok ? k : a.K - 1;
-    const T wr = ok ? weight_of<T>(a.cost[kk[r]], beta, inv_lambda) : T(0);
-    eta += wr;
-    if (ok && jt == 0 && a.wnz != nullptr) a.wnz[k] = wr;
-    w[r] = (a.k_offset + k < n_over) ? T(0) : wr;   // overwritten rows: see overwrite_correction
-  }
-
-  T acc[UPD_TJ];
-#pragma unroll
-  for (int i = 0; i < UPD_TJ; ++i) acc[i] = T(0);
-
-  // Samples whose weight is EXACTLY zero (exp underflow: (cost - beta)/lambda > ~104 in fp32) add
-  // exactly nothing to any column, so their rows are neither read nor generated.  With the peaked
-  // softmax of everyday MPPI settings (N_eff of tens to hundreds among 65536) that is almost every
-  // 64-sample group; with a flat softmax every group is live and the dense loop runs unchanged.
-  bool live[R], all_live = true, any_live = false;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    live[r] = __ballot(w[r] != T(0)) != 0ull;          // wave-uniform
-    all_live = all_live && live[r];
-    any_live = any_live || live[r];
-  }
-  const int nrows = a.J4 - jt * (UPD_TJ / 4);   // rows-of-4 of this tile that exist (block-uniform)
-  if (all_live)
-    k3_tile_loop<T, NOISE, R, false>(a, jt, nrows, kk, w, live, cU, cS, cM, cLo, cHi, acc);
-  else if (any_live)
-    k3_tile_loop<T, NOISE, R, true>(a, jt, nrows, kk, w, live, cU, cS, cM, cLo, cHi, acc);
-
-  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-  // lane l: this wave's sum of column j0+l (all accumulators are still zero without a live group)
-  const T colsum = any_live ? wave_reduce_transpose64<T>(acc) : T(0);
-  wsum[wv][lane] = colsum;
-  const T eta_b = block_sum<T>(eta, red);             // barriers also publish wsum
-  if (threadIdx.x < UPD_TJ) {
-    T s = wsum[0][threadIdx.x];
-#pragma unroll
-    for (int i = 1; i < BLOCK / WAVE; ++i) s += wsum[i][threadIdx.x];
-    const int j = j0 + threadIdx.x;
-    const int kbeg = kc * R * BLOCK;
-    if (a.k_offset + kbeg < n_over && j < a.J) {
-      const int kend = (kbeg + R * BLOCK) < a.K ? (kbeg + R * BLOCK) : a.K;
-      s += overwrite_correction<T>(a, kbeg, kend, j, cU[threadIdx.x], cLo[threadIdx.x], cHi[threadIdx.x],
-                                   beta, inv_lambda);
-    }
-    if (j < a.Jpad) a.P_part[(long long)kc * a.Jpad + j] = s * a.e_scale;   // 1 | 1/dt (SMPPI)
-  }
-  if (jt == 0 && threadIdx.x == 0) a.eta_part[kc] = eta_b;
+  k3_diag_block<T, NOISE, R>(a_in, blockIdx.x, blockIdx.y);
 }
 
 // (K,T,nu)-layout variant (MPPI_NOISE_KTN, fp32, diagonal Sigma): the draw is row-major in the

@@ -86,6 +86,15 @@ class MPPI:
     """Model Predictive Path Integral control (Williams et al. 2017, alg. 2), drop-in for
     `pytorch_mppi.MPPI` on MI355X."""
 
+    def __new__(cls, *args, devices=None, **kw):
+        # devices=[d0, d1, ...] (two or more): ONE Python process commanding on several GPUs -- the object is a device group
+        # (pytorch_mppi_amd/group.py: one shard controller per device, a subclass of `cls`); SURVEY.md 8b / 8e
+        if devices is not None and len(devices) > 1:
+            from .group import DeviceGroup, group_class
+            if not issubclass(cls, DeviceGroup):
+                return object.__new__(group_class(cls))
+        return object.__new__(cls)
+
     def __init__(self, dynamics, running_cost, nx, noise_sigma, num_samples=100, horizon=15, device="cpu",
                  terminal_state_cost=None,
                  lambda_=1.,
@@ -103,7 +112,11 @@ class MPPI:
                  sample_null_action=False,
                  specific_action_sampler: typing.Optional[SpecificActionSampler] = None,
                  noise_abs_cost=False,
-                 *, rng="torch", seed=None, shard=None, auto_jit=None):
+                 *, rng="torch", seed=None, shard=None, auto_jit=None, devices=None):
+        if devices is not None:
+            if len(devices) != 1:
+                raise ValueError("devices= needs at least one device")       # (two or more never get here: __new__)
+            device = torch.device("cuda", devices[0]) if isinstance(devices[0], int) else torch.device(devices[0])
         self.d = torch.device(device) if not isinstance(device, torch.device) else device
         self.dtype = noise_sigma.dtype                                   # mppi.py:88
         if self.dtype not in _DT:
@@ -229,6 +242,13 @@ class MPPI:
         # rng="torch": compute torch.randn's values straight into the engine's rows (see _torch_stream_fill); off: call
         # torch.randn and read / convert its (K,T,nu) array
         self.torch_rows = os.environ.get("MPPI_TORCH_ROWS", "1") != "0"
+        # ... and the NEXT command's draw inside this command's K3 launch (ABI 21; adopted at the next command when the generator
+        # is where that assumed: _torch_stream_fill).  Costs a second row buffer
+        self.draw_ahead = os.environ.get("MPPI_DRAW_AHEAD", "1") != "0"
+        self._next_draw = None         # (shape key, generator, seed, offset, rows): generated, waiting for the next command
+        self._next_armed = None        # ... handed to the engine with this command, not yet confirmed (_settle_next)
+        self._next_hits = self._next_misses = self._next_cmds = 0
+        self._zbuf_alt = {}
         self._generic_memo = None
         self._in_capture = False
         self._force_collective = False
@@ -1007,15 +1027,53 @@ class MPPI:
                 return False
         elif not _TORCH_ROWS[key]:
             return False
-        off = gen.get_offset()
-        N.check(lib.mppi_noise_fill_torch(_ptr(zn), K, Tn, nu, pitch, gen.initial_seed(), off, grid, self._stream()),
-                "mppi_noise_fill_torch")
+        off, seed = gen.get_offset(), gen.initial_seed()
+        nd, self._next_draw, self._next_armed = self._next_draw, None, None
+        nkey = (K, Tn, nu, pitch, grid)
+        if nd is not None and nd[0] == nkey and nd[1] is gen and nd[2] == seed and nd[3] == off:
+            # command n-1's K3 launch generated exactly this draw beside its row stream (ABI 21, csrc/noise_torch.hip): the
+            # generator is where that launch assumed it would be -- same seed, same offset: the same values, by construction.
+            # The two row buffers change roles
+            n_el = self._zelems(Tn)
+            self._zbuf_alt[n_el], self._zbuf[n_el] = zn, nd[4]
+            zn = nd[4]
+            self._next_hits += 1
+            self._next_misses = 0
+            self.last_draw = "torch-rows-ahead"
+        else:
+            if nd is not None:
+                self._next_misses += 1        # generated for nothing: somebody else drew from the generator (reset(), the user's own randn)
+            N.check(lib.mppi_noise_fill_torch(_ptr(zn), K, Tn, nu, pitch, seed, off, grid, self._stream()), "mppi_noise_fill_torch")
+            self.last_draw = "torch-rows"
         gen.set_offset(off + inc)
         p.noise_src = N.NOISE_TNK4
         p.z = _ptr(zn)
         p._keep["z"] = zn
-        self.last_draw = "torch-rows"
+        self._next_cmds += 1
+        if self.draw_ahead and (self._next_misses < 2 or self._next_cmds % 64 == 0):
+            # (a caller that draws from the generator between every two commands -- the reference's benchmark protocol calls
+            # reset() -- makes every draw-ahead useless and K3 pays for it: after two misses in a row it is tried only every 64th
+            # command)
+            # ... and this command's K3 launch generates the NEXT draw -- the values torch.randn will produce from (seed,
+            # off + inc) if nobody else draws from this generator in between -- into the other row buffer, on the VALU the
+            # HBM-bound row stream leaves idle.  Whether the engine did (only the streaming diagonal K3 carries it) is read
+            # back behind the command (_settle_next); whether the assumption held is checked above, at the next command
+            n_el = self._zelems(Tn)
+            alt = self._zbuf_alt.get(n_el)
+            if alt is None or alt.dtype != self.dtype or alt.device != zn.device:
+                if len(self._zbuf_alt) > 2:
+                    self._zbuf_alt.clear()
+                alt = self._zbuf_alt[n_el] = torch.empty(n_el, device=self.d, dtype=self.dtype)
+            p.next_z, p.next_seed, p.next_philox_offset, p.next_grid_blocks = _ptr(alt), seed, off + inc, grid
+            p._keep["next_z"] = alt
+            self._next_armed = (nkey, gen, seed, off + inc, alt)
         return True
+
+    def _settle_next(self):
+        """behind the launches of a command: did its K3 generate the next draw (mppi_last_next_draw, thread-local)?"""
+        armed, self._next_armed = self._next_armed, None
+        if armed is not None and int(N.lib().mppi_last_next_draw()) == 1:
+            self._next_draw = armed
 
     def _onchip_wanted(self, K, Tn, nu):
         """rng="philox": does this command go without a row array (include/mppi_amd.h, ABI 18; scope as checked again by
@@ -1305,6 +1363,7 @@ class MPPI:
                 self._convert_noise(p)
                 rc = launch()
             N.check(rc, "mppi_command")
+            self._settle_next()
             if self.last_draw == "philox-onchip" and int(lib.mppi_last_command_form()) != N.FORM_ONCHIP:
                 # the engine ran K1 + K3 with the rows generated twice instead (a model without the on-chip kernel, ...):
                 # correct, slower -- store the rows from the next command on
@@ -1318,6 +1377,7 @@ class MPPI:
         if p.noise_src == N.NOISE_PHILOX and p.z:
             p.noise_src = N.NOISE_TNK4            # the rows mppi_prepare generated are in p.z now
         N.check(lib.mppi_weights_partial(C.byref(p), st), "mppi_weights_partial")
+        self._settle_next()
         N.check(lib.mppi_finalize(C.byref(p), apply, st), "mppi_finalize")
         return p
 
@@ -2040,7 +2100,9 @@ class KMPPI(MPPI):
     def _noise_shape(self):
         return (self.K_local, int(self.num_support_pts), self.nu)
 
-    def _command(self, state, shift):
+    def _begin(self, state, shift):
+        """everything local to this shard (MPPI._begin): support-point draw, K1 on the interpolated trajectories, K3 / K4 on the
+        theta problem; returns the THETA problem -- its record is what a sharded command exchanges"""
         lib = N.lib()
         self.state = self._to_state(state)
         if shift:
@@ -2124,17 +2186,19 @@ class KMPPI(MPPI):
         if not updated:
             N.check(lib.mppi_weights_partial(C.byref(pt), st), "mppi_weights_partial")
             N.check(lib.mppi_finalize(C.byref(pt), 0 if sharded else 1, st), "mppi_finalize")
-        if sharded:
-            comm = self._shard.native_comm(self.d)
-            if comm is not None:
-                self._exchange_native(pt, comm)
-            else:
-                self._combine(pt, self._shard.all_gather(record))
-        self._omega, self._wnz = omega, wnz
-        self._lazy_w = (float(self.lambda_), record) if lazy else None
+        self._settle_next()
+        # the record of the exchange (MPPI._command / group.DeviceGroup) is the THETA problem's: {beta, eta, P_theta[S nu]}
+        pt._keep.update(record=record, omega=omega, wnz=wnz, theta_new=theta_new, lazy=lazy, traj=p)
+        return pt
+
+    def _end(self, pt):
+        p = pt._keep["traj"]
+        self._omega, self._wnz = pt._keep["omega"], pt._keep["wnz"]
+        record = pt._keep["record"]
+        self._lazy_w = (float(self.lambda_), record) if pt._keep["lazy"] else None
         self._record = record
         self._last, self._last_theta = p, pt
-        self.theta = theta_new
+        self.theta = pt._keep["theta_new"]
         self.U = self._trajectory_of(self.theta)                          # mppi.py:682
         action = self.U[:self.u_per_command]
         if self.u_per_command == 1:

@@ -246,14 +246,14 @@ def test_bench_two_ranks_prints_one_valid_json_line():
 
 
 def test_bench_gpus_2_starts_its_own_ranks():
-    """`python bench.py --gpus 2` with no launcher around it (what the driver runs): bench.py starts its own two ranks;
+    """`python bench.py --gpus 2 --process-model spawn` with no launcher around it: bench.py starts its own two ranks;
     on this 1-GPU box they share cuda:0 and exchange through gloo (labelled a test rig in config.backend)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MPPI_BENCH_BACKEND")}
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--workload", "c2"],
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--workload", "c2", "--process-model", "spawn"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -298,3 +298,24 @@ def test_sharded_kmppi_with_the_interpolation_inside_k1_rolls_out_its_own_global
         ref = full.cost_total[lo:hi]
         assert float((c.cost_total - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max())), r
     assert lib.mppi_stat_kmppi_fused_rollouts() == n0 + 1 + world
+
+
+def test_bench_gpus_2_in_one_process_on_a_device_group():
+    """`python bench.py --gpus 2` with no launcher around it: ONE process, MPPI(..., devices=[0, 1]) -- on this 1-GPU box
+    devices=[0, 0], records staged through device copies (labelled)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MPPI_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["K_global"] == 2 * d["config"]["K_per_gpu"] and d["value"] > 0
+    assert d["config"]["devices_hold_identical_U"] is True and "ONE process" in d["config"]["process_model"]
+    if torch.cuda.device_count() < 2:
+        assert d["config"]["devices"] == [0, 0] and "not a measurement" in d["config"]["process_model"]
+    assert d["weak_scaling"]["single_gpu_ms_per_step"] > 0

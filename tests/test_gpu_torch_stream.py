@@ -89,7 +89,7 @@ def test_controller_on_the_engines_rows_is_the_controller_on_torch_randn(cls, K,
         for _ in range(3):
             acts.append(c.command(x).clone())
             if rows:
-                assert c.last_draw == "torch-rows", c.last_draw
+                assert c.last_draw in ("torch-rows", "torch-rows-ahead"), c.last_draw
             else:
                 assert c.last_draw is None
         tail = torch.randn(9, device="cuda")                 # where did the command leave the generator?
@@ -132,7 +132,7 @@ def test_where_it_does_not_apply_the_command_draws_with_torch_randn(why):
         assert not torch.equal(a, b), "replays must advance the generator"
         assert c.last_draw is None
         c.command(x)
-        assert c.last_draw == "torch-rows"                   # outside the graph the controller is back on its rows
+        assert c.last_draw in ("torch-rows", "torch-rows-ahead")     # outside the graph the controller is back on its rows
         return
     torch.manual_seed(4)
     c.command(x)
@@ -156,3 +156,86 @@ def test_a_users_own_graph_capture_is_noticed():
         with torch.cuda.graph(g, stream=side):
             took = c._torch_stream_fill(c._problem(), 1024, 8, 4)
     assert took is False
+
+
+# ---- ABI 21: the NEXT command's draw inside this command's K3 launch (csrc/noise_torch.hip weights_partial_diag_next_kernel) ----
+def _pair(cls, K, T, nx, nu, **kw):
+    torch.manual_seed(1)                      # (KMPPI draws its initial control points at construction)
+    a = _ctrl(cls, K, T, nx, nu, True, **kw)
+    torch.manual_seed(1)
+    b = _ctrl(cls, K, T, nx, nu, True, **kw)
+    b.draw_ahead = False
+    return a, b
+
+
+@pytest.mark.parametrize("cls,K,T,nx,nu,kw,ahead", [
+    ("MPPI", 65536, 64, 16, 12, {}, True),
+    ("MPPI", 20000, 32, 8, 4, dict(sample_null_action=True, u_min=torch.tensor([-0.4] * 4), u_max=torch.tensor([0.5] * 4)), True),
+    ("MPPI", 30011, 20, 8, 6, {}, True),                     # ragged K, a control width that is no multiple of 4
+    ("SMPPI", 24000, 24, 8, 4, {}, True),
+    ("KMPPI", 24000, 32, 8, 4, dict(num_support_pts=16), None),      # (its fused control-point update has no K3 launch: either way)
+    ("MPPI", 2048, 8, 6, 4, {}, False),                      # single-launch command: no K3 to carry the draw
+])
+def test_draw_ahead_changes_no_bit(cls, K, T, nx, nu, kw, ahead):
+    """A controller whose K3 launches generate the next draw commands the SAME bits as one that draws at the start of every command:
+    the rows are a pure function of (seed, offset, shape), K3's arithmetic is the same code in both launches, and the generator is
+    advanced by the same amounts at the same commands."""
+    x = torch.linspace(-1, 1, nx, device="cuda")
+    out = []
+    for c in _pair(cls, K, T, nx, nu, **kw):
+        torch.manual_seed(99)
+        acts, draws = [], []
+        for i in range(5):
+            acts.append(c.command(x).clone())
+            draws.append(c.last_draw)
+        tail = torch.randn(9, device="cuda")
+        out.append((torch.stack(acts), c.cost_total.clone(), c.U.clone(), c.noise.clone(), tail, draws, c._next_hits))
+    a, b = out
+    for i in range(5):
+        assert torch.equal(a[i], b[i]), f"output {i} differs between draw-ahead and draw-at-start"
+    assert b[6] == 0 and all(d == "torch-rows" for d in b[5])
+    if ahead is True:
+        assert a[5] == ["torch-rows"] + ["torch-rows-ahead"] * 4 and a[6] == 4, (a[5], a[6])
+    elif ahead is False:
+        assert a[6] == 0
+
+
+def test_a_draw_by_somebody_else_between_two_commands_is_noticed():
+    """the user calls torch.randn between two commands -- the draw generated ahead assumed an offset that is no
+    longer the generator's: it is dropped, the command draws at the generator's present state, and the stream is the reference's"""
+    K, T, nx, nu = 32768, 32, 8, 4             # (a streaming command: the single-launch form of small problems has no K3 launch)
+    x = torch.zeros(nx, device="cuda")
+    out = []
+    for c in _pair("MPPI", K, T, nx, nu):
+        torch.manual_seed(5)
+        seq = []
+        for i in range(6):
+            if i == 2:
+                seq.append(torch.randn(5, device="cuda"))            # the user's own draw
+            if i == 5:
+                torch.manual_seed(5)                                 # ... and a re-seed: (seed, offset) of the FIRST command again
+            seq.append(c.command(x).clone())
+            seq.append(c.noise[:3].clone())
+            seq.append(c.last_draw)
+        out.append((seq, c._next_hits))
+    (a, ha), (b, hb) = out
+    assert [v for v in a if isinstance(v, str)] == ["torch-rows", "torch-rows-ahead", "torch-rows", "torch-rows-ahead", "torch-rows-ahead", "torch-rows"]
+    assert ha == 3 and hb == 0
+    for u, v in zip(a, b):
+        if not isinstance(u, str):
+            assert torch.equal(u, v)
+    # the first and the last command drew from the same (seed, offset): the same rows, whoever generated them
+    assert torch.equal(a[1], a[-2])
+
+
+def test_useless_draws_ahead_are_given_up():
+    """the reference's benchmark protocol calls reset() -- a draw from the generator -- before every command: after two draws
+    generated for nothing the controller stops asking for them (and tries again every 64th command)"""
+    c = _ctrl("MPPI", 32768, 32, 8, 4, True)
+    x = torch.zeros(8, device="cuda")
+    asked = []
+    for i in range(8):
+        c.reset()
+        c.command(x)
+        asked.append(c._last.next_z is not None and c._last.next_z != 0)
+    assert c._next_hits == 0 and asked[:2] == [True, True] and not any(asked[2:]), asked
