@@ -44,6 +44,7 @@ extern "C" {
 #define MPPI_ABI_VERSION 21
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
+enum { MPPI_NEXT_DRAW_TORCH = 0, MPPI_NEXT_DRAW_PHILOX = 1 };   /* MppiProblem.next_kind (ABI 21) */
 enum { MPPI_NOISE_TNK4 = 0, MPPI_NOISE_PHILOX = 1,
        MPPI_NOISE_ACTIONS = 2 /* p->z holds pre-made raw actions (TNK4), KMPPI; K1/prepare only */,
        MPPI_NOISE_KTN = 3     /* p->z is the reference's own (K,T,nu) row-major fp32 draw (mppi.py:203), read in
@@ -170,7 +171,10 @@ typedef struct MppiProblem {
   uint64_t next_seed;
   uint64_t next_philox_offset;
   int32_t next_grid_blocks;   /* ATen's launch grid for that call (see mppi_noise_fill_torch) */
-  int32_t _reserved0;
+  int32_t next_kind;          /* MPPI_NEXT_DRAW_TORCH: as above.  MPPI_NEXT_DRAW_PHILOX (rng = the engine's generator, rows in memory):
+                                 next_z receives what mppi_noise_fill_philox writes for command next_philox_offset (the caller passes
+                                 p->call + 1) with key next_seed -- the rows of the NEXT command, for this problem's samples; the
+                                 generator launch of small and mid-size commands disappears into K3's launch (uncoloured rows only) */
 } MppiProblem;
 
 int mppi_abi_version(void);

@@ -15,6 +15,7 @@ F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
 E_UNSUPPORTED = -2
 FORM_NONE, FORM_STREAMING, FORM_SINGLE_LAUNCH, FORM_ONCHIP = 0, 1, 2, 3      # mppi_last_command_form()
+NEXT_DRAW_TORCH, NEXT_DRAW_PHILOX = 0, 1                                       # MppiProblem.next_kind
 E_DIST = -4
 MODEL_NONE, MODEL_PENDULUM, MODEL_INTEGRATOR, MODEL_LINEAR_GOAL, MODEL_MLP = 0, 1, 2, 3, 4
 MODEL_CUSTOM_BASE = 100
@@ -48,7 +49,7 @@ class MppiProblem(C.Structure):
         ("workspace", _vp), ("workspace_elems", C.c_int64),
         ("onchip_spill", _vp), ("onchip_spill_elems", C.c_int64),
         # ABI 21: the next command's torch-stream draw inside this command's K3 launch
-        ("next_z", _vp), ("next_seed", C.c_uint64), ("next_philox_offset", C.c_uint64), ("next_grid_blocks", C.c_int32), ("_reserved0", C.c_int32),
+        ("next_z", _vp), ("next_seed", C.c_uint64), ("next_philox_offset", C.c_uint64), ("next_grid_blocks", C.c_int32), ("next_kind", C.c_int32),
     ]
 
 

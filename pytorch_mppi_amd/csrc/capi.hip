@@ -549,7 +549,7 @@ template <typename T>
 static int weights_rows(const KArgs<T>&, void*, const MppiProblem*, hipStream_t) { return MPPI_E_UNSUPPORTED; }
 template <>
 int weights_rows<float>(const KArgs<float>& a, void* next_z, const MppiProblem* p, hipStream_t st) {
-  return launch_weights_partial_rows_f32(a, next_z, p->next_seed, p->next_philox_offset, p->next_grid_blocks, st);
+  return launch_weights_partial_rows_f32(a, next_z, p->next_kind, p->next_seed, p->next_philox_offset, p->next_grid_blocks, st);
 }
 template <typename T>
 static int do_weights(const MppiProblem* p, hipStream_t st) {

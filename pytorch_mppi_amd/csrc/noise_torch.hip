@@ -48,7 +48,44 @@ struct TorchDraw {
   unsigned kchunks, nrows4;
   unsigned nk3, ngen;            // the draw beside K3 (weights_partial_rows_kernel): workgroups of either kind
   unsigned long long seed, offset;
+  // kind 1 (the ENGINE's stream, rng="philox"): the rows of command `offset` (= this command's call + 1) for the samples
+  // [k_offset, k_offset + K) -- what noise_fill_philox_kernel (update.hip) writes; unit = (256-sample chunk, row-of-4)
+  int kind;
+  long long k_offset;
 };
+
+// units [u0, u1) of the engine's own stream, lane t of 256: unit u = row jb = u / nchunks of chunk u % nchunks (one division per
+// slice, then counted up); two rows at a time -- two independent Philox chains in the instruction stream, as below
+__device__ __forceinline__ void philox_stream_units(const TorchDraw& d, unsigned long long u, const unsigned long long u1, const int t) {
+  if (u >= u1) return;
+  const unsigned nchunks = d.kchunks;
+  unsigned jb = (unsigned)(u / nchunks), ch = (unsigned)(u - (unsigned long long)jb * nchunks);
+  unsigned n = (unsigned)(u1 - u);
+  auto row = [&](unsigned jb_, unsigned ch_, float (&r)[4]) {
+    philox_normal4<float>(d.seed, d.offset, d.k_offset + (long long)ch_ * BLOCK + t, (long long)jb_, r);
+  };
+  auto put = [&](unsigned jb_, unsigned ch_, const float (&r)[4]) {
+    const long long k = (long long)ch_ * BLOCK + t;
+    if (k < d.K) *reinterpret_cast<float4*>(d.z + ((long long)jb_ * d.pitch + k) * 4) = make_float4(r[0], r[1], r[2], r[3]);
+  };
+  auto next = [&](unsigned& jb_, unsigned& ch_) { if (++ch_ == nchunks) { ch_ = 0; ++jb_; } };
+  for (; n >= 2; n -= 2) {
+    unsigned jb1 = jb, ch1 = ch;
+    next(jb1, ch1);
+    float r0[4], r1[4];
+    row(jb, ch, r0);
+    row(jb1, ch1, r1);
+    put(jb, ch, r0);
+    put(jb1, ch1, r1);
+    jb = jb1; ch = ch1;
+    next(jb, ch);
+  }
+  if (n) {
+    float r0[4];
+    row(jb, ch, r0);
+    put(jb, ch, r0);
+  }
+}
 
 // Calls [m0, m1) of the ATen threads of generator block (x, y), lane t of 256: thread (kk, c) = (t >> 2, t & 3) -> ATen thread
 // idx = k J + 4 y + c (k = 64 x + kk), so that component 0 of call 0 of a wave is 16 samples x one row-of-4 of the row layout.
@@ -148,6 +185,10 @@ weights_partial_rows_kernel(const KArgs<float> a, const TorchDraw d) {
   const unsigned long long units = (unsigned long long)d.kchunks * d.nrows4 * (unsigned)d.ncalls;
   unsigned long long u = units * i / ngen;
   const unsigned long long u1 = units * (i + 1) / ngen;
+  if (d.kind == 1) {
+    philox_stream_units(d, u, u1, (int)threadIdx.x);
+    return;
+  }
   while (u < u1) {
     const unsigned gb = (unsigned)(u / (unsigned)d.ncalls);
     const int m0 = (int)(u - (unsigned long long)gb * (unsigned)d.ncalls);
@@ -175,12 +216,22 @@ static int torch_draw_args(TorchDraw& d, void* z, int64_t K, int64_t J, int64_t 
 // update.hip's: the same source in the two units is not the same arithmetic to the last bit).  next_z == NULL: 256 threads per
 // workgroup, K3 alone.  Otherwise the next draw must have the shape and pitch of the rows this K3 reads; MPPI_E_UNSUPPORTED when
 // the launch cannot carry it (several environments on grid.z, (T nu) % 4 != 0, next_z == z): the caller runs K3 alone.
-int launch_weights_partial_rows_f32(const KArgs<float>& a, void* next_z, uint64_t seed, uint64_t philox_offset, int32_t grid_blocks, hipStream_t st) {
+int launch_weights_partial_rows_f32(const KArgs<float>& a, void* next_z, int kind, uint64_t seed, uint64_t philox_offset, int32_t grid_blocks, hipStream_t st) {
   if (a.noise_src != MPPI_NOISE_TNK4 || !(a.diag || a.coloured)) return MPPI_E_UNSUPPORTED;
   TorchDraw d{};
   if (next_z != nullptr) {
-    if (a.n_env > 1 || a.J % 4 != 0 || next_z == (const void*)a.z) return MPPI_E_UNSUPPORTED;
-    if (int e = torch_draw_args(d, next_z, a.K, a.J, a.zp, seed, philox_offset, grid_blocks)) return e;
+    if (a.n_env > 1 || next_z == (const void*)a.z) return MPPI_E_UNSUPPORTED;
+    if (kind == MPPI_NEXT_DRAW_PHILOX) {
+      // the engine's own stream: rows of command `philox_offset` (the caller passes call + 1), uncoloured
+      if (a.coloured) return MPPI_E_UNSUPPORTED;
+      d.z = (float*)next_z; d.K = a.K; d.pitch = a.zp; d.J = a.J; d.ncalls = 1; d.kchunks = (unsigned)((a.K + BLOCK - 1) / BLOCK);
+      d.nrows4 = (unsigned)a.J4; d.seed = seed; d.offset = philox_offset; d.kind = 1; d.k_offset = a.k_offset;
+    } else if (kind == MPPI_NEXT_DRAW_TORCH) {
+      if (a.J % 4 != 0) return MPPI_E_UNSUPPORTED;
+      if (int e = torch_draw_args(d, next_z, a.K, a.J, a.zp, seed, philox_offset, grid_blocks)) return e;
+    } else {
+      return MPPI_E_BADARG;
+    }
   }
   const unsigned njt = (unsigned)((a.J4 * 4 + UPD_TJ - 1) / UPD_TJ);
   dim3 grid(a.nkc, njt, a.n_env);
@@ -192,7 +243,7 @@ int launch_weights_partial_rows_f32(const KArgs<float>& a, void* next_z, uint64_
     const unsigned long long units = (unsigned long long)d.kchunks * d.nrows4 * (unsigned)d.ncalls;
     d.nk3 = (unsigned)a.nkc * njt;
     unsigned long long ng = (unsigned long long)d.nk3 * (ratio_env > 0 ? ratio_env : 4);
-    if (ng > units / 2) ng = units / 2 / d.nk3 * d.nk3;       // at least two calls per generator workgroup
+    if (ng > units / 2) ng = units / 2 / d.nk3 * d.nk3;       // at least two calls (rows, for the engine's stream) per generator workgroup
     if (ng < d.nk3) ng = d.nk3;
     d.ngen = (unsigned)ng;
     grid = dim3(d.nk3 + d.ngen, 1, 1);

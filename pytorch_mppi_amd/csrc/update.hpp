@@ -11,7 +11,7 @@ template <typename T> int launch_cost_block_min(const KArgs<T>& a, hipStream_t s
 template <typename T> int launch_weights_partial(const KArgs<T>& a, hipStream_t st);
 // the diagonal K3 on fp32 TNK4 rows, with (next_z != NULL) or without the next command's torch-stream draw generated beside it
 // (noise_torch.hip); MPPI_E_UNSUPPORTED: not that kind of problem / the launch cannot carry the draw
-int launch_weights_partial_rows_f32(const KArgs<float>& a, void* next_z, uint64_t seed, uint64_t philox_offset, int32_t grid_blocks, hipStream_t st);
+int launch_weights_partial_rows_f32(const KArgs<float>& a, void* next_z, int kind, uint64_t seed, uint64_t philox_offset, int32_t grid_blocks, hipStream_t st);
 template <typename T> int launch_finalize(const KArgs<T>& a, int apply, hipStream_t st);
 // K4 of the on-chip command: combines the per-workgroup partial records (a.nkc of them) in block order
 template <typename T> int launch_finalize_blocks(const KArgs<T>& a, int apply, hipStream_t st);

@@ -245,6 +245,14 @@ class MPPI:
         # ... and the NEXT command's draw inside this command's K3 launch (ABI 21; adopted at the next command when the generator
         # is where that assumed: _torch_stream_fill).  Costs a second row buffer
         self.draw_ahead = os.environ.get("MPPI_DRAW_AHEAD", "1") != "0"
+        # (draws of fewer normals than this keep their own tiny launch: carving them into K3's few workgroups costs more than it saves
+        # -- profiles/r05_small_k_sweep.txt)
+        self.draw_ahead_min = int(os.environ.get("MPPI_DRAW_AHEAD_MIN", str(1 << 19)))
+        # the same for the ENGINE's generator (rng="philox" with rows in memory, MPPI_NEXT_DRAW_PHILOX): built, bit-exact, and OFF --
+        # that generator launch is already bound by its 201 MB of stores (34 us at C3), not by the VALU, and a launch that reads K3's
+        # rows while it writes the next ones moves the same 403 MB slower (mixed traffic: 5.3 TB/s against 5.9 one after the other;
+        # C3 rows-in-memory command 0.1186 ms with, 0.1096 without; profiles/r05_draw_ahead_forms.txt)
+        self.draw_ahead_philox = os.environ.get("MPPI_DRAW_AHEAD_PHILOX", "0") == "1"
         self._next_draw = None         # (shape key, generator, seed, offset, rows): generated, waiting for the next command
         self._next_armed = None        # ... handed to the engine with this command, not yet confirmed (_settle_next)
         self._next_hits = self._next_misses = self._next_cmds = 0
@@ -942,16 +950,29 @@ class MPPI:
                     fill = True            # the multi-rollout K1 reads its rows from memory
                 self.last_draw = "philox-fill" if fill else "philox-k1"
                 pf, self._pf_rows = self._pf_rows, None
-                if fill and pf is not None and pf[0] == (K, Tn, nu, int(p.k_offset), int(p.seed), int(p.call)):
-                    zn = pf[1]                     # generated while the previous command's collective ran
+                self._next_armed = None
+                ahead = (self.draw_ahead and self.draw_ahead_philox and self.dtype == torch.float32 and (self._diagonal_sigma or not self.coloured_fill)
+                         and self.d.type == "cuda" and not self._in_capture and K * Tn * nu >= self.draw_ahead_min)
+                if pf is not None and pf[0] == (K, Tn, nu, int(p.k_offset), int(p.seed), int(p.call)) and (fill or pf[2]):
+                    # the rows of THIS command exist already: generated inside the previous command's K3 launch (ABI 21,
+                    # csrc/noise_torch.hip -- the VALU that HBM-bound launch leaves idle; for small commands, the CUs) or while the
+                    # previous command's collective ran.  Rows are a pure function of (seed, command, sample, row).
+                    zn = pf[1]
                     self._pf_hits += 1
+                    if pf[2]:
+                        self._zbuf_alt[n], self._zbuf[n] = self._zbuf.get(n), zn        # the two row buffers change roles
+                        self.last_draw = "philox-rows-ahead"
                     p.z = _ptr(zn)
                     p._keep["z"] = zn
                     p.noise_src = N.NOISE_TNK4
+                    if ahead:
+                        self._arm_next_philox(p, n)
                     return
                 zn = self._row_buffer(n)
                 p.z = _ptr(zn)
                 p._keep["z"] = zn
+                if ahead:
+                    self._arm_next_philox(p, n)
                 if fill:
                     # a separate generator launch at full occupancy (32 us for C3's 50 M normals, write
                     # floor 26 us), then K1 as the pure HBM-read kernel.  Short horizons keep the
@@ -1050,7 +1071,7 @@ class MPPI:
         p.z = _ptr(zn)
         p._keep["z"] = zn
         self._next_cmds += 1
-        if self.draw_ahead and (self._next_misses < 2 or self._next_cmds % 64 == 0):
+        if self.draw_ahead and numel >= self.draw_ahead_min and (self._next_misses < 2 or self._next_cmds % 64 == 0):
             # (a caller that draws from the generator between every two commands -- the reference's benchmark protocol calls
             # reset() -- makes every draw-ahead useless and K3 pays for it: after two misses in a row it is tried only every 64th
             # command)
@@ -1064,16 +1085,31 @@ class MPPI:
                 if len(self._zbuf_alt) > 2:
                     self._zbuf_alt.clear()
                 alt = self._zbuf_alt[n_el] = torch.empty(n_el, device=self.d, dtype=self.dtype)
-            p.next_z, p.next_seed, p.next_philox_offset, p.next_grid_blocks = _ptr(alt), seed, off + inc, grid
+            p.next_z, p.next_seed, p.next_philox_offset, p.next_grid_blocks, p.next_kind = _ptr(alt), seed, off + inc, grid, N.NEXT_DRAW_TORCH
             p._keep["next_z"] = alt
             self._next_armed = (nkey, gen, seed, off + inc, alt)
         return True
+
+    def _arm_next_philox(self, p, n_el):
+        """rng="philox", rows in memory: let this command's K3 launch generate the rows of the NEXT command (call + 1) into the
+        other row buffer (MppiProblem.next_*, kind MPPI_NEXT_DRAW_PHILOX); _settle_next reads back whether it did"""
+        alt = self._zbuf_alt.get(n_el)
+        if alt is None or alt.dtype != self.dtype or alt.device != self.d or alt.data_ptr() == p.z:
+            if len(self._zbuf_alt) > 2:
+                self._zbuf_alt.clear()
+            alt = self._zbuf_alt[n_el] = torch.empty(n_el, device=self.d, dtype=self.dtype)
+        p.next_z, p.next_seed, p.next_philox_offset, p.next_grid_blocks, p.next_kind = _ptr(alt), int(p.seed), int(p.call) + 1, 0, N.NEXT_DRAW_PHILOX
+        p._keep["next_z"] = alt
+        self._next_armed = ("philox", (int(p.K), int(p.T), int(p.nu), int(p.k_offset), int(p.seed), int(p.call) + 1), alt)
 
     def _settle_next(self):
         """behind the launches of a command: did its K3 generate the next draw (mppi_last_next_draw, thread-local)?"""
         armed, self._next_armed = self._next_armed, None
         if armed is not None and int(N.lib().mppi_last_next_draw()) == 1:
-            self._next_draw = armed
+            if armed[0] == "philox":
+                self._pf_rows = (armed[1], armed[2], True)
+            else:
+                self._next_draw = armed
 
     def _onchip_wanted(self, K, Tn, nu):
         """rng="philox": does this command go without a row array (include/mppi_amd.h, ABI 18; scope as checked again by
@@ -1293,7 +1329,7 @@ class MPPI:
         n = self._zelems(q.T)
         zn = torch.empty(n, device=self.d, dtype=self.dtype)
         N.check(N.lib().mppi_noise_fill_philox(C.byref(q), _ptr(zn), self._stream()), "mppi_noise_fill_philox")
-        self._pf_rows = ((q.K, q.T, q.nu, int(q.k_offset), int(q.seed), int(q.call)), zn)
+        self._pf_rows = ((q.K, q.T, q.nu, int(q.k_offset), int(q.seed), int(q.call)), zn, False)
 
     def _sharded(self):
         # _force_collective: measurement seam (tools/shard_overhead.py) -- run record -> all_gather -> K5 at world_size 1
