@@ -333,7 +333,7 @@ class MPPI:
             code = jit.trace_and_verify(dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent, horizon=self.T,
                                         device=self.d, dtype=self.dtype, dynamic=dynamic, verify=not verify_in_background)
             w.forget([src.path for src, _ in code["param_tensors"] if isinstance(src, trace.PathParam)])
-            cached = jit.traced_is_cached(code, self.nx, self.nu)
+            cached = jit.traced_is_cached(code, self.nx, self.nu, dtype=self.dtype)
             if verify_in_background or (background and not cached):
                 # the hipcc run (30 s - 2 min) happens beside the control loop: callbacks until it has finished
                 import threading
@@ -344,7 +344,7 @@ class MPPI:
                         if verify_in_background:
                             jit.verify_traced(code, dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent, self.T)
                         box["model"] = jit.compile_traced(code, dynamics, running_cost, self.nx, self.nu, terminal_state_cost,
-                                                          step_dependent=step_dependent)
+                                                          step_dependent=step_dependent, dtype=self.dtype)
                     except Exception as e:                      # a failed check / hipcc run: stay on the callbacks
                         box["error"] = e
                 th = threading.Thread(target=work, name="pytorch_mppi_amd-jit", daemon=True)
@@ -354,7 +354,8 @@ class MPPI:
                     self.jit_note = "generic path for now: the fused kernels of the traced callables are being compiled in the background"
                     log.warning("pytorch_mppi_amd: %s (auto_jit='sync' / MPPI_AUTO_JIT=sync waits for them instead)", self.jit_note)
                 return None
-            m = jit.compile_traced(code, dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent=step_dependent)
+            m = jit.compile_traced(code, dynamics, running_cost, self.nx, self.nu, terminal_state_cost, step_dependent=step_dependent,
+                                   dtype=self.dtype)
         except trace.TraceUnsupported as e:
             self.jit_note = f"generic path: {e}"
             log.info("pytorch_mppi_amd: dynamics / running_cost stay on the generic (callback) path: %s", e)

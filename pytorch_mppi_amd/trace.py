@@ -1605,6 +1605,66 @@ def emit(g, roots, assign=None, ret=False, used=None):
     return " ".join(lines)
 
 
+def match_mlp_residual(g, step_roots, cost_root, term_root, nx, nu):
+    """Is the traced model the shape the engine's hand-written matrix-core kernel rolls out (csrc/rollout_mlp_split.hip, BASELINE
+    configs[3]: x' = x + s (W2 tanh(W1 [x; u] + b1) + b2), cost = sum x^2, /root/reference/tests/pendulum_approximate.py:47-67 with
+    one hidden layer)?  Structural: exactly one chain of two dense layers with a bare tanh between them, the first reading
+    [x_0 .. x_nx-1, u_0 .. u_nu-1] in order, every state component's update `x_i + s * layer2_i` with ONE constant s (or none), the
+    cost the sum of the squares of all state components, no terminal cost.  Returns where W1, b1, W2, b2 sit in the functor's
+    parameter vector and s -- or None.  (Whether the kernel exists for (nx, nu, hidden) is the caller's question: jit.compile_traced.)"""
+    if term_root is not None or len(g.layers) != 2:
+        return None
+    chains, _ = _dense_chains(g, list(step_roots) + [cost_root])
+    if len(chains) != 1:
+        return None
+    chain = next(iter(chains.values()))
+    if len(chain) != 2 or chain[1][1] != (("tanh",),):
+        return None
+    L1, L2 = chain[0][0], chain[1][0]
+    l1, l2 = g.layers[L1], g.layers[L2]
+    if l1["IN"] != nx + nu or l2["OUT"] != nx or l2["IN"] != l1["OUT"] or len(step_roots) != nx:
+        return None
+    if [g.nodes[a] for a in l1["inputs"]] != [("x", i) for i in range(nx)] + [("u", n) for n in range(nu)]:
+        return None
+    scale = None
+    for i, r in enumerate(step_roots):
+        n = g.nodes[r]
+        if n[0] != "add" or len(n) != 3:
+            return None
+        if g.nodes[n[1]] == ("x", i):
+            other = n[2]
+        elif g.nodes[n[2]] == ("x", i):
+            other = n[1]
+        else:
+            return None
+        m = g.nodes[other]
+        if m == ("lin", L2, i):
+            c = 1.0
+        elif m[0] == "mul" and len(m) == 3 and g.cval(m[1]) is not None and g.nodes[m[2]] == ("lin", L2, i):
+            c = g.cval(m[1])
+        elif m[0] == "mul" and len(m) == 3 and g.cval(m[2]) is not None and g.nodes[m[1]] == ("lin", L2, i):
+            c = g.cval(m[2])
+        else:
+            return None
+        if scale is not None and c != scale:
+            return None
+        scale = c
+    squares = []
+
+    def walk(i):
+        n = g.nodes[i]
+        if n[0] == "add" and len(n) == 3:
+            return walk(n[1]) and walk(n[2])
+        if n[0] == "mul" and len(n) == 3 and n[1] == n[2] and g.nodes[n[1]][0] == "x":
+            squares.append(g.nodes[n[1]][1])
+            return True
+        return False
+    if not walk(cost_root) or sorted(squares) != list(range(nx)):
+        return None
+    return dict(H=int(l1["OUT"]), w1=int(l1["wbase"]), b1=None if l1["bbase"] is None else int(l1["bbase"]), w2=int(l2["wbase"]),
+                b2=None if l2["bbase"] is None else int(l2["bbase"]), scale=float(scale))
+
+
 def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, device=None, dtype=None, dynamic=()):
     """-> dict(step=..., cost=..., terminal=... or None, n_ops=...): the C++ bodies for jit.compile_model.
     device / dtype: what the symbolic inputs report (the controller's; default cpu / float64).
@@ -1618,6 +1678,7 @@ def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_depe
     return dict(step=step, cost=cost, terminal=term, n_ops=len(g.nodes), captured=g.captured, param_tensors=g.param_tensors,
                 n_params=g.n_params, dynamic=list(dynamic), members=members, ctor=ctor,
                 numbers=frozenset(n[1] for n in g.nodes if n[0] == "c"),     # every numeric constant of the graph (mppi.MPPI._settle_moved)
+                mlp_residual=None if step_dependent else match_mlp_residual(g, so, co, to, nx, nu),
                 dense=[dict(IN=g.layers[L]["IN"], OUT=g.layers[L]["OUT"], kind=k) for (L, k) in sorted(used)])   # layers kept as layers
 
 

@@ -509,3 +509,69 @@ def test_traced_network_with_mixed_activations_and_a_wide_state():
         c.U = torch.zeros(10, 2, dtype=torch.float64, device="cuda")
         c.inject_noise(z)
     assert float((d.command(x0.double()) - e.command(x0.double())).abs().max()) <= 1e-9
+
+
+def test_c4_shaped_torch_callables_take_the_matrix_core_mlp_kernel():
+    """VERDICT r04 missing #2 / item 4: BASELINE configs[3] written as the reference's plugin API -- a plain
+    nn.Sequential(Linear(20, 256), Tanh(), Linear(256, 16)) residual model and cost sum x^2 as torch callables -- is recognised by
+    the tracer (trace.match_mlp_residual) and rolled out by the hand-written split-operand matrix-core kernel
+    (csrc/rollout_mlp_split.hip) instead of the exact-fp32 wide form of the traced layers: no hipcc run, the trainable weights
+    are run-time parameters (retraining between commands keeps the kernel), parity against the fp64 oracle on the consumed draw
+    by the C4 criterion, and the C4-sized command in <= 0.5 ms."""
+    import gpu_util
+    import pytorch_mppi_amd as pm
+    from pytorch_mppi_amd import _native as N
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(20, 256), torch.nn.Tanh(), torch.nn.Linear(256, 16)).cuda()
+    f = lambda x, u: x + 0.1 * net(torch.cat((x, u), dim=-1))
+    q = lambda x, u: (x ** 2).sum(dim=-1)
+    nx, nu, K, T = 16, 4, 16384, 32
+    g = torch.Generator().manual_seed(2)
+    U0 = torch.randn(T, nu, generator=g) * 0.05
+    x0 = torch.randn(nx, generator=g)
+    mk = lambda K_, T_, lam: pm.MPPI(f, q, nx, torch.eye(nu), num_samples=K_, horizon=T_, device="cuda", lambda_=lam, rng="philox", seed=11,
+                                     U_init=(U0 if T_ == T else torch.zeros(T_, nu)), auto_jit="sync")
+    c = mk(K, T, 1.0)
+    assert c._model is not None and c._model.model_id == N.MODEL_MLP and c._model.hidden == 256 and not c._needs_generic(), c.jit_note
+    c.command(x0.cuda())
+    lam = float(c.cost_total.std())
+    for rnd in range(2):
+        c = mk(K, T, lam)
+        act = c.command(x0.cuda())
+        z = gpu_util.consumed_normals(c)
+        net_cpu = [p_.detach().cpu() for p_ in net.parameters()]
+
+        def f_ref(dt):
+            W1, b1, W2, b2 = (w.to(dt) for w in net_cpu)
+            return lambda x, u: x + 0.1 * (torch.tanh(torch.cat((x, u), dim=-1) @ W1.T + b1) @ W2.T + b2)
+        outs = []
+        from oracle import mppi_oracle as orc
+        for dt in (torch.float64, torch.float32):
+            p = orc.Problem(dynamics=f_ref(dt), running_cost=q, nx=nx, noise_sigma=torch.eye(nu, dtype=dt), K=K, T=T, lambda_=lam)
+            outs.append(orc.command(p, U0.to(dt), x0.to(dt), z.to(dt), True))
+        r64, r32 = outs
+        for name, got in (("action", act), ("U", c.U), ("cost_total", c.cost_total), ("omega", c.omega)):
+            margins.check(f"from_torch/c4-shaped callables on the split MFMA kernel round {rnd}", name, got.detach().cpu().numpy(), r64[name].numpy(),
+                          r32[name].numpy(), rtol=1e-5)
+        # retrain between commands: in-place parameter updates reach the kernel's blob (refresh_params), nothing is compiled
+        opt = torch.optim.SGD(net.parameters(), lr=1e-2)
+        loss = (net(torch.randn(64, 20, device="cuda")) ** 2).mean()
+        loss.backward()
+        opt.step()
+    # the C4-sized command
+    big = mk(65536, 64, lam)
+    assert big._model.model_id == N.MODEL_MLP
+    for _ in range(3):
+        big.command(x0.cuda())
+    xd = x0.cuda()
+    ms = _best_batch_ms(big, xd, 20, 3)
+    # the built-in model object of the same shape through the same loop (what bench.py's C4 line runs), for the record
+    ref = pm.models.MLPResidual.random(nx, nu, 256, seed=2)
+    cb = pm.MPPI(ref.dynamics, ref.running_cost, nx, torch.eye(nu), num_samples=65536, horizon=64, device="cuda", lambda_=lam, rng="philox", seed=11)
+    for _ in range(3):
+        cb.command(xd)
+    ms_builtin = _best_batch_ms(cb, xd, 20, 3)
+    margins.record("from_torch/c4-shaped callables on the split MFMA kernel", "ms_per_command", ms, None, 0.5,
+                   "nn.Sequential(Linear(20,256), Tanh(), Linear(256,16)) residual + sum x^2 as torch callables, K 65536 x T 64; "
+                   "the built-in models.MLPResidual through the same loop: %.4f ms" % ms_builtin)
+    assert ms <= 0.50 and ms <= 1.06 * ms_builtin, (ms, ms_builtin)

@@ -289,3 +289,33 @@ def test_dense_layers_can_be_switched_off(monkeypatch):
     net = torch.nn.Sequential(torch.nn.Linear(3, 16), torch.nn.Tanh(), torch.nn.Linear(16, 2)).double()
     code = jit.trace_and_verify(lambda s, a: s + net(torch.cat((s, a), 1)), lambda s, a: (s ** 2).sum(1), 2, 1)
     assert not code["dense"] and "mlp_" not in code["step"] and code["members"] == ""
+
+
+def test_a_trace_that_is_the_matrix_core_mlp_is_recognised():
+    """VERDICT r04 item 4 (first half): torch callables whose trace is x + s (W2 tanh(W1 [x; u] + b1) + b2) with cost sum x^2 --
+    BASELINE configs[3] written as the reference's plugin API -- are matched structurally (trace.match_mlp_residual) so that the
+    controller can hand them to the hand-written matrix-core kernel instead of compiling a functor"""
+    import torch
+    from pytorch_mppi_amd import jit, trace
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.Tanh(), torch.nn.Linear(64, 16)).double()
+    dyn = lambda x, u: x + 0.1 * net(torch.cat((x, u), -1))
+    sq = lambda x, u: (x ** 2).sum(-1)
+    code = trace.generate(dyn, sq, 16, 4)
+    sp = code["mlp_residual"]
+    assert sp == dict(H=64, w1=0, b1=1280, w2=1344, b2=2368, scale=0.1)
+    # the parameter blob the kernel wants, out of the trace's parameter vector
+    m = jit.TracedMLPResidual("t", 16, 4, dyn, sq, sp, trace.gather_params(code["param_tensors"], code["n_params"]))
+    W1, b1, W2, b2, s = m._param_list()
+    assert torch.equal(W1.reshape(64, 20), net[0].weight.detach()) and torch.equal(b1, net[0].bias.detach())
+    assert torch.equal(W2.reshape(16, 64), net[2].weight.detach()) and torch.equal(b2, net[2].bias.detach()) and float(s) == 0.1
+    assert m.model_id == 4 and m.hidden == 64 and m.flags() == 0
+    # what is NOT that shape keeps its functor
+    for d_, c_ in ((dyn, lambda x, u: (x ** 2).sum(-1) + 0.1 * (u ** 2).sum(-1)),                    # another cost
+                   (lambda x, u: x + 0.1 * net(torch.cat((u, x), -1)), sq),                          # inputs in another order
+                   (lambda x, u: 0.9 * x + 0.1 * net(torch.cat((x, u), -1)), sq),                    # no plain residual
+                   (lambda x, u: x + 0.1 * torch.nn.functional.relu(net[0](torch.cat((x, u), -1))) @ net[2].weight.T, sq)):   # another activation
+        assert trace.generate(d_, c_, 16, 4)["mlp_residual"] is None
+    two = torch.nn.Sequential(torch.nn.Linear(20, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(), torch.nn.Linear(32, 16)).double()
+    assert trace.generate(lambda x, u: x + two(torch.cat((x, u), -1)), sq, 16, 4)["mlp_residual"] is None
+    assert trace.generate(lambda x, u, t: x + 0.1 * net(torch.cat((x, u), -1)), lambda x, u, t: (x ** 2).sum(-1), 16, 4, step_dependent=True)["mlp_residual"] is None
