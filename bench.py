@@ -431,6 +431,7 @@ def main():
     ap.add_argument("--rng", default="philox", choices=["torch", "torch-native", "philox", "philox-stream", "philox-fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--hbm-cold", action="store_true", help="with --no-extras: still run the HBM-cold K1 pass (for a rocprofv3 trace of those launches)")
     ap.add_argument("--process-model", default="auto", choices=["auto", "devices", "spawn"],
                     help="--gpus N outside torch.distributed.run: 'devices' (auto) = ONE process, MPPI(..., devices=[0..N-1]); 'spawn' = start "
                          "N ranks (one process per GPU, shard=(rank, N)) like the driver's launcher does")
@@ -704,7 +705,7 @@ def main():
                                      "untimed pass over every buffer, + the dispatch offset measured for those launches)"}
             # the HBM-cold pass allocates 1.6 GB and takes a while: rank 0 only, after the barrier above, with the
             # other ranks parked at the barrier below
-            cold = k1_hbm_cold(roof_ctrl) if (rank == 0 and not args.no_extras) else None
+            cold = k1_hbm_cold(roof_ctrl) if (rank == 0 and (not args.no_extras or args.hbm_cold)) else None
             if cold and cold["launch_us_device_span"]:
                 us_c = cold["launch_us_device_span"]["median"] + DISPATCH_OFFSET_US_COLD
                 if dump and rank == 0:     # the cold launches, for tools/clock_calibration.py (the LAST dispatches of K1 in the trace)

@@ -175,6 +175,12 @@ typedef struct MppiProblem {
                                  next_z receives what mppi_noise_fill_philox writes for command next_philox_offset (the caller passes
                                  p->call + 1) with key next_seed -- the rows of the NEXT command, for this problem's samples; the
                                  generator launch of small and mid-size commands disappears into K3's launch (uncoloured rows only) */
+  int32_t philox_rounds;      /* rounds of the ENGINE's generator (noise_src = PHILOX, mppi_noise_fill_philox*, process noise): 0 or 10 =
+                                 Philox4x32-10 (every library's default); 7 = Philox4x32-7, the fewest rounds that pass BigCrush
+                                 (Salmon et al. 2011; Random123's philox4x32_R<7>, pinned by its known-answer vectors) -- a different
+                                 stream, 30 % fewer multiplies in the kernel whose time they are (on-chip K1 71 -> 66 us at C3).
+                                 Any other value: MPPI_E_BADARG */
+  int32_t _reserved0;
 } MppiProblem;
 
 int mppi_abi_version(void);

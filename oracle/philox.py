@@ -11,12 +11,13 @@ M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 W0, W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
+def philox4x32_10(c0, c1, c2, c3, k0, k1, rounds=10):
+    """Philox4x32-R (R = 10: the default everywhere; R = 7: rng="philox7", Random123's philox4x32_R<7>)"""
     c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint32) for x in (c0, c1, c2, c3))
     k0 = np.uint32(k0)
     k1 = np.uint32(k1)
     with np.errstate(over="ignore"):
-        for _ in range(10):
+        for _ in range(rounds):
             p0 = M0 * c0.astype(np.uint64)
             p1 = M1 * c2.astype(np.uint64)
             n0 = (p1 >> np.uint64(32)).astype(np.uint32) ^ c1 ^ k0
@@ -43,7 +44,7 @@ def rows4(T, nu):
     return -(-T // tt) * p4
 
 
-def normals_tnk4(seed, call, K, T, nu, k_offset=0):
+def normals_tnk4(seed, call, K, T, nu, k_offset=0, rounds=10):
     """(J4, K, 4) float32 -- the engine's native layout."""
     J4 = rows4(T, nu)
     kg = (np.arange(K, dtype=np.uint64) + np.uint64(k_offset))[None, :].repeat(J4, 0)
@@ -51,16 +52,16 @@ def normals_tnk4(seed, call, K, T, nu, k_offset=0):
     c0 = kg.astype(np.uint32)
     c2 = np.full_like(c0, np.uint32(call & 0xFFFFFFFF))
     c3 = np.uint32((call >> 32) & 0xFFFFFFFF) ^ (kg >> np.uint64(32)).astype(np.uint32)
-    r0, r1, r2, r3 = philox4x32_10(c0, jb, c2, c3, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    r0, r1, r2, r3 = philox4x32_10(c0, jb, c2, c3, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, rounds)
     a, b = box_muller(r0, r1)
     c, d = box_muller(r2, r3)
     return np.stack([a, b, c, d], axis=-1)
 
 
-def normals_ktn(seed, call, K, T, nu, k_offset=0):
+def normals_ktn(seed, call, K, T, nu, k_offset=0, rounds=10):
     """The same draws re-indexed to the reference's (K,T,nu) layout: element (k,t,n) is
     component (t*nu+n)%4 of row (t*nu+n)//4."""
-    z4 = normals_tnk4(seed, call, K, T, nu, k_offset)          # (J4,K,4)
+    z4 = normals_tnk4(seed, call, K, T, nu, k_offset, rounds)          # (J4,K,4)
     flat = z4.transpose(1, 0, 2).reshape(K, -1)                # (K, J4*4)
     return np.ascontiguousarray(flat[:, :T * nu].reshape(K, T, nu))
 

@@ -49,7 +49,7 @@ class MppiProblem(C.Structure):
         ("workspace", _vp), ("workspace_elems", C.c_int64),
         ("onchip_spill", _vp), ("onchip_spill_elems", C.c_int64),
         # ABI 21: the next command's torch-stream draw inside this command's K3 launch
-        ("next_z", _vp), ("next_seed", C.c_uint64), ("next_philox_offset", C.c_uint64), ("next_grid_blocks", C.c_int32), ("next_kind", C.c_int32),
+        ("next_z", _vp), ("next_seed", C.c_uint64), ("next_philox_offset", C.c_uint64), ("next_grid_blocks", C.c_int32), ("next_kind", C.c_int32), ("philox_rounds", C.c_int32), ("_reserved0", C.c_int32),
     ]
 
 

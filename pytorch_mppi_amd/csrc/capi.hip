@@ -212,6 +212,7 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   if (p == nullptr) return fail(MPPI_E_BADARG, "null problem");
   if (p->K <= 0 || p->T <= 0 || p->nx <= 0 || p->nu <= 0) return fail(MPPI_E_BADARG, "bad dims");
   if (!(p->lambda_ > 0)) return fail(MPPI_E_BADARG, "lambda_ must be > 0");
+  if (p->philox_rounds != 0 && p->philox_rounds != 7 && p->philox_rounds != 10) return fail(MPPI_E_BADARG, "philox_rounds must be 0, 7 or 10");
   if (!p->U || !p->u_init || !p->noise_mu || !p->noise_L || !p->sigma_inv || !p->u_min || !p->u_max)
     return fail(MPPI_E_BADARG, "missing parameter array");
   if (p->n_sampler_rows > 0 && !p->sampler_actions) return fail(MPPI_E_BADARG, "sampler rows without actions");
@@ -230,6 +231,7 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   a.model_flags = p->model_flags;
   a.spill = (T*)p->onchip_spill;
   a.spill_cap = p->onchip_spill != nullptr ? p->onchip_spill_elems : 0;
+  a.seven = p->philox_rounds == 7;
   a.lambda_ = (T)p->lambda_; a.u_scale = (T)p->u_scale;
   a.e_scale = (T)(p->noise_rescale == 0.0 ? 1.0 : p->noise_rescale); a.smooth_w = (T)p->smooth_weight;
   a.seed = p->seed; a.call = p->call;
@@ -455,7 +457,7 @@ extern "C" int mppi_upload_small(const void* src_host, int64_t nbytes, void* dst
 namespace {
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) process_noise_export_kernel(unsigned long long seed, unsigned long long call, long long k_offset,
-                                                                     int K, int Tn, int M, int nx, T* __restrict__ out) {
+                                                                     int K, int Tn, int M, int nx, int seven, T* __restrict__ out) {
   const int k = blockIdx.x * BLOCK + threadIdx.x;
   if (k >= K) return;
   const int nxb = (nx + 3) / 4;
@@ -463,7 +465,7 @@ __global__ void __launch_bounds__(BLOCK) process_noise_export_kernel(unsigned lo
     for (int m = 0; m < M; ++m)
       for (int q = 0; q < nxb; ++q) {
         T w[4];
-        philox_normal4<T>(seed ^ PROCESS_NOISE_KEY_TAG, call, k_offset + k, ((long long)t * PROCESS_NOISE_MM + m) * nxb + q, w);
+        philox_normal4<T>(seed ^ PROCESS_NOISE_KEY_TAG, call, k_offset + k, ((long long)t * PROCESS_NOISE_MM + m) * nxb + q, w, seven != 0);
         for (int i = 0; i < 4; ++i)
           if (4 * q + i < nx) out[(((long long)m * K + k) * Tn + t) * nx + 4 * q + i] = w[i];
       }
@@ -476,10 +478,10 @@ extern "C" int mppi_process_noise_export(const MppiProblem* p, void* out, void* 
   const dim3 grid((p->K + BLOCK - 1) / BLOCK, p->T < 64 ? p->T : 64);
   if (p->dtype == MPPI_F32)
     hipLaunchKernelGGL(process_noise_export_kernel<float>, grid, dim3(BLOCK), 0, (hipStream_t)stream, p->seed, p->call, p->k_offset,
-                       p->K, p->T, M, p->nx, (float*)out);
+                       p->K, p->T, M, p->nx, p->philox_rounds == 7 ? 1 : 0, (float*)out);
   else if (p->dtype == MPPI_F64)
     hipLaunchKernelGGL(process_noise_export_kernel<double>, grid, dim3(BLOCK), 0, (hipStream_t)stream, p->seed, p->call, p->k_offset,
-                       p->K, p->T, M, p->nx, (double*)out);
+                       p->K, p->T, M, p->nx, p->philox_rounds == 7 ? 1 : 0, (double*)out);
   else
     return fail(MPPI_E_BADARG, "bad dtype");
   return hipfail((int)hipGetLastError(), "mppi_process_noise_export");

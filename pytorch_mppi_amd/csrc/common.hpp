@@ -51,6 +51,7 @@ struct KArgs {
   int model_flags;              // MPPI_MODEL_FLAG_* (include/mppi_amd.h)
   T* spill;                     // on-chip command (rollout_onchip.hpp): where bounded noise that fits neither registers nor LDS waits for
   long long spill_cap;          //   its sample's weight, [row][padded sample][4], spill_cap elements; null / 0: generated a second time
+  int seven;                    // the engine's generator runs Philox4x32-7 instead of -10 (MppiProblem.philox_rounds == 7; rng="philox7")
 };
 
 // Measurement hook (mppi_profile_enable, capi.hip): every workgroup stamps its entry and its exit on the device's wall clock
@@ -319,24 +320,41 @@ __host__ __device__ __forceinline__ unsigned xor3(unsigned a, unsigned b, unsign
 #ifndef MPPI_PHILOX_ROUNDS
 #define MPPI_PHILOX_ROUNDS 10     // measurement seam (tools/micro/onchip_parts.hip -DMPPI_PHILOX_ROUNDS=7); the product is Philox4x32-10
 #endif
-__host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
+// one round.  Round 0: c.z (the command number), c.y (the row) and the key are wave-uniform in every kernel whose lane is a sample,
+// so this word is scalar work (s_mul_hi / s_xor) when spelled with ^ -- v_bitop3_b32 has no scalar form: as a builtin it
+// put the word into a VGPR, and the KMPPI-fused K1, which hoists these row constants out of its chunk loop, spilled
+// 131 of them to scratch (94 us instead of 70.7)
+template <bool FIRST>
+__host__ __device__ __forceinline__ void philox_round(U4& c, unsigned& k0, unsigned& k1) {
   constexpr unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  const unsigned long long p0 = (unsigned long long)M0 * c.x;
+  const unsigned long long p1 = (unsigned long long)M1 * c.z;
+  U4 n;
+  n.x = FIRST ? ((unsigned)(p1 >> 32) ^ c.y ^ k0) : xor3((unsigned)(p1 >> 32), c.y, k0);
+  n.y = (unsigned)p1;
+  n.z = xor3((unsigned)(p0 >> 32), c.w, k1);
+  n.w = (unsigned)p0;
+  c = n;
+  k0 += W0;
+  k1 += W1;
+}
+__host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
+  philox_round<true>(c, k0, k1);
 #pragma unroll
-  for (int r = 0; r < MPPI_PHILOX_ROUNDS; ++r) {
-    unsigned long long p0 = (unsigned long long)M0 * c.x;
-    unsigned long long p1 = (unsigned long long)M1 * c.z;
-    U4 n;
-    // round 0: c.z (the command number), c.y (the row) and the key are wave-uniform in every kernel whose lane is a sample,
-    // so this word is scalar work (s_mul_hi / s_xor) when spelled with ^ -- v_bitop3_b32 has no scalar form: as a builtin it
-    // put the word into a VGPR, and the KMPPI-fused K1, which hoists these row constants out of its chunk loop, spilled
-    // 131 of them to scratch (94 us instead of 70.7)
-    n.x = r == 0 ? ((unsigned)(p1 >> 32) ^ c.y ^ k0) : xor3((unsigned)(p1 >> 32), c.y, k0);
-    n.y = (unsigned)p1;
-    n.z = xor3((unsigned)(p0 >> 32), c.w, k1);
-    n.w = (unsigned)p0;
-    c = n;
-    k0 += W0;
-    k1 += W1;
+  for (int r = 1; r < MPPI_PHILOX_ROUNDS; ++r) philox_round<false>(c, k0, k1);
+  return c;
+}
+// Philox4x32-R for R = 7 (`seven`, wave-uniform: rng="philox7") or 10.  Seven rounds is the fewest that pass BigCrush (Salmon et
+// al. 2011, table 2; Random123 ships it as philox4x32_R<7> and pins it with its own known-answer vectors: oracle/philox.py), ten
+// is the conservative default of every library; the three rounds are 30 % of the generator's multiplies, which are what the on-chip
+// command's time is made of (profiles/r05_philox_rounds.txt: K1 71.4 -> 66.4 us at C3).  One uniform branch per call.
+__host__ __device__ __forceinline__ U4 philox4x32_r(U4 c, unsigned k0, unsigned k1, const bool seven) {
+  philox_round<true>(c, k0, k1);
+#pragma unroll
+  for (int r = 1; r < 7; ++r) philox_round<false>(c, k0, k1);
+  if (!seven) {
+#pragma unroll
+    for (int r = 7; r < MPPI_PHILOX_ROUNDS; ++r) philox_round<false>(c, k0, k1);
   }
   return c;
 }
@@ -355,9 +373,9 @@ __device__ __forceinline__ void box_muller(unsigned a, unsigned b, float& z0, fl
 
 template <typename T>
 __device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned long long call,
-                                               long long kg, long long jb, T (&out)[4]) {
+                                               long long kg, long long jb, T (&out)[4], const bool seven = false) {
   U4 c{(unsigned)kg, (unsigned)jb, (unsigned)call, (unsigned)(call >> 32) ^ (unsigned)(kg >> 32)};
-  U4 r = philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+  U4 r = philox4x32_r(c, (unsigned)seed, (unsigned)(seed >> 32), seven);
   float a, b, d, e;
   box_muller(r.x, r.y, a, b);
   box_muller(r.z, r.w, d, e);
@@ -423,7 +441,7 @@ template <typename T, int NOISE>
 __device__ __forceinline__ void noise4(const KArgs<T>& a, long long jb, int k, T (&out)[4]) {
   static_assert(NOISE != MPPI_NOISE_KTN, "the (K,T,nu) layout has its own loaders");
   if constexpr (NOISE == MPPI_NOISE_PHILOX) {
-    philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, out);
+    philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, out, a.seven != 0);
   } else {
     load4<T>(a.z, a.zp, jb, k, out);
   }
@@ -432,7 +450,7 @@ __device__ __forceinline__ void noise4(const KArgs<T>& a, long long jb, int k, T
 template <typename T, int NOISE>
 __device__ __forceinline__ void noise4_last(const KArgs<T>& a, long long jb, int k, T (&out)[4]) {
   if constexpr (NOISE == MPPI_NOISE_PHILOX) {
-    philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, out);
+    philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, out, a.seven != 0);
   } else {
     load4_last<T>(a.z, a.zp, jb, k, out);
   }

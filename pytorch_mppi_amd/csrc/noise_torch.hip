@@ -50,7 +50,7 @@ struct TorchDraw {
   unsigned long long seed, offset;
   // kind 1 (the ENGINE's stream, rng="philox"): the rows of command `offset` (= this command's call + 1) for the samples
   // [k_offset, k_offset + K) -- what noise_fill_philox_kernel (update.hip) writes; unit = (256-sample chunk, row-of-4)
-  int kind;
+  int kind, seven;
   long long k_offset;
 };
 
@@ -62,7 +62,7 @@ __device__ __forceinline__ void philox_stream_units(const TorchDraw& d, unsigned
   unsigned jb = (unsigned)(u / nchunks), ch = (unsigned)(u - (unsigned long long)jb * nchunks);
   unsigned n = (unsigned)(u1 - u);
   auto row = [&](unsigned jb_, unsigned ch_, float (&r)[4]) {
-    philox_normal4<float>(d.seed, d.offset, d.k_offset + (long long)ch_ * BLOCK + t, (long long)jb_, r);
+    philox_normal4<float>(d.seed, d.offset, d.k_offset + (long long)ch_ * BLOCK + t, (long long)jb_, r, d.seven != 0);
   };
   auto put = [&](unsigned jb_, unsigned ch_, const float (&r)[4]) {
     const long long k = (long long)ch_ * BLOCK + t;
@@ -225,7 +225,7 @@ int launch_weights_partial_rows_f32(const KArgs<float>& a, void* next_z, int kin
       // the engine's own stream: rows of command `philox_offset` (the caller passes call + 1), uncoloured
       if (a.coloured) return MPPI_E_UNSUPPORTED;
       d.z = (float*)next_z; d.K = a.K; d.pitch = a.zp; d.J = a.J; d.ncalls = 1; d.kchunks = (unsigned)((a.K + BLOCK - 1) / BLOCK);
-      d.nrows4 = (unsigned)a.J4; d.seed = seed; d.offset = philox_offset; d.kind = 1; d.k_offset = a.k_offset;
+      d.nrows4 = (unsigned)a.J4; d.seed = seed; d.offset = philox_offset; d.kind = 1; d.k_offset = a.k_offset; d.seven = a.seven;
     } else if (kind == MPPI_NEXT_DRAW_TORCH) {
       if (a.J % 4 != 0) return MPPI_E_UNSUPPORTED;
       if (int e = torch_draw_args(d, next_z, a.K, a.J, a.zp, seed, philox_offset, grid_blocks)) return e;

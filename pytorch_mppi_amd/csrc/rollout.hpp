@@ -206,7 +206,7 @@ __device__ __forceinline__ void rollout_stream_multi(const KArgs<T>& a, const Ac
             for (int q = 0; q < NXB; ++q) {
               T w[4];
               static_assert(MM == PROCESS_NOISE_MM, "the process-noise counter scheme is defined for MM = PROCESS_NOISE_MM copies");
-              philox_normal4<T>(a.seed ^ PROCESS_NOISE_KEY_TAG, a.call, a.k_offset + k, ((long long)t * MM + m) * NXB + q, w);
+              philox_normal4<T>(a.seed ^ PROCESS_NOISE_KEY_TAG, a.call, a.k_offset + k, ((long long)t * MM + m) * NXB + q, w, a.seven != 0);
 #pragma unroll
               for (int i = 0; i < 4; ++i)
                 if (4 * q + i < NX) xm[m][4 * q + i] = m_fma(a.proc_sd[4 * q + i], w[i], xm[m][4 * q + i]);

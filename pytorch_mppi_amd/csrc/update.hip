@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(BLOCK) noise_fill_philox_kernel(const KArgs<T>
   if (k >= a.K) return;
   for (int jb = blockIdx.y; jb < a.J4; jb += gridDim.y) {
     T r[4];
-    philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, r);
+    philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, r, a.seven != 0);
     T* o = out + ((long long)jb * a.zp + k) * 4;
     o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
   }
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(BLOCK) noise_fill_philox_coloured_kernel(const
 #pragma unroll
     for (int i = 0; i < P4; ++i) {
       T r[4];
-      philox_normal4<T>(a.seed, a.call, a.k_offset + k, (long long)ss * P4 + i, r);
+      philox_normal4<T>(a.seed, a.call, a.k_offset + k, (long long)ss * P4 + i, r, a.seven != 0);
       zc[4 * i] = r[0]; zc[4 * i + 1] = r[1]; zc[4 * i + 2] = r[2]; zc[4 * i + 3] = r[3];
     }
 #pragma unroll

@@ -212,9 +212,13 @@ class MPPI:
         self._last = None          # what the lazy attributes need to re-derive (K,T,nu) arrays
 
         # ---- engine state ----
-        if rng not in ("torch", "torch-native", "philox"):
-            raise ValueError("rng must be 'torch', 'torch-native' or 'philox'")
-        self.rng = rng
+        if rng not in ("torch", "torch-native", "philox", "philox7"):
+            raise ValueError("rng must be 'torch', 'torch-native', 'philox' or 'philox7'")
+        # rng="philox7": the engine's generator with Philox4x32-7 (Random123's philox4x32_R<7>: the fewest rounds that pass BigCrush)
+        # instead of -10 -- another stream, everything else as rng="philox"; 30 % fewer of the multiplies the on-chip command's
+        # time is made of (MppiProblem.philox_rounds; oracle/philox.py `rounds`)
+        self.philox_rounds = 7 if rng == "philox7" else 10
+        self.rng = rng = "philox" if rng == "philox7" else rng
         self.philox_store = True   # rng="philox": K1 stores the generated rows, K3 re-reads them
         # sharded + Philox generator launch: queue the next command's rows behind K4 so that they
         # run while the record all-gather is in flight.  OFF: on this stack a kernel on torch's
@@ -821,6 +825,7 @@ class MPPI:
             p.rollout_var_cost = float(self.rollout_var_cost)
             p.rollout_var_discount = float(self.rollout_var_discount)
             p.seed = self.seed
+            p.philox_rounds = self.philox_rounds
             keep = dict(
                 u_init=self._vec(self.u_init), mu=self._vec(self.noise_mu),
                 L=self._noise_L.to(device=self.d, dtype=self.dtype).contiguous(),
@@ -1890,7 +1895,7 @@ class MPPI_Batched:
         if shard is not None:
             from .dist import ShardPlan
             self._env_shard = ShardPlan(num_envs, *shard)
-            if self._env_shard.world_size > 1 and rng != "philox":
+            if self._env_shard.world_size > 1 and rng not in ("philox", "philox7"):
                 raise ValueError("MPPI_Batched(shard=...) needs rng='philox': the shared noise draw must be identical on "
                                  "every rank (or inject it with inject_noise)")
             num_envs = self._env_shard.K_local

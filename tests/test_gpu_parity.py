@@ -757,3 +757,62 @@ def test_kmppi_interpolation_inside_k1_through_the_api_surface():
     n0 = lib.mppi_stat_kmppi_fused_rollouts()
     a.command(x)
     assert lib.mppi_stat_kmppi_fused_rollouts() == n0 + 1
+
+
+def test_philox7_is_random123s_seven_round_stream_in_every_form_of_the_command():
+    """rng="philox7" (Philox4x32-7, the fewest rounds that pass BigCrush; 30 % fewer of the multiplies the on-chip
+    command's time is made of): the device words are the numpy restatement's (oracle/philox.py `rounds=7`, pinned by Random123's own
+    seven-round known answers in tests/test_host_logic.py), another stream than rng="philox", and the on-chip command, the
+    generator launch and the in-K1 generation all consume exactly it; the command on it meets the oracle like any other."""
+    import pytorch_mppi_amd as pm
+    from oracle import philox as oph
+    from oracle import mppi_oracle as orc
+    from oracle import dynamics as dyn
+    nx, nu = 8, 4
+    m = pm.models.Integrator(nx, nu)
+    x0 = torch.linspace(-1, 1, nx)
+    for K, T, want in ((300, 10, None), (20000, 48, "philox-fill"), (49152, 24, "philox-onchip"), (32768, 3, "philox-k1")):
+        U0 = torch.randn(T, nu, generator=torch.Generator().manual_seed(K)) * 0.1
+        mk = lambda rng: pm.MPPI(m.dynamics, m.running_cost, nx, torch.eye(nu) * 0.7, num_samples=K, horizon=T, device="cuda", lambda_=25.0,
+                                 U_init=U0.clone(), rng=rng, seed=0xC0FFEE1234)
+        c = mk("philox7")
+        assert c.rng == "philox" and c.philox_rounds == 7
+        act = c.command(x0.cuda())
+        if want is not None:
+            assert c.last_draw == want, (K, T, c.last_draw)
+        z_dev = gpu_util.device_philox_normals(c, 1)
+        assert torch.equal(gpu_util.consumed_normals(c), z_dev), (K, T, "the command did not consume the seven-round stream")
+        if K <= 20000:
+            z_np = torch.from_numpy(oph.normals_ktn(seed=c.seed, call=1, K=K, T=T, nu=nu, rounds=7))
+            assert float((z_dev - z_np).abs().max()) <= 4e-6
+            z10 = gpu_util.device_philox_normals(mk("philox"), 1)
+            assert float((z_dev - z10).abs().mean()) > 0.5                                  # another stream altogether
+        f, q = dyn.make_quadtoy(nx, nu)
+        outs = []
+        for dt in (torch.float64, torch.float32):
+            p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=(torch.eye(nu) * 0.7).to(dt), K=K, T=T, lambda_=25.0)
+            outs.append(orc.command(p, U0.to(dt), x0.to(dt), z_dev.to(dt), True))
+        for k, got in (("action", act), ("U", c.U), ("cost_total", c.cost_total)):
+            margins.check(_test_id(), f"K{K} T{T} {k}", got.detach().cpu().numpy(), outs[0][k].numpy(), outs[1][k].numpy(), rtol=1e-5)
+
+
+def test_philox7_moments_and_lag_correlations():
+    """50 M normals of the seven-round stream (C3's draw): moments of N(0,1) and no linear dependence between neighbours along
+    any axis of the counter -- sample, row, component within a block, command -- beyond 5 / sqrt(N)"""
+    import pytorch_mppi_amd as pm
+    K, T, nx, nu = 65536, 64, 16, 12
+    m = pm.models.Integrator(nx, nu)
+    c = pm.MPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), num_samples=K, horizon=T, device="cuda", rng="philox7", seed=20250925)
+    z1 = gpu_util.device_philox_normals(c, 1).double()
+    z2 = gpu_util.device_philox_normals(c, 2).double()
+    n = z1.numel()
+    tol = 5.0 / n ** 0.5
+    assert abs(float(z1.mean())) < tol and abs(float(z1.var()) - 1.0) < 3 * tol * 2 ** 0.5
+    assert abs(float((z1 ** 3).mean())) < tol * 15 ** 0.5 and abs(float((z1 ** 4).mean()) - 3.0) < tol * 96 ** 0.5
+    corr = lambda a, b: float((a * b).mean())
+    flat = z1.reshape(K, -1)
+    assert abs(corr(flat[1:], flat[:-1])) < tol                       # neighbouring samples (counter word 0)
+    assert abs(corr(flat[:, 4:], flat[:, :-4])) < tol                 # neighbouring rows-of-4 (counter word 1)
+    assert abs(corr(flat[:, 1:], flat[:, :-1])) < tol                 # neighbouring components (words of one block / Box-Muller pairs)
+    assert abs(corr(z1, z2)) < tol                                    # neighbouring commands (counter word 2)
+    assert abs(corr(flat[1:] ** 2, flat[:-1] ** 2) - 1.0) < 3 * tol   # ... and no dependence of the magnitudes either

@@ -209,7 +209,17 @@ def test_philox_known_answers_and_moments():
     assert [int(x[0]) for x in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     r = oph.philox4x32_10([0x243f6a88], [0x85a308d3], [0x13198a2e], [0x03707344], 0xa4093822, 0x299f31d0)
     assert [int(x[0]) for x in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # Philox4x32-7 (rng="philox7"): Random123's own known-answer vectors for philox4x32 with 7 rounds (kat_vectors)
+    r = oph.philox4x32_10([0], [0], [0], [0], 0, 0, rounds=7)
+    assert [int(x[0]) for x in r] == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    r = oph.philox4x32_10([0xffffffff], [0xffffffff], [0xffffffff], [0xffffffff], 0xffffffff, 0xffffffff, rounds=7)
+    assert [int(x[0]) for x in r] == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
+    r = oph.philox4x32_10([0x243f6a88], [0x85a308d3], [0x13198a2e], [0x03707344], 0xa4093822, 0x299f31d0, rounds=7)
+    assert [int(x[0]) for x in r] == [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]
+    z7 = oph.normals_ktn(seed=42, call=1, K=4096, T=16, nu=3, rounds=7)
+    assert abs(z7.mean()) < 0.01 and abs(z7.std() - 1) < 0.01 and abs(np.mean(z7 ** 4) - 3.0) < 0.1
     z = oph.normals_ktn(seed=42, call=1, K=4096, T=16, nu=3)
+    assert not np.array_equal(z, z7)
     assert z.shape == (4096, 16, 3)
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
     assert abs(np.mean(z ** 4) - 3.0) < 0.1
