@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- rollouts/sec per `.command()` call (BASELINE.json metric) on N MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2|c4] [--rng philox|philox-stream|philox-fused|torch-native|torch]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2|c4] [--rng philox|philox7|philox-stream|philox-fused|torch-native|torch]
 
 A "step" is one full `MPPI.command(state)`: on-device noise draw, fused rollout+cost (K1),
 exp-weighting + weighted update (K3/K4) and, for N>1, the single record all-gather + combine.
@@ -97,7 +97,7 @@ def make_controller(pm, wl, device, rng, shard, K, devices=None):
     # which must stay O(1) for a healthy softmax (N_eff >> 1)
     U0 = torch.randn(T, nu, dtype=dtype) * 0.02
     ctrl = pm.MPPI(model.dynamics, model.running_cost, nx, sigma, num_samples=K, horizon=T, device=device,
-                   U_init=U0, rng="philox" if rng.startswith("philox") else rng, seed=1234, shard=shard, devices=devices, **kw)
+                   U_init=U0, rng="philox7" if rng == "philox7" else ("philox" if rng.startswith("philox") else rng), seed=1234, shard=shard, devices=devices, **kw)
     if rng == "philox-fused":
         ctrl.philox_fill = False                  # force the generation into K1
         ctrl.philox_onchip = False
@@ -428,7 +428,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--rng", default="philox", choices=["torch", "torch-native", "philox", "philox-stream", "philox-fused"])
+    ap.add_argument("--rng", default="philox", choices=["torch", "torch-native", "philox", "philox7", "philox-stream", "philox-fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--hbm-cold", action="store_true", help="with --no-extras: still run the HBM-cold K1 pass (for a rocprofv3 trace of those launches)")
@@ -843,7 +843,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         # other noise modes of the same workload (short runs), for the record
         extras = {}
-        for mode in ("philox", "philox-stream", "philox-fused", "torch-native", "torch"):
+        for mode in ("philox", "philox7", "philox-stream", "philox-fused", "torch-native", "torch"):
             if mode == args.rng:
                 continue
             c2, x2, _ = make_controller(pm, args.workload, device, mode, None, Kglobal)

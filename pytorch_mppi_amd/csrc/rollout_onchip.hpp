@@ -177,7 +177,9 @@ __device__ __forceinline__ void onchip_steps(const KArgs<float>& a, const Action
   }
 }
 
-template <class Model, bool DIAG>
+// SEVEN: Philox4x32-7 instead of -10 (rng="philox7") -- a template parameter here: as a run-time (wave-uniform) branch inside the twelve
+// interleaved generator chains it cost the kernel 10 spilled VGPRs (44 B of scratch)
+template <class Model, bool DIAG, bool SEVEN = false>
 __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<float> a, const int nsl, const int nsm) {
   using T = float;
   constexpr int NX = Model::NX, NU = Model::NU;
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
 #pragma unroll
       for (int i = 0; i < P4; ++i) {
         T r[4];
-        philox_normal4<T>(a.seed, a.call, kg, (long long)(bi * PB + b) * P4 + i, r, a.seven != 0);   // rows past the horizon: unused
+        philox_normal4<T>(a.seed, a.call, kg, (long long)(bi * PB + b) * P4 + i, r, SEVEN);   // rows past the horizon: unused
         zb[b][4 * i + 0] = r[0]; zb[b][4 * i + 1] = r[1]; zb[b][4 * i + 2] = r[2]; zb[b][4 * i + 3] = r[3];
       }
     }
@@ -426,7 +428,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
 #pragma unroll
             for (int i = 0; i < P4; ++i) {
               T r[4];
-              philox_normal4<T>(a.seed, a.call, kgd, (long long)(ss0 + s) * P4 + i, r, a.seven != 0);
+              philox_normal4<T>(a.seed, a.call, kgd, (long long)(ss0 + s) * P4 + i, r, SEVEN);
               zg[s][4 * i + 0] = r[0]; zg[s][4 * i + 1] = r[1]; zg[s][4 * i + 2] = r[2]; zg[s][4 * i + 3] = r[3];
             }
 #pragma unroll
@@ -521,9 +523,10 @@ static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
     if (ev1 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a, nsl, nsm);             \
     else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, a, nsl, nsm);                                            \
   } while (0)
-    if (diag) MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, true>));
+    if (diag && a.seven) MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, true, true>));
+    else if (diag) MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, true, false>));
 #ifdef MPPI_ONCHIP_FULL_SIGMA
-    else MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, false>));
+    else MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, false, false>));
 #endif
 #undef MPPI_ONCHIP_LAUNCH
     const int e = (int)hipGetLastError();

@@ -28,9 +28,10 @@ def _one(table, *needles):
 # (what to find in the demangled name, max scratch bytes per lane, max spilled VGPRs)
 BUDGETS = [
     # the headline command: on-chip K1 (C3 and the other fp32 integrator / pendulum / linear shapes)
-    (("rollout_onchip_kernel<mppi::IntegratorModel<float, 16, 12>, true>",), 0, 0),
-    (("rollout_onchip_kernel<mppi::PendulumModel<float>, true>",), 0, 0),
-    (("rollout_onchip_kernel<mppi::LinearGoalModel<float, 12, 4>, true>",), 0, 0),
+    (("rollout_onchip_kernel<mppi::IntegratorModel<float, 16, 12>, true, false>",), 0, 0),
+    (("rollout_onchip_kernel<mppi::IntegratorModel<float, 16, 12>, true, true>",), 0, 0),      # rng="philox7"
+    (("rollout_onchip_kernel<mppi::PendulumModel<float>, true, false>",), 0, 0),
+    (("rollout_onchip_kernel<mppi::LinearGoalModel<float, 12, 4>, true, false>",), 0, 0),
     (("finalize_blocks_kernel<float>",), 0, 0),
     # streaming K1 at C3 (rows from memory; diagonal Sigma; the plain and the select-only variants run per wave)
     (("rollout_cost_kernel<mppi::IntegratorModel<float, 16, 12>, float, 0, true, 0, false, 1>",), 0, 0),
