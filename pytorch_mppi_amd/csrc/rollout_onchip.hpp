@@ -480,6 +480,14 @@ static bool onchip_problem_ok(const KArgs<T>& a) {
          (a.K + K1_BLOCK - 1) / K1_BLOCK <= 8192;
 }
 
+// Models whose seven-round instantiation (rng="philox7") the register allocator does not fit into the 512 registers of the kernel
+// (tests/test_kernel_resources.py reads the code objects): those keep the rows-in-memory forms under philox7.  LinearGoal (12, 4):
+// 44 spilled VGPRs with SEVEN = true, none with ten rounds (the shorter chains are scheduled differently).
+template <class Model>
+struct onchip_seven_ok : std::true_type {};
+template <>
+struct onchip_seven_ok<LinearGoalModel<float, 12, 4>> : std::false_type {};
+
 // returns MPPI_OK_ONCHIP when the launch was issued, a positive HIP error, or -1: not this path
 template <class Model, typename T>
 static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
@@ -487,6 +495,7 @@ static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
     return -1;
   } else {
     if (!onchip_problem_ok(a_in)) return -1;
+    if (a_in.seven && !onchip_seven_ok<Model>::value) return -1;
 #ifndef MPPI_ONCHIP_FULL_SIGMA
     // The full-Sigma form (DIAG = false: L z + mu per timestep in the lane) is written and was tested at full size, but it is
     // LDS-issue-bound on the factor rows -- 0.127 ms at C3 against 0.104 ms for rows coloured by the generator launch and
@@ -523,8 +532,9 @@ static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
     if (ev1 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a, nsl, nsm);             \
     else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, a, nsl, nsm);                                            \
   } while (0)
-    if (diag && a.seven) MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, true, true>));
-    else if (diag) MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, true, false>));
+    if (diag && a.seven) {
+      if constexpr (onchip_seven_ok<Model>::value) MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, true, true>));
+    } else if (diag) MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, true, false>));
 #ifdef MPPI_ONCHIP_FULL_SIGMA
     else MPPI_ONCHIP_LAUNCH((rollout_onchip_kernel<Model, false, false>));
 #endif

@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(BLOCK) kmppi_interp_mfma_kernel(const KArgs<fl
     for (int ks = 0; ks < SK; ++ks) {
       const int sp = 4 * ks + g;
       const int sl = sp < S ? sp : S - 1;
-      noise4<float, NOISE>(a, (long long)sl * P4 + q, k, zr[ks]);
+      noise4<float, NOISE, 10>(a, (long long)sl * P4 + q, k, zr[ks]);
     }
 #pragma unroll
     for (int ks = 0; ks < SK; ++ks) {
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(BLOCK) kmppi_interp_mfma_kernel(const KArgs<fl
 #pragma unroll
       for (int qq = 0; qq < P4; ++qq) {
         float r[4];
-        noise4<float, NOISE>(a, (long long)sl * P4 + qq, k, r);
+        noise4<float, NOISE, 10>(a, (long long)sl * P4 + qq, k, r);
         z[4 * qq] = r[0]; z[4 * qq + 1] = r[1]; z[4 * qq + 2] = r[2]; z[4 * qq + 3] = r[3];
       }
       make_action<float, NU, false, false>(ac, thl + sl * NU, nullptr, z, -2, v, e);
@@ -824,7 +824,9 @@ template <>
 bool try_kmppi_interp_mfma<float>(const KArgs<float>& a, const float* W, int Thor, int J4out, float* out,
                                   hipStream_t st) {
   static const bool off = getenv("MPPI_KMPPI_NO_MFMA") != nullptr;      // A/B knob for tools/, read once
-  if (off || a.nu % 4 != 0 || a.Tn > 64 || J4out != Thor * (a.nu / 4)) return false;
+  // (rng="philox7": this kernel generates its rows with the ten-round generator fixed at compile time -- the run-time choice cost
+  // its widest instantiation 241 spilled registers -- so the seven-round stream takes the plain interpolation kernel below)
+  if (off || a.nu % 4 != 0 || a.Tn > 64 || J4out != Thor * (a.nu / 4) || (a.seven && a.noise_src == MPPI_NOISE_PHILOX)) return false;
   const dim3 grid((a.K + 63) / 64, a.nu / 4), block(BLOCK);
   const int Tpad = (Thor + 15) & ~15;
 #define LK2(N, SKK, NS, DG)                                                                         \
