@@ -320,37 +320,47 @@ __host__ __device__ __forceinline__ unsigned xor3(unsigned a, unsigned b, unsign
 #ifndef MPPI_PHILOX_ROUNDS
 #define MPPI_PHILOX_ROUNDS 10     // measurement seam (tools/micro/onchip_parts.hip -DMPPI_PHILOX_ROUNDS=7); the product is Philox4x32-10
 #endif
+__host__ __device__ __forceinline__ void philox_round(U4& c, unsigned& k0, unsigned& k1, const bool first) {
+  constexpr unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  unsigned long long p0 = (unsigned long long)M0 * c.x;
+  unsigned long long p1 = (unsigned long long)M1 * c.z;
+  U4 n;
+  // round 0: c.z (the command number), c.y (the row) and the key are wave-uniform in every kernel whose lane is a sample,
+  // so this word is scalar work (s_mul_hi / s_xor) when spelled with ^ -- v_bitop3_b32 has no scalar form: as a builtin it
+  // put the word into a VGPR, and the KMPPI-fused K1, which hoists these row constants out of its chunk loop, spilled
+  // 131 of them to scratch (94 us instead of 70.7)
+  n.x = first ? ((unsigned)(p1 >> 32) ^ c.y ^ k0) : xor3((unsigned)(p1 >> 32), c.y, k0);
+  n.y = (unsigned)p1;
+  n.z = xor3((unsigned)(p0 >> 32), c.w, k1);
+  n.w = (unsigned)p0;
+  c = n;
+  k0 += W0;
+  k1 += W1;
+}
 template <int ROUNDS>
 __host__ __device__ __forceinline__ U4 philox4x32_rounds(U4 c, unsigned k0, unsigned k1) {
-  constexpr unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    unsigned long long p0 = (unsigned long long)M0 * c.x;
-    unsigned long long p1 = (unsigned long long)M1 * c.z;
-    U4 n;
-    // round 0: c.z (the command number), c.y (the row) and the key are wave-uniform in every kernel whose lane is a sample,
-    // so this word is scalar work (s_mul_hi / s_xor) when spelled with ^ -- v_bitop3_b32 has no scalar form: as a builtin it
-    // put the word into a VGPR, and the KMPPI-fused K1, which hoists these row constants out of its chunk loop, spilled
-    // 131 of them to scratch (94 us instead of 70.7)
-    n.x = r == 0 ? ((unsigned)(p1 >> 32) ^ c.y ^ k0) : xor3((unsigned)(p1 >> 32), c.y, k0);
-    n.y = (unsigned)p1;
-    n.z = xor3((unsigned)(p0 >> 32), c.w, k1);
-    n.w = (unsigned)p0;
-    c = n;
-    k0 += W0;
-    k1 += W1;
-  }
+  for (int r = 0; r < ROUNDS; ++r) philox_round(c, k0, k1, r == 0);
   return c;
 }
 __host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) { return philox4x32_rounds<MPPI_PHILOX_ROUNDS>(c, k0, k1); }
-// Philox4x32-R for R = 7 (`seven`, wave-uniform: rng="philox7") or 10.  Seven rounds is the fewest that pass BigCrush (Salmon et
-// al. 2011, table 2; Random123 ships it as philox4x32_R<7> and pins it with its own known-answer vectors: oracle/philox.py), ten
-// is the conservative default of every library; the three rounds are 30 % of the generator's multiplies, which are what the on-chip
-// command's time is made of (profiles/r05_philox_rounds.txt: K1 71.4 -> 66.4 us at C3).  Two whole chains behind one uniform
-// branch (a shared seven-round prefix with the last three rounds behind a branch changed the register allocation of kernels that
-// interleave many chains -- 241 spilled registers in the widest KMPPI interpolation kernel -- even with the choice known at compile time).
+// Philox4x32-R for R = 7 (`seven`, wave-uniform: rng="philox7") or 10, chosen at RUN time.  Seven rounds is the fewest that pass
+// BigCrush (Salmon et al. 2011, table 2; Random123 ships it as philox4x32_R<7> and pins it with its own known-answer vectors:
+// oracle/philox.py), ten is the conservative default of every library; the three rounds are 30 % of the generator's multiplies, which
+// are what the on-chip command's time is made of (profiles/r05_philox_rounds.txt: K1 71.4 -> 66.4 us at C3) -- THAT kernel takes the
+// round count as a template parameter.  Here: seven unrolled rounds, then a ROLLED loop of zero or three more behind a scalar
+// counter -- one round of extra code and no extra live values.  (Two whole chains behind a branch, and also a shared prefix with
+// three unrolled rounds behind a branch, cost kernels that generate in the lane their registers: K1 generating its own rows
+// 0.102 -> 0.129 ms at C3, 241 spilled registers in the widest KMPPI interpolation kernel.)  Kernels whose allocation does not
+// survive even this keep ten rounds at compile time (noise4<.., 10>) and their launchers refuse seven-round problems.
 __host__ __device__ __forceinline__ U4 philox4x32_r(U4 c, unsigned k0, unsigned k1, const bool seven) {
-  return seven ? philox4x32_rounds<7>(c, k0, k1) : philox4x32_10(c, k0, k1);
+  philox_round(c, k0, k1, true);
+#pragma unroll
+  for (int r = 1; r < 7; ++r) philox_round(c, k0, k1, false);
+  const int extra = seven ? 0 : MPPI_PHILOX_ROUNDS - 7;
+#pragma unroll 1
+  for (int r = 0; r < extra; ++r) philox_round(c, k0, k1, false);
+  return c;
 }
 
 // Box-Muller on two 32-bit words -> two N(0,1) floats.  u1 in (0,1], u2 in [0,1).
@@ -365,11 +375,15 @@ __device__ __forceinline__ void box_muller(unsigned a, unsigned b, float& z0, fl
   z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
-template <typename T>
+// ROUNDS: 0 = the round count is `seven`'s, at run time | 7 / 10 = fixed at compile time
+template <typename T, int ROUNDS = 0>
 __device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned long long call,
                                                long long kg, long long jb, T (&out)[4], const bool seven = false) {
   U4 c{(unsigned)kg, (unsigned)jb, (unsigned)call, (unsigned)(call >> 32) ^ (unsigned)(kg >> 32)};
-  U4 r = philox4x32_r(c, (unsigned)seed, (unsigned)(seed >> 32), seven);
+  U4 r;
+  if constexpr (ROUNDS == 10) r = philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+  else if constexpr (ROUNDS == 7) r = philox4x32_rounds<7>(c, (unsigned)seed, (unsigned)(seed >> 32));
+  else r = philox4x32_r(c, (unsigned)seed, (unsigned)(seed >> 32), seven);
   float a, b, d, e;
   box_muller(r.x, r.y, a, b);
   box_muller(r.z, r.w, d, e);
@@ -437,7 +451,7 @@ template <typename T, int NOISE, int ROUNDS = 0>
 __device__ __forceinline__ void noise4(const KArgs<T>& a, long long jb, int k, T (&out)[4]) {
   static_assert(NOISE != MPPI_NOISE_KTN, "the (K,T,nu) layout has its own loaders");
   if constexpr (NOISE == MPPI_NOISE_PHILOX) {
-    philox_normal4<T>(a.seed, a.call, a.k_offset + k, jb, out, ROUNDS == 10 ? false : a.seven != 0);
+    philox_normal4<T, ROUNDS>(a.seed, a.call, a.k_offset + k, jb, out, a.seven != 0);
   } else {
     load4<T>(a.z, a.zp, jb, k, out);
   }

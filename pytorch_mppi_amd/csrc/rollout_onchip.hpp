@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
 #pragma unroll
       for (int i = 0; i < P4; ++i) {
         T r[4];
-        philox_normal4<T>(a.seed, a.call, kg, (long long)(bi * PB + b) * P4 + i, r, SEVEN);   // rows past the horizon: unused
+        philox_normal4<T, SEVEN ? 7 : 10>(a.seed, a.call, kg, (long long)(bi * PB + b) * P4 + i, r);   // rows past the horizon: unused
         zb[b][4 * i + 0] = r[0]; zb[b][4 * i + 1] = r[1]; zb[b][4 * i + 2] = r[2]; zb[b][4 * i + 3] = r[3];
       }
     }
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<fl
 #pragma unroll
             for (int i = 0; i < P4; ++i) {
               T r[4];
-              philox_normal4<T>(a.seed, a.call, kgd, (long long)(ss0 + s) * P4 + i, r, SEVEN);
+              philox_normal4<T, SEVEN ? 7 : 10>(a.seed, a.call, kgd, (long long)(ss0 + s) * P4 + i, r);
               zg[s][4 * i + 0] = r[0]; zg[s][4 * i + 1] = r[1]; zg[s][4 * i + 2] = r[2]; zg[s][4 * i + 3] = r[3];
             }
 #pragma unroll
