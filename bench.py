@@ -512,12 +512,17 @@ def main():
     n_clock_warmup = clock_warmup(ctrl, x0)
     # device-clock stamps on every K1 launch of the timed region: no extra packets, no events (see the docstring)
     lib.mppi_profile_enable(STAMPS_ONLY)
+    # (the timed region is `steps` commands -- 1.6 ms at the driver's 20: one collector pause inside it is 5-10 % of the figure)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctrl.command(x0)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     k1_dev_us, _ = N.profile_read_launches()
     lib.mppi_profile_enable(0)
     dump = os.environ.get("MPPI_BENCH_DUMP_LAUNCHES")
