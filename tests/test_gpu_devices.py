@@ -166,3 +166,28 @@ def test_communicators_of_a_one_device_group_from_ncclcomminitall():
         assert torch.equal(records[0], p._keep["record"]) and torch.isfinite(a).all()
     finally:
         lib.mppi_dist_destroy(comms[0])
+
+
+@pytest.mark.parametrize("K,G", [(30011, 3), (8192, 4), (1000, 7)])
+def test_odd_splits_over_several_shards(K, G):
+    """ragged K over 3 / 4 / 7 shards of the one device: the contiguous split by global index, a sampler's rows on shard 0, every
+    shard's U bit-identical, the command the unsharded controller's"""
+    T, nx, nu = 12, 6, 4
+    sa = torch.randn(2, T, nu, generator=torch.Generator().manual_seed(5)) * 0.3
+
+    class S(pm.SpecificActionSampler):
+        def sample_trajectories(self, state, info):
+            return sa.clone()
+    kw = dict(sample_null_action=True, specific_action_sampler=S())
+    grp = _mk(pm.MPPI, K, T, nx, nu, "philox", [0] * G, **kw)
+    kw = dict(sample_null_action=True, specific_action_sampler=S())
+    one = _mk(pm.MPPI, K, T, nx, nu, "philox", None, **kw)
+    assert sum(s.K_local for s in grp.shards) == K and [s.k_offset for s in grp.shards] == [sum(t.K_local for t in grp.shards[:i]) for i in range(G)]
+    x = torch.linspace(-1, 1, nx, device="cuda")
+    for _ in range(2):
+        a, b = grp.command(x), one.command(x)
+        assert all(torch.equal(grp.shards[0].U, s.U) for s in grp.shards[1:])
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+        assert float((grp.cost_total - one.cost_total).abs().max()) <= 1e-5 * float(one.cost_total.abs().max())
+    assert torch.equal(grp.perturbed_action[0], torch.zeros(T, nu, device="cuda"))
+    assert torch.allclose(grp.perturbed_action[1:3].cpu(), sa, atol=0)

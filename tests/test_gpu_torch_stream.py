@@ -268,3 +268,46 @@ def test_engine_stream_rows_generated_ahead_are_the_rows_of_the_generator_launch
         assert torch.equal(a[i], b[i]), i
     assert a[4] == ["philox-fill"] + ["philox-rows-ahead"] * 3 and a[5] == 3, (a[4], a[5])
     assert b[4] == ["philox-fill"] * 4 and b[5] == 0
+
+
+def test_rows_generated_ahead_are_torch_randn_bit_for_bit_over_random_shapes():
+    """the draw a K3 launch generated for the NEXT command (slices of ATen's (block, call) units spread over generator workgroups,
+    arbitrary first call per slice) against torch.randn itself from the generator state the adopting command found: 24 random shapes
+    on both sides of ATen's grid cap, ragged K, every control width with (T nu) % 4 == 0"""
+    import random
+    import gpu_util
+    import pytorch_mppi_amd as pm
+    rnd = random.Random(20250925)
+    gen = torch.cuda.default_generators[0]
+    done = 0
+    for trial in range(60):
+        nu = rnd.choice([1, 2, 3, 4, 6, 8, 12, 16])
+        T = rnd.randint(5, 80)
+        if (T * nu) % 4:
+            continue
+        K = rnd.choice([rnd.randint(20000, 140000), 16384 * rnd.randint(2, 6), rnd.randint(20000, 40000) | 1])
+        if K * T * nu < (1 << 19) or K * T * nu > 60_000_000 or (K <= 16384 and T * nu <= 256):
+            continue
+        nx = max(nu, 4)
+        m = pm.models.Integrator(nx, nu)
+        c = pm.MPPI(m.dynamics, m.running_cost, nx, torch.eye(nu) * 0.5, num_samples=K, horizon=T, device="cuda", lambda_=10.0)
+        x = torch.zeros(nx, device="cuda")
+        torch.manual_seed(1000 + trial)
+        torch.randn(rnd.randint(1, 9), device="cuda")            # somewhere in the stream
+        c.command(x)
+        if c._next_draw is None:
+            continue                                             # (a shape whose command has no streaming K3: nothing generated ahead)
+        state = gen.get_state()
+        ref = torch.randn(K, T, nu, device="cuda")               # what the reference's next command would draw
+        after = gen.get_offset()
+        gen.set_state(state)
+        c.command(x)
+        assert c.last_draw == "torch-rows-ahead", (K, T, nu, c.last_draw)
+        assert gen.get_offset() == after, (K, T, nu)
+        got = gpu_util.consumed_normals(c)
+        assert torch.equal(got, ref.cpu()), (K, T, nu, int((got != ref.cpu()).sum()))
+        done += 1
+        del c
+        if done >= 24:
+            break
+    assert done >= 12, done
