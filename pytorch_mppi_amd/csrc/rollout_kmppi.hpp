@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_kmppi_kernel(const KArgs<flo
 #if defined(MPPI_KMPPI_EXP) && (MPPI_KMPPI_EXP & 1)   // experiment (tools/micro/kmppi_k1_parts.hip): no row traffic
       r[0] = r[1] = r[2] = r[3] = 0.25f * (float)((row + k) & 7);
 #else
-      noise4<float, NOISE>(a, (long long)(row < last_row ? row : last_row), k, r);
+      noise4<float, NOISE, 10>(a, (long long)(row < last_row ? row : last_row), k, r);   // (ten rounds at compile time: launch_rollout_kmppi refuses seven-round in-kernel generation)
 #endif
       return kf32x4_t{r[0], r[1], r[2], r[3]};
     };
@@ -363,6 +363,9 @@ static int launch_rollout_kmppi(const KArgs<T>& a, hipStream_t st) {
     if (a.S <= 0 || a.S > KmppiFuse<NU>::SMAX || a.theta == nullptr || a.W == nullptr) return MPPI_E_UNSUPPORTED;
     if (!a.diag || a.coloured || a.B != nullptr || a.smooth_w != 0.f || a.M != 1 || a.n_env != 1) return MPPI_E_UNSUPPORTED;
     if (a.noise_src != MPPI_NOISE_TNK4 && a.noise_src != MPPI_NOISE_PHILOX) return MPPI_E_UNSUPPORTED;
+    // rng="philox7": this kernel's in-lane generator is the ten-round one (a run-time round count cost it 9 us of 72: 96 rows per
+    // sample generated in its prologue); seven-round problems come with their rows in memory (the host runs the generator launch)
+    if (a.seven && a.noise_src == MPPI_NOISE_PHILOX) return MPPI_E_UNSUPPORTED;
     const int S4 = (a.S + 3) & ~3, T4 = (a.Tn + 3) & ~3;
     const int in_lds = S4 * NU > KmppiRegs<NU>::NA ? S4 * NU - KmppiRegs<NU>::NA : 0;     // control points per lane beyond the AGPRs
     const size_t smem0 = (size_t)(2 * ((a.J + 3) & ~3) + ((a.S * NU + 3) & ~3) + T4 * (S4 + 4) + in_lds * K1_BLOCK) * sizeof(float);

@@ -2159,7 +2159,7 @@ class KMPPI(MPPI):
         pt.sample_null_action = 0
         self._attach_workspace(pt)
         fill_keep = self.philox_fill
-        if self.philox_fill is None and self._fused_interp_expected():
+        if self.philox_fill is None and self._fused_interp_expected() and self.philox_rounds != 7:
             # K1 keeps the bounded control points in registers: generating their rows there (and again in K3)
             # costs +4 us of K1 and saves the 19 us generator launch and its 100 MB (C3-sized work)
             self.philox_fill = False
@@ -2230,11 +2230,14 @@ class KMPPI(MPPI):
             N.check(lib.mppi_finalize(C.byref(pt), 0 if sharded else 1, st), "mppi_finalize")
         self._settle_next()
         # the record of the exchange (MPPI._command / group.DeviceGroup) is the THETA problem's: {beta, eta, P_theta[S nu]}
-        pt._keep.update(record=record, omega=omega, wnz=wnz, theta_new=theta_new, lazy=lazy, traj=p)
+        pt._keep.update(record=record, omega=omega, wnz=wnz, theta_new=theta_new, lazy=lazy)
+        pt._traj = p        # (an attribute of the block, NOT an entry of pt._keep: p._keep["theta_keep"] IS that dictionary, and a reference
+        #                      cycle would keep every command's buffers -- 200 MB of raw actions in the two-launch form -- alive until
+        #                      the cycle collector runs: fresh hipMallocs per command in the meantime, 0.7 ms each)
         return pt
 
     def _end(self, pt):
-        p = pt._keep["traj"]
+        p = pt._traj
         self._omega, self._wnz = pt._keep["omega"], pt._keep["wnz"]
         record = pt._keep["record"]
         self._lazy_w = (float(self.lambda_), record) if pt._keep["lazy"] else None
