@@ -477,3 +477,44 @@ def test_builtin_models_stay_fused_with_step_dependent_dynamics(name):
     for c in (g, b2):
         c.inject_noise(z)
     assert torch.allclose(g.command(x), b2.command(x), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["mppi-philox", "mppi-torch", "smppi", "kmppi", "kmppi-two-launch", "group"])
+def test_commands_leave_no_garbage_for_the_cycle_collector(kind):
+    """a command's buffers must die by reference count: with the cycle collector OFF (a control loop may well run that way, and
+    bench.py's timed region does) device memory must not grow from command to command.  Round 5's KMPPI once tied its two problem
+    blocks into a cycle: 200 MB of raw actions per command stayed alive until the collector ran, and the allocator answered with a
+    fresh hipMalloc per command (0.7-0.9 ms, intermittently)."""
+    import gc
+    import pytorch_mppi_amd as pm
+    nx, nu, K, T = 8, 4, 32768, 32
+    m = pm.models.Integrator(nx, nu)
+    kw = dict(num_samples=K, horizon=T, device="cuda", lambda_=20.0)
+    if kind == "mppi-philox":
+        c = pm.MPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), rng="philox", **kw)
+    elif kind == "mppi-torch":
+        c = pm.MPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), **kw)
+    elif kind == "smppi":
+        c = pm.SMPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), action_max=torch.ones(nu), delta_t=0.1, **kw)
+    elif kind == "group":
+        c = pm.MPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), rng="philox", devices=[0, 0], **kw)
+    else:
+        c = pm.KMPPI(m.dynamics, m.running_cost, nx, torch.eye(nu), num_support_pts=8, rng="philox", **kw)
+        if kind == "kmppi-two-launch":
+            c.fuse_interpolation = False
+            c.onchip_update = False
+    x = torch.zeros(nx, device="cuda")
+    for _ in range(5):
+        c.command(x)
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated()
+        for _ in range(40):
+            c.command(x)
+        torch.cuda.synchronize()
+        grown = torch.cuda.memory_allocated() - base
+    finally:
+        gc.enable()
+    assert grown <= 4 * K * 4, f"{kind}: {grown / 1e6:.1f} MB of device memory held by garbage after 40 commands"
