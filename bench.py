@@ -509,13 +509,15 @@ def main():
     lib = N.lib()
     for _ in range(args.warmup):
         ctrl.command(x0)
-    n_clock_warmup = clock_warmup(ctrl, x0)
-    # device-clock stamps on every K1 launch of the timed region: no extra packets, no events (see the docstring)
-    lib.mppi_profile_enable(STAMPS_ONLY)
-    # (the timed region is `steps` commands -- 1.6 ms at the driver's 20: one collector pause inside it is 5-10 % of the figure)
+    # (the timed region is `steps` commands -- 1.6 ms at the driver's 20: one collector pause inside it is 5-10 % of the figure.
+    #  Collected and switched off HERE, in front of the clock warm-up: a collection takes milliseconds in which the GPU idles and
+    #  clocks down -- put between the warm-up and the region it cost the on-chip K1 5 us per launch, 75.4 against 70.7)
     import gc
     gc.collect()
     gc.disable()
+    n_clock_warmup = clock_warmup(ctrl, x0)
+    # device-clock stamps on every K1 launch of the timed region: no extra packets, no events (see the docstring)
+    lib.mppi_profile_enable(STAMPS_ONLY)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
