@@ -859,7 +859,7 @@ def main():
                 c2.command(x2)
             clock_warmup(c2, x2)
             t1 = time.perf_counter()
-            n = max(5, args.steps // 5)
+            n = max(40, args.steps)        # (5 commands were mostly pipeline edges: philox7 read 0.077 here and 0.071 over 200)
             for _ in range(n):
                 c2.command(x2)
             torch.cuda.synchronize()
@@ -910,6 +910,27 @@ def main():
             others[wl] = rec
             del cw
         out["other_workloads"] = others
+        # small / typical problem sizes at the headline's T, nx, nu (launch-bound, and not in the line until now):
+        # which form the command takes and what it costs, pipelined and by the reference's synchronised protocol
+        if args.workload == "c3":
+            forms = {N.FORM_STREAMING: "streaming (generator, K1, K3, K4)", N.FORM_SINGLE_LAUNCH: "single launch", N.FORM_ONCHIP: "on chip"}
+            small = {}
+            for Ks in (1024, 8192, 32768):
+                cs_, xs_, _ = make_controller(pm, "c3", device, args.rng, None, Ks)
+                cs_.lambda_ = ctrl.lambda_
+                for _ in range(10):
+                    cs_.command(xs_)
+                clock_warmup(cs_, xs_)
+                t1 = time.perf_counter()
+                for _ in range(200):
+                    cs_.command(xs_)
+                torch.cuda.synchronize()
+                dws = time.perf_counter() - t1
+                small[f"K{Ks}"] = {"ms_per_step": dws / 200 * 1e3, "rollouts_per_s": Ks * 200 / dws, "draw": cs_.last_draw,
+                                   "form": forms.get(int(lib.mppi_last_command_form()), "?"),
+                                   "latency_ms_synced_median": latency_synced(cs_, xs_)["median_ms"]}
+                del cs_
+            out["small_sizes_on_c3_shape"] = small
         # the rest of the controller family on the headline shape, same lambda recipe
         if args.workload == "c3":
             fam = {}
