@@ -26,6 +26,7 @@ re-copied from shard 0 (a `reset()` draws on device 0 only, like rank 0's draw i
 Host cost: the shards' launches are issued one after the other by one Python thread (~40 us each), so commands shorter than
 N x 40 us are host-bound here; the per-process model (`shard=`, what `bench.py` runs under torch.distributed.run) has no such
 limit.  For C5-sized commands (0.5 ms) it does not matter."""
+import contextlib
 import ctypes as C
 
 import torch
@@ -46,6 +47,11 @@ def group_class(cls):
     if g is None:
         g = _classes[cls] = type(cls.__name__ + "OnDevices", (DeviceGroup, cls), {"_base": cls})
     return g
+
+
+def _on(device):
+    """the shard's device as the calling thread's current one (what the engine's launches and torch's allocations follow)"""
+    return torch.cuda.device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()
 
 
 def _dev_index(d):
@@ -123,7 +129,7 @@ class DeviceGroup:
             def on_every_shard(*a, **k):
                 out = None
                 for i, s in enumerate(shards):
-                    with torch.cuda.device(s.d):
+                    with _on(s.d):
                         r = getattr(s, name)(*[self._to(x, s) for x in a], **{kk: self._to(x, s) for kk, x in k.items()})
                     if i == 0:
                         out = r
@@ -168,7 +174,7 @@ class DeviceGroup:
         ps = []
         for s in shards:
             s.info = info
-            with torch.cuda.device(s.d):
+            with _on(s.d):
                 if s._jit_pending is not None:
                     s._adopt_background_model()
                 if getattr(s._model, "watch", None) is not None:
@@ -179,7 +185,7 @@ class DeviceGroup:
         self._exchange(ps)
         action = None
         for s, p in zip(shards, ps):
-            with torch.cuda.device(s.d):
+            with _on(s.d):
                 a = s._end(p)
             if s is s0:
                 action = a
@@ -205,5 +211,5 @@ class DeviceGroup:
             return
         # staged: the records travel by device copies (torch orders them against the streams involved), K5 on every device
         for s, p in zip(shards, ps):
-            with torch.cuda.device(s.d):
+            with _on(s.d):
                 s._combine(p, torch.stack([r if r.device == s.d else r.to(s.d) for r in recs]))
