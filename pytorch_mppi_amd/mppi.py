@@ -15,9 +15,12 @@ csrc/*.hip through the C-ABI (include/mppi_amd.h).  Two ways into the engine:
 
 Additive, keyword-only extras (not in the reference): ``rng`` ("torch": draw
 ``torch.randn(K,T,nu)`` like mppi.py:203 -- identical generator consumption and, on the same
-device and seed, identical draws; "torch-native": the same generator drawn directly in the
-engine's sample-minor layout; "philox": generate in-kernel, no (K,T,nu) array at all),
-``seed``, ``shard`` (multi-GPU, see dist.py).
+device and seed, identical draws -- computed by the engine's own launch straight into its rows,
+command n+1's draw inside command n's K3 launch where nobody else touches the generator in
+between; "torch-native": the same generator drawn directly in the engine's sample-minor layout;
+"philox": generate in-kernel, no (K,T,nu) array at all; "philox7": the same with Philox4x32-7),
+``seed``, ``shard`` (multi-GPU, one process per GPU: dist.py), ``devices`` (multi-GPU from ONE
+process: group.py), ``auto_jit`` (plain torch callables traced into device functors: trace.py).
 """
 import ctypes as C
 import logging
