@@ -89,14 +89,20 @@ def make_mlp_weights(nx, nu, hidden, seed=2, dtype=torch.float32):
                 l2.weight.detach().to(dtype).clone(), l2.bias.detach().to(dtype).clone())
 
 
-def make_mlp(W1, b1, W2, b2, res_scale=0.1):
+def make_mlp(W1, b1, W2, b2, res_scale=0.1, q_state=None, q_control=None):
+    """q_state / q_control: the diagonal quadratic running cost sum q_i x_i^2 + sum r_n u_n^2 (None: the plain sum x^2)"""
     def dynamics(state, action):
         xu = torch.cat((state, action), dim=1)
         h = torch.tanh(xu @ W1.T + b1)
         return state + res_scale * (h @ W2.T + b2)
 
     def cost(state, action):
-        return (state ** 2).sum(dim=-1)
+        if q_state is None and q_control is None:
+            return (state ** 2).sum(dim=-1)
+        c = ((state ** 2) * (1.0 if q_state is None else q_state.to(state))).sum(dim=-1)
+        if q_control is not None:
+            c = c + ((action ** 2) * q_control.to(action)).sum(dim=-1)
+        return c
 
     return dynamics, cost
 

@@ -84,9 +84,9 @@ struct LinearGoalModel {
 };
 
 // --- 2-layer MLP residual dynamics, per-lane VALU form (any hidden width) ---------------------
-// x' = x + s * (W2 tanh(W1 [x;u] + b1) + b2), cost = sum x^2
-// (shape after reference tests/pendulum_approximate.py:47-67; BASELINE.json configs[3..4]).
-// blob: W1 (H, NX+NU) row-major | b1 (H) | W2 (NX, H) row-major | b2 (NX) | s (1)
+// x' = x + s * (W2 tanh(W1 [x;u] + b1) + b2), cost = sum_i qx_i x_i^2 + sum_n qu_n u_n^2  (qx = 1, qu = 0: the plain sum x^2 of
+// BASELINE.json configs[3..4]; shape after reference tests/pendulum_approximate.py:47-67; the diagonal quadratic cost since round 5)
+// blob: W1 (H, NX+NU) row-major | b1 (H) | W2 (NX, H) row-major | b2 (NX) | s (1) | qx (NX) | qu (NU)
 // Weights are wave-uniform -> scalar loads; the MFMA formulation lives in rollout_mlp_mfma.hip.
 template <typename T, int NX_, int NU_>
 struct MlpModel {
@@ -96,6 +96,8 @@ struct MlpModel {
   const T* __restrict__ b1;
   const T* __restrict__ W2;
   const T* __restrict__ b2;
+  const T* __restrict__ qx;
+  const T* __restrict__ qu;
   T s;
   int H;
   __device__ explicit MlpModel(const KArgs<T>& a) {
@@ -105,6 +107,8 @@ struct MlpModel {
     W2 = b1 + H;
     b2 = W2 + (long long)NX * H;
     s = b2[NX];
+    qx = b2 + NX + 1;
+    qu = qx + NX;
   }
   __device__ __forceinline__ void step(T (&x)[NX], const T (&u)[NU], int) const {
     T o[NX];
@@ -124,10 +128,13 @@ struct MlpModel {
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = x[i] + s * (o[i] + b2[i]);
   }
-  __device__ __forceinline__ T cost(const T (&x)[NX], const T (&)[NU], int) const {
-    T c = x[0] * x[0];
+  __device__ __forceinline__ T cost(const T (&x)[NX], const T (&u)[NU], int) const {
+    // (qx = 1, qu = 0 give the bits of the plain sum of squares: 1 * x is x, and + 0 changes nothing)
+    T c = (qx[0] * x[0]) * x[0];
 #pragma unroll
-    for (int i = 1; i < NX; ++i) c += x[i] * x[i];
+    for (int i = 1; i < NX; ++i) c += (qx[i] * x[i]) * x[i];
+#pragma unroll
+    for (int n = 0; n < NU; ++n) c += (qu[n] * u[n]) * u[n];
     return c;
   }
   __device__ __forceinline__ T terminal(const T (&)[NX]) const { return T(0); }

@@ -79,6 +79,10 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
   const float* __restrict__ W2 = b1 + H;
   const float* __restrict__ b2 = W2 + NX * H;
   const float rs = b2[NX];
+  float qx4[4];                                      // cost weights (blob: ... | res_scale | qx (16) | qu (4)): rows 4g + r, control g
+#pragma unroll
+  for (int r = 0; r < 4; ++r) qx4[r] = b2[NX + 1 + 4 * g + r];
+  const float qu_g = b2[NX + 1 + NX + g];
   float w1r[HT][5], w2r[HT][4], b2r[4];
 #pragma unroll
   for (int m = 0; m < HT; ++m) {
@@ -207,6 +211,7 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
       const float e = v - Ut;
       ppart[i] = fmaf(Gt, ac.abs_cost ? fabsf(e) : e, ppart[i]);
       ub[i] = a.u_scale * v;
+      cpart[i] = fmaf(qu_g * ub[i], ub[i], cpart[i]);
     }
 
     f32x4 O[NT];
@@ -263,7 +268,7 @@ __global__ void __launch_bounds__(MLP_THREADS) rollout_mlp_mfma_kernel(const KAr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         x[i][r] = fmaf(rs, O[i][r] + b2r[r], x[i][r]);
-        cpart[i] = fmaf(x[i][r], x[i][r], cpart[i]);
+        cpart[i] = fmaf(qx4[r] * x[i][r], x[i][r], cpart[i]);
       }
     }
   }

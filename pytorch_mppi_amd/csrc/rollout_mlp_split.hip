@@ -191,12 +191,17 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int g = lane >> 4, s = lane & 15;
 
-  // ---- parameters: blob = W1 (H,20) | b1 (H) | W2 (16,H) | b2 (16) | res_scale ----
+  // ---- parameters: blob = W1 (H,20) | b1 (H) | W2 (16,H) | b2 (16) | res_scale | qx (16) | qu (4) ----
   const float* __restrict__ W1 = a.mp;
   const float* __restrict__ b1 = W1 + H * B3_NI;
   const float* __restrict__ W2 = b1 + H;
   const float* __restrict__ b2 = W2 + NX * H;
   const float rs = b2[NX];
+  // cost = sum_i qx_i x_i^2 + sum_n qu_n u_n^2: this lane's four state rows 4g + r and its control dimension g
+  float qx4[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) qx4[r] = b2[NX + 1 + 4 * g + r];
+  const float qu_g = b2[NX + 1 + NX + g];
 
   // A fragments, three bf16 planes each, resident for the whole launch
   Planes A1[HT];
@@ -353,7 +358,9 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
           if (t > 0) cpart[i] = fmaf(a.smooth_w * d, d, cpart[i]);
           vprev[i] = v;
         }
-        const float in[8] = {x[i][0], x[i][1], x[i][2], x[i][3], a.u_scale * v, g == 0 ? 1.0f : 0.0f, 0.f, 0.f};
+        const float uu = a.u_scale * v;
+        cpart[i] = fmaf(qu_g * uu, uu, cpart[i]);                               // control effort (qu = 0: + 0)
+        const float in[8] = {x[i][0], x[i][1], x[i][2], x[i][3], uu, g == 0 ? 1.0f : 0.0f, 0.f, 0.f};
         B1[i] = split_pack8(in);
       }
 
@@ -468,7 +475,7 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           x[i][r] = fmaf(rs, O[i][r] + b2r[r], x[i][r]);
-          cpart[i] = fmaf(x[i][r], x[i][r], cpart[i]);
+          cpart[i] = fmaf(qx4[r] * x[i][r], x[i][r], cpart[i]);
         }
       }
     }

@@ -160,17 +160,22 @@ class LinearGoal(NativeModel):
 
 
 class MLPResidual(NativeModel):
-    """x' = x + res_scale * (W2 tanh(W1 [x;u] + b1) + b2), cost = sum x^2 -- the 2-layer
-    approximate-dynamics shape of /root/reference/tests/pendulum_approximate.py:47-67."""
+    """x' = x + res_scale * (W2 tanh(W1 [x;u] + b1) + b2) -- the 2-layer approximate-dynamics shape of
+    /root/reference/tests/pendulum_approximate.py:47-67 -- with the diagonal quadratic running cost
+    sum_i q_state[i] x_i^2 + sum_n q_control[n] u_n^2 (defaults 1 and 0: the plain sum x^2 of BASELINE configs[3..4])."""
     model_id = N.MODEL_MLP
 
-    def __init__(self, W1, b1, W2, b2, nx, nu, res_scale=0.1):
+    def __init__(self, W1, b1, W2, b2, nx, nu, res_scale=0.1, q_state=None, q_control=None):
         super().__init__()
         self.W1, self.b1, self.W2, self.b2 = (torch.as_tensor(t) for t in (W1, b1, W2, b2))
         self.nx, self.nu = int(nx), int(nu)
         self.hidden = int(self.W1.shape[0])
         self.res_scale = float(res_scale)
+        self.q_state = torch.ones(self.nx, dtype=torch.float64) if q_state is None else torch.as_tensor(q_state, dtype=torch.float64).reshape(-1)
+        self.q_control = torch.zeros(self.nu, dtype=torch.float64) if q_control is None else torch.as_tensor(q_control, dtype=torch.float64).reshape(-1)
         assert self.W1.shape == (self.hidden, self.nx + self.nu) and self.W2.shape == (self.nx, self.hidden)
+        assert self.q_state.numel() == self.nx and self.q_control.numel() == self.nu
+        self._plain_cost = q_state is None and q_control is None
 
     def flags(self):
         """The default matrix-core kernel runs layer 2 on two-piece fp16 operands (csrc/rollout_mlp_split.hip): its weights
@@ -195,7 +200,7 @@ class MLPResidual(NativeModel):
                        nx, nu, res_scale)
 
     def _param_list(self):
-        return [self.W1, self.b1, self.W2, self.b2, torch.tensor([self.res_scale], dtype=torch.float64)]
+        return [self.W1, self.b1, self.W2, self.b2, torch.tensor([self.res_scale], dtype=torch.float64), self.q_state, self.q_control]
 
     def dynamics(self, state, action, t=None):
         W1, b1, W2, b2 = (t.to(state.device, state.dtype) for t in (self.W1, self.b1, self.W2, self.b2))
@@ -203,7 +208,10 @@ class MLPResidual(NativeModel):
         return self._noisy(state + self.res_scale * (h @ W2.T + b2))
 
     def running_cost(self, state, action, t=None):
-        return (state ** 2).sum(dim=-1)
+        if self._plain_cost:
+            return (state ** 2).sum(dim=-1)
+        return ((self.q_state.to(state.device, state.dtype) * state ** 2).sum(dim=-1)
+                + (self.q_control.to(state.device, state.dtype) * action ** 2).sum(dim=-1))
 
 
 def native_model_of(dynamics, running_cost, terminal_state_cost=None):

@@ -1610,7 +1610,7 @@ def match_mlp_residual(g, step_roots, cost_root, term_root, nx, nu):
     configs[3]: x' = x + s (W2 tanh(W1 [x; u] + b1) + b2), cost = sum x^2, /root/reference/tests/pendulum_approximate.py:47-67 with
     one hidden layer)?  Structural: exactly one chain of two dense layers with a bare tanh between them, the first reading
     [x_0 .. x_nx-1, u_0 .. u_nu-1] in order, every state component's update `x_i + s * layer2_i` with ONE constant s (or none), the
-    cost the sum of the squares of all state components, no terminal cost.  Returns where W1, b1, W2, b2 sit in the functor's
+    cost a diagonal quadratic form sum_i qx_i x_i^2 + sum_n qu_n u_n^2 with constant weights (the plain sum x^2 included), no terminal cost.  Returns where W1, b1, W2, b2 sit in the functor's
     parameter vector and s -- or None.  (Whether the kernel exists for (nx, nu, hidden) is the caller's question: jit.compile_traced.)"""
     if term_root is not None or len(g.layers) != 2:
         return None
@@ -1649,20 +1649,39 @@ def match_mlp_residual(g, step_roots, cost_root, term_root, nx, nu):
         if scale is not None and c != scale:
             return None
         scale = c
-    squares = []
+    # cost: a sum of constant multiples of squares of state components and of controls (any association; factors in front of
+    # sub-sums distribute): sum_i qx_i x_i^2 + sum_n qu_n u_n^2, nothing else
+    qx, qu = [0.0] * nx, [0.0] * nu
 
-    def walk(i):
+    def walk(i, f):
         n = g.nodes[i]
         if n[0] == "add" and len(n) == 3:
-            return walk(n[1]) and walk(n[2])
-        if n[0] == "mul" and len(n) == 3 and n[1] == n[2] and g.nodes[n[1]][0] == "x":
-            squares.append(g.nodes[n[1]][1])
-            return True
+            return walk(n[1], f) and walk(n[2], f)
+        if n[0] == "neg" and len(n) == 2:
+            return walk(n[1], -f)
+        if n[0] == "mul" and len(n) == 3:
+            a_, b_ = n[1], n[2]
+            if a_ == b_ and g.nodes[a_][0] in ("x", "u"):
+                (qx if g.nodes[a_][0] == "x" else qu)[g.nodes[a_][1]] += f
+                return True
+            if g.cval(a_) is not None:
+                return walk(b_, f * g.cval(a_))
+            if g.cval(b_) is not None:
+                return walk(a_, f * g.cval(b_))
+            # (c x_i) x_i
+            for p_, q_ in ((a_, b_), (b_, a_)):
+                m_ = g.nodes[p_]
+                if g.nodes[q_][0] in ("x", "u") and m_[0] == "mul" and len(m_) == 3:
+                    for c_, v_ in ((m_[1], m_[2]), (m_[2], m_[1])):
+                        if g.cval(c_) is not None and v_ == q_:
+                            (qx if g.nodes[q_][0] == "x" else qu)[g.nodes[q_][1]] += f * g.cval(c_)
+                            return True
         return False
-    if not walk(cost_root) or sorted(squares) != list(range(nx)):
+    if not walk(cost_root, 1.0):
         return None
+    plain = qx == [1.0] * nx and qu == [0.0] * nu
     return dict(H=int(l1["OUT"]), w1=int(l1["wbase"]), b1=None if l1["bbase"] is None else int(l1["bbase"]), w2=int(l2["wbase"]),
-                b2=None if l2["bbase"] is None else int(l2["bbase"]), scale=float(scale))
+                b2=None if l2["bbase"] is None else int(l2["bbase"]), scale=float(scale), **({} if plain else dict(qx=qx, qu=qu)))
 
 
 def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, device=None, dtype=None, dynamic=()):

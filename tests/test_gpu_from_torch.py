@@ -575,3 +575,57 @@ def test_c4_shaped_torch_callables_take_the_matrix_core_mlp_kernel():
                    "nn.Sequential(Linear(20,256), Tanh(), Linear(256,16)) residual + sum x^2 as torch callables, K 65536 x T 64; "
                    "the built-in models.MLPResidual through the same loop: %.4f ms" % ms_builtin)
     assert ms <= 0.50 and ms <= 1.06 * ms_builtin, (ms, ms_builtin)
+
+
+@pytest.mark.parametrize("kernel", ["split", "exact", "valu"])
+def test_mlp_model_with_a_diagonal_quadratic_cost(kernel, monkeypatch):
+    """round 5: the MLP model family's running cost is sum_i q_i x_i^2 + sum_n r_n u_n^2 (weights in the blob behind res_scale; ones and
+    zeros = the plain sum x^2 of BASELINE configs[3..4], same bits as before) -- in the split-operand matrix-core kernel, the exact
+    fp32 one and the per-lane functor; as a built-in model object and as torch callables the tracer recognises"""
+    import gpu_util
+    import pytorch_mppi_amd as pm
+    from pytorch_mppi_amd import _native as N
+    from oracle import dynamics as dyn
+    from oracle import mppi_oracle as orc
+    if kernel == "exact":
+        monkeypatch.setenv("MPPI_MLP_EXACT", "1")
+    elif kernel == "valu":
+        monkeypatch.setenv("MPPI_MLP_VALU", "1")
+    nx, nu, H, K, T = 16, 4, 64, 8192, 24
+    W = dyn.make_mlp_weights(nx, nu, H, seed=7)
+    qs = torch.linspace(0.25, 2.0, nx)
+    qc = torch.tensor([0.05, 0.1, 0.2, 0.4])
+    g = torch.Generator().manual_seed(2)
+    U0 = torch.randn(T, nu, generator=g) * 0.05
+    x0 = torch.randn(nx, generator=g)
+    built_in = pm.models.MLPResidual(*W, nx, nu, q_state=qs, q_control=qc)
+    net = torch.nn.Sequential(torch.nn.Linear(nx + nu, H), torch.nn.Tanh(), torch.nn.Linear(H, nx))
+    with torch.no_grad():
+        for p_, w in zip(net.parameters(), W):
+            p_.copy_(w)
+    net.cuda()
+    qsd, qcd = qs.cuda(), qc.cuda()
+    f_t = lambda x, u: x + 0.1 * net(torch.cat((x, u), dim=-1))
+    q_t = lambda x, u: (qsd * x ** 2).sum(dim=-1) + (qcd * u ** 2).sum(dim=-1)
+    ctrls = {"built-in": lambda lam: pm.MPPI(built_in.dynamics, built_in.running_cost, nx, torch.eye(nu), num_samples=K, horizon=T, device="cuda",
+                                            lambda_=lam, rng="philox", seed=5, U_init=U0.clone(), u_scale=1.5),
+             "callables": lambda lam: pm.MPPI(f_t, q_t, nx, torch.eye(nu), num_samples=K, horizon=T, device="cuda", lambda_=lam, rng="philox",
+                                             seed=5, U_init=U0.clone(), u_scale=1.5, auto_jit="sync")}
+    probe = ctrls["built-in"](1.0)
+    probe.command(x0.cuda())
+    lam = float(probe.cost_total.std())
+    outs = {}
+    for name, mk in ctrls.items():
+        c = mk(lam)
+        assert c._model is not None and c._model.model_id == N.MODEL_MLP and not c._needs_generic(), (name, c.jit_note)
+        act = c.command(x0.cuda())
+        z = gpu_util.consumed_normals(c)
+        res = []
+        for dt in (torch.float64, torch.float32):
+            f, q = dyn.make_mlp(*[w.to(dt) for w in W], q_state=qs.to(dt), q_control=qc.to(dt))
+            p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=torch.eye(nu, dtype=dt), K=K, T=T, lambda_=lam, u_scale=1.5)
+            res.append(orc.command(p, U0.to(dt), x0.to(dt), z.to(dt), True))
+        for k_, got in (("action", act), ("U", c.U), ("cost_total", c.cost_total), ("omega", c.omega)):
+            margins.check(f"mlp diagonal quadratic cost / {kernel} / {name}", k_, got.detach().cpu().numpy(), res[0][k_].numpy(), res[1][k_].numpy(), rtol=1e-5)
+        outs[name] = (act, c.cost_total)
+    assert torch.equal(outs["built-in"][1], outs["callables"][1]), "the same kernel on the same blob"

@@ -109,7 +109,13 @@ def test_native_models_equal_oracle_callables():
     M2 = models.MLPResidual.random(16, 4, 32, seed=2)
     assert torch.equal(M2.W1, W[0]) and torch.equal(M2.b2, W[3])
     blob = M.param_blob("cpu", torch.float32)
-    assert blob.numel() == 32 * 20 + 32 + 16 * 32 + 16 + 1
+    assert blob.numel() == 32 * 20 + 32 + 16 * 32 + 16 + 1 + 16 + 4            # W1 | b1 | W2 | b2 | res_scale | qx | qu
+    assert blob[-20:-4].tolist() == [1.0] * 16 and blob[-4:].tolist() == [0.0] * 4       # the plain sum x^2
+    qs, qc = torch.linspace(0.5, 2.0, 16), torch.tensor([0.1, 0.2, 0.3, 0.4])
+    Mq = models.MLPResidual(*W, 16, 4, q_state=qs, q_control=qc)
+    _, qq = dyn.make_mlp(*W, q_state=qs, q_control=qc)
+    assert torch.allclose(Mq.running_cost(x16, u4b), qq(x16, u4b), rtol=1e-6) and torch.equal(M.running_cost(x16, u4b), qm(x16, u4b))
+    assert torch.allclose(Mq.running_cost(x16, u4b), (qs * x16 ** 2).sum(-1) + (qc * u4b ** 2).sum(-1), rtol=1e-6)
 
 
 def test_cpu_device_has_no_compute_path():

@@ -306,12 +306,21 @@ def test_a_trace_that_is_the_matrix_core_mlp_is_recognised():
     assert sp == dict(H=64, w1=0, b1=1280, w2=1344, b2=2368, scale=0.1)
     # the parameter blob the kernel wants, out of the trace's parameter vector
     m = jit.TracedMLPResidual("t", 16, 4, dyn, sq, sp, trace.gather_params(code["param_tensors"], code["n_params"]))
-    W1, b1, W2, b2, s = m._param_list()
+    W1, b1, W2, b2, s = m._param_list()[:5]
     assert torch.equal(W1.reshape(64, 20), net[0].weight.detach()) and torch.equal(b1, net[0].bias.detach())
     assert torch.equal(W2.reshape(16, 64), net[2].weight.detach()) and torch.equal(b2, net[2].bias.detach()) and float(s) == 0.1
     assert m.model_id == 4 and m.hidden == 64 and m.flags() == 0
     # what is NOT that shape keeps its functor
-    for d_, c_ in ((dyn, lambda x, u: (x ** 2).sum(-1) + 0.1 * (u ** 2).sum(-1)),                    # another cost
+    # a diagonal quadratic cost with control effort is the kernel's too (round 5): weights end up in the blob behind res_scale
+    qw = torch.linspace(0.5, 2.0, 16, dtype=torch.float64)
+    code_q = trace.generate(dyn, lambda x, u: (qw * x ** 2).sum(-1) + 0.1 * (u ** 2).sum(-1), 16, 4)
+    spq = code_q["mlp_residual"]
+    assert spq is not None and spq["qu"] == [0.1] * 4 and max(abs(a - b) for a, b in zip(spq["qx"], qw.tolist())) < 1e-15
+    mq = jit.TracedMLPResidual("tq", 16, 4, dyn, sq, spq, trace.gather_params(code_q["param_tensors"], code_q["n_params"]))
+    assert torch.equal(mq._param_list()[5], qw) and mq._param_list()[6].tolist() == [0.1] * 4
+    assert [t_.numel() for t_ in m._param_list()] == [1280, 64, 1024, 16, 1, 16, 4] and m._param_list()[5].tolist() == [1.0] * 16
+    for d_, c_ in ((dyn, lambda x, u: (x ** 2).sum(-1) + x[..., 0] * x[..., 1]),                     # a cross term: no diagonal form
+                   (dyn, lambda x, u: x.abs().sum(-1)),                                              # another cost altogether
                    (lambda x, u: x + 0.1 * net(torch.cat((u, x), -1)), sq),                          # inputs in another order
                    (lambda x, u: 0.9 * x + 0.1 * net(torch.cat((x, u), -1)), sq),                    # no plain residual
                    (lambda x, u: x + 0.1 * torch.nn.functional.relu(net[0](torch.cat((x, u), -1))) @ net[2].weight.T, sq)):   # another activation
