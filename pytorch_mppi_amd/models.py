@@ -159,6 +159,32 @@ class LinearGoal(NativeModel):
         return ((goal - states[..., -1, :]) ** 2).sum(dim=-1)
 
 
+def mlp_kernel_width(nx, nu, hidden):
+    """The hidden width the engine's matrix-core MLP kernels are built for (csrc/rollout_mlp_split.hip: (nx, nu) = (16, 4), hidden 64 /
+    128 / 256) that holds `hidden` units, or `hidden` itself where no such kernel exists (the per-lane kernel takes any width).  Padding
+    units have zero weights in and out and zero bias: tanh(0) = 0 contributes exactly nothing."""
+    if (int(nx), int(nu)) == (16, 4):
+        for w in (64, 128, 256):
+            if hidden <= w:
+                return w
+    return int(hidden)
+
+
+def pad_hidden(W1, b1, W2, width):
+    """(W1 (H, ni), b1 (H), W2 (nx, H)) with the hidden axis zero-padded to `width` units (float64 copies)"""
+    W1, b1, W2 = (torch.as_tensor(t).detach().to("cpu", torch.float64) for t in (W1, b1, W2))
+    H = W1.shape[0]
+    if width == H:
+        return W1, b1, W2
+    W1p = torch.zeros(width, W1.shape[1], dtype=torch.float64)
+    W1p[:H] = W1
+    b1p = torch.zeros(width, dtype=torch.float64)
+    b1p[:H] = b1
+    W2p = torch.zeros(W2.shape[0], width, dtype=torch.float64)
+    W2p[:, :H] = W2
+    return W1p, b1p, W2p
+
+
 class MLPResidual(NativeModel):
     """x' = x + res_scale * (W2 tanh(W1 [x;u] + b1) + b2) -- the 2-layer approximate-dynamics shape of
     /root/reference/tests/pendulum_approximate.py:47-67 -- with the diagonal quadratic running cost
@@ -169,11 +195,14 @@ class MLPResidual(NativeModel):
         super().__init__()
         self.W1, self.b1, self.W2, self.b2 = (torch.as_tensor(t) for t in (W1, b1, W2, b2))
         self.nx, self.nu = int(nx), int(nu)
-        self.hidden = int(self.W1.shape[0])
+        # `hidden` is what the kernels see: odd widths are zero-padded to the next width the matrix-core kernels are built for
+        # (hidden 100 on the per-lane kernel costs 13 x the matrix-core time)
+        self.hidden_units = int(self.W1.shape[0])
+        self.hidden = mlp_kernel_width(nx, nu, self.hidden_units)
         self.res_scale = float(res_scale)
         self.q_state = torch.ones(self.nx, dtype=torch.float64) if q_state is None else torch.as_tensor(q_state, dtype=torch.float64).reshape(-1)
         self.q_control = torch.zeros(self.nu, dtype=torch.float64) if q_control is None else torch.as_tensor(q_control, dtype=torch.float64).reshape(-1)
-        assert self.W1.shape == (self.hidden, self.nx + self.nu) and self.W2.shape == (self.nx, self.hidden)
+        assert self.W1.shape == (self.hidden_units, self.nx + self.nu) and self.W2.shape == (self.nx, self.hidden_units)
         assert self.q_state.numel() == self.nx and self.q_control.numel() == self.nu
         self._plain_cost = q_state is None and q_control is None
 
@@ -200,7 +229,8 @@ class MLPResidual(NativeModel):
                        nx, nu, res_scale)
 
     def _param_list(self):
-        return [self.W1, self.b1, self.W2, self.b2, torch.tensor([self.res_scale], dtype=torch.float64), self.q_state, self.q_control]
+        W1, b1, W2 = (self.W1, self.b1, self.W2) if self.hidden == self.hidden_units else pad_hidden(self.W1, self.b1, self.W2, self.hidden)
+        return [W1, b1, W2, self.b2, torch.tensor([self.res_scale], dtype=torch.float64), self.q_state, self.q_control]
 
     def dynamics(self, state, action, t=None):
         W1, b1, W2, b2 = (t.to(state.device, state.dtype) for t in (self.W1, self.b1, self.W2, self.b2))

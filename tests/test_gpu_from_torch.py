@@ -629,3 +629,63 @@ def test_mlp_model_with_a_diagonal_quadratic_cost(kernel, monkeypatch):
             margins.check(f"mlp diagonal quadratic cost / {kernel} / {name}", k_, got.detach().cpu().numpy(), res[0][k_].numpy(), res[1][k_].numpy(), rtol=1e-5)
         outs[name] = (act, c.cost_total)
     assert torch.equal(outs["built-in"][1], outs["callables"][1]), "the same kernel on the same blob"
+
+
+@pytest.mark.parametrize("H", [100, 200])
+def test_mlp_of_an_odd_hidden_width_runs_on_the_matrix_core_kernel_with_padding_units(H):
+    """a hidden width between the widths the matrix-core kernels are built for (64 / 128 / 256) is zero-padded to the next one
+    (models.mlp_kernel_width / pad_hidden: padding units have zero weights in and out, tanh(0) = 0 adds exactly nothing) instead of
+    falling to the per-lane kernel -- as a built-in model object and as torch callables; parity with the fp64 oracle of the UNPADDED
+    network, and the same bits as a model somebody padded by hand"""
+    import gpu_util
+    import pytorch_mppi_amd as pm
+    from pytorch_mppi_amd import _native as N
+    from oracle import dynamics as dyn
+    from oracle import mppi_oracle as orc
+    nx, nu, K, T = 16, 4, 8192, 24
+    Hp = 128 if H <= 128 else 256
+    W = dyn.make_mlp_weights(nx, nu, H, seed=9)
+    g = torch.Generator().manual_seed(4)
+    U0 = torch.randn(T, nu, generator=g) * 0.05
+    x0 = torch.randn(nx, generator=g)
+    built_in = pm.models.MLPResidual(*W, nx, nu)
+    assert built_in.hidden == Hp and built_in.hidden_units == H
+    W1p, b1p, W2p = pm.models.pad_hidden(W[0], W[1], W[2], Hp)
+    by_hand = pm.models.MLPResidual(W1p, b1p, W2p, W[3], nx, nu)
+    net = torch.nn.Sequential(torch.nn.Linear(nx + nu, H), torch.nn.Tanh(), torch.nn.Linear(H, nx))
+    with torch.no_grad():
+        for p_, w in zip(net.parameters(), W):
+            p_.copy_(w)
+    net.cuda()
+    f_t = lambda x, u: x + 0.1 * net(torch.cat((x, u), dim=-1))
+    q_t = lambda x, u: (x ** 2).sum(dim=-1)
+    mk = lambda f, q, lam, **kw: pm.MPPI(f, q, nx, torch.eye(nu), num_samples=K, horizon=T, device="cuda", lambda_=lam, rng="philox", seed=5,
+                                         U_init=U0.clone(), **kw)
+    probe = mk(built_in.dynamics, built_in.running_cost, 1.0)
+    probe.command(x0.cuda())
+    lam = float(probe.cost_total.std())
+    outs = {}
+    for name, c in (("built-in", mk(built_in.dynamics, built_in.running_cost, lam)), ("padded by hand", mk(by_hand.dynamics, by_hand.running_cost, lam)),
+                    ("callables", mk(f_t, q_t, lam, auto_jit="sync"))):
+        assert c._model is not None and c._model.model_id == N.MODEL_MLP and c._model.hidden == Hp and not c._needs_generic(), (name, c.jit_note)
+        act = c.command(x0.cuda())
+        z = gpu_util.consumed_normals(c)
+        res = []
+        for dt in (torch.float64, torch.float32):
+            f, q = dyn.make_mlp(*[w.to(dt) for w in W])
+            p = orc.Problem(dynamics=f, running_cost=q, nx=nx, noise_sigma=torch.eye(nu, dtype=dt), K=K, T=T, lambda_=lam)
+            res.append(orc.command(p, U0.to(dt), x0.to(dt), z.to(dt), True))
+        for k_, got in (("action", act), ("U", c.U), ("cost_total", c.cost_total), ("omega", c.omega)):
+            margins.check(f"mlp hidden {H} padded to {Hp} / {name}", k_, got.detach().cpu().numpy(), res[0][k_].numpy(), res[1][k_].numpy(), rtol=1e-5)
+        outs[name] = c.cost_total.clone()
+    assert torch.equal(outs["built-in"], outs["padded by hand"]) and torch.equal(outs["built-in"], outs["callables"])
+    # retraining the callables' network still reaches the (padded) blob
+    c = mk(f_t, q_t, lam, auto_jit="sync")
+    c.command(x0.cuda())
+    before = c.cost_total.clone()
+    with torch.no_grad():
+        net[2].weight.mul_(1.5)
+    c.reset()
+    c.U = U0.clone().cuda()
+    c.command(x0.cuda())
+    assert not torch.equal(before, c.cost_total)

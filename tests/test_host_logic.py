@@ -109,7 +109,10 @@ def test_native_models_equal_oracle_callables():
     M2 = models.MLPResidual.random(16, 4, 32, seed=2)
     assert torch.equal(M2.W1, W[0]) and torch.equal(M2.b2, W[3])
     blob = M.param_blob("cpu", torch.float32)
-    assert blob.numel() == 32 * 20 + 32 + 16 * 32 + 16 + 1 + 16 + 4            # W1 | b1 | W2 | b2 | res_scale | qx | qu
+    # W1 | b1 | W2 | b2 | res_scale | qx | qu, the hidden axis zero-padded to the matrix-core kernels' next width (32 units -> 64)
+    assert (M.hidden_units, M.hidden) == (32, 64) and blob.numel() == 64 * 20 + 64 + 16 * 64 + 16 + 1 + 16 + 4
+    assert torch.equal(blob[:32 * 20].reshape(32, 20), W[0]) and not blob[32 * 20:64 * 20].any()
+    assert models.MLPResidual(*dyn.make_mlp_weights(6, 2, 50, seed=2), 6, 2).hidden == 50      # (no matrix-core kernel of that shape: as is)
     assert blob[-20:-4].tolist() == [1.0] * 16 and blob[-4:].tolist() == [0.0] * 4       # the plain sum x^2
     qs, qc = torch.linspace(0.5, 2.0, 16), torch.tensor([0.1, 0.2, 0.3, 0.4])
     Mq = models.MLPResidual(*W, 16, 4, q_state=qs, q_control=qc)

@@ -310,6 +310,18 @@ def test_a_trace_that_is_the_matrix_core_mlp_is_recognised():
     assert torch.equal(W1.reshape(64, 20), net[0].weight.detach()) and torch.equal(b1, net[0].bias.detach())
     assert torch.equal(W2.reshape(16, 64), net[2].weight.detach()) and torch.equal(b2, net[2].bias.detach()) and float(s) == 0.1
     assert m.model_id == 4 and m.hidden == 64 and m.flags() == 0
+    # a width between the kernels' widths: zero-padded units (exactly nothing added), the kernel sees the next width
+    net100 = torch.nn.Sequential(torch.nn.Linear(20, 100), torch.nn.Tanh(), torch.nn.Linear(100, 16)).double()
+    dyn100 = lambda x, u: x + 0.1 * net100(torch.cat((x, u), -1))
+    c100 = trace.generate(dyn100, sq, 16, 4)
+    m100 = jit.TracedMLPResidual("t100", 16, 4, dyn100, sq, c100["mlp_residual"], trace.gather_params(c100["param_tensors"], c100["n_params"]))
+    P = m100._param_list()
+    assert (m100.hidden, m100.hidden_units) == (128, 100) and [t_.numel() for t_ in P] == [128 * 20, 128, 16 * 128, 16, 1, 16, 4]
+    assert torch.equal(P[0][:100], net100[0].weight.detach()) and not P[0][100:].any() and not P[1][100:].any() and not P[2][:, 100:].any()
+    assert torch.equal(P[2][:, :100], net100[2].weight.detach())
+    x_, u_ = torch.randn(5, 16, dtype=torch.float64), torch.randn(5, 4, dtype=torch.float64)
+    padded = x_ + 0.1 * (torch.tanh(torch.cat((x_, u_), -1) @ P[0].T + P[1]) @ P[2].T + P[3])
+    assert torch.allclose(padded, dyn100(x_, u_), rtol=0, atol=1e-15)
     # what is NOT that shape keeps its functor
     # a diagonal quadratic cost with control effort is the kernel's too (round 5): weights end up in the blob behind res_scale
     qw = torch.linspace(0.5, 2.0, 16, dtype=torch.float64)
