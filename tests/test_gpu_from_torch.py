@@ -650,7 +650,9 @@ def test_mlp_of_an_odd_hidden_width_runs_on_the_matrix_core_kernel_with_padding_
     W = dyn.make_mlp_weights(nx, nu, H, seed=9)
     g = torch.Generator().manual_seed(4)
     U0 = torch.randn(T, nu, generator=g) * 0.05
-    x0 = torch.randn(nx, generator=g)
+    # (a start near the goal: with |x0| ~ 4 the cost every sample shares is ~40 lambda, and omega = exp(-(c - min) / lambda) / eta then
+    #  carries 40 x the costs' fp32 rounding -- in the reference's own fp32 run as much as here, a test of nothing)
+    x0 = torch.randn(nx, generator=g) * 0.3
     built_in = pm.models.MLPResidual(*W, nx, nu)
     assert built_in.hidden == Hp and built_in.hidden_units == H
     W1p, b1p, W2p = pm.models.pad_hidden(W[0], W[1], W[2], Hp)
