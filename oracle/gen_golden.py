@@ -30,9 +30,20 @@ def _np(x):
     return x.detach().cpu().numpy().copy() if torch.is_tensor(x) else np.array(x)
 
 
-def run_case(name, *, model, model_args, nx, nu, K, T, dtype, sigma, steps=2, state=None,
-             per_sample_state=False, kmppi=False, S=None, sampler_rows=0, terminal=False,
-             seed=0, smppi=None, **ctor):
+def run_case(name, **spec):
+    """one fixture: build_case() on the live reference, written to tests/golden/<name>.npz"""
+    cfg, out = build_case(name, **spec)
+    out["config"] = np.array(json.dumps(cfg))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: action0={out['action0']}")
+
+
+def build_case(name, *, model, model_args, nx, nu, K, T, dtype, sigma, steps=2, state=None,
+               per_sample_state=False, kmppi=False, S=None, sampler_rows=0, terminal=False,
+               seed=0, smppi=None, **ctor):
+    """(config, arrays) of one case run on the LIVE reference with injected draws -- what a fixture file holds; also what
+    tests/test_oracle_reference.py's random-configuration test replays through the oracle without writing anything"""
     mod, proxy = load_reference()
     tdt = {"f32": torch.float32, "f64": torch.float64}[dtype]
     g = torch.Generator().manual_seed(seed)
@@ -120,10 +131,7 @@ def run_case(name, *, model, model_args, nx, nu, K, T, dtype, sigma, steps=2, st
                S=(int(ctrl.num_support_pts) if kmppi else None), sampler_rows=sampler_rows,
                terminal=terminal, ctor=ctor, smppi=smppi, reference="UM-ARM-Lab/pytorch_mppi v0.9.1",
                torch=torch.__version__)
-    out["config"] = np.array(json.dumps(cfg))
-    os.makedirs(OUT, exist_ok=True)
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
-    print(f"{name}: action0={out['action0']}")
+    return cfg, out
 
 
 def run_batched_case(name, *, N, K, T, dtype, sigma, steps=2, seed=0, **ctor):

@@ -43,6 +43,7 @@ def test_oracle_bitwise_vs_live_reference(name):
 
 
 def test_batch_wrapper_stub_2d_3d():
+    ref_loader.load_reference()                 # (installs the stub of the absent dependency: not only behind another test of this file)
     from arm_pytorch_utilities import handle_batch_input
 
     @handle_batch_input(n=2)
@@ -65,3 +66,99 @@ def test_batch_wrapper_stub_2d_3d():
     assert torch.allclose(add_3d(a3, b3), e2[None])
     a4b, b4b = torch.tile(a3, [2, 1, 1]), torch.tile(b3, [2, 1, 1])
     assert torch.allclose(add_3d(a4b, b4b), torch.tile(e2[None], [2, 1, 1]))
+
+
+def _random_spec(seed):
+    """one random configuration of the path's constructor surface (mppi.py:45-184, :445-483, :593-615): controller class, model,
+    dtype, sizes, Sigma (0-dim / diagonal / full), every optional keyword with probability ~1/2"""
+    r = np.random.RandomState(1000 + seed)
+    coin = lambda p=0.5: bool(r.rand() < p)
+    kind = ["mppi", "smppi", "kmppi"][seed % 3]
+    model = ["pendulum", "linear_goal", "quadtoy", "linear_multi"][(seed // 3) % 4]
+    spec = dict(model=model, model_args={}, dtype="f64" if coin(0.7) else "f32", K=int(r.randint(6, 48)), T=int(r.randint(3, 11)),
+                steps=3, seed=seed, lambda_=float(np.round(10 ** r.uniform(-0.5, 1.2), 3)))
+    if model == "pendulum":
+        nx, nu = 2, 1
+        spec["sigma"] = float(np.round(r.uniform(0.5, 8.0), 2))
+        if coin():
+            spec["u_min"], spec["u_max"] = -2.0, 2.0
+    else:
+        if model == "quadtoy":
+            nu = int(r.randint(2, 5))
+            nx = nu + int(r.randint(0, 4))
+        else:
+            nx = nu = 2
+            B = np.round(r.uniform(-1, 1, (2, 2)) + np.eye(2), 2)
+            spec["model_args"] = dict(B=B.tolist(), goal=np.round(r.uniform(-2, 2, 2), 2).tolist())
+        d = np.round(r.uniform(0.3, 2.0, nu), 2)
+        S = np.diag(d)
+        if coin():                                     # full Sigma: SPD by construction
+            L = np.tril(np.round(r.uniform(-0.4, 0.4, (nu, nu)), 2), -1) + np.diag(np.sqrt(d))
+            S = np.round(L @ L.T, 4)
+            S = (S + S.T) / 2
+        spec["sigma"] = S.tolist()
+        if coin():
+            spec["noise_mu"] = np.round(r.uniform(-0.3, 0.3, nu), 2).tolist()
+        if coin():
+            spec["u_init"] = np.round(r.uniform(-0.1, 0.1, nu), 2).tolist()
+        b = coin(0.6), coin(0.3)
+        if b[0]:
+            spec["u_max"] = np.round(r.uniform(0.5, 2.0, nu), 2).tolist()        # one-sided: mirrored (mppi.py:112-119)
+            if b[1]:
+                spec["u_min"] = (-np.round(r.uniform(0.5, 2.0, nu), 2)).tolist()
+    spec["nx"], spec["nu"] = nx, nu
+    if coin():
+        spec["u_scale"] = float(np.round(r.uniform(0.3, 1.5), 2))
+    if coin(0.4):
+        spec["u_per_command"] = int(r.randint(1, min(4, spec["T"])))
+    if coin():
+        spec["sample_null_action"] = True
+    if coin(0.4):
+        spec["noise_abs_cost"] = True
+    if model in ("linear_goal", "linear_multi") and coin():
+        spec["terminal"] = True
+    if coin(0.4) and model != "linear_multi":
+        spec["per_sample_state"] = True
+    if coin(0.4):
+        spec["sampler_rows"] = int(r.randint(1, 4))
+    if model == "linear_multi":
+        spec["model_args"]["w_scale"] = float(np.round(r.uniform(0.05, 0.3), 2))
+        spec.update(rollout_samples=int(r.randint(2, 5)), rollout_var_cost=float(np.round(r.uniform(0, 0.5), 2)),
+                    rollout_var_discount=float(np.round(r.uniform(0.8, 1.0), 2)), step_dependent_dynamics=True)
+    if kind == "smppi":
+        sm = dict(w_action_seq_cost=float(np.round(r.uniform(0.0, 2.0), 2)), delta_t=float(np.round(r.uniform(0.2, 1.0), 2)))
+        if coin() and nu > 1:
+            sm["action_max"] = np.round(r.uniform(0.5, 1.5, nu), 2).tolist()
+        spec["smppi"] = sm
+    if kind == "kmppi":
+        spec["kmppi"] = True
+        if coin():
+            spec["S"] = int(r.randint(2, spec["T"] + 1))
+    return kind, spec
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_oracle_vs_live_reference_on_random_configurations(seed):
+    """differential test over the constructor surface: a random configuration is run on the LIVE reference with injected draws
+    (oracle/gen_golden.py build_case -- the code that wrote the committed fixtures) and replayed through the oracle; three commands,
+    every public result.  MPPI / SMPPI: bit for bit; KMPPI: the oracle's constant interpolation matrix against the reference's
+    vmap(solve), 1e-9 / 1e-4."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import gen_golden
+    kind, spec = _random_spec(seed)
+    cfg, d = gen_golden.build_case(f"random{seed}", **spec)
+    outs = gu.oracle_run(cfg, d)
+    keys = ["action", "U", "cost_total", "omega", "noise", "perturbed_action"] + (["theta", "noise_theta"] if kind == "kmppi" else []) \
+        + (["action_sequence"] if kind == "smppi" else [])
+    for s, r in enumerate(outs):
+        for k in keys:
+            ref, got = np.array(d[f"{k}{s}"]), r[k].numpy()
+            if kind == "kmppi":
+                rtol = 1e-9 if cfg["dtype"] == "f64" else 1e-4
+                np.testing.assert_allclose(got, ref, rtol=rtol, atol=rtol * max(1.0, float(np.abs(ref).max())), err_msg=f"{spec} step {s} {k}")
+            else:
+                assert np.array_equal(got, ref), (spec, s, k, float(np.abs(got - ref).max()))
+        if cfg["sampler_rows"]:
+            assert tuple(d[f"slice{s}"]) == tuple(r["sampler_slice"])
