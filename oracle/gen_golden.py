@@ -134,7 +134,14 @@ def build_case(name, *, model, model_args, nx, nu, K, T, dtype, sigma, steps=2, 
     return cfg, out
 
 
-def run_batched_case(name, *, N, K, T, dtype, sigma, steps=2, seed=0, **ctor):
+def run_batched_case(name, **spec):
+    cfg, out = build_batched_case(name, **spec)
+    out["config"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: action0={out['action0'][0]}")
+
+
+def build_batched_case(name, *, N, K, T, dtype, sigma, steps=2, seed=0, **ctor):
     """MPPI_Batched (mppi.py:691-873) on the linear-goal environment: U (N,T,nu), shared z per command."""
     mod, proxy = load_reference()
     tdt = {"f32": torch.float32, "f64": torch.float64}[dtype]
@@ -159,9 +166,7 @@ def run_batched_case(name, *, N, K, T, dtype, sigma, steps=2, seed=0, **ctor):
         out[f"z{s}"], out[f"shift{s}"], out[f"action{s}"], out[f"U{s}"] = _np(z), np.array(shift), _np(act), _np(ctrl.U)
     cfg = dict(name=name, model="linear_goal", nx=2, nu=nu, N=N, K=K, T=T, dtype=dtype, sigma=sigma, steps=steps,
                ctor=ctor, batched=True, reference="UM-ARM-Lab/pytorch_mppi v0.9.1", torch=torch.__version__)
-    out["config"] = np.array(json.dumps(cfg))
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
-    print(f"{name}: action0={out['action0'][0]}")
+    return cfg, out
 
 
 def main():

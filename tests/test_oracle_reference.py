@@ -162,3 +162,40 @@ def test_oracle_vs_live_reference_on_random_configurations(seed):
                 assert np.array_equal(got, ref), (spec, s, k, float(np.abs(got - ref).max()))
         if cfg["sampler_rows"]:
             assert tuple(d[f"slice{s}"]) == tuple(r["sampler_slice"])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_oracle_vs_live_reference_batched_on_random_configurations(seed):
+    """MPPI_Batched (mppi.py:691-873) == N independent oracle commands sharing one draw: random N, K, T, Sigma and keywords on the
+    live reference (gen_golden.build_batched_case), action and U of three commands"""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import gen_golden
+    r = np.random.RandomState(5000 + seed)
+    coin = lambda p=0.5: bool(r.rand() < p)
+    d_ = np.round(r.uniform(0.3, 2.0, 2), 2)
+    S = np.diag(d_)
+    if coin():
+        L = np.array([[np.sqrt(d_[0]), 0.0], [np.round(r.uniform(-0.4, 0.4), 2), np.sqrt(d_[1])]])
+        S = np.round(L @ L.T, 4)
+        S = (S + S.T) / 2
+    spec = dict(N=int(r.randint(1, 6)), K=int(r.randint(6, 48)), T=int(r.randint(3, 11)), dtype="f64" if coin(0.7) else "f32", sigma=S.tolist(),
+                steps=3, seed=seed, lambda_=float(np.round(10 ** r.uniform(-0.5, 1.2), 3)))
+    if coin():
+        spec["noise_mu"] = np.round(r.uniform(-0.3, 0.3, 2), 2).tolist()
+    if coin(0.6):
+        spec["u_max"] = np.round(r.uniform(0.5, 2.0, 2), 2).tolist()
+    if coin():
+        spec["u_scale"] = float(np.round(r.uniform(0.3, 1.5), 2))
+    if coin(0.4):
+        spec["u_per_command"] = int(r.randint(1, min(4, spec["T"])))
+    if coin(0.4):
+        spec["noise_abs_cost"] = True
+    cfg, d = gen_golden.build_batched_case(f"random_batched{seed}", **spec)
+    outs = gu.oracle_run_batched(cfg, d)
+    rtol = 1e-12 if cfg["dtype"] == "f64" else 2e-6
+    for s, o in enumerate(outs):
+        for k in ("action", "U"):
+            ref = np.array(d[f"{k}{s}"])
+            np.testing.assert_allclose(o[k].numpy(), ref, rtol=rtol, atol=rtol * max(1.0, float(np.abs(ref).max())), err_msg=f"{spec} step {s} {k}")
