@@ -199,3 +199,33 @@ def test_oracle_vs_live_reference_batched_on_random_configurations(seed):
         for k in ("action", "U"):
             ref = np.array(d[f"{k}{s}"])
             np.testing.assert_allclose(o[k].numpy(), ref, rtol=rtol, atol=rtol * max(1.0, float(np.abs(ref).max())), err_msg=f"{spec} step {s} {k}")
+
+
+@pytest.mark.parametrize("name", ["MPPI", "SMPPI", "KMPPI", "MPPI_Batched"])
+def test_constructor_signature_and_public_members_are_the_references(name):
+    """the drop-in boundary, checked against the LIVE classes: every constructor parameter of the reference in the same
+    position, of the same kind, with the same default; whatever this package adds is keyword-only (rng, seed, shard, auto_jit, devices);
+    every public method / property of the reference class exists here"""
+    import inspect
+    import pytorch_mppi_amd as pm
+    mod, _ = ref_loader.load_reference()
+    R, O = getattr(mod, name), getattr(pm, name)
+    rp = list(inspect.signature(R.__init__).parameters.values())
+    op = list(inspect.signature(O.__init__).parameters.values())
+    for a, b in zip(rp, op):
+        assert (a.name, a.kind) == (b.name, b.kind), (a, b)
+        if a.default is inspect.Parameter.empty or b.default is inspect.Parameter.empty:
+            assert a.default is b.default, (a, b)
+        else:
+            assert type(a.default).__name__ == type(b.default).__name__ and str(a.default) == str(b.default), (a, b)
+    assert len(op) >= len(rp)
+    for b in op[len(rp):]:
+        assert b.kind in (inspect.Parameter.KEYWORD_ONLY, inspect.Parameter.VAR_KEYWORD) and b.name in ("rng", "seed", "shard", "auto_jit", "devices", "kwargs"), b
+    public = lambda c: {n for n, _ in inspect.getmembers(c) if not n.startswith("_")}
+    assert not public(R) - public(O), public(R) - public(O)
+    for n in public(R):
+        sr, so = getattr(R, n), getattr(O, n)
+        if inspect.isfunction(sr):
+            pr = [(p.name, p.kind) for p in inspect.signature(sr).parameters.values()]
+            po = [(p.name, p.kind) for p in inspect.signature(so).parameters.values()]
+            assert po[:len(pr)] == pr, (n, pr, po)
