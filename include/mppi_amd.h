@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 21
+#define MPPI_ABI_VERSION 22
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_NEXT_DRAW_TORCH = 0, MPPI_NEXT_DRAW_PHILOX = 1 };   /* MppiProblem.next_kind (ABI 21) */
@@ -66,7 +66,9 @@ enum {
   MPPI_E_BADARG = -1,      /* null pointer / inconsistent sizes                            */
   MPPI_E_UNSUPPORTED = -2, /* no kernel instantiated for this (model, nx, nu, dtype, ...)  */
   MPPI_E_WORKSPACE = -3,   /* workspace too small                                          */
-  MPPI_E_DIST = -4         /* RCCL reported an error (message in mppi_last_error)          */
+  MPPI_E_DIST = -4,        /* RCCL reported an error (message in mppi_last_error)          */
+  MPPI_E_GROUP_PEER = -5   /* device group (ABI 22): ANOTHER device failed to issue its part of the command (or the
+                              command was abandoned); this device issued no exchange and no combine */
 };
 
 /* One command()'s worth of inputs/outputs.  Pointers marked [opt] may be NULL. */
@@ -180,7 +182,13 @@ typedef struct MppiProblem {
                                  (Salmon et al. 2011; Random123's philox4x32_R<7>, pinned by its known-answer vectors) -- a different
                                  stream, 30 % fewer multiplies in the kernel whose time they are (on-chip K1 71 -> 66 us at C3).
                                  Any other value: MPPI_E_BADARG */
-  int32_t _reserved0;
+  int32_t model_params_elems; /* ABI 22: elements behind `model_params`.  The built-in models with a parameter blob check it against
+                                 their layout (csrc/models.hpp) and refuse a short blob with MPPI_E_BADARG instead of reading past it:
+                                   MPPI_MODEL_LINEAR_GOAL  B (nx,nu) row-major | goal (nx)                          = nx*nu + nx
+                                   MPPI_MODEL_MLP          W1 (H,nx+nu) | b1 (H) | W2 (nx,H) | b2 (nx) | s (1) | qx (nx) | qu (nu)
+                                                           = H*(nx+nu) + H + nx*H + 2*nx + 1 + nu   (qx | qu: the diagonal quadratic
+                                                           cost sum qx x^2 + sum qu u^2, appended in ABI 21; ones | zeros = sum x^2)
+                                 run-time registered models (MPPI_MODEL_CUSTOM_BASE + slot) know their own blob: not checked */
 } MppiProblem;
 
 int mppi_abi_version(void);
@@ -361,6 +369,12 @@ int mppi_last_next_draw(void);
  * on every rank: beta = min beta_g; s_g = exp(-(beta_g-beta)/lambda); eta = sum s_g eta_g;
  * U_out = shift(U) + sum s_g P_g / eta; rescales this shard's omega. */
 int mppi_combine(const MppiProblem* p, const void* records, int32_t n_shards, void* stream);
+/* ABI 22: the same combine with every shard's record read WHERE ITS K4 LEFT IT (record_ptrs[g] -> the (2 + J) elements of shard g:
+ * memory of this device, or of a peer this device can access) instead of from one gathered array: no copy, no collective -- the
+ * staged exchange of a device group (mppi_group_*).  The caller orders the launch behind the writers (events).  Same arithmetic,
+ * same order, same bits as mppi_combine on the gathered records.  n_shards <= MPPI_MAX_GROUP. */
+#define MPPI_MAX_GROUP 16
+int mppi_combine_ptrs(const MppiProblem* p, const void* const* record_ptrs, int32_t n_shards, void* stream);
 
 /* Multi-GPU exchange (the reference has none): K is sharded over one process per GPU,
  * the only data-path collective of a command is ONE all-gather of the (2 + T*nu)-element shard
@@ -387,6 +401,34 @@ int mppi_command_sharded(const MppiProblem* p, void* comm, void* records, int32_
 int mppi_dist_init_all(int32_t ndev, const int32_t* devs, void** comms_out);
 int mppi_exchange_combine_all(int32_t ndev, const int32_t* devs, const MppiProblem* const* problems, void* const* comms,
                               void* const* records, void* const* streams);
+
+/* ABI 22 -- one process, N devices, the WHOLE command from one place (csrc/group.hip; reference caller: mppi.py:876-898, one
+ * process stepping one environment).  A group owns one worker thread per listed device (that device current in it, once): the
+ * caller fills the N problem blocks and hands each over with mppi_group_submit -- the worker starts issuing that device's K1 / K3 /
+ * K4 (mppi_command(apply = 0), or mppi_command_kmppi when a theta problem comes with it) at once, while the caller fills the next
+ * block -- and mppi_group_wait commits the command (all N parts are in), after which every worker, behind a host barrier of the
+ * workers (nobody enters a collective that a failed peer would never join), issues the exchange of the (2 + T nu)-element shard
+ * records into records[g] ((ndev, 2 + T nu) elements on device g) and mppi_combine on its stream, and returns once all have ISSUED
+ * their part (no device synchronisation).  The exchange: `comms` from mppi_dist_init_all -> ncclAllGather on each device's own
+ * communicator (one thread per device: no ncclGroupStart / End); comms = NULL ("staged": a device listed twice -- the one-GPU test
+ * rig -- or no RCCL) -> an event behind K4, and K5 reads the other shards' records in place behind their events
+ * (mppi_combine_ptrs) where every device can access every other's memory, else after peer copies into records[g]; ndev <=
+ * MPPI_MAX_GROUP.  The blocks are COPIED at submit; the device buffers they point to must stay valid until the stream has run.
+ *   mppi_group_broadcast   optional, before the first submit of a command: `nbytes` at `src` (memory of devs[0], ready in the
+ *                          order of stream0) are copied to dst[g] in front of device g's K1 (dst[g] == src or NULL: nothing)
+ *   mppi_group_wait        forms[g] / next_draws[g]: what mppi_last_command_form() / mppi_last_next_draw() read on worker g.
+ *                          Returns the first device's own error (message: "device d: ..."); the others report
+ *                          MPPI_E_GROUP_PEER and issue nothing further.  Called with parts missing it abandons the command
+ *   mppi_group_abort       abandon the command being assembled (the caller could not fill every block): the devices that did
+ *                          get their part have issued K1 / K3 / K4 -- harmless, nothing was applied -- and skip the exchange
+ * One caller thread per group (the reference's controller is not re-entrant either). */
+int mppi_group_create(int32_t ndev, const int32_t* devs, void* const* comms, void** group_out);
+int mppi_group_destroy(void* group);
+int mppi_group_size(void* group);
+int mppi_group_broadcast(void* group, const void* src, int64_t nbytes, void* const* dst, void* stream0);
+int mppi_group_submit(void* group, int32_t index, const MppiProblem* p, const MppiProblem* theta_problem, void* records, void* stream);
+int mppi_group_wait(void* group, int32_t* forms, int32_t* next_draws);
+int mppi_group_abort(void* group);
 
 /* User models.  The reference's plugin API is "any Python callable" (mppi.py:63-64); the fused
  * equivalent is a device functor {step, cost, terminal} that pytorch_mppi_amd/jit.py wraps around

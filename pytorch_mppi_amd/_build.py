@@ -16,7 +16,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SUFFIX = os.environ.get("MPPI_LIB_SUFFIX", "")
 LIB = os.path.join(HERE, f"libmppi_amd{SUFFIX}.so")
 OBJ_DIR = os.path.join(CSRC, "build" + SUFFIX)
-SOURCES = ["capi.hip", "dist.hip", "update.hip", "rollout_pendulum.hip", "rollout_integrator.hip",
+SOURCES = ["capi.hip", "dist.hip", "group.hip", "update.hip", "rollout_pendulum.hip", "rollout_integrator.hip",
            "rollout_linear_goal.hip", "rollout_mlp.hip", "rollout_mlp_mfma.hip", "rollout_mlp_split.hip", "noise_torch.hip"]
 # translation units: (source, object name, extra flags).  The two heaviest sources are compiled as several units each
 # (groups of model dimensions selected with a define) so that the parallel build is not one long compile

@@ -9,7 +9,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 F32, F64 = 0, 1
 NOISE_TNK4, NOISE_PHILOX, NOISE_ACTIONS, NOISE_KTN = 0, 1, 2, 3
@@ -17,6 +17,7 @@ E_UNSUPPORTED = -2
 FORM_NONE, FORM_STREAMING, FORM_SINGLE_LAUNCH, FORM_ONCHIP = 0, 1, 2, 3      # mppi_last_command_form()
 NEXT_DRAW_TORCH, NEXT_DRAW_PHILOX = 0, 1                                       # MppiProblem.next_kind
 E_DIST = -4
+E_GROUP_PEER = -5
 MODEL_NONE, MODEL_PENDULUM, MODEL_INTEGRATOR, MODEL_LINEAR_GOAL, MODEL_MLP = 0, 1, 2, 3, 4
 MODEL_CUSTOM_BASE = 100
 MODEL_FLAG_EXACT_FP32 = 1
@@ -49,7 +50,8 @@ class MppiProblem(C.Structure):
         ("workspace", _vp), ("workspace_elems", C.c_int64),
         ("onchip_spill", _vp), ("onchip_spill_elems", C.c_int64),
         # ABI 21: the next command's torch-stream draw inside this command's K3 launch
-        ("next_z", _vp), ("next_seed", C.c_uint64), ("next_philox_offset", C.c_uint64), ("next_grid_blocks", C.c_int32), ("next_kind", C.c_int32), ("philox_rounds", C.c_int32), ("_reserved0", C.c_int32),
+        ("next_z", _vp), ("next_seed", C.c_uint64), ("next_philox_offset", C.c_uint64), ("next_grid_blocks", C.c_int32), ("next_kind", C.c_int32), ("philox_rounds", C.c_int32),
+        ("model_params_elems", C.c_int32),     # ABI 22
     ]
 
 
@@ -90,6 +92,7 @@ SYMBOLS = {
     "mppi_command_kmppi": (C.c_int, [_PP, _PP, C.c_int, _vp]),
     "mppi_stat_kmppi_onchip_updates": (C.c_int64, []),
     "mppi_combine": (C.c_int, [_PP, _vp, C.c_int32, _vp]),
+    "mppi_combine_ptrs": (C.c_int, [_PP, C.POINTER(C.c_void_p), C.c_int32, _vp]),
     "mppi_register_model": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "mppi_dist_available": (C.c_int, []),
     "mppi_dist_unique_id": (C.c_int, [_vp]),
@@ -100,6 +103,13 @@ SYMBOLS = {
     "mppi_dist_init_all": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
     "mppi_exchange_combine_all": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(_PP), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p)]),
+    "mppi_group_create": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "mppi_group_destroy": (C.c_int, [_vp]),
+    "mppi_group_size": (C.c_int, [_vp]),
+    "mppi_group_broadcast": (C.c_int, [_vp, _vp, C.c_int64, C.POINTER(C.c_void_p), _vp]),
+    "mppi_group_submit": (C.c_int, [_vp, C.c_int32, _PP, _PP, _vp, _vp]),
+    "mppi_group_wait": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mppi_group_abort": (C.c_int, [_vp]),
     "mppi_profile_enable": (C.c_int, [C.c_int]),
     "mppi_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mppi_profile_read2": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -216,6 +216,19 @@ int make_args(const MppiProblem* p, KArgs<T>& a) {
   if (!p->U || !p->u_init || !p->noise_mu || !p->noise_L || !p->sigma_inv || !p->u_min || !p->u_max)
     return fail(MPPI_E_BADARG, "missing parameter array");
   if (p->n_sampler_rows > 0 && !p->sampler_actions) return fail(MPPI_E_BADARG, "sampler rows without actions");
+  {
+    // ABI 22: the built-in models' parameter blobs have a stated length (a caller still passing an older, shorter layout is
+    // refused instead of being read past its end)
+    int64_t need = 0;
+    if (p->model_id == MPPI_MODEL_MLP) need = (int64_t)p->hidden * (p->nx + p->nu) + p->hidden + (int64_t)p->nx * p->hidden + 2 * p->nx + 1 + p->nu;
+    if (p->model_id == MPPI_MODEL_LINEAR_GOAL) need = (int64_t)p->nx * p->nu + p->nx;
+    if (need > 0 && p->model_params != nullptr && p->model_params_elems < need) {
+      char msg[200];
+      snprintf(msg, sizeof(msg), "model_params holds %d elements (model_params_elems), this model's blob needs %lld (layout: include/mppi_amd.h)",
+               (int)p->model_params_elems, (long long)need);
+      return fail(MPPI_E_BADARG, msg);
+    }
+  }
   const Carve c = carve(p);
   if (!p->workspace || p->workspace_elems < c.total) return fail(MPPI_E_WORKSPACE, "workspace too small");
   a.K = p->K; a.Tn = p->T; a.nx = p->nx; a.nu = p->nu; a.J = p->T * p->nu;
@@ -670,4 +683,18 @@ static int do_combine(const MppiProblem* p, const void* rec, int G, hipStream_t 
 extern "C" int mppi_combine(const MppiProblem* p, const void* rec, int32_t G, void* stream) {
   return BY_DTYPE(p, do_combine<float>(p, rec, G, (hipStream_t)stream),
                   do_combine<double>(p, rec, G, (hipStream_t)stream));
+}
+
+template <typename T>
+static int do_combine_ptrs(const MppiProblem* p, const void* const* ptrs, int G, hipStream_t st) {
+  KArgs<T> a;
+  if (int e = make_args<T>(p, a)) return e;
+  if (!ptrs || G <= 0 || G > MPPI_MAX_GROUP || !a.U_out || !a.cost) return fail(MPPI_E_BADARG, "combine needs 1..MPPI_MAX_GROUP record pointers, U_out, cost_total");
+  for (int g = 0; g < G; ++g)
+    if (ptrs[g] == nullptr) return fail(MPPI_E_BADARG, "mppi_combine_ptrs: null record pointer");
+  return hipfail(launch_combine<T>(a, (const T*)nullptr, G, st, (const T* const*)ptrs), "mppi_combine_ptrs");
+}
+extern "C" int mppi_combine_ptrs(const MppiProblem* p, const void* const* record_ptrs, int32_t G, void* stream) {
+  return BY_DTYPE(p, do_combine_ptrs<float>(p, record_ptrs, G, (hipStream_t)stream),
+                  do_combine_ptrs<double>(p, record_ptrs, G, (hipStream_t)stream));
 }

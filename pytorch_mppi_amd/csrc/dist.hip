@@ -108,14 +108,24 @@ extern "C" int mppi_dist_destroy(void* comm) {
   return r == 0 ? 0 : mppi_fail_message(MPPI_E_DIST, "ncclCommDestroy failed");
 }
 
-extern "C" int mppi_exchange_combine(const MppiProblem* p, void* comm, void* records, int32_t world_size, void* stream) {
-  if (p == nullptr || comm == nullptr || records == nullptr || p->record == nullptr || world_size <= 0)
-    return mppi_fail_message(MPPI_E_BADARG, "mppi_exchange_combine needs a problem with a record, a communicator and the records buffer");
+// the ONE data-path collective of a sharded command: p->record -> records[world][2 + J] (also called by the device group's
+// workers, csrc/group.hip: one thread per device, each on its own communicator)
+namespace mppi_dist {
+int all_gather_record(const MppiProblem* p, void* comm, void* records, void* stream) {
+  if (p == nullptr || comm == nullptr || records == nullptr || p->record == nullptr)
+    return mppi_fail_message(MPPI_E_BADARG, "the record all-gather needs a problem with a record, a communicator and the records buffer");
   if (!rccl_load()) return mppi_fail_message(MPPI_E_UNSUPPORTED, g_rccl.why);
   const size_t n = 2 + (size_t)p->T * p->nu;                       // elements of one shard record
   const int dt = p->dtype == MPPI_F64 ? NCCL_FLOAT64 : NCCL_FLOAT32;
   const int r = g_rccl.all_gather(p->record, records, n, dt, (NcclComm)comm, (hipStream_t)stream);
   if (r != 0) return mppi_fail_message(MPPI_E_DIST, g_rccl.error_string ? g_rccl.error_string(r) : "ncclAllGather failed");
+  return 0;
+}
+}  // namespace mppi_dist
+
+extern "C" int mppi_exchange_combine(const MppiProblem* p, void* comm, void* records, int32_t world_size, void* stream) {
+  if (world_size <= 0) return mppi_fail_message(MPPI_E_BADARG, "mppi_exchange_combine: world_size <= 0");
+  if (int e = mppi_dist::all_gather_record(p, comm, records, stream)) return e;
   return mppi_combine(p, records, world_size, stream);
 }
 

@@ -731,22 +731,27 @@ __global__ void __launch_bounds__(BLOCK) finalize_blocks_kernel(const KArgs<T> a
   }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(BLOCK) combine_kernel(const KArgs<T> a, const T* __restrict__ rec,
+// K5.  The G shard records either sit one behind the other in `rec` (all-gathered: RCCL, copies) or are read where each shard's
+// K4 left them (`ptrs`: the device group's staged exchange on one device / between peer-accessible devices, csrc/group.hip) --
+// the same arithmetic in the same order either way.
+template <typename T> struct RecordPtrs { const T* p[MPPI_MAX_GROUP]; };
+template <typename T, bool PTRS>
+__global__ void __launch_bounds__(BLOCK) combine_kernel(const KArgs<T> a, const T* __restrict__ rec, const RecordPtrs<T> ptrs,
                                                         int G) {
   const int stride = 2 + a.J;
-  T beta = rec[0];
-  for (int g = 1; g < G; ++g) { const T b = rec[(long long)g * stride]; beta = b < beta ? b : beta; }
+  auto R = [&](int g, int i) -> T { return PTRS ? ptrs.p[g][i] : rec[(long long)g * stride + i]; };
+  T beta = R(0, 0);
+  for (int g = 1; g < G; ++g) { const T b = R(g, 0); beta = b < beta ? b : beta; }
   const T inv_lambda = T(1) / a.lambda_;
   T eta = T(0);
   for (int g = 0; g < G; ++g)
-    eta += m_exp(-inv_lambda * (rec[(long long)g * stride] - beta)) * rec[(long long)g * stride + 1];
+    eta += m_exp(-inv_lambda * (R(g, 0) - beta)) * R(g, 1);
   const T inv_eta = T(1) / eta;
   const int gid = blockIdx.x * BLOCK + threadIdx.x;
   if (gid < a.J) {
     T P = T(0);
     for (int g = 0; g < G; ++g)
-      P += m_exp(-inv_lambda * (rec[(long long)g * stride] - beta)) * rec[(long long)g * stride + 2 + gid];
+      P += m_exp(-inv_lambda * (R(g, 0) - beta)) * R(g, 2 + gid);
     const T un = u_eff(a, gid) + P * inv_eta;
     a.U_out[gid] = un;
     if (a.action_out != nullptr && gid < a.u_per_command * a.nu) a.action_out[gid] = un;
@@ -1000,7 +1005,7 @@ int launch_finalize_blocks(const KArgs<T>& a, int apply, hipStream_t st) {
 }
 
 template <typename T>
-int launch_combine(const KArgs<T>& a, const T* rec, int G, hipStream_t st) {
+int launch_combine(const KArgs<T>& a, const T* rec, int G, hipStream_t st, const T* const* ptrs) {
   if (a.n_env > 1) return MPPI_E_UNSUPPORTED;   // sharded MPPI_Batched: not built
   int nb = (a.J + BLOCK - 1) / BLOCK;
   if (a.omega != nullptr) {
@@ -1008,7 +1013,14 @@ int launch_combine(const KArgs<T>& a, const T* rec, int G, hipStream_t st) {
     nb = nbk > nb ? nbk : nb;
     if (nb > 1024) nb = 1024;
   }
-  hipLaunchKernelGGL(combine_kernel<T>, dim3(nb), dim3(BLOCK), 0, st, a, rec, G);
+  if (ptrs != nullptr) {
+    if (G > MPPI_MAX_GROUP) return MPPI_E_UNSUPPORTED;
+    RecordPtrs<T> rp;
+    for (int g = 0; g < MPPI_MAX_GROUP; ++g) rp.p[g] = g < G ? ptrs[g] : nullptr;
+    hipLaunchKernelGGL((combine_kernel<T, true>), dim3(nb), dim3(BLOCK), 0, st, a, (const T*)nullptr, rp, G);
+  } else {
+    hipLaunchKernelGGL((combine_kernel<T, false>), dim3(nb), dim3(BLOCK), 0, st, a, rec, RecordPtrs<T>{}, G);
+  }
   return (int)hipGetLastError();
 }
 
@@ -1078,7 +1090,7 @@ int launch_smppi_shift(int Tn, int nu, const T* U, const T* u_init, const T* A, 
   template int launch_weights_partial<T>(const KArgs<T>&, hipStream_t);                   \
   template int launch_finalize<T>(const KArgs<T>&, int, hipStream_t);                     \
   template int launch_finalize_blocks<T>(const KArgs<T>&, int, hipStream_t);              \
-  template int launch_combine<T>(const KArgs<T>&, const T*, int, hipStream_t);              \
+  template int launch_combine<T>(const KArgs<T>&, const T*, int, hipStream_t, const T* const*);              \
   template int launch_kmppi_sequences<T>(int, int, int, const T*, const T*, T*, int, const T*, const T*, T*, hipStream_t); \
   template int launch_smppi_shift<T>(int, int, const T*, const T*, const T*, T, T*, T*, T*, hipStream_t);
 MPPI_INST(float)

@@ -15,7 +15,7 @@ int launch_weights_partial_rows_f32(const KArgs<float>& a, void* next_z, int kin
 template <typename T> int launch_finalize(const KArgs<T>& a, int apply, hipStream_t st);
 // K4 of the on-chip command: combines the per-workgroup partial records (a.nkc of them) in block order
 template <typename T> int launch_finalize_blocks(const KArgs<T>& a, int apply, hipStream_t st);
-template <typename T> int launch_combine(const KArgs<T>& a, const T* rec, int G, hipStream_t st);
+template <typename T> int launch_combine(const KArgs<T>& a, const T* rec, int G, hipStream_t st, const T* const* ptrs = nullptr);
 // KMPPI's small sequence operators: out = M (R x S) . x (S x nu), optionally plus the rolled nominal sequence
 template <typename T> int launch_kmppi_sequences(int R, int S, int nu, const T* M, const T* x, T* out,
                                                    int Troll, const T* U, const T* u_init, T* U_out, hipStream_t st);

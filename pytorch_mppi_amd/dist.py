@@ -91,12 +91,21 @@ class NativeComm:
             self.handle = None
 
 
+LOCAL = "local"      # ShardPlan(..., group=LOCAL): the shards are the devices of ONE process (group.py), not ranks of a process group
+
+
 class ShardPlan:
     def __init__(self, K, rank, world_size, group=None):
         if not (0 <= rank < world_size):
             raise ValueError("bad rank/world_size")
         if K < world_size:
             raise ValueError("need at least one sample per rank")
+        # a process-local plan (a device group's shard: `rank` is the shard's index, not a process rank) never touches
+        # torch.distributed -- in a process whose default group is RCCL-backed (a device group per torchrun rank) a broadcast
+        # of U or an ncclCommInitRank with shard indices for ranks would hang or mix the ranks' sequences
+        self.local = isinstance(group, str) and group == LOCAL
+        if self.local:
+            group = None
         self.K, self.rank, self.world_size, self.group = int(K), int(rank), int(world_size), group
         base, rem = divmod(self.K, self.world_size)
         self.K_local = base + (1 if rank < rem else 0)
@@ -109,6 +118,8 @@ class ShardPlan:
         MPPI_NATIVE_RCCL=0 keeps the exchange on torch.distributed.  The decision is COLLECTIVE: whether this
         rank wants the native path (environment, device) enters the same all-reduce(MIN) as what can fail
         inside NativeComm, so either every rank gets a communicator or every rank gets None."""
+        if self.local:
+            return None                 # the device group owns the exchange (csrc/group.hip)
         if self._native is None:
             self._native = False
             group_ok = self.world_size == 1 or (dist.is_available() and dist.is_initialized()

@@ -7,15 +7,18 @@ constructor returns holds one shard controller per listed device (the same code 
 split of the K samples by global index, K1 / K3 / K4 against the shard's own minimum, one (2 + T nu)-element record per shard), and
 a command is
 
-    state -> every device (peer copies)          U, the parameters and the model are replicated
-    per device: K1, K3, K4(record only)          issued device by device from this thread, each on its device's current stream
-    ONE exchange                                  the N all-gathers of the records inside one ncclGroupStart / ncclGroupEnd
-                                                  (C-ABI mppi_exchange_combine_all, communicators from ncclCommInitAll), then
-    per device: K5                                the rank-order combine -> bit-identical U on every device
-    return device 0's action
+    this thread:  the state to device 0; per shard the problem block of this command (`MPPI._prepare`: draw, buffers, parameters)
+                  -> handed to the ENGINE's device group (C-ABI 22, csrc/group.hip: mppi_group_broadcast / _submit / _wait)
+    worker g:     one thread per device inside the library, that device current in it: the state from device 0 (peer copy),
+                  K1, K3, K4 (record only), the exchange -- ncclAllGather on the device's own communicator (ncclCommInitAll), or
+                  copies behind events when a device is listed twice / there is no RCCL ("staged") -- and K5, the rank-order
+                  combine -> bit-identical U on every device
+    this thread:  return device 0's action
 
-A device listed more than once (`devices=[0, 0]`: the one-GPU test rig) or a process without RCCL stages the records through
-device copies instead of RCCL (which takes one rank per device); everything else is the same code.
+so the host's share of a command is N block hand-overs plus ONE device's launches, not N x (Python + launches): commands no longer
+have to be longer than N x 40 us to be GPU-bound (profiles/r06_group_host_issue.txt).  What has no one-call form (the callback
+path, KMPPI's two-launch form) is issued shard by shard from this thread as before, the exchange through
+mppi_exchange_combine_all / device copies.  MPPI_GROUP_THREADS=0 forces that serial form (A/B).
 
 The returned object is an instance of the class that was asked for (a subclass made on the fly), but holds no controller state of
 its own: attribute reads go to shard 0 -- except the per-sample results (`cost_total`, `omega`, `noise`, ...), which are the
@@ -23,9 +26,12 @@ shards' parts concatenated on device 0 in global sample order --, attribute writ
 device), methods other than `command` run on every shard and the replicated sequences (`U`, `theta`, `action_sequence`) are then
 re-copied from shard 0 (a `reset()` draws on device 0 only, like rank 0's draw is broadcast in the per-process model).
 
-Host cost: the shards' launches are issued one after the other by one Python thread (~40 us each), so commands shorter than
-N x 40 us are host-bound here; the per-process model (`shard=`, what `bench.py` runs under torch.distributed.run) has no such
-limit.  For C5-sized commands (0.5 ms) it does not matter."""
+User callables (the reference's plugin API) are called by every shard with tensors on THAT shard's device.  `torch.nn.Module`s --
+the callable itself or the object a bound method belongs to: /root/reference/tests/pendulum_approximate.py's network -- are
+deep-copied onto each further device at construction and re-synchronised (`load_state_dict`) whenever the original's parameters
+were written (retraining between commands, mppi.py:890-893); `models.NativeModel`s keep a parameter blob per device themselves.
+Anything else -- a closure over a tensor on cuda:0 -- must be device-agnostic (`tensor.to(state.device)`): the error a device
+mismatch raises inside such a callable is re-raised with that advice."""
 import contextlib
 import ctypes as C
 
@@ -37,7 +43,6 @@ from . import _native as N
 _PER_SAMPLE = {"cost_total": 0, "omega": 0, "cost_total_non_zero": 0, "noise": 0, "perturbed_action": 0, "noise_theta": 0,
                "perturbed_control": 0, "states": 1, "actions": 1}
 _REPLICATED = ("U", "theta", "action_sequence")
-_OWN = frozenset(("_shards", "_devs", "_comms", "_staged", "_base", "exchange"))
 _classes = {}
 
 
@@ -63,8 +68,58 @@ def _dev_index(d):
     return d.index if d.index is not None else torch.cuda.current_device()
 
 
+_OWN = frozenset(("_shards", "_devs", "_comms", "_staged", "_base", "exchange", "_engine", "_replicas", "_state_bufs", "_rec_bufs",
+                  "_threads", "issue"))
+
+
+def _module_of(fn):
+    """the torch.nn.Module a user callable is (or is a bound method of), else None"""
+    if isinstance(fn, torch.nn.Module):
+        return fn, None
+    owner = getattr(fn, "__self__", None)
+    if isinstance(owner, torch.nn.Module) and getattr(fn, "__name__", None):
+        return owner, fn.__name__
+    return None, None
+
+
+class _Replicas:
+    """nn.Modules among the user's callables, copied to the further devices of a group and kept equal to the originals"""
+
+    def __init__(self):
+        self.items = {}          # id(original) -> (original, {device: copy}, versions at the last sync)
+
+    def on(self, fn, device):
+        mod, name = _module_of(fn)
+        if mod is None:
+            return fn
+        it = self.items.get(id(mod))
+        if it is None:
+            it = self.items[id(mod)] = [mod, {}, self._versions(mod)]
+        cp = it[1].get(device)
+        if cp is None:
+            import copy
+            cp = it[1][device] = copy.deepcopy(mod).to(device)
+        return cp if name is None else getattr(cp, name)
+
+    @staticmethod
+    def _versions(mod):
+        return tuple(t._version for t in list(mod.parameters()) + list(mod.buffers()))
+
+    def sync(self):
+        """before a command: originals written since the last look (an optimizer step, load_state_dict) -> copies follow"""
+        for it in self.items.values():
+            v = self._versions(it[0])
+            if v != it[2]:
+                sd = it[0].state_dict()
+                for dev, cp in it[1].items():
+                    cp.load_state_dict({k: t.to(dev) for k, t in sd.items()})
+                it[2] = v
+
+
 class DeviceGroup:
     def __init__(self, *args, devices=None, **kw):
+        import os
+        from .dist import LOCAL
         cls = type(self)._base
         devs = [_dev_index(d) for d in devices]
         if len(devs) < 2:
@@ -73,28 +128,46 @@ class DeviceGroup:
         kw.pop("device", None)
         args = list(args)
         shards = []
+        replicas = _Replicas()
+        dev0 = torch.device("cuda", devs[0])
         for g, dv in enumerate(devs):
             a = list(args)
             k = dict(kw)
+            d = torch.device("cuda", dv)
             if len(a) > 6:
-                a[6] = torch.device("cuda", dv)          # `device` given positionally (mppi.py:45-61 order)
+                a[6] = d                                 # `device` given positionally (mppi.py:45-61 order)
             else:
-                k["device"] = torch.device("cuda", dv)
+                k["device"] = d
+            if d != dev0:
+                # the user's callables see tensors of THIS device: modules travel with the shard (see the module docstring)
+                for i in (0, 1):
+                    if len(a) > i:
+                        a[i] = replicas.on(a[i], d)
+                for name in ("dynamics", "running_cost", "terminal_state_cost"):
+                    if k.get(name) is not None:
+                        k[name] = replicas.on(k[name], d)
+                if len(a) > 7 and a[7] is not None:
+                    a[7] = replicas.on(a[7], d)          # terminal_state_cost given positionally
             with torch.cuda.device(dv):
-                shards.append(cls(*a, shard=(g, len(devs)), **k))
+                shards.append(cls(*a, shard=(g, len(devs), LOCAL), **k))
         object.__setattr__(self, "_shards", shards)
         object.__setattr__(self, "_devs", devs)
         object.__setattr__(self, "_comms", None)
+        object.__setattr__(self, "_engine", None)
+        object.__setattr__(self, "_replicas", replicas)
+        object.__setattr__(self, "_state_bufs", None)
+        object.__setattr__(self, "_rec_bufs", {})
         object.__setattr__(self, "_staged", len(set(devs)) < len(devs))
         object.__setattr__(self, "exchange", None)
+        object.__setattr__(self, "issue", None)
         self._sync_replicated()
+        lib = N.lib()
+        import weakref
         if not self._staged:
-            lib = N.lib()
             comms = (C.c_void_p * len(devs))()
             rc = lib.mppi_dist_init_all(len(devs), (C.c_int32 * len(devs))(*devs), comms)
             if rc == 0:
                 object.__setattr__(self, "_comms", comms)
-                import weakref
                 weakref.finalize(self, DeviceGroup._destroy, lib, [C.c_void_p(c) for c in comms])
             elif rc != N.E_UNSUPPORTED:
                 N.check(rc, "mppi_dist_init_all")
@@ -102,7 +175,30 @@ class DeviceGroup:
                 object.__setattr__(self, "_staged", True)          # no RCCL in this process: device copies
         object.__setattr__(self, "exchange", "staged through device copies" + (" (a device is listed twice: TEST RIG)" if len(set(devs)) < len(devs) else
                                                                                " (no RCCL)") if self._staged else
-                           "engine-owned RCCL communicators (ncclCommInitAll), one grouped all-gather per command")
+                           "engine-owned RCCL communicators (ncclCommInitAll), one all-gather per device and command")
+        # the engine's device group: one worker thread per device issues that device's launches (csrc/group.hip)
+        object.__setattr__(self, "_threads", os.environ.get("MPPI_GROUP_THREADS", "1") != "0")
+        if self._threads:
+            eng = C.c_void_p()
+            rc = lib.mppi_group_create(len(devs), (C.c_int32 * len(devs))(*devs), self._comms, C.byref(eng))
+            if rc == 0:
+                object.__setattr__(self, "_engine", eng)
+                weakref.finalize(self, DeviceGroup._destroy_engine, lib, eng)
+            else:
+                import logging
+                logging.getLogger("pytorch_mppi_amd").warning(
+                    "pytorch_mppi_amd: no engine device group (%s): the shards' launches are issued from the calling thread",
+                    lib.mppi_last_error().decode(errors="replace"))
+        object.__setattr__(self, "issue", "one worker thread per device inside the engine (mppi_group_submit / mppi_group_wait)"
+                           if self._engine is not None else "shard by shard from the calling thread")
+
+    @staticmethod
+    def _destroy_engine(lib, eng):
+        try:
+            if eng.value:
+                lib.mppi_group_destroy(eng)
+        except Exception:
+            pass
 
     @staticmethod
     def _destroy(lib, comms):
@@ -171,27 +267,116 @@ class DeviceGroup:
         """mppi.py:240-252 on N devices: the action (device 0), without synchronising."""
         shards = object.__getattribute__(self, "_shards")
         s0 = shards[0]
+        shift = bool(shift_nominal_trajectory)
+        object.__getattribute__(self, "_replicas").sync()
+        eng = object.__getattribute__(self, "_engine")
+        # the state: ONCE to device 0 (a host state travels in a launch packet, MPPI._to_state); the other devices get it by a
+        # peer copy in front of their K1, issued by their worker thread -- unless the shards take different rows of it
+        # (per-sample initial states of the global problem, mppi.py:302-305) or there are no workers
+        states, bc = [state] * len(shards), None
+        if eng is not None:
+            with _on(s0.d):
+                st0 = s0._to_state(state) if tuple(getattr(state, "shape", ())) != (s0.K, s0.nx) or s0.K_local == s0.K else None
+            if st0 is not None:
+                st0 = st0.contiguous()
+                states, bc = self._state_copies(st0), st0
         ps = []
-        for s in shards:
-            s.info = info
-            with _on(s.d):
-                if s._jit_pending is not None:
-                    s._adopt_background_model()
-                if getattr(s._model, "watch", None) is not None:
-                    s._check_traced(state if s is s0 else None)
-                # (MPPI._to_state moves the state to the shard's device and, for per-sample initial states of the global
-                # problem -- (K, nx), mppi.py:302-305 --, takes this shard's rows)
-                ps.append(s._begin(state, bool(shift_nominal_trajectory)))
-        self._exchange(ps)
+        try:
+            for g, s in enumerate(shards):
+                s.info = info
+                with (_on(s.d) if not self._light(s) else contextlib.nullcontext()):
+                    if s._jit_pending is not None:
+                        s._adopt_background_model()
+                    if getattr(s._model, "watch", None) is not None:
+                        s._check_traced(state if s is s0 else None)
+                    # (MPPI._to_state moves the state to the shard's device and, for per-sample initial states of the global
+                    # problem -- (K, nx), mppi.py:302-305 --, takes this shard's rows)
+                    ps.append(s._prepare(states[g], shift))
+        except RuntimeError as e:
+            if "Expected all tensors to be on the same device" in str(e):
+                raise RuntimeError(f"{e}\n(pytorch_mppi_amd device group: every shard calls dynamics / running_cost with tensors on ITS "
+                                   "device; torch.nn.Modules are copied there, anything else the callables read must follow "
+                                   "`state.device` -- pytorch_mppi_amd/group.py)") from e
+            raise
+        self._issue(ps, bc, states)
         action = None
         for s, p in zip(shards, ps):
-            with _on(s.d):
-                a = s._end(p)
+            if type(s)._end is _plain_end:
+                a = s._end(p)                           # (no launches in there: no need for the shard's device to be current)
+            else:
+                with _on(s.d):
+                    a = s._end(p)
             if s is s0:
                 action = a
         return action
 
+    @staticmethod
+    def _light(s):
+        """a shard whose `_prepare` launches nothing from this thread (the engine's generator inside K1, nothing to convert or
+        upload): its device need not be made current for it"""
+        return (s.rng == "philox" and s.last_draw in ("philox-onchip", "philox-k1") and not s._injected and s.M == 1
+                and s.specific_action_sampler is None and type(s)._prepare is _plain_prepare and s._model is not None
+                and getattr(s._model, "watch", None) is None and s._jit_pending is None)
+
+    def _state_copies(self, st0):
+        """per shard the tensor its K1 reads the state from: device 0's itself where the shard lives there, else a buffer on
+        the shard's device that its worker fills from device 0's in front of K1 (mppi_group_broadcast)"""
+        shards = object.__getattribute__(self, "_shards")
+        bufs = object.__getattribute__(self, "_state_bufs")
+        key = (tuple(st0.shape), st0.dtype)
+        if bufs is None or bufs[0] != key:
+            bufs = (key, [None if s.d == st0.device else torch.empty(st0.shape, dtype=st0.dtype, device=s.d) for s in shards])
+            object.__setattr__(self, "_state_bufs", bufs)
+        return [st0 if b is None else b for b in bufs[1]]
+
+    def _records_for(self, g, s, n):
+        """the (G, 2 + J) buffer the exchange fills on device g: one per shard and record size, touched on that shard's stream only"""
+        rb = object.__getattribute__(self, "_rec_bufs")
+        b = rb.get((g, n, s.dtype))
+        if b is None:
+            if len(rb) > 4 * len(object.__getattribute__(self, "_shards")):
+                rb.clear()
+            b = rb[(g, n, s.dtype)] = torch.empty(len(object.__getattribute__(self, "_shards")), n, device=s.d, dtype=s.dtype)
+        return b
+
+    def _issue(self, ps, bc, states):
+        """the launches of a prepared command on every device + the exchange + K5"""
+        shards = object.__getattribute__(self, "_shards")
+        eng = object.__getattribute__(self, "_engine")
+        lib = N.lib()
+        G = len(shards)
+        blocks = [s._group_blocks(p) if p._deferred else None for s, p in zip(shards, ps)]
+        if eng is not None and all(b is not None for b in blocks):
+            streams = [torch._C._cuda_getCurrentRawStream(s._dev_index) for s in shards]
+            if bc is not None and any(t is not bc for t in states):
+                dst = (C.c_void_p * G)(*[None if t is bc else t.data_ptr() for t in states])
+                N.check(lib.mppi_group_broadcast(eng, bc.data_ptr(), bc.numel() * bc.element_size(), dst, streams[0]), "mppi_group_broadcast")
+            for g, (s, p, (b, bt)) in enumerate(zip(shards, ps, blocks)):
+                q = bt if bt is not None else b
+                rec = self._records_for(g, s, 2 + q.T * q.nu)
+                p._keep["records"] = rec
+                rc = lib.mppi_group_submit(eng, g, C.byref(b), C.byref(bt) if bt is not None else None, rec.data_ptr(), streams[g])
+                if rc != 0:
+                    lib.mppi_group_abort(eng)
+                    N.check(rc, "mppi_group_submit")
+            forms, nds = (C.c_int32 * G)(), (C.c_int32 * G)()
+            rc = lib.mppi_group_wait(eng, forms, nds)
+            if rc == 0:
+                for g, (s, p) in enumerate(zip(shards, ps)):
+                    s._launched(p, int(forms[g]), int(nds[g]))
+                return
+            if rc != N.E_UNSUPPORTED:
+                N.check(rc, "mppi_group_wait")
+            # no one-call form for this command on this model (the in-place (K,T,nu) K1, KMPPI's fused interpolation): the shards
+            # issue it themselves, their own way.  Nothing was exchanged or applied; what was launched is launched again
+        for s, p in zip(shards, ps):
+            if p._deferred:
+                with _on(s.d):
+                    s._launch_prepared(p)
+        self._exchange(ps)
+
     def _exchange(self, ps):
+        """records -> every device, K5 everywhere, from THIS thread (the form without worker threads)"""
         shards = object.__getattribute__(self, "_shards")
         G = len(shards)
         recs = [p._keep["record"] for p in ps]
@@ -213,3 +398,9 @@ class DeviceGroup:
         for s, p in zip(shards, ps):
             with _on(s.d):
                 s._combine(p, torch.stack([r if r.device == s.d else r.to(s.d) for r in recs]))
+
+
+from .mppi import MPPI as _MPPI     # noqa: E402  (mppi.py imports this module lazily, inside MPPI.__new__)
+
+_plain_end = _MPPI._end
+_plain_prepare = _MPPI._prepare

@@ -739,8 +739,8 @@ class MPPI:
         nominal sequence, mppi.py:144-145 / :290) is rank 0's draw, broadcast.  No process group (the
         single-process shard emulation of the tests) or one shard: unchanged."""
         sh = self._shard
-        if sh is None or sh.world_size <= 1:
-            return t
+        if sh is None or sh.world_size <= 1 or sh.local:
+            return t                     # (a device group's shards live in ONE process: group.py copies shard 0's sequences)
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             return t
@@ -840,6 +840,7 @@ class MPPI:
             if self._model is not None:
                 keep["mp"] = self._model.param_blob(self.d, self.dtype)
                 p.model_params = _ptr(keep["mp"])
+                p.model_params_elems = int(keep["mp"].numel())
                 if self._model.process_noise is not None:
                     keep["psd"] = self._model.process_noise.to(device=self.d, dtype=self.dtype).contiguous()
                     p.process_noise_sd = _ptr(keep["psd"])
@@ -1111,10 +1112,11 @@ class MPPI:
         p._keep["next_z"] = alt
         self._next_armed = ("philox", (int(p.K), int(p.T), int(p.nu), int(p.k_offset), int(p.seed), int(p.call) + 1), alt)
 
-    def _settle_next(self):
-        """behind the launches of a command: did its K3 generate the next draw (mppi_last_next_draw, thread-local)?"""
+    def _settle_next(self, took=None):
+        """behind the launches of a command: did its K3 generate the next draw (mppi_last_next_draw, thread-local -- `took`:
+        what the thread that issued the launches read there)?"""
         armed, self._next_armed = self._next_armed, None
-        if armed is not None and int(N.lib().mppi_last_next_draw()) == 1:
+        if armed is not None and (int(N.lib().mppi_last_next_draw()) if took is None else int(took)) == 1:
             if armed[0] == "philox":
                 self._pf_rows = (armed[1], armed[2], True)
             else:
@@ -1302,6 +1304,8 @@ class MPPI:
     def _command(self, state, shift):
         p = self._begin(state, shift)
         if self._sharded() and not getattr(p, "_combined", False):
+            if getattr(self._shard, "local", False):
+                raise RuntimeError("this controller is one shard of a device group (MPPI(..., devices=[...])): command the group, not the shard")
             comm = None if self.overlap_collective else self._shard.native_comm(self.d)
             if comm is not None:
                 # generic path: the engine issues the record all-gather itself (RCCL C API on this stream) + K5
@@ -1347,6 +1351,16 @@ class MPPI:
     def _begin(self, state, shift):
         """Everything local to this shard: noise, K1 (or the generic callback loop), K3, K4.
         Single shard: K4 also applies the update.  Sharded: K4 only writes the shard record."""
+        p = self._prepare(state, shift)
+        if p._deferred:
+            self._launch_prepared(p)
+        return p
+
+    def _prepare(self, state, shift):
+        """The host part of a command up to (not including) the fused path's launch: the problem block with this command's
+        draw, buffers and state bound.  `p._deferred`: the fused launch is still to be issued -- by `_launch_prepared` on
+        this thread, or by the device group's worker thread of this shard's device (group.py, csrc/group.hip).  The generic
+        (callback) path cannot be handed over: it has run K1's stand-in, K3 and K4 when this returns (`_deferred` False)."""
         lib = N.lib()
         self.state = self._to_state(state)
         p = self._problem()
@@ -1389,35 +1403,10 @@ class MPPI:
             p._keep["state"] = s0
             p.state_per_sample = int(per_sample)
             p.use_terminal = int(self.terminal_state_cost is not None)
-            comm = None
-            if apply == 0 and not self.overlap_collective:
-                comm = self._shard.native_comm(self.d)
-
-            def launch():
-                if comm is None:
-                    return lib.mppi_command(C.byref(p), apply, st)            # K1 + K3 + K4, one call
-                # sharded: K1 + K3 + K4 + ncclAllGather + K5 on this stream, one call
-                records = torch.empty(comm.world_size, 2 + p.T * p.nu, device=self.d, dtype=self.dtype)
-                p._keep["records"] = records
-                p._combined = True
-                return lib.mppi_command_sharded(C.byref(p), comm.handle, _ptr(records), comm.world_size, st)
-
-            rc = launch()
-            if rc == N.E_UNSUPPORTED and p.noise_src == N.NOISE_KTN:
-                self.ktn_direct = False            # no in-place instantiation for this model: convert from now on
-                self._convert_noise(p)
-                rc = launch()
-            N.check(rc, "mppi_command")
-            self._settle_next()
-            if self.last_draw == "philox-onchip" and int(lib.mppi_last_command_form()) != N.FORM_ONCHIP:
-                # the engine ran K1 + K3 with the rows generated twice instead (a model without the on-chip kernel, ...):
-                # correct, slower -- store the rows from the next command on
-                self._onchip_refused = True
-                self.last_draw = "philox-twice"
-            if p.noise_src == N.NOISE_PHILOX and p.z:
-                p.noise_src = N.NOISE_TNK4        # the rows K1 generated are in p.z now (lazy attributes)
+            p._deferred, p._apply = True, apply
             return p
 
+        p._deferred = False
         self._generic_total_cost(p, cost_total, st)
         if p.noise_src == N.NOISE_PHILOX and p.z:
             p.noise_src = N.NOISE_TNK4            # the rows mppi_prepare generated are in p.z now
@@ -1425,6 +1414,47 @@ class MPPI:
         self._settle_next()
         N.check(lib.mppi_finalize(C.byref(p), apply, st), "mppi_finalize")
         return p
+
+    def _launch_prepared(self, p):
+        """the fused path's launches of a prepared command, on the calling thread: K1 + K3 + K4 from one C call (a sharded rank
+        with an engine-owned communicator: + the record all-gather + K5)"""
+        lib, st, apply = N.lib(), self._stream(), p._apply
+        comm = None
+        if apply == 0 and not self.overlap_collective and not getattr(self._shard, "local", False):
+            comm = self._shard.native_comm(self.d)
+
+        def launch():
+            if comm is None:
+                return lib.mppi_command(C.byref(p), apply, st)            # K1 + K3 + K4, one call
+            # sharded: K1 + K3 + K4 + ncclAllGather + K5 on this stream, one call
+            records = torch.empty(comm.world_size, 2 + p.T * p.nu, device=self.d, dtype=self.dtype)
+            p._keep["records"] = records
+            p._combined = True
+            return lib.mppi_command_sharded(C.byref(p), comm.handle, _ptr(records), comm.world_size, st)
+
+        rc = launch()
+        if rc == N.E_UNSUPPORTED and p.noise_src == N.NOISE_KTN:
+            self.ktn_direct = False            # no in-place instantiation for this model: convert from now on
+            self._convert_noise(p)
+            rc = launch()
+        N.check(rc, "mppi_command")
+        self._launched(p, int(lib.mppi_last_command_form()), int(lib.mppi_last_next_draw()))
+
+    def _group_blocks(self, p):
+        """what a device group's worker issues for this prepared command (csrc/group.hip): (problem, theta problem | None)"""
+        return p, None
+
+    def _launched(self, p, form, next_draw):
+        """behind the fused launches of a command (issued here or by the device group's worker): what the engine reported"""
+        p._deferred = False
+        self._settle_next(next_draw)
+        if self.last_draw == "philox-onchip" and form != N.FORM_ONCHIP:
+            # the engine ran K1 + K3 with the rows generated twice instead (a model without the on-chip kernel, ...):
+            # correct, slower -- store the rows from the next command on
+            self._onchip_refused = True
+            self.last_draw = "philox-twice"
+        if p.noise_src == N.NOISE_PHILOX and p.z:
+            p.noise_src = N.NOISE_TNK4        # the rows K1 generated are in p.z now (lazy attributes)
 
     def _fused_state(self, per_sample):
         """Initial state as the fused kernels read it: (K_local,nx) rows or one (nx,) vector.  The
@@ -1825,11 +1855,11 @@ class SMPPI(MPPI):
         p.smooth_weight = float(self.w_action_seq_cost) * float(self.u_scale) ** 2
         return p
 
-    def _begin(self, state, shift):
+    def _prepare(self, state, shift):
         if shift:
             self.shift_nominal_trajectory()       # U and the action sequence move together (host, tiny)
         self._perturbed_control = None
-        return super()._begin(state, False)
+        return super()._prepare(state, False)
 
     def _end(self, p):
         super()._end(p)
@@ -2145,10 +2175,10 @@ class KMPPI(MPPI):
     def _noise_shape(self):
         return (self.K_local, int(self.num_support_pts), self.nu)
 
-    def _begin(self, state, shift):
-        """everything local to this shard (MPPI._begin): support-point draw, K1 on the interpolated trajectories, K3 / K4 on the
-        theta problem; returns the THETA problem -- its record is what a sharded command exchanges"""
-        lib = N.lib()
+    def _prepare(self, state, shift):
+        """the host part of a KMPPI command (MPPI._prepare): support-point draw, the trajectory problem `p` and the THETA problem
+        `pt` (K3 / K4 run on the support-point stream, mppi.py:679-681); returns `pt` -- its record is what a sharded command
+        exchanges -- with `pt._traj = p`"""
         self.state = self._to_state(state)
         if shift:
             # explicit shift (tiny (T,nu)/(S,S) host-launched ops) so that theta and U move together
@@ -2188,7 +2218,6 @@ class KMPPI(MPPI):
         per_sample = tuple(self.state.shape) == (K, self.nx)
         self._states = self._actions = self._noise = self._perturbed_action = None
         self._noise_theta = None
-        # --- theta update: K3/K4 on the support-point stream (mppi.py:679-681) ---
         sharded = self._sharded()
         # omega = (1/eta) exp(-(c - beta)/lambda) and cost_total_non_zero are functions of cost_total and the record: a
         # single-shard command leaves them to their first read (MPPI.omega); a sharded one has K5 rescale them
@@ -2200,44 +2229,71 @@ class KMPPI(MPPI):
         pt.cost_total = p.cost_total
         pt.omega, pt.cost_total_non_zero, pt.U_out, pt.record = _ptr(omega), _ptr(wnz), _ptr(theta_new), _ptr(record)
         pt.u_per_command = 0
-        updated = False
+        self.cost_total = cost_total
+        # the record of the exchange (MPPI._command / group.DeviceGroup) is the THETA problem's: {beta, eta, P_theta[S nu]}
+        pt._keep.update(record=record, omega=omega, wnz=wnz, theta_new=theta_new, lazy=lazy)
+        pt._traj = p        # (an attribute of the block, NOT an entry of pt._keep: p._keep["theta_keep"] IS that dictionary, and a reference
+        #                      cycle would keep every command's buffers -- 200 MB of raw actions in the two-launch form -- alive until
+        #                      the cycle collector runs: fresh hipMallocs per command in the meantime, 0.7 ms each)
+        pt._apply = 0 if sharded else 1
         if not self._needs_generic():
             s0 = self._fused_state(per_sample)
             p.state = _ptr(s0)
             p._keep["state"] = s0
             p.state_per_sample = int(per_sample)
             p.use_terminal = int(self.terminal_state_cost is not None)
-            # interpolation inside K1 where that kernel exists (fp32, diagonal Sigma, nu % 4 == 0, S*nu <= 384):
-            # the (K,T,nu) raw actions are never written; lazy attributes build them on demand (_raw_actions).
-            # ONE call for the command (mppi_command_kmppi): where it can, that kernel also reduces its workgroups' part of
-            # the theta update from the control points the lanes still hold, and the stand-alone K3 -- which re-creates all
-            # S*nu control-point rows per sample -- is replaced by the small combine launch of the on-chip MPPI command
-            if not self.fuse_interpolation:
-                rc = N.E_UNSUPPORTED
-            elif self.onchip_update:
-                rc = lib.mppi_command_kmppi(C.byref(p), C.byref(pt), 0 if sharded else 1, st)
-                updated = rc == 0
-            else:
-                rc = lib.mppi_rollout_cost_kmppi(C.byref(p), st)      # (A/B seam: K1 here, the stand-alone K3 / K4 below)
-            if rc == N.E_UNSUPPORTED:
-                self._raw_actions(p)
-                N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
-            else:
-                N.check(rc, "mppi_command_kmppi")
-        else:
-            self._raw_actions(p)
-            self._generic_total_cost(p, cost_total, st)
-        self.cost_total = cost_total
-        if not updated:
-            N.check(lib.mppi_weights_partial(C.byref(pt), st), "mppi_weights_partial")
-            N.check(lib.mppi_finalize(C.byref(pt), 0 if sharded else 1, st), "mppi_finalize")
-        self._settle_next()
-        # the record of the exchange (MPPI._command / group.DeviceGroup) is the THETA problem's: {beta, eta, P_theta[S nu]}
-        pt._keep.update(record=record, omega=omega, wnz=wnz, theta_new=theta_new, lazy=lazy)
-        pt._traj = p        # (an attribute of the block, NOT an entry of pt._keep: p._keep["theta_keep"] IS that dictionary, and a reference
-        #                      cycle would keep every command's buffers -- 200 MB of raw actions in the two-launch form -- alive until
-        #                      the cycle collector runs: fresh hipMallocs per command in the meantime, 0.7 ms each)
+            pt._deferred = True
+            return pt
+        pt._deferred = False
+        self._raw_actions(p)
+        self._generic_total_cost(p, cost_total, st)
+        self._theta_update(pt, st)
         return pt
+
+    def _theta_update(self, pt, st):
+        """K3 / K4 on the support-point stream (mppi.py:679-681), stand-alone"""
+        lib = N.lib()
+        N.check(lib.mppi_weights_partial(C.byref(pt), st), "mppi_weights_partial")
+        N.check(lib.mppi_finalize(C.byref(pt), pt._apply, st), "mppi_finalize")
+        self._settle_next()
+
+    def _group_blocks(self, pt):
+        """what a device group's worker issues for this prepared command (csrc/group.hip: mppi_command_kmppi(trajectory problem,
+        theta problem)) -- or None: this command has no one-call form, the shard launches it itself"""
+        if self.fuse_interpolation and self.onchip_update:
+            return pt._traj, pt
+        return None
+
+    def _launch_prepared(self, pt):
+        """the fused path's launches of a prepared KMPPI command, on the calling thread"""
+        lib, st, p = N.lib(), self._stream(), pt._traj
+        # interpolation inside K1 where that kernel exists (fp32, diagonal Sigma, nu % 4 == 0, S*nu <= 384):
+        # the (K,T,nu) raw actions are never written; lazy attributes build them on demand (_raw_actions).
+        # ONE call for the command (mppi_command_kmppi): where it can, that kernel also reduces its workgroups' part of
+        # the theta update from the control points the lanes still hold, and the stand-alone K3 -- which re-creates all
+        # S*nu control-point rows per sample -- is replaced by the small combine launch of the on-chip MPPI command
+        updated = False
+        if not self.fuse_interpolation:
+            rc = N.E_UNSUPPORTED
+        elif self.onchip_update:
+            rc = lib.mppi_command_kmppi(C.byref(p), C.byref(pt), pt._apply, st)
+            updated = rc == 0
+        else:
+            rc = lib.mppi_rollout_cost_kmppi(C.byref(p), st)      # (A/B seam: K1 here, the stand-alone K3 / K4 below)
+        if rc == N.E_UNSUPPORTED:
+            self._raw_actions(p)
+            N.check(lib.mppi_rollout_cost(C.byref(p), st), "mppi_rollout_cost")
+        else:
+            N.check(rc, "mppi_command_kmppi")
+        if updated:
+            self._launched(pt, 0, int(lib.mppi_last_next_draw()))
+        else:
+            pt._deferred = False
+            self._theta_update(pt, st)
+
+    def _launched(self, pt, form, next_draw):
+        pt._deferred = False
+        self._settle_next(next_draw)
 
     def _end(self, pt):
         p = pt._traj

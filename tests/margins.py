@@ -6,12 +6,21 @@ import json
 import os
 
 _LEDGER = []
+TAG = None       # tools/margin_distributions.py: (seed, kernel) of the run an entry belongs to
+
+
+def seed_offset():
+    """MPPI_MARGIN_SEED (default 0): added to the seeds of the full-size parity scenarios (initial state, nominal sequence,
+    generator key) so that tools/margin_distributions.py can re-run them on other draws -- VERDICT r05 next #2: a margin
+    measured on one seed is a sample of one"""
+    return int(os.environ.get("MPPI_MARGIN_SEED", "0"))
 
 
 def record(test, quantity, err_over_scale, floor_over_scale=None, rtol=None, note=None, scale=None):
     _LEDGER.append({"test": test, "quantity": quantity, "err_over_scale": float(err_over_scale),
                     "floor_over_scale": None if floor_over_scale is None else float(floor_over_scale),
-                    "rtol": rtol, "note": note, "scale": None if scale is None else float(scale)})
+                    "rtol": rtol, "note": note, "scale": None if scale is None else float(scale),
+                    **({"tag": TAG} if TAG is not None else {})})
 
 
 BUDGET = 1.5      # of the reference's own fp32-vs-fp64 error, for entries above rtol (tests/test_zz_margin_budget.py)

@@ -126,6 +126,51 @@ def test_bad_calls_refused_on_host():
         N.check(-1, "x")
 
 
+def test_a_short_model_blob_is_refused_not_read_past():
+    """ABI 22: the MLP blob grew by qx | qu in ABI 21; a caller still passing the older, shorter layout used to get
+    garbage cost weights.  `model_params_elems` is checked before anything is launched (fake non-null addresses: nothing here is
+    dereferenced on the host)."""
+    lib = N.lib()
+    import numpy as np
+    keep = np.zeros(1 << 16, dtype=np.float32)
+    addr = keep.ctypes.data
+    p = N.MppiProblem()
+    p.K, p.T, p.nx, p.nu, p.dtype, p.hidden, p.model_id, p.lambda_ = 256, 8, 16, 4, N.F32, 64, N.MODEL_MLP, 1.0
+    for f in ("U", "u_init", "noise_mu", "noise_L", "sigma_inv", "u_min", "u_max", "model_params", "workspace"):
+        setattr(p, f, addr)
+    p.workspace_elems = keep.size
+    need = 64 * 20 + 64 + 16 * 64 + 2 * 16 + 1 + 4
+    p.model_params_elems = need - 20                               # the ABI-20 blob: no qx | qu behind the residual scale
+    assert lib.mppi_prepare(C.byref(p), None) == -1
+    msg = lib.mppi_last_error().decode()
+    assert "model_params holds" in msg and str(need) in msg, msg
+    p.model_params_elems = 0                                       # unstated counts as too short, too
+    assert lib.mppi_prepare(C.byref(p), None) == -1 and b"model_params holds" in lib.mppi_last_error()
+    p.model_params_elems = need
+    rc = lib.mppi_prepare(C.byref(p), None)                        # past that check: refused for the missing noise stream instead
+    assert rc == -1 and b"model_params holds" not in lib.mppi_last_error()
+
+
+def test_device_group_entry_points_refuse_bad_calls_on_the_host():
+    """csrc/group.hip (ABI 22): argument checks need no GPU; creating a group without one fails cleanly (the workers cannot make
+    their device current) instead of hanging"""
+    lib = N.lib()
+    grp = C.c_void_p()
+    devs = (C.c_int32 * 2)(0, 0)
+    assert lib.mppi_group_create(0, devs, None, C.byref(grp)) == -1
+    assert lib.mppi_group_create(2, None, None, C.byref(grp)) == -1
+    comms = (C.c_void_p * 2)(1, 1)
+    assert lib.mppi_group_create(2, devs, comms, C.byref(grp)) == N.E_UNSUPPORTED      # RCCL: one rank per device
+    assert b"listed twice" in lib.mppi_last_error()
+    assert lib.mppi_group_wait(None, None, None) == -1 and lib.mppi_group_abort(None) == -1
+    assert lib.mppi_group_submit(None, 0, None, None, None, None) == -1
+    assert lib.mppi_group_destroy(None) == 0 and lib.mppi_group_size(None) == 0
+    import torch
+    if not torch.cuda.is_available():
+        rc = lib.mppi_group_create(2, devs, None, C.byref(grp))
+        assert rc != 0 and not grp.value, "no GPU: the workers cannot initialise, the group must not exist"
+
+
 def test_plain_c_client_links_and_agrees_on_the_struct(tmp_path):
     """The boundary is a C ABI: the header compiles as strict C99 (no C++, no torch types), a C program links
     against the shared library, sees the same ABI version and sizeof(MppiProblem), and a compute entry point

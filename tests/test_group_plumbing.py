@@ -1,6 +1,6 @@
 """CPU: the attribute / method plumbing of a device group (pytorch_mppi_amd/group.py) on stand-in shards -- reads go to shard 0,
 per-sample results are concatenated in global sample order, writes reach every shard, methods run on all of them and the replicated
-sequences are re-copied from shard 0, `command` stitches begin / exchange / end.  (The real thing -- shard controllers on the GPU --
+sequences are re-copied from shard 0, `command` stitches prepare / issue + exchange / end; nn.Module callables are copied per device and follow the original.  (The real thing -- shard controllers on the GPU --
 is tests/test_gpu_devices.py.)"""
 import pytest
 import torch
@@ -23,6 +23,7 @@ class FakeShard:
         self.info = None
         self._jit_pending = None
         self._model = None
+        self.rng, self.last_draw, self._injected, self.M, self.specific_action_sampler = "torch", None, [], 1, None
 
     def reset(self):
         self.calls.append("reset")
@@ -33,10 +34,12 @@ class FakeShard:
         self.calls.append(("scale", t.device, gain))
         return float(t.sum()) * gain
 
-    def _begin(self, state, shift):
+    def _prepare(self, state, shift):
+        # (a shard on the callback path: everything local to it has been issued when _prepare returns -- MPPI._prepare)
         self.calls.append(("begin", tuple(torch.as_tensor(state).shape), shift))
         p = type("P", (), {})()
         p._keep = {"record": torch.tensor([float(self.k_offset), 1.0, 2.0])}
+        p._deferred = False
         return p
 
     def _combine(self, p, records):
@@ -56,6 +59,10 @@ def _group(G=3, K=12):
     object.__setattr__(g, "_comms", None)
     object.__setattr__(g, "_staged", True)
     object.__setattr__(g, "exchange", "staged")
+    object.__setattr__(g, "_engine", None)
+    object.__setattr__(g, "_replicas", group._Replicas())
+    object.__setattr__(g, "_state_bufs", None)
+    object.__setattr__(g, "_rec_bufs", {})
     return g
 
 
@@ -98,3 +105,37 @@ def test_command_is_begin_on_every_shard_one_exchange_end_on_every_shard():
         assert s.calls[0] == ("begin", (3,), False) and s.calls[1] == ("combine", (2, 3))
     # the records of BOTH shards, in shard order, reached every shard: {k_offset, 1, 2} summed = {0 + 4, 2, ...}
     assert a.tolist() == [4.0, 2.0] and torch.equal(g.shards[0].U, g.shards[1].U)
+
+
+def test_module_callables_travel_with_the_shard_and_follow_the_original():
+    """pendulum_approximate.py:47-67's pattern: the dynamics is a network (here: the module itself, and a bound method of one)"""
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(3, 2)
+
+        def forward(self, x, u):
+            return self.lin(torch.cat((x, u), dim=1))
+
+        def cost(self, x, u):
+            return (x * self.lin.bias).sum(dim=1)
+    net = Net()
+    r = group._Replicas()
+    d = torch.device("cpu")                                  # (what matters here is the copy / sync bookkeeping, not the device)
+    f, c = r.on(net, d), r.on(net.cost, d)
+    assert isinstance(f, Net) and f is not net and c.__self__ is f          # ONE copy serves both callables
+    assert r.on(net, d) is f and r.on(len, d) is len                         # cached; non-modules pass through
+    x, u = torch.ones(4, 2), torch.ones(4, 1)
+    assert torch.equal(f(x, u), net(x, u))
+    with torch.no_grad():
+        net.lin.weight.mul_(2.0)                              # "retraining" between two commands (mppi.py:890-893)
+    assert not torch.equal(f(x, u), net(x, u))
+    r.sync()
+    assert torch.equal(f(x, u), net(x, u)) and torch.equal(c(x, u), net.cost(x, u))
+
+
+def test_a_process_local_plan_never_touches_torch_distributed():
+    from pytorch_mppi_amd.dist import LOCAL, ShardPlan
+    sp = ShardPlan(10, 1, 3, LOCAL)
+    assert sp.local and sp.group is None and (sp.k_offset, sp.K_local) == (4, 3) and sp.native_comm("cuda") is None
+    assert not ShardPlan(10, 1, 3).local

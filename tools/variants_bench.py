@@ -1,7 +1,7 @@
 """Per-command time of every controller of the family on C3-sized work (one MI355X):
 MPPI / KMPPI / SMPPI with K=65536, T=64, nx=16, nu=12 and MPPI_Batched with N envs x K/N samples,
 fused path (Integrator native model), rng = torch-native unless given.
-    python tools/variants_bench.py [rng] [name-substring]"""
+    python tools/variants_bench.py [rng] [name-substring | =exact-name]        (VARIANTS_N: commands per entry, default 50)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -19,8 +19,12 @@ x0 = torch.randn(nx, device=dev)
 only = sys.argv[2] if len(sys.argv) > 2 else ""
 
 
-def timeit(name, ctrl, state, n=50):
-    if only not in name:
+N_CMDS = int(os.environ.get("VARIANTS_N", "50"))
+
+
+def timeit(name, ctrl, state, n=None):
+    n = n or N_CMDS
+    if (only[1:] != name) if only.startswith("=") else (only not in name):      # "=MPPI": that entry alone
         return
     for _ in range(5):
         ctrl.command(state)
