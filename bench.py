@@ -29,9 +29,11 @@ reported as `avg_launch_us_hip_events`.
 `latency_ms_synced` is the reference's own protocol (tests/benchmark_mppi.py:84-113: reset, sync, one
 command, sync; 3 warm-ups, 20 iterations, 10 % trimmed mean) beside the pipelined `ms_per_step`.
 N > 1: under torch.distributed.run (what the driver does) every rank is one process on one GPU, `shard=(rank, N)`, RCCL.
-`python bench.py --gpus N` outside a launcher runs ONE process on N devices -- `MPPI(..., devices=[0..N-1])`, SURVEY 8b / 8e's
-process model -- and says so in `config.process_model`; `--process-model spawn` starts N ranks itself instead
-(torch.distributed.run on 127.0.0.1).  On a box with fewer than N GPUs the shards / ranks share the devices and the record
+`python bench.py --gpus N` outside a launcher picks the process model that scales on this box (`--process-model auto`,
+choose_process_model): ONE process on N devices -- `MPPI(..., devices=[0..N-1])`, SURVEY 8b / 8e's process model, each device's
+launches issued by a worker thread of the engine -- when the measured host-only issue time of a sharded command fits under the
+single-GPU command and the group validates, else N self-started ranks (torch.distributed.run on 127.0.0.1); the line says which
+ran and why (`config.process_model`, `config.process_model_choice`, `host_issue_us_per_device`).  On a box with fewer than N GPUs the shards / ranks share the devices and the record
 exchange is staged (device copies / gloo): a test rig for the code path, labelled as such.
 `cpu_baseline` times the oracle (CPU restatement of the reference path, kind "port") on the same
 workload at the full K on the host cores (at most 3 timed calls); the live reference itself, timed
@@ -244,45 +246,63 @@ def k1_hbm_cold(ctrl, n=32):
             "buffers": nbuf, "bytes_cycled": 4 * n_el * nbuf}
 
 
-def _pmc_lookup(key, kernel):
+LOOKUPS_USED = {}      # lookup name -> stale? (the committed counter passes this line quotes)
+
+
+def _lookup_stale(entry, kernel, name):
+    """Is a committed counter-pass entry still evidence for the kernel this run timed?  Every entry of profiles/pmc_*.json records
+    the sha256 of the kernel's translation unit (source, included headers, flags: pytorch_mppi_amd/_build.kernel_sources_hash) as it
+    was when the counters were collected; a different hash now -- or none on record -- means the numbers describe another build."""
+    from pytorch_mppi_amd import _build
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[key][kernel]["traffic_bytes"]
+        stale = entry.get("sources_sha256") != _build.kernel_sources_hash(kernel)
     except Exception:
-        return None
+        stale = True
+    LOOKUPS_USED[name] = bool(stale)
+    return bool(stale)
+
+
+def _pmc_lookup(key, kernel):
+    """(HBM bytes per launch, stale?) from the committed FETCH_SIZE / WRITE_SIZE passes"""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[key][kernel]
+        return e["traffic_bytes"], _lookup_stale(e, kernel, f"pmc_traffic.json:{key}/{kernel}")
+    except Exception:
+        return None, None
 
 
 def _c4_lookup():
     """Matrix-pipe busy share and VALU issue share of the C4 kernel from the committed counter pass / ISA budget (lookups)."""
     try:
         c = json.load(open(os.path.join(ROOT, "profiles", "pmc_c4_mfma.json")))
-        return {"mfma_busy": c["mfma_busy"], "valu_issue_frac": c["valu_issue_frac"], "c4_lookup_source": c["source"]}
+        return {"mfma_busy": c["mfma_busy"], "valu_issue_frac": c["valu_issue_frac"], "c4_lookup_source": c["source"],
+                "c4_lookup_stale": _lookup_stale(c, "rollout_mlp_split_kernel", "pmc_c4_mfma.json")}
     except Exception:
         return {"mfma_busy": None, "valu_issue_frac": None}
 
 
-def _onchip_valu_roofline(workload, k1_us):
-    """The headline kernel's own roofline: it is bound by VALU issue -- the generator -- and moves 187 MB
-    (the rows that wait in memory for their sample's weight: a third of what HBM could move in its time).
-    From the committed SQ counter passes of this command (profiles/pmc_onchip_valu.json; a lookup, like `traffic`): VALU
-    instructions per wave, the share of the wave's cycles in which the VALU is executing one (`frac`: what the kernel achieves
-    of the one thing that bounds it -- a wave alone on its SIMD cannot issue while it waits for its own previous result,
-    LDS or the scalar unit), and the time the same instruction stream would take with the VALU never idle."""
+def _onchip_valu_lookup(workload, k1_us):
+    """What bounds the headline kernel: VALU issue -- the generator.  From the committed SQ counter passes of
+    this command (profiles/pmc_onchip_valu.json; a LOOKUP, flagged `stale` when the kernel's sources have changed since): VALU
+    instructions per wave, the share of the wave's cycles in which the VALU is executing one (a wave alone on its SIMD cannot issue
+    while it waits for its own previous result, LDS or the scalar unit), and the time the same instruction stream would take with
+    the VALU never idle."""
     try:
         c = json.load(open(os.path.join(ROOT, "profiles", "pmc_onchip_valu.json")))[f"{workload}/philox-onchip"]["rollout_onchip_kernel"]
     except Exception:
         return None
     w = c["waves"]
     frac = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
-    return {"bound": "valu", "valu_insts_per_wave": c["SQ_INSTS_VALU"] / w,
+    return {"stale": _lookup_stale(c, "rollout_onchip_kernel", "pmc_onchip_valu.json"),
+            "valu_active_share_of_wave_cycles": frac, "valu_insts_per_wave": c["SQ_INSTS_VALU"] / w,
             "valu_active_cycles_per_wave": 4.0 * c["SQ_ACTIVE_INST_VALU"] / w, "wave_cycles": 4.0 * c["SQ_WAVE_CYCLES"] / w,
-            "frac": frac, "achieved": frac, "peak": 1.0, "unit": "VALU-active share of wave cycles",
             "issue_floor_us": frac * k1_us if k1_us else None,
             "cycles_per_valu_inst": 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"],
             "waiting_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stall_share": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
             "traffic_bytes": (2 * c["FETCH_SIZE_KiB"] + c["WRITE_SIZE_KiB"]) * 1024,
-            "hbm_share_of_8TBs": (2 * c["FETCH_SIZE_KiB"] + c["WRITE_SIZE_KiB"]) * 1024 / (k1_us * 1e-6) / 8e12 if k1_us else None,
             "source": "profiles/pmc_onchip_valu.json (rocprofv3 --pmc passes: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES, SQ_WAIT_*; "
-                      "FETCH_SIZE doubled per the gfx950 note) -- a lookup; `issue_floor_us` = frac x this run's measured launch time"}
+                      "FETCH_SIZE doubled per the gfx950 note) -- a lookup, not measured in this run; `issue_floor_us` = the share x this "
+                      "run's measured launch time"}
 
 
 def latency_synced(ctrl, x0, warmup=3, iters=20):
@@ -329,11 +349,98 @@ def _self_spawn(n, argv):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
-def main_devices(args):
+def host_issue_probe(pm, wl, devs, commands=400):
+    """What the host needs to get ONE sharded command out (VERDICT r05 next #1a): a device group over `devs` on the workload's model
+    and horizon but K = 256 per shard -- the GPU's share of such a command is a few microseconds, what is left is the host: the
+    N problem blocks, the hand-over to the engine's worker threads, one device's launches.  Microseconds per command."""
+    _, kind, nx, nu, _, T = WORKLOADS[wl]
+    dev0 = torch.device("cuda", devs[0])
+    ctrl, x0, _ = make_controller(pm, wl, dev0, "philox", None, 256 * len(devs), devices=devs)
+    for _ in range(50):
+        ctrl.command(x0)
+    for d in sorted(set(devs)):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for _ in range(commands):
+        ctrl.command(x0)
+    issue = (time.perf_counter() - t0) / commands
+    for d in sorted(set(devs)):
+        torch.cuda.synchronize(d)
+    return issue * 1e6, ctrl.issue
+
+
+def validate_devices(args):
+    """`bench.py --validate-devices N` (run by `--process-model auto` in a subprocess with a timeout, so that a hang of a path that
+    has never met this hardware cannot take the bench with it): a device group over N REAL devices commands five times; every
+    device must hold bit-identical U, finite, and equal to the unsharded controller's to 2e-5.  Prints one JSON line."""
+    import pytorch_mppi_amd as pm
+    n = args.validate_devices
+    devs = list(range(n))
+    dev0 = torch.device("cuda", 0)
+    torch.cuda.set_device(dev0)
+    _, kind, nx, nu, Kper, T = WORKLOADS[args.workload]
+    grp, x0, _ = make_controller(pm, args.workload, dev0, "philox", None, 4096 * n, devices=devs)
+    one, _, _ = make_controller(pm, args.workload, dev0, "philox", None, 4096 * n)
+    grp.lambda_ = one.lambda_ = 5.0
+    ok, why = True, ""
+    for i in range(5):
+        a, b = grp.command(x0), one.command(x0)
+        U0 = grp.shards[0].U.cpu()
+        if not all(torch.equal(U0, s_.U.cpu()) for s_ in grp.shards[1:]):
+            ok, why = False, f"command {i}: the devices hold different U"
+        if not bool(torch.isfinite(a).all()) or float((a - b).abs().max()) > 2e-5 * max(1.0, float(b.abs().max())):
+            ok, why = False, f"command {i}: the group's action differs from the unsharded controller's"
+    print(json.dumps({"validate_devices": n, "ok": ok, "why": why, "exchange": grp.exchange, "issue": grp.issue}), flush=True)
+
+
+def choose_process_model(args):
+    """`--process-model auto`, `--gpus N` outside a launcher: the model that SCALES on this box for this workload.  One process on N
+    devices (`MPPI(..., devices=[...])`) keeps the caller's loop a single process, but its host share per command must fit under
+    the GPU's: chosen when (a) the measured host-only issue time of one sharded command is below 0.8 x the single-GPU time of one
+    command of the workload, and (b) -- on N real devices -- a short validation run of the group passes (subprocess, timeout).
+    Otherwise N self-started ranks (one process per GPU).  Returns (model, evidence dict)."""
+    import subprocess
+    import pytorch_mppi_amd as pm
+    n = args.gpus
+    have = torch.cuda.device_count()
+    devs = list(range(n)) if have >= n else [i % max(1, have) for i in range(n)]
+    ev = {"rule": "devices iff host_issue_us < 0.8 * single_gpu_us_per_step (and, on N real devices, the group validates); else spawn"}
+    dev0 = torch.device("cuda", devs[0])
+    torch.cuda.set_device(dev0)
+    desc, kind, nx, nu, Kper, T = WORKLOADS[args.workload]
+    one, x1, _ = make_controller(pm, args.workload, dev0, args.rng, None, Kper)
+    for _ in range(20):
+        one.command(x1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        one.command(x1)
+    torch.cuda.synchronize()
+    ev["single_gpu_us_per_step"] = (time.perf_counter() - t0) / 100 * 1e6
+    del one
+    try:
+        if have >= n:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--validate-devices", str(n), "--workload", args.workload],
+                               capture_output=True, text=True, timeout=240)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            ev["validation"] = json.loads(line[-1]) if line else {"ok": False, "why": (r.stderr or r.stdout)[-300:]}
+            if not ev["validation"].get("ok"):
+                return "spawn", ev
+        else:
+            ev["validation"] = f"skipped: {n} shards share {have} GPU(s) (a rig for the code path)"
+        us, how = host_issue_probe(pm, args.workload, devs)
+        ev["host_issue_us"], ev["host_issue_us_per_device"], ev["issued_by"] = us, us / n, how
+    except Exception as e:                           # (subprocess timeout, a failing group: the per-process model needs neither)
+        ev["error"] = f"{type(e).__name__}: {e}"[:300]
+        return "spawn", ev
+    return ("devices" if ev["host_issue_us"] < 0.8 * ev["single_gpu_us_per_step"] else "spawn"), ev
+
+
+def main_devices(args, choice=None):
     """`python bench.py --gpus N` outside any launcher: ONE Python process commanding on N devices through
-    `MPPI(..., devices=[0..N-1])` (pytorch_mppi_amd/group.py; SURVEY.md 8b / 8e: ncclCommInitAll communicators, the record
-    all-gathers of a command in one RCCL group).  On a box with fewer than N GPUs the shards share the devices and the records are
-    staged through device copies (a rig for the code path, labelled in config.process_model).  K is per GPU (weak scaling)."""
+    `MPPI(..., devices=[0..N-1])` (pytorch_mppi_amd/group.py; SURVEY.md 8b / 8e: ncclCommInitAll communicators, one worker thread per
+    device inside the engine).  On a box with fewer than N GPUs the shards share the devices and the records are
+    staged (a rig for the code path, labelled in config.process_model).  K is per GPU (weak scaling)."""
     import pytorch_mppi_amd as pm
     n = args.gpus
     have = torch.cuda.device_count()
@@ -361,6 +468,7 @@ def main_devices(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctrl.command(x0)
+    t_issue = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
     identical = bool(all(torch.equal(ctrl.shards[0].U.cpu(), s_.U.cpu()) for s_ in ctrl.shards[1:]))
@@ -375,6 +483,9 @@ def main_devices(args):
         one.command(x1)
     torch.cuda.synchronize()
     d1 = time.perf_counter() - t1
+    if choice is None:
+        us, how = host_issue_probe(pm, args.workload, devs)
+        choice = {"host_issue_us": us, "host_issue_us_per_device": us / n, "issued_by": how, "rule": "--process-model devices (forced)"}
     out = {
         "metric": "rollouts/sec (K x T state evals) per .command() call",
         "value": Kglobal * args.steps / dt, "unit": "rollouts/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -383,16 +494,18 @@ def main_devices(args):
         "config": {"workload": desc, "K_per_gpu": Kper, "K_global": Kglobal, "T": T, "nx": nx, "nu": nu, "rng": args.rng,
                    "draw": ctrl.last_draw or "torch.randn", "lambda": float(ctrl.lambda_), "sharding": f"samples/{n}",
                    "devices": devs, "devices_hold_identical_U": identical,
-                   "process_model": "ONE process, MPPI(..., devices=[...]) (pytorch_mppi_amd/group.py): " + ctrl.exchange
-                                    + ("" if have >= n else f" -- {n} shards share {have} GPU(s): exercises the code path, not a measurement")},
+                   "process_model": "ONE process, MPPI(..., devices=[...]) (pytorch_mppi_amd/group.py): " + ctrl.exchange + "; launches issued by "
+                                    + ctrl.issue + ("" if have >= n else f" -- {n} shards share {have} GPU(s): exercises the code path, not a measurement"),
+                   "process_model_choice": choice},
         "state_evals_per_s": Kglobal * T * args.steps / dt,
+        "host_issue_us_per_command_in_the_timed_region": t_issue / args.steps * 1e6,
+        "host_issue_us_per_device": choice.get("host_issue_us_per_device"),
         "roofline": None,
         "weak_scaling": {"single_gpu_ms_per_step": d1 / args.steps * 1e3, "single_gpu_rollouts_per_s": Kper * args.steps / d1,
                          "weak_scaling_speedup": n * d1 / dt, "weak_scaling_efficiency": d1 / dt,
-                         "note": "against the same workload unsharded at K_per_gpu on device 0, timed in this run with the same loop; the "
-                                 "shards' launches are issued by one Python thread, so commands shorter than N x ~40 us are host-bound "
-                                 "in this process model (the per-process model -- this script under torch.distributed.run, or "
-                                 "--process-model spawn -- is not)"},
+                         "note": "against the same workload unsharded at K_per_gpu on device 0, timed in this run with the same loop.  Each "
+                                 "device's launches are issued by a worker thread of the engine (csrc/group.hip): the calling thread's share "
+                                 "is the N problem blocks (`host_issue_us_per_device` x N, measured on a K = 256 problem)"},
     }
     print(json.dumps(out), flush=True)
 
@@ -433,18 +546,30 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--hbm-cold", action="store_true", help="with --no-extras: still run the HBM-cold K1 pass (for a rocprofv3 trace of those launches)")
     ap.add_argument("--process-model", default="auto", choices=["auto", "devices", "spawn"],
-                    help="--gpus N outside torch.distributed.run: 'devices' (auto) = ONE process, MPPI(..., devices=[0..N-1]); 'spawn' = start "
-                         "N ranks (one process per GPU, shard=(rank, N)) like the driver's launcher does")
+                    help="--gpus N outside torch.distributed.run: 'devices' = ONE process, MPPI(..., devices=[0..N-1]); 'spawn' = start N ranks "
+                         "(one process per GPU, shard=(rank, N)) like the driver's launcher does; 'auto' = whichever scales here: devices "
+                         "when the measured host-only issue time of a sharded command fits under the single-GPU command (and the group "
+                         "validates on N real devices), else spawn (choose_process_model)")
+    ap.add_argument("--validate-devices", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.validate_devices:
+        return validate_devices(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-            if args.process_model == "spawn" or os.environ.get("MPPI_BENCH_SPAWN_ONLY") == "1":
+            if os.environ.get("MPPI_BENCH_SPAWN_ONLY") == "1":
                 _self_spawn(args.gpus, sys.argv[1:])           # does not return
-            return main_devices(args)
+            model, choice = args.process_model, None
+            if model == "auto":
+                model, choice = choose_process_model(args)
+                choice["chosen"] = model
+                os.environ["MPPI_BENCH_CHOICE_JSON"] = json.dumps(choice)
+            if model == "spawn":
+                _self_spawn(args.gpus, sys.argv[1:])           # does not return
+            return main_devices(args, choice)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if os.environ.get("MPPI_BENCH_SPAWN_ONLY") == "1":
         # plumbing check without a GPU (tests/test_dist_gloo.py): the self-started ranks rendezvous on gloo, agree on
@@ -609,6 +734,7 @@ def main():
         oc_us = (oc_dev["avg"] + DISPATCH_OFFSET_US_ONCHIP) if oc_dev else 0.0
         ext_bytes = 4 * ctrl.K_local * T * nu + 4 * ctrl.K_local
         spill_bytes = 4 * ctrl._spill[1].numel() if getattr(ctrl, "_spill", None) and ctrl._spill[1] is not None else 0
+        oc_traffic = _pmc_lookup(f"{args.workload}/philox-onchip", "rollout_onchip_kernel") if world == 1 else (None, None)
         onchip = {"kernel": "rollout_onchip_kernel (csrc/rollout_onchip.hpp) + finalize_blocks_kernel",
                   "no_hbm_mode": spill_bytes == 0,
                   "spill_array_bytes": spill_bytes,
@@ -616,20 +742,19 @@ def main():
                   "launch_us_device_span": oc_dev, "avg_launch_us_hip_events": oc_ev["avg"] if oc_ev else None,
                   "dispatch_offset_us": DISPATCH_OFFSET_US_ONCHIP,
                   "hbm_bytes_algorithmic": 4 * ctrl.K_local + 4 * (ctrl.K_local // 256 + 1) * (T * nu + 2) + 2 * spill_bytes,
-                  "traffic": _pmc_lookup(f"{args.workload}/philox-onchip", "rollout_onchip_kernel") if world == 1 else None,
-                  "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                                    "profiles/r04_spill_pmc_c3_fetch.txt / _write.txt; a lookup, not measured in this run)",
+                  "traffic": oc_traffic[0], "traffic_stale": oc_traffic[1],
+                  "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; a lookup, "
+                                    "not measured in this run -- `traffic_stale`: the kernel's sources changed since)",
                   "external_z_equivalent_GBs": ext_bytes / (oc_us * 1e-6) / 1e9 if oc_us else None,
                   "bound": "VALU: Philox4x32-10 + Box-Muller of the sample's T*nu normals, generated ONCE; the bounded noise waits for "
                            "its sample's weight in accumulation registers / LDS (105 of 192 rows at C3) and, since ABI 20, in the "
                            "spill array (87 rows: stored once, fetched once, 2 x 94 MB against the streaming command's 604 MB) "
                            "instead of being generated a second time (tools/micro/onchip_parts.hip, profiles/r04_onchip_spill.txt)",
-                  "roofline": _onchip_valu_roofline(args.workload, oc_us) if world == 1 else None,
+                  "valu_lookup": _onchip_valu_lookup(args.workload, oc_us) if world == 1 else None,
                   "streaming_form_ms_per_step": dts / args.steps * 1e3,
                   "speedup_vs_streaming_form": (dts / args.steps) / (dt / args.steps),
-                  "note": "SURVEY.md 8d: with the engine's generator inside K1 the kernel is RNG-bound (its own `roofline`: VALU-active "
-                          "share of the wave cycles) -- no bandwidth fraction is claimed for it; the top-level `roofline` is the "
-                          "HBM-bound K1 of the streaming form of the SAME command, measured in this run"}
+                  "note": "SURVEY.md 8d: with the engine's generator inside K1 the kernel is RNG / VALU-bound and reads no (K,T,nu) array: "
+                          "the top-level `roofline` prices its LIVE launch time against the algorithmic bytes of the work it replaces"}
 
     # ---- roofline of K1 ----
     dev_st = _stats(k1_dev_us)
@@ -688,15 +813,10 @@ def main():
             # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: separate
             # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 note); null if not collected
             # for this exact workload/mode
-            traffic = None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                if world == 1:
-                    traffic = pmc[f"{args.workload}/{args.rng}"]["rollout_cost_kernel"]["traffic_bytes"]
-            except Exception:
-                traffic = None
+            traffic, traffic_stale = _pmc_lookup(f"{args.workload}/{'philox-stream' if args.rng.startswith('philox') else args.rng}",
+                                                 "rollout_cost_kernel") if world == 1 else (None, None)
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
                         "kernel": "rollout_cost_kernel", "avg_launch_us": k1_us,
                         "avg_launch_us_device_span": k1_us_span, "launch_us_device_span": dev_st,
                         "frac_device_span": alg_bytes / (k1_us_span * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -749,21 +869,28 @@ def main():
         b1 = 4 * ctrl.K_local * T * nu + 4 * ctrl.K_local
         b_cmd = b1 + 4 * ctrl.K_local * T * nu + 4 * ctrl.K_local + 8 * T * nu
         oc_us = onchip["avg_launch_us"]
-        valu = onchip.pop("roofline")
-        head = {"bound": "valu", "kernel": "rollout_onchip_kernel", "unit": "VALU-active share of wave cycles",
-                "achieved": valu["frac"] if valu else None, "peak": 1.0, "frac": valu["frac"] if valu else None,
+        valu = onchip.pop("valu_lookup")
+        ach = b_cmd / (oc_us * 1e-6) / 1e9 if oc_us else None
+        # `frac` is recomputable from this object alone -- bytes / (avg_launch_us * 1e-6) / 1e9 / peak, every term
+        # measured in this run (the launch time) or a formula of the workload (the bytes) -- nothing looked up.  The bytes are SURVEY
+        # 8d's B_cmd = B1 + B3, the algorithmic HBM bytes of the rollout + update this ONE launch performs (K1 reads the K*T*nu
+        # normals and writes K costs; K3 reads them again with the costs and writes the (T,nu) update): the kernel itself keeps the
+        # normals on chip and is VALU-bound, so this is an HBM-EQUIVALENT rate (how fast the replaced streaming work would have to
+        # move its bytes to keep up), not traffic; `frac_k1_bytes` prices the same launch against K1's bytes alone.
+        head = {"bound": "hbm", "kernel": "rollout_onchip_kernel", "unit": "GB/s",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS if ach else None,
+                "bytes": b_cmd, "bytes_kind": "algorithmic bytes of the work one launch does: B_cmd = B1 + B3 (SURVEY.md 8d) = "
+                                              "2 * (4*K*T*nu + 4*K) + 8*T*nu -- HBM-equivalent, the kernel itself streams no (K,T,nu) array",
                 "avg_launch_us": oc_us, "avg_launch_us_device_span": onchip["avg_launch_us_device_span"],
                 "avg_launch_us_hip_events": onchip["avg_launch_us_hip_events"], "dispatch_offset_us": DISPATCH_OFFSET_US_ONCHIP,
-                "traffic": onchip["traffic"], "traffic_source": onchip["traffic_source"],
-                "algorithmic_hbm_bytes": onchip["hbm_bytes_algorithmic"],
-                "hbm_equiv_bytes_k1": b1, "hbm_equiv_frac_k1": b1 / (oc_us * 1e-6) / 1e9 / HBM_PEAK_GBS if oc_us else None,
-                "hbm_equiv_bytes_cmd": b_cmd, "hbm_equiv_frac_cmd": b_cmd / (oc_us * 1e-6) / 1e9 / HBM_PEAK_GBS if oc_us else None,
-                "valu": valu,
-                "note": "kernel of the timed headline region.  frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of this kernel (profiles/"
-                        "pmc_onchip_valu.json, separate rocprofv3 --pmc passes of this command line; a lookup).  hbm_equiv_frac_k1 = "
-                        "(4*K*T*nu + 4*K) / avg_launch_us / 8 TB/s; hbm_equiv_frac_cmd = B_cmd (SURVEY 8d: B1 + B3, what K1 + K3 of the "
-                        "streaming form move) / avg_launch_us / 8 TB/s; avg_launch_us is measured live in this run (device-clock stamps "
-                        "+ dispatch offset = the rocprofv3 figure, profiles/r05_*clock_calibration_c3.txt)"}
+                "recompute": "frac = bytes / (avg_launch_us * 1e-6) / 1e9 / peak",
+                "bytes_k1": b1, "frac_k1_bytes": b1 / (oc_us * 1e-6) / 1e9 / HBM_PEAK_GBS if oc_us else None,
+                "traffic": onchip["traffic"], "traffic_stale": onchip["traffic_stale"], "traffic_source": onchip["traffic_source"],
+                "algorithmic_hbm_bytes_of_the_kernel_itself": onchip["hbm_bytes_algorithmic"],
+                "valu_active_lookup": valu,
+                "note": "kernel of the timed headline region; avg_launch_us is measured live in this run (device-clock stamps + dispatch "
+                        "offset = the rocprofv3 figure, profiles/r05_*clock_calibration_c3.txt).  What bounds the kernel is VALU issue: "
+                        "`valu_active_lookup` (committed counter passes, flagged when stale)"}
         if roofline is not None:
             roofline["measured_on"] = ("the streaming form of this command (rng=philox rows in memory: generator launch -> K1 -> K3 -> K4; "
                                        f"{onchip['streaming_form_ms_per_step']:.4f} ms per command here), timed in this run right behind the "
@@ -837,6 +964,10 @@ def main():
                                     f"{backend}: TEST RIG -- {world} ranks share {torch.cuda.device_count()} GPU(s), record "
                                     "exchange staged through the host; exercises the N > 1 code path, not a measurement")
         out["config"]["world_size"] = dist.get_world_size()
+        out["config"]["process_model"] = "one process per GPU (torch.distributed.run ranks, shard=(rank, N)); engine-owned RCCL communicator"
+        if os.environ.get("MPPI_BENCH_CHOICE_JSON"):
+            out["config"]["process_model_choice"] = json.loads(os.environ["MPPI_BENCH_CHOICE_JSON"])
+            out["host_issue_us_per_device"] = out["config"]["process_model_choice"].get("host_issue_us_per_device")
         out["config"]["collective_per_command"] = exchange
 
     if rank == 0 and world == 1:
@@ -960,6 +1091,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:
+        # every committed counter pass this line quoted, and whether the kernel it describes is still the one that was timed
+        out["lookup_stale"] = any(LOOKUPS_USED.values()) if LOOKUPS_USED else False
+        out["lookups"] = dict(LOOKUPS_USED)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

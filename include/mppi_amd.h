@@ -261,6 +261,12 @@ int mppi_kmppi_shift(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void
                      const void* theta, const void* W_shift, void* U_out, void* theta_out, void* stream);
 int mppi_kmppi_trajectory(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void* W, const void* theta,
                           void* U_out, void* stream);
+/* ABI 22: behind a KMPPI update, ONE launch for the trajectory of the new control points and for both sequences as the next
+ * command's shift will want them: U_out = W theta (mppi.py:682); theta_shift_out = W_shift theta (:617-619); U_shift_out =
+ * roll(U_out, -1) with u_init in the last row (:232-238) -- the bits mppi_kmppi_trajectory followed by mppi_kmppi_shift produce.
+ * A loop that shifts on every command (mppi.py:240's default) then launches nothing for the shift. */
+int mppi_kmppi_after_update(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void* W, const void* W_shift, const void* theta,
+                            const void* u_init, void* U_out, void* theta_shift_out, void* U_shift_out, void* stream);
 
 /* Host -> device hand-over of a SMALL buffer (the state of a closed loop: mppi.py:262-264) inside the launch packet of
  * a one-wave kernel: 4..2048 bytes, a multiple of 4, from ordinary (pageable) host memory, which is consumed before

@@ -2,4 +2,5 @@
 from .mppi import MPPI, SMPPI, KMPPI, MPPI_Batched, run_mppi, SpecificActionSampler, TimeKernel, RBFKernel
 from . import models, jit
 
-__all__ = ["MPPI", "SMPPI", "KMPPI", "MPPI_Batched", "run_mppi", "SpecificActionSampler", "TimeKernel", "RBFKernel", "models", "jit"]
+__all__ = ["MPPI", "SMPPI", "KMPPI", "MPPI_Batched", "run_mppi", "SpecificActionSampler", "TimeKernel", "RBFKernel",
+        "models", "jit"]

@@ -17,7 +17,8 @@ SUFFIX = os.environ.get("MPPI_LIB_SUFFIX", "")
 LIB = os.path.join(HERE, f"libmppi_amd{SUFFIX}.so")
 OBJ_DIR = os.path.join(CSRC, "build" + SUFFIX)
 SOURCES = ["capi.hip", "dist.hip", "group.hip", "update.hip", "rollout_pendulum.hip", "rollout_integrator.hip",
-           "rollout_linear_goal.hip", "rollout_mlp.hip", "rollout_mlp_mfma.hip", "rollout_mlp_split.hip", "noise_torch.hip"]
+           "rollout_linear_goal.hip", "rollout_mlp.hip", "rollout_mlp_mfma.hip", "rollout_mlp_split.hip",
+                   "noise_torch.hip"]
 # translation units: (source, object name, extra flags).  The two heaviest sources are compiled as several units each
 # (groups of model dimensions selected with a define) so that the parallel build is not one long compile
 _GROUPS = {"rollout_integrator.hip": ("MPPI_INTEGRATOR_GROUP", 4), "rollout_linear_goal.hip": ("MPPI_LINEAR_GROUP", 3),
@@ -33,9 +34,12 @@ def _units():
         else:
             units.append((src, src.replace(".hip", ".o"), []))
     # longest first (measured seconds per unit on the build container, 8 at a time): the pool starts the big ones first
-    cost = {"update.o": 165, "rollout_linear_goal_g2.o": 126, "rollout_integrator_g2.o": 90, "rollout_integrator_g0.o": 88,
-            "rollout_integrator_g1.o": 83, "rollout_linear_goal_g0.o": 79, "rollout_mlp_g0.o": 78, "rollout_mlp_g1.o": 75,
-            "rollout_mlp_g2.o": 75, "rollout_pendulum.o": 70, "rollout_linear_goal_g1.o": 68, "rollout_integrator_g3.o": 45,
+    cost = {"update.o": 165, "rollout_linear_goal_g2.o": 126, "rollout_integrator_g2.o": 90,
+            "rollout_integrator_g0.o": 88,
+            "rollout_integrator_g1.o": 83, "rollout_linear_goal_g0.o": 79, "rollout_mlp_g0.o": 78,
+                    "rollout_mlp_g1.o": 75,
+            "rollout_mlp_g2.o": 75, "rollout_pendulum.o": 70, "rollout_linear_goal_g1.o": 68,
+                    "rollout_integrator_g3.o": 45,
             "rollout_mlp_split.o": 27}
     return sorted(units, key=lambda u: -cost.get(u[1], 5))
 # -ffp-contract=fast: mul+add pairs fuse into v_fma / v_pk_fma.  torch eager rounds twice where
@@ -57,13 +61,16 @@ EXTRA = {"update.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
          # accumulator tile with the VALU: same flag for every unit that instantiates it (jit.py passes it too)
          "rollout_integrator.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
          "rollout_linear_goal.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-         # the torch.randn stream, bit for bit: rocrand's Box-Muller with the contraction rule the library itself is built
+         # the torch.randn stream, bit for bit: rocrand's Box-Muller with the contraction rule the library itself is
+         # built
          # with (a later -ffp-contract wins; with =fast one value in ~10^5 differs from torch's in its last bit)
          "noise_torch.hip": ["-ffp-contract=on"]}
 K1_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]     # for translation units built around csrc/rollout.hpp (jit.py)
 # heavy user models (jit.py) only: the SLP vectorizer pairs the products of a traced network into v_pk_mul_f32 before fp
-# contraction sees them (570 mul + add pairs instead of fmas in a 3700-operation step); packed fp32 arithmetic is no faster
-# than two scalar instructions on gfx950.  Light models keep the flags of the built-in units (a snippet model that restates a
+# contraction sees them (570 mul + add pairs instead of fmas in a 3700-operation step); packed fp32 arithmetic is no
+# faster
+# than two scalar instructions on gfx950.  Light models keep the flags of the built-in units (a snippet model that
+# restates a
 # built-in one compiles to the same kernel, bit for bit: tests/test_gpu_jit_models.py)
 K1_HEAVY_FLAGS = ["-fno-slp-vectorize"]
 
@@ -89,6 +96,45 @@ def _deps_hash():
     return h.hexdigest()
 
 
+# ---- evidence guard: which sources a measured kernel was built from
+# -----------------------------------
+# bench.py quotes counter passes committed under profiles/ (pmc_*.json).  Each such entry records the hash below of the
+# kernel's
+# translation unit AS IT WAS WHEN THE COUNTERS WERE COLLECTED; bench.py prints `lookup_stale` and
+# tests/test_lookup_evidence.py
+# fails when a committed entry no longer matches the tree.
+KERNEL_UNITS = {"rollout_onchip_kernel": "rollout_integrator.hip", "rollout_cost_kernel": "rollout_integrator.hip",
+                "rollout_kmppi_kernel": "rollout_integrator.hip", "rollout_mlp_split_kernel": "rollout_mlp_split.hip",
+                "rollout_mlp_mfma_kernel": "rollout_mlp_mfma.hip", "weights_partial_rows_kernel": "noise_torch.hip",
+                "weights_partial_diag_kernel": "update.hip", "noise_fill_philox_kernel": "update.hip",
+                        "finalize_blocks_kernel": "update.hip"}
+
+
+def _include_closure(src, seen=None):
+    """`src` (a file of csrc/) and every csrc/ or include/ header it reaches through #include "..." """
+    import re
+    seen = [] if seen is None else seen
+    path = os.path.join(CSRC, src) if os.path.exists(os.path.join(CSRC, src)) else os.path.join(INCLUDE, src)
+    if not os.path.exists(path) or path in seen:
+        return seen
+    seen.append(path)
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), flags=re.M):
+        _include_closure(os.path.basename(inc), seen)
+    return seen
+
+
+def kernel_sources_hash(kernel):
+    """sha256 over the translation unit that instantiates `kernel` (KERNEL_UNITS), every header it includes, and its
+    flags"""
+    unit = KERNEL_UNITS[kernel]
+    h = hashlib.sha256()
+    for path in sorted(_include_closure(unit)):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    h.update(" ".join(FLAGS + EXTRA.get(unit, [])).encode())
+    return h.hexdigest()
+
+
 def is_current():
     stamp = LIB + ".stamp"
     return os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == _deps_hash()
@@ -102,13 +148,31 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = [u for u in _units() if os.path.exists(os.path.join(CSRC, u[0]))]
 
+    # what every unit sees besides its own source: the headers of csrc/ and the C-ABI header
+    hh = hashlib.sha256()
+    for n in sorted(os.listdir(CSRC)):
+        if n.endswith((".hpp", ".h")):
+            hh.update(n.encode())
+            hh.update(open(os.path.join(CSRC, n), "rb").read())
+    hh.update(open(os.path.join(INCLUDE, "mppi_amd.h"), "rb").read())
+    headers = hh.hexdigest()
+
     def one(unit):
         src, objname, defs = unit
         obj = os.path.join(OBJ_DIR, objname)
         cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), *defs, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+        # an object is kept while its source, the headers and its command line are what they were (one edited .hip = one
+        # unit)
+        key = hashlib.sha256((headers + " ".join(cmd[1:])).encode() + open(os.path.join(CSRC, src),
+                "rb").read()).hexdigest()
+        stamp = obj + ".stamp"
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == key:
+            return obj
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        with open(stamp, "w") as f:
+            f.write(key)
         return obj
 
     with cf.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 8, len(srcs))) as ex:

@@ -50,7 +50,8 @@ class MppiProblem(C.Structure):
         ("workspace", _vp), ("workspace_elems", C.c_int64),
         ("onchip_spill", _vp), ("onchip_spill_elems", C.c_int64),
         # ABI 21: the next command's torch-stream draw inside this command's K3 launch
-        ("next_z", _vp), ("next_seed", C.c_uint64), ("next_philox_offset", C.c_uint64), ("next_grid_blocks", C.c_int32), ("next_kind", C.c_int32), ("philox_rounds", C.c_int32),
+        ("next_z", _vp), ("next_seed", C.c_uint64), ("next_philox_offset", C.c_uint64), ("next_grid_blocks",
+                C.c_int32), ("next_kind", C.c_int32), ("philox_rounds", C.c_int32),
         ("model_params_elems", C.c_int32),     # ABI 22
     ]
 
@@ -69,7 +70,8 @@ SYMBOLS = {
     "mppi_model_supported": (C.c_int, [C.c_int32] * 5),
     "mppi_noise_fill_philox": (C.c_int, [_PP, _vp, _vp]),
     "mppi_noise_fill_philox_coloured": (C.c_int, [_PP, _vp, _vp]),
-    "mppi_noise_fill_torch": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _vp]),
+    "mppi_noise_fill_torch": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64,
+            C.c_int32, _vp]),
     "mppi_noise_from_ktn": (C.c_int, [_PP, _vp, _vp, _vp]),
     "mppi_process_noise_export": (C.c_int, [_PP, _vp, _vp]),
     "mppi_kmppi_interp": (C.c_int, [_PP, _vp, _vp]),
@@ -77,6 +79,7 @@ SYMBOLS = {
     "mppi_rollout_cost_kmppi": (C.c_int, [_PP, _vp]),
     "mppi_kmppi_shift": (C.c_int, [C.c_int32] * 4 + [_vp] * 7),
     "mppi_kmppi_trajectory": (C.c_int, [C.c_int32] * 4 + [_vp] * 4),
+    "mppi_kmppi_after_update": (C.c_int, [C.c_int32] * 4 + [_vp] * 8),
     "mppi_upload_small": (C.c_int, [_vp, C.c_int64, _vp, _vp]),
     "mppi_smppi_shift": (C.c_int, [C.c_int32] * 3 + [_vp] * 3 + [C.c_double] + [_vp] * 4),
     "mppi_prepare": (C.c_int, [_PP, _vp]),
@@ -101,7 +104,8 @@ SYMBOLS = {
     "mppi_exchange_combine": (C.c_int, [_PP, _vp, _vp, C.c_int32, _vp]),
     "mppi_command_sharded": (C.c_int, [_PP, _vp, _vp, C.c_int32, _vp]),
     "mppi_dist_init_all": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
-    "mppi_exchange_combine_all": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(_PP), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+    "mppi_exchange_combine_all": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(_PP), C.POINTER(C.c_void_p),
+            C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p)]),
     "mppi_group_create": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mppi_group_destroy": (C.c_int, [_vp]),
@@ -112,8 +116,10 @@ SYMBOLS = {
     "mppi_group_abort": (C.c_int, [_vp]),
     "mppi_profile_enable": (C.c_int, [C.c_int]),
     "mppi_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
-    "mppi_profile_read2": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    "mppi_profile_read_launches": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]),
+    "mppi_profile_read2": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+            C.POINTER(C.c_int64)]),
+    "mppi_profile_read_launches": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64,
+            C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -176,7 +182,8 @@ def profile_read_launches(capacity=8192):
     return [dev[i] for i in range(m)], [disp[i] if disp[i] >= 0 else None for i in range(m)]
 
 
-_PURE = {}      # results of the pure geometry / capability queries (a ctypes call costs ~1 us; these sit on every command's path)
+# results of the pure geometry / capability queries (a ctypes call costs ~1 us; these sit on every command's path)
+_PURE = {}
 
 
 def noise_rows4(T, nu):

@@ -3,7 +3,8 @@
 `kernels(path)` copies the shared object into a temporary directory, extracts the offload bundles (`llvm-objdump
 --offloading` writes them next to its input), reads the AMDGPU metadata note of each gfx950 code object (`llvm-readelf
 --notes`) and returns {demangled kernel name: {vgpr, agpr, sgpr, scratch, vgpr_spill, sgpr_spill, lds}}.  Used by
-tests/test_kernel_resources.py (a kernel that starts spilling is a performance regression no parity test sees: VERDICT r03
+tests/test_kernel_resources.py (a kernel that starts spilling is a performance regression no parity test sees: VERDICT
+r03
 weak #2, the KMPPI-fused K1 went from 20 B to 528 B of scratch and from 70.7 to 94 us unnoticed) and by
 tools/kernel_resources.py.  Needs no GPU."""
 import os
@@ -13,7 +14,8 @@ import subprocess
 import tempfile
 
 _LLVM = "/opt/rocm/lib/llvm/bin"
-_FIELDS = {".vgpr_count": "vgpr", ".agpr_count": "agpr", ".sgpr_count": "sgpr", ".private_segment_fixed_size": "scratch",
+_FIELDS = {".vgpr_count": "vgpr", ".agpr_count": "agpr", ".sgpr_count": "sgpr",
+        ".private_segment_fixed_size": "scratch",
            ".vgpr_spill_count": "vgpr_spill", ".sgpr_spill_count": "sgpr_spill", ".group_segment_fixed_size": "lds"}
 
 
@@ -33,7 +35,8 @@ def kernels(path, demangle=True):
         for f in sorted(os.listdir(d)):
             if "gfx950" not in f:
                 continue
-            notes = subprocess.run([_tool("llvm-readelf"), "--notes", os.path.join(d, f)], capture_output=True, text=True, check=True).stdout
+            notes = subprocess.run([_tool("llvm-readelf"), "--notes", os.path.join(d, f)], capture_output=True,
+                    text=True, check=True).stdout
             cur = None
             for line in notes.splitlines():
                 s = line.strip()
@@ -54,7 +57,8 @@ def kernels(path, demangle=True):
     if demangle and out:
         filt = shutil.which("c++filt") or _tool("llvm-cxxfilt")
         names = list(out)
-        dem = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True, check=True).stdout.splitlines()
+        dem = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True,
+                check=True).stdout.splitlines()
         out = {re.sub(r"\s+", " ", dn): out[n] for n, dn in zip(names, dem)}
     return out
 

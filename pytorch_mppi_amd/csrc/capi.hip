@@ -523,6 +523,19 @@ extern "C" int mppi_kmppi_trajectory(int32_t dtype, int32_t T, int32_t S, int32_
   return fail(MPPI_E_BADARG, "bad dtype");
 }
 
+extern "C" int mppi_kmppi_after_update(int32_t dtype, int32_t T, int32_t S, int32_t nu, const void* W, const void* W_shift, const void* theta,
+                                       const void* u_init, void* U_out, void* theta_shift_out, void* U_shift_out, void* stream) {
+  if (T <= 0 || S <= 0 || nu <= 0 || !W || !W_shift || !theta || !u_init || !U_out || !theta_shift_out || !U_shift_out)
+    return fail(MPPI_E_BADARG, "mppi_kmppi_after_update: bad argument");
+  if (dtype == MPPI_F32)
+    return hipfail(launch_kmppi_after_update<float>(T, S, nu, (const float*)W, (const float*)W_shift, (const float*)theta, (const float*)u_init,
+                                                    (float*)U_out, (float*)theta_shift_out, (float*)U_shift_out, (hipStream_t)stream), "mppi_kmppi_after_update");
+  if (dtype == MPPI_F64)
+    return hipfail(launch_kmppi_after_update<double>(T, S, nu, (const double*)W, (const double*)W_shift, (const double*)theta, (const double*)u_init,
+                                                     (double*)U_out, (double*)theta_shift_out, (double*)U_shift_out, (hipStream_t)stream), "mppi_kmppi_after_update");
+  return fail(MPPI_E_BADARG, "bad dtype");
+}
+
 extern "C" int mppi_rollout_cost(const MppiProblem* p, void* stream) {
   return BY_DTYPE(p, do_rollout<float>(p, (hipStream_t)stream), do_rollout<double>(p, (hipStream_t)stream));
 }

@@ -1057,6 +1057,40 @@ int launch_kmppi_sequences(int R, int S, int nu, const T* M, const T* x, T* out,
   return (int)hipGetLastError();
 }
 
+// Behind a KMPPI update (ABI 22): the trajectory of the new control points AND both sequences as the next command's shift will want
+// them, in one launch -- U = W theta (mppi.py:682); theta_s = W_shift theta (:617-619); U_s = roll(U, -1) with u_init in the last
+// row (:232-238), row t of it computed as row t + 1 of W theta with the very fma chain that makes U (the same bits as a roll of U).
+// A control loop that shifts every command (the default) then launches nothing for the shift.
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) kmppi_after_update_kernel(int Tn, int S, int nu, const T* __restrict__ W, const T* __restrict__ Ws,
+                                                                   const T* __restrict__ theta, const T* __restrict__ u_init,
+                                                                   T* __restrict__ U_out, T* __restrict__ theta_s, T* __restrict__ U_s) {
+  const int g = blockIdx.x * BLOCK + threadIdx.x;
+  if (g < Tn * nu) {
+    const int r = g / nu, n = g - r * nu;
+    T acc = T(0);
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) acc = m_fma(W[r * S + s], theta[s * nu + n], acc);
+    U_out[g] = acc;
+    if (r > 0) U_s[g - nu] = acc;
+    if (r == Tn - 1) U_s[g] = u_init[n];
+  } else if (g - Tn * nu < S * nu) {
+    const int j = g - Tn * nu, r = j / nu, n = j - r * nu;
+    T acc = T(0);
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) acc = m_fma(Ws[r * S + s], theta[s * nu + n], acc);
+    theta_s[j] = acc;
+  }
+}
+template <typename T>
+int launch_kmppi_after_update(int Tn, int S, int nu, const T* W, const T* Ws, const T* theta, const T* u_init, T* U_out, T* theta_s,
+                              T* U_s, hipStream_t st) {
+  const int n = (Tn + S) * nu;
+  hipLaunchKernelGGL(kmppi_after_update_kernel<T>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, Tn, S, nu, W, Ws, theta, u_init,
+                     U_out, theta_s, U_s);
+  return (int)hipGetLastError();
+}
+
 // SMPPI.shift_nominal_trajectory (mppi.py:488-492) and the base sequence of the next command (:540) in one
 // launch (host-side: two concatenations and an add):
 //   U_out = roll(U, -1), last row = u_init;   A_out = roll(A, -1), last row repeats;   B_out = A_out + U_out * dt
@@ -1092,6 +1126,7 @@ int launch_smppi_shift(int Tn, int nu, const T* U, const T* u_init, const T* A, 
   template int launch_finalize_blocks<T>(const KArgs<T>&, int, hipStream_t);              \
   template int launch_combine<T>(const KArgs<T>&, const T*, int, hipStream_t, const T* const*);              \
   template int launch_kmppi_sequences<T>(int, int, int, const T*, const T*, T*, int, const T*, const T*, T*, hipStream_t); \
+  template int launch_kmppi_after_update<T>(int, int, int, const T*, const T*, const T*, const T*, T*, T*, T*, hipStream_t); \
   template int launch_smppi_shift<T>(int, int, const T*, const T*, const T*, T, T*, T*, T*, hipStream_t);
 MPPI_INST(float)
 MPPI_INST(double)

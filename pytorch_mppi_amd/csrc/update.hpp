@@ -20,6 +20,8 @@ template <typename T> int launch_combine(const KArgs<T>& a, const T* rec, int G,
 template <typename T> int launch_kmppi_sequences(int R, int S, int nu, const T* M, const T* x, T* out,
                                                    int Troll, const T* U, const T* u_init, T* U_out, hipStream_t st);
 // SMPPI: shifted U / action sequence and the base sequence A + U*dt in one launch
+template <typename T> int launch_kmppi_after_update(int Tn, int S, int nu, const T* W, const T* Ws, const T* theta, const T* u_init,
+                                                    T* U_out, T* theta_s, T* U_s, hipStream_t st);
 template <typename T> int launch_smppi_shift(int Tn, int nu, const T* U, const T* u_init, const T* A, T dt, T* U_out, T* A_out,
                                              T* B_out, hipStream_t st);
 }  // namespace mppi

@@ -32,7 +32,8 @@ class NativeComm:
         lib = N.lib()
         multi = world_size > 1
         if multi and not (dist.is_available() and dist.is_initialized()):
-            raise RuntimeError("NativeComm with world_size > 1 needs an initialised torch.distributed group for the id hand-out")
+            raise RuntimeError("NativeComm with world_size > 1 needs an initialised torch.distributed group for the "
+                    "id hand-out")
         on_dev = multi and dist.get_backend(group) == "nccl"
         flag_dev = device if on_dev else "cpu"
 
@@ -91,7 +92,8 @@ class NativeComm:
             self.handle = None
 
 
-LOCAL = "local"      # ShardPlan(..., group=LOCAL): the shards are the devices of ONE process (group.py), not ranks of a process group
+# ShardPlan(..., group=LOCAL): the shards are the devices of ONE process (group.py), not ranks of a process group
+LOCAL = "local"
 
 
 class ShardPlan:
@@ -101,7 +103,8 @@ class ShardPlan:
         if K < world_size:
             raise ValueError("need at least one sample per rank")
         # a process-local plan (a device group's shard: `rank` is the shard's index, not a process rank) never touches
-        # torch.distributed -- in a process whose default group is RCCL-backed (a device group per torchrun rank) a broadcast
+        # torch.distributed -- in a process whose default group is RCCL-backed (a device group per torchrun rank) a
+        # broadcast
         # of U or an ncclCommInitRank with shard indices for ranks would hang or mix the ranks' sequences
         self.local = isinstance(group, str) and group == LOCAL
         if self.local:

@@ -1,36 +1,56 @@
 """One Python process, N devices: `MPPI(..., devices=[0, 1, ..., 7])`  (SURVEY.md 8b / 8e).
 
 The reference's caller is ONE process stepping ONE environment (/root/reference/src/pytorch_mppi/mppi.py:876-898,
-tests/pendulum.py:68-79): with `shard=(rank, world)` it has to re-launch its whole loop under torch.distributed.run and step a
-replica of the environment on every rank.  `devices=[...]` keeps `.command(state)` the single drop-in call: the object the
-constructor returns holds one shard controller per listed device (the same code a rank of the per-process model runs -- contiguous
-split of the K samples by global index, K1 / K3 / K4 against the shard's own minimum, one (2 + T nu)-element record per shard), and
+tests/pendulum.py:68-79): with `shard=(rank, world)` it has to re-launch its whole loop under torch.distributed.run and
+step a
+replica of the environment on every rank.  `devices=[...]` keeps `.command(state)` the single drop-in call: the object
+the
+constructor returns holds one shard controller per listed device (the same code a rank of the per-process model runs --
+contiguous
+split of the K samples by global index, K1 / K3 / K4 against the shard's own minimum, one (2 + T nu)-element record per
+shard), and
 a command is
 
-    this thread:  the state to device 0; per shard the problem block of this command (`MPPI._prepare`: draw, buffers, parameters)
-                  -> handed to the ENGINE's device group (C-ABI 22, csrc/group.hip: mppi_group_broadcast / _submit / _wait)
-    worker g:     one thread per device inside the library, that device current in it: the state from device 0 (peer copy),
-                  K1, K3, K4 (record only), the exchange -- ncclAllGather on the device's own communicator (ncclCommInitAll), or
-                  copies behind events when a device is listed twice / there is no RCCL ("staged") -- and K5, the rank-order
+    this thread:  the state to device 0; per shard the problem block of this command (`MPPI._prepare`: draw, buffers,
+    parameters)
+                  -> handed to the ENGINE's device group (C-ABI 22, csrc/group.hip: mppi_group_broadcast / _submit /
+                  _wait)
+    worker g:     one thread per device inside the library, that device current in it: the state from device 0 (peer
+    copy),
+                  K1, K3, K4 (record only), the exchange -- ncclAllGather on the device's own communicator
+                  (ncclCommInitAll), or
+                  copies behind events when a device is listed twice / there is no RCCL ("staged") -- and K5, the
+                  rank-order
                   combine -> bit-identical U on every device
     this thread:  return device 0's action
 
-so the host's share of a command is N block hand-overs plus ONE device's launches, not N x (Python + launches): commands no longer
-have to be longer than N x 40 us to be GPU-bound (profiles/r06_group_host_issue.txt).  What has no one-call form (the callback
+so the host's share of a command is N block hand-overs plus ONE device's launches, not N x (Python + launches): commands
+no longer
+have to be longer than N x 40 us to be GPU-bound (profiles/r06_group_host_issue.txt).  What has no one-call form (the
+callback
 path, KMPPI's two-launch form) is issued shard by shard from this thread as before, the exchange through
 mppi_exchange_combine_all / device copies.  MPPI_GROUP_THREADS=0 forces that serial form (A/B).
 
-The returned object is an instance of the class that was asked for (a subclass made on the fly), but holds no controller state of
-its own: attribute reads go to shard 0 -- except the per-sample results (`cost_total`, `omega`, `noise`, ...), which are the
-shards' parts concatenated on device 0 in global sample order --, attribute writes go to every shard (tensors moved to the shard's
-device), methods other than `command` run on every shard and the replicated sequences (`U`, `theta`, `action_sequence`) are then
+The returned object is an instance of the class that was asked for (a subclass made on the fly), but holds no controller
+state of
+its own: attribute reads go to shard 0 -- except the per-sample results (`cost_total`, `omega`, `noise`, ...), which are
+the
+shards' parts concatenated on device 0 in global sample order --, attribute writes go to every shard (tensors moved to
+the shard's
+device), methods other than `command` run on every shard and the replicated sequences (`U`, `theta`, `action_sequence`)
+are then
 re-copied from shard 0 (a `reset()` draws on device 0 only, like rank 0's draw is broadcast in the per-process model).
 
-User callables (the reference's plugin API) are called by every shard with tensors on THAT shard's device.  `torch.nn.Module`s --
-the callable itself or the object a bound method belongs to: /root/reference/tests/pendulum_approximate.py's network -- are
-deep-copied onto each further device at construction and re-synchronised (`load_state_dict`) whenever the original's parameters
-were written (retraining between commands, mppi.py:890-893); `models.NativeModel`s keep a parameter blob per device themselves.
-Anything else -- a closure over a tensor on cuda:0 -- must be device-agnostic (`tensor.to(state.device)`): the error a device
+User callables (the reference's plugin API) are called by every shard with tensors on THAT shard's device.
+`torch.nn.Module`s --
+the callable itself or the object a bound method belongs to: /root/reference/tests/pendulum_approximate.py's network --
+are
+deep-copied onto each further device at construction and re-synchronised (`load_state_dict`) whenever the original's
+parameters
+were written (retraining between commands, mppi.py:890-893); `models.NativeModel`s keep a parameter blob per device
+themselves.
+Anything else -- a closure over a tensor on cuda:0 -- must be device-agnostic (`tensor.to(state.device)`): the error a
+device
 mismatch raises inside such a callable is re-raised with that advice."""
 import contextlib
 import ctypes as C
@@ -40,7 +60,8 @@ import torch
 from . import _native as N
 
 # per-sample results of the last command: name -> the axis that is the sample axis
-_PER_SAMPLE = {"cost_total": 0, "omega": 0, "cost_total_non_zero": 0, "noise": 0, "perturbed_action": 0, "noise_theta": 0,
+_PER_SAMPLE = {"cost_total": 0, "omega": 0, "cost_total_non_zero": 0, "noise": 0, "perturbed_action": 0,
+        "noise_theta": 0,
                "perturbed_control": 0, "states": 1, "actions": 1}
 _REPLICATED = ("U", "theta", "action_sequence")
 _classes = {}
@@ -55,7 +76,8 @@ def group_class(cls):
 
 
 def _on(device):
-    """the shard's device as the calling thread's current one (what the engine's launches and torch's allocations follow)"""
+    """the shard's device as the calling thread's current one (what the engine's launches and torch's allocations
+    follow)"""
     return torch.cuda.device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()
 
 
@@ -68,7 +90,8 @@ def _dev_index(d):
     return d.index if d.index is not None else torch.cuda.current_device()
 
 
-_OWN = frozenset(("_shards", "_devs", "_comms", "_staged", "_base", "exchange", "_engine", "_replicas", "_state_bufs", "_rec_bufs",
+_OWN = frozenset(("_shards", "_devs", "_comms", "_staged", "_base", "exchange", "_engine", "_replicas", "_state_bufs",
+        "_rec_bufs",
                   "_threads", "issue"))
 
 
@@ -83,7 +106,8 @@ def _module_of(fn):
 
 
 class _Replicas:
-    """nn.Modules among the user's callables, copied to the further devices of a group and kept equal to the originals"""
+    """nn.Modules among the user's callables, copied to the further devices of a group and kept equal to the
+    originals"""
 
     def __init__(self):
         self.items = {}          # id(original) -> (original, {device: copy}, versions at the last sync)
@@ -106,7 +130,8 @@ class _Replicas:
         return tuple(t._version for t in list(mod.parameters()) + list(mod.buffers()))
 
     def sync(self):
-        """before a command: originals written since the last look (an optimizer step, load_state_dict) -> copies follow"""
+        """before a command: originals written since the last look (an optimizer step, load_state_dict) -> copies
+        follow"""
         for it in self.items.values():
             v = self._versions(it[0])
             if v != it[2]:
@@ -139,7 +164,8 @@ class DeviceGroup:
             else:
                 k["device"] = d
             if d != dev0:
-                # the user's callables see tensors of THIS device: modules travel with the shard (see the module docstring)
+                # the user's callables see tensors of THIS device: modules travel with the shard (see the module
+                # docstring)
                 for i in (0, 1):
                     if len(a) > i:
                         a[i] = replicas.on(a[i], d)
@@ -173,7 +199,9 @@ class DeviceGroup:
                 N.check(rc, "mppi_dist_init_all")
             else:
                 object.__setattr__(self, "_staged", True)          # no RCCL in this process: device copies
-        object.__setattr__(self, "exchange", "staged through device copies" + (" (a device is listed twice: TEST RIG)" if len(set(devs)) < len(devs) else
+        object.__setattr__(self, "exchange",
+                "staged through device copies" + (" (a device is listed twice: TEST RIG)"
+                        if len(set(devs)) < len(devs) else
                                                                                " (no RCCL)") if self._staged else
                            "engine-owned RCCL communicators (ncclCommInitAll), one all-gather per device and command")
         # the engine's device group: one worker thread per device issues that device's launches (csrc/group.hip)
@@ -187,9 +215,11 @@ class DeviceGroup:
             else:
                 import logging
                 logging.getLogger("pytorch_mppi_amd").warning(
-                    "pytorch_mppi_amd: no engine device group (%s): the shards' launches are issued from the calling thread",
+                    "pytorch_mppi_amd: no engine device group (%s): the shards' launches are issued from the calling "
+                            "thread",
                     lib.mppi_last_error().decode(errors="replace"))
-        object.__setattr__(self, "issue", "one worker thread per device inside the engine (mppi_group_submit / mppi_group_wait)"
+        object.__setattr__(self, "issue", "one worker thread per device inside the engine (mppi_group_submit / "
+                "mppi_group_wait)"
                            if self._engine is not None else "shard by shard from the calling thread")
 
     @staticmethod
@@ -209,7 +239,8 @@ class DeviceGroup:
             except Exception:
                 pass
 
-    # ---- attribute plumbing --------------------------------------------------------------------------------------------
+    # ---- attribute plumbing
+    # --------------------------------------------------------------------------------------------
     def __getattribute__(self, name):
         if name in _OWN or name.startswith("__") or name in DeviceGroup.__dict__:
             return object.__getattribute__(self, name)
@@ -226,7 +257,8 @@ class DeviceGroup:
                 out = None
                 for i, s in enumerate(shards):
                     with _on(s.d):
-                        r = getattr(s, name)(*[self._to(x, s) for x in a], **{kk: self._to(x, s) for kk, x in k.items()})
+                        r = getattr(s, name)(*[self._to(x, s) for x in a], **{kk: self._to(x, s) for kk,
+                                x in k.items()})
                     if i == 0:
                         out = r
                 self._sync_replicated()
@@ -245,7 +277,8 @@ class DeviceGroup:
         return v
 
     def _sync_replicated(self):
-        """the sequences every shard must hold identically are shard 0's (a constructor / reset() draw happens per device)"""
+        """the sequences every shard must hold identically are shard 0's (a constructor / reset() draw happens per
+        device)"""
         shards = object.__getattribute__(self, "_shards")
         s0 = shards[0]
         for name in _REPLICATED:
@@ -262,7 +295,8 @@ class DeviceGroup:
     def shards(self):
         return list(object.__getattribute__(self, "_shards"))
 
-    # ---- one command ---------------------------------------------------------------------------------------------------
+    # ---- one command
+    # ---------------------------------------------------------------------------------------------------
     def command(self, state, shift_nominal_trajectory=True, info=None):
         """mppi.py:240-252 on N devices: the action (device 0), without synchronising."""
         shards = object.__getattribute__(self, "_shards")
@@ -270,13 +304,15 @@ class DeviceGroup:
         shift = bool(shift_nominal_trajectory)
         object.__getattribute__(self, "_replicas").sync()
         eng = object.__getattribute__(self, "_engine")
-        # the state: ONCE to device 0 (a host state travels in a launch packet, MPPI._to_state); the other devices get it by a
+        # the state: ONCE to device 0 (a host state travels in a launch packet, MPPI._to_state); the other devices get
+        # it by a
         # peer copy in front of their K1, issued by their worker thread -- unless the shards take different rows of it
         # (per-sample initial states of the global problem, mppi.py:302-305) or there are no workers
         states, bc = [state] * len(shards), None
         if eng is not None:
             with _on(s0.d):
-                st0 = s0._to_state(state) if tuple(getattr(state, "shape", ())) != (s0.K, s0.nx) or s0.K_local == s0.K else None
+                st0 = s0._to_state(state) if tuple(getattr(state, "shape", ())) != (s0.K,
+                        s0.nx) or s0.K_local == s0.K else None
             if st0 is not None:
                 st0 = st0.contiguous()
                 states, bc = self._state_copies(st0), st0
@@ -289,20 +325,24 @@ class DeviceGroup:
                         s._adopt_background_model()
                     if getattr(s._model, "watch", None) is not None:
                         s._check_traced(state if s is s0 else None)
-                    # (MPPI._to_state moves the state to the shard's device and, for per-sample initial states of the global
+                    # (MPPI._to_state moves the state to the shard's device and, for per-sample initial states of the
+                    # global
                     # problem -- (K, nx), mppi.py:302-305 --, takes this shard's rows)
                     ps.append(s._prepare(states[g], shift))
         except RuntimeError as e:
             if "Expected all tensors to be on the same device" in str(e):
-                raise RuntimeError(f"{e}\n(pytorch_mppi_amd device group: every shard calls dynamics / running_cost with tensors on ITS "
-                                   "device; torch.nn.Modules are copied there, anything else the callables read must follow "
+                raise RuntimeError(f"{e}\n(pytorch_mppi_amd device group: every shard calls dynamics / running_cost "
+                        f"with tensors on ITS "
+                                   "device; torch.nn.Modules are copied there, anything else the callables read must "
+                                           "follow "
                                    "`state.device` -- pytorch_mppi_amd/group.py)") from e
             raise
         self._issue(ps, bc, states)
         action = None
         for s, p in zip(shards, ps):
             if type(s)._end is _plain_end:
-                a = s._end(p)                           # (no launches in there: no need for the shard's device to be current)
+                # (no launches in there: no need for the shard's device to be current)
+                a = s._end(p)
             else:
                 with _on(s.d):
                     a = s._end(p)
@@ -312,31 +352,36 @@ class DeviceGroup:
 
     @staticmethod
     def _light(s):
-        """a shard whose `_prepare` launches nothing from this thread (the engine's generator inside K1, nothing to convert or
+        """a shard whose `_prepare` launches nothing from this thread (the engine's generator inside K1, nothing to
+        convert or
         upload): its device need not be made current for it"""
         return (s.rng == "philox" and s.last_draw in ("philox-onchip", "philox-k1") and not s._injected and s.M == 1
                 and s.specific_action_sampler is None and type(s)._prepare is _plain_prepare and s._model is not None
                 and getattr(s._model, "watch", None) is None and s._jit_pending is None)
 
     def _state_copies(self, st0):
-        """per shard the tensor its K1 reads the state from: device 0's itself where the shard lives there, else a buffer on
+        """per shard the tensor its K1 reads the state from: device 0's itself where the shard lives there, else a
+        buffer on
         the shard's device that its worker fills from device 0's in front of K1 (mppi_group_broadcast)"""
         shards = object.__getattribute__(self, "_shards")
         bufs = object.__getattribute__(self, "_state_bufs")
         key = (tuple(st0.shape), st0.dtype)
         if bufs is None or bufs[0] != key:
-            bufs = (key, [None if s.d == st0.device else torch.empty(st0.shape, dtype=st0.dtype, device=s.d) for s in shards])
+            bufs = (key, [None if s.d == st0.device else torch.empty(st0.shape, dtype=st0.dtype,
+                    device=s.d) for s in shards])
             object.__setattr__(self, "_state_bufs", bufs)
         return [st0 if b is None else b for b in bufs[1]]
 
     def _records_for(self, g, s, n):
-        """the (G, 2 + J) buffer the exchange fills on device g: one per shard and record size, touched on that shard's stream only"""
+        """the (G, 2 + J) buffer the exchange fills on device g: one per shard and record size, touched on that shard's
+        stream only"""
         rb = object.__getattribute__(self, "_rec_bufs")
         b = rb.get((g, n, s.dtype))
         if b is None:
             if len(rb) > 4 * len(object.__getattribute__(self, "_shards")):
                 rb.clear()
-            b = rb[(g, n, s.dtype)] = torch.empty(len(object.__getattribute__(self, "_shards")), n, device=s.d, dtype=s.dtype)
+            b = rb[(g, n, s.dtype)] = torch.empty(len(object.__getattribute__(self, "_shards")), n, device=s.d,
+                    dtype=s.dtype)
         return b
 
     def _issue(self, ps, bc, states):
@@ -350,12 +395,14 @@ class DeviceGroup:
             streams = [torch._C._cuda_getCurrentRawStream(s._dev_index) for s in shards]
             if bc is not None and any(t is not bc for t in states):
                 dst = (C.c_void_p * G)(*[None if t is bc else t.data_ptr() for t in states])
-                N.check(lib.mppi_group_broadcast(eng, bc.data_ptr(), bc.numel() * bc.element_size(), dst, streams[0]), "mppi_group_broadcast")
+                N.check(lib.mppi_group_broadcast(eng, bc.data_ptr(), bc.numel() * bc.element_size(), dst, streams[0]),
+                        "mppi_group_broadcast")
             for g, (s, p, (b, bt)) in enumerate(zip(shards, ps, blocks)):
                 q = bt if bt is not None else b
                 rec = self._records_for(g, s, 2 + q.T * q.nu)
                 p._keep["records"] = rec
-                rc = lib.mppi_group_submit(eng, g, C.byref(b), C.byref(bt) if bt is not None else None, rec.data_ptr(), streams[g])
+                rc = lib.mppi_group_submit(eng, g, C.byref(b), C.byref(bt) if bt is not None else None, rec.data_ptr(),
+                        streams[g])
                 if rc != 0:
                     lib.mppi_group_abort(eng)
                     N.check(rc, "mppi_group_submit")
@@ -367,7 +414,8 @@ class DeviceGroup:
                 return
             if rc != N.E_UNSUPPORTED:
                 N.check(rc, "mppi_group_wait")
-            # no one-call form for this command on this model (the in-place (K,T,nu) K1, KMPPI's fused interpolation): the shards
+            # no one-call form for this command on this model (the in-place (K,T,nu) K1, KMPPI's fused interpolation):
+            # the shards
             # issue it themselves, their own way.  Nothing was exchanged or applied; what was launched is launched again
         for s, p in zip(shards, ps):
             if p._deferred:
@@ -392,9 +440,11 @@ class DeviceGroup:
             streams = [torch.cuda.current_stream(s.d).cuda_stream for s in shards]
             N.check(N.lib().mppi_exchange_combine_all(
                 G, (C.c_int32 * G)(*devs), (C.POINTER(N.MppiProblem) * G)(*[C.pointer(p) for p in ps]), comms,
-                (C.c_void_p * G)(*[b.data_ptr() for b in bufs]), (C.c_void_p * G)(*streams)), "mppi_exchange_combine_all")
+                (C.c_void_p * G)(*[b.data_ptr() for b in bufs]), (C.c_void_p * G)(*streams)),
+                        "mppi_exchange_combine_all")
             return
-        # staged: the records travel by device copies (torch orders them against the streams involved), K5 on every device
+        # staged: the records travel by device copies (torch orders them against the streams involved), K5 on every
+        # device
         for s, p in zip(shards, ps):
             with _on(s.d):
                 s._combine(p, torch.stack([r if r.device == s.d else r.to(s.d) for r in recs]))

@@ -160,8 +160,10 @@ class LinearGoal(NativeModel):
 
 
 def mlp_kernel_width(nx, nu, hidden):
-    """The hidden width the engine's matrix-core MLP kernels are built for (csrc/rollout_mlp_split.hip: (nx, nu) = (16, 4), hidden 64 /
-    128 / 256) that holds `hidden` units, or `hidden` itself where no such kernel exists (the per-lane kernel takes any width).  Padding
+    """The hidden width the engine's matrix-core MLP kernels are built for (csrc/rollout_mlp_split.hip: (nx, nu) = (16,
+    4), hidden 64 /
+    128 / 256) that holds `hidden` units, or `hidden` itself where no such kernel exists (the per-lane kernel takes any
+    width).  Padding
     units have zero weights in and out and zero bias: tanh(0) = 0 contributes exactly nothing."""
     if (int(nx), int(nu)) == (16, 4):
         for w in (64, 128, 256):
@@ -188,28 +190,35 @@ def pad_hidden(W1, b1, W2, width):
 class MLPResidual(NativeModel):
     """x' = x + res_scale * (W2 tanh(W1 [x;u] + b1) + b2) -- the 2-layer approximate-dynamics shape of
     /root/reference/tests/pendulum_approximate.py:47-67 -- with the diagonal quadratic running cost
-    sum_i q_state[i] x_i^2 + sum_n q_control[n] u_n^2 (defaults 1 and 0: the plain sum x^2 of BASELINE configs[3..4])."""
+    sum_i q_state[i] x_i^2 + sum_n q_control[n] u_n^2 (defaults 1 and 0: the plain sum x^2 of BASELINE
+    configs[3..4])."""
     model_id = N.MODEL_MLP
 
     def __init__(self, W1, b1, W2, b2, nx, nu, res_scale=0.1, q_state=None, q_control=None):
         super().__init__()
         self.W1, self.b1, self.W2, self.b2 = (torch.as_tensor(t) for t in (W1, b1, W2, b2))
         self.nx, self.nu = int(nx), int(nu)
-        # `hidden` is what the kernels see: odd widths are zero-padded to the next width the matrix-core kernels are built for
+        # `hidden` is what the kernels see: odd widths are zero-padded to the next width the matrix-core kernels are
+        # built for
         # (hidden 100 on the per-lane kernel costs 13 x the matrix-core time)
         self.hidden_units = int(self.W1.shape[0])
         self.hidden = mlp_kernel_width(nx, nu, self.hidden_units)
         self.res_scale = float(res_scale)
-        self.q_state = torch.ones(self.nx, dtype=torch.float64) if q_state is None else torch.as_tensor(q_state, dtype=torch.float64).reshape(-1)
-        self.q_control = torch.zeros(self.nu, dtype=torch.float64) if q_control is None else torch.as_tensor(q_control, dtype=torch.float64).reshape(-1)
+        self.q_state = torch.ones(self.nx, dtype=torch.float64) if q_state is None else torch.as_tensor(q_state,
+                dtype=torch.float64).reshape(-1)
+        self.q_control = torch.zeros(self.nu, dtype=torch.float64) if q_control is None else torch.as_tensor(q_control,
+                dtype=torch.float64).reshape(-1)
         assert self.W1.shape == (self.hidden_units, self.nx + self.nu) and self.W2.shape == (self.nx, self.hidden_units)
         assert self.q_state.numel() == self.nx and self.q_control.numel() == self.nu
         self._plain_cost = q_state is None and q_control is None
 
     def flags(self):
-        """The default matrix-core kernel runs layer 2 on two-piece fp16 operands (csrc/rollout_mlp_split.hip): its weights
-        (-2 W2) must stay inside fp16's range.  Weights beyond it -- checked here every time the parameter version changes,
-        i.e. also after `invalidate()` behind an in-place update -- select the exact fp32 MFMA kernel, which has no such limit."""
+        """The default matrix-core kernel runs layer 2 on two-piece fp16 operands (csrc/rollout_mlp_split.hip): its
+        weights
+        (-2 W2) must stay inside fp16's range.  Weights beyond it -- checked here every time the parameter version
+        changes,
+        i.e. also after `invalidate()` behind an in-place update -- select the exact fp32 MFMA kernel, which has no such
+        limit."""
         if getattr(self, "_flags_version", None) != self._param_version:
             self._flags = N.MODEL_FLAG_EXACT_FP32 if float(torch.as_tensor(self.W2).abs().max()) >= 3.0e4 else 0
             self._flags_version = self._param_version
@@ -229,7 +238,8 @@ class MLPResidual(NativeModel):
                        nx, nu, res_scale)
 
     def _param_list(self):
-        W1, b1, W2 = (self.W1, self.b1, self.W2) if self.hidden == self.hidden_units else pad_hidden(self.W1, self.b1, self.W2, self.hidden)
+        W1, b1, W2 = (self.W1, self.b1, self.W2) if self.hidden == self.hidden_units else pad_hidden(self.W1, self.b1,
+                self.W2, self.hidden)
         return [W1, b1, W2, self.b2, torch.tensor([self.res_scale], dtype=torch.float64), self.q_state, self.q_control]
 
     def dynamics(self, state, action, t=None):

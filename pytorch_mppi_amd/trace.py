@@ -9,7 +9,8 @@ every element an expression node), records the arithmetic, and prints it as the 
 Symbolic tensors are NOT torch.Tensor subclasses: `SymT` implements the tensor methods users call on states and actions
 (indexing, views, arithmetic, reductions, elementwise maths), `__torch_function__` for the torch.* / torch.nn.functional
 entry points (torch.cat, torch.clamp, F.linear through an nn.Module, ...) and `__array_ufunc__` for numpy ufuncs applied
-to tensors (the reference's own pendulum uses np.sin / np.clip on tensors: tests/pendulum.py:45-46).  Shapes are concrete
+to tensors (the reference's own pendulum uses np.sin / np.clip on tensors: tests/pendulum.py:45-46).  Shapes are
+concrete
 (numpy arrays of node ids with a batch axis of size 1), so every view / broadcast / concatenation is numpy's.
 
 Scope: elementwise maths, + - * / ** %, clamp / where / min / max, small constant matrices (captured tensors, nn.Linear
@@ -33,13 +34,16 @@ class TraceUnsupported(Exception):
 
 
 class StaleTrace(Exception):
-    """a run-time parameter of a traced functor is no longer what the trace saw (another shape, not a tensor any more)"""
+    """a run-time parameter of a traced functor is no longer what the trace saw (another shape, not a tensor any
+    more)"""
 
 
 class PathParam:
     """A NON-trainable tensor the callables read from a fixed place (watch.Path: an attribute, a closure cell, a global)
-    whose values the functor reads from its parameter vector instead of carrying them as constants: the controller promotes
-    a tensor to this once it has SEEN it change (`cost.goal = new_goal`; mppi.MPPI._traced_state_moved), so that the next
+    whose values the functor reads from its parameter vector instead of carrying them as constants: the controller
+    promotes
+    a tensor to this once it has SEEN it change (`cost.goal = new_goal`; mppi.MPPI._traced_state_moved), so that the
+    next
     change is one small copy, not a compile.  `tensor()` is whatever sits at the place now."""
     def __init__(self, path, t):
         self.path, self.shape = path, tuple(t.shape)
@@ -52,7 +56,8 @@ class PathParam:
 
 
 def param_tensor(src):
-    """the tensor behind an entry of `param_tensors` (a trainable tensor itself, or what a PathParam's place holds now)"""
+    """the tensor behind an entry of `param_tensors` (a trainable tensor itself, or what a PathParam's place holds
+    now)"""
     return src.tensor() if isinstance(src, PathParam) else src
 
 
@@ -62,12 +67,14 @@ def param_tensor(src):
 _UNARY = {"neg": lambda a: -a, "sin": math.sin, "cos": math.cos, "tan": math.tan, "tanh": math.tanh, "exp": math.exp,
           "log": math.log, "sqrt": math.sqrt, "abs": abs, "floor": math.floor,
           "sigmoid": lambda a: 1.0 / (1.0 + math.exp(-a)), "sign": lambda a: (a > 0) - (a < 0),
-          "erf": math.erf, "atan": math.atan, "asin": math.asin, "acos": math.acos, "sinh": math.sinh, "cosh": math.cosh,
+          "erf": math.erf, "atan": math.atan, "asin": math.asin, "acos": math.acos, "sinh": math.sinh,
+                  "cosh": math.cosh,
           "expm1": math.expm1, "log1p": math.log1p, "ceil": math.ceil, "round": lambda a: float(np.round(a)),
           "trunc": math.trunc}
 _BINARY = {"add": lambda a, b: a + b, "sub": lambda a, b: a - b, "mul": lambda a, b: a * b, "div": lambda a, b: a / b,
            "min": min, "max": max, "pow": lambda a, b: a ** b, "atan2": math.atan2,
-           "floormod": lambda a, b: a % b, "fmod": math.fmod}        # (Python's float % is torch.remainder: exact, sign of b)
+           # (Python's float % is torch.remainder: exact, sign of b)
+           "floormod": lambda a, b: a % b, "fmod": math.fmod}
 _CMP = {"lt": lambda a, b: a < b, "le": lambda a, b: a <= b, "gt": lambda a, b: a > b, "ge": lambda a, b: a >= b,
         "eq": lambda a, b: a == b, "ne": lambda a, b: a != b}
 
@@ -80,23 +87,32 @@ class Graph:
             v = path.get()
             if isinstance(v, torch.Tensor) and v.is_floating_point() and v.numel() > 0:
                 self.dynamic[id(v)] = (v, path)
-        # what the symbolic inputs report as .device / .dtype: the controller's own, so that `net.to(state.device, state.dtype)`
-        # or `if state.is_cuda:` inside the callables behave as they will at run time (and a module is not dragged to the host)
+        # what the symbolic inputs report as .device / .dtype: the controller's own, so that `net.to(state.device,
+        # state.dtype)`
+        # or `if state.is_cuda:` inside the callables behave as they will at run time (and a module is not dragged to
+        # the host)
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.dtype = dtype if dtype is not None else torch.float64
         self.nodes = []          # tuples: ("c", float) | ("x", i) | ("u", n) | ("t",) | ("y", i) | (op, ids...)
         self.index = {}
-        self.captured = []       # (tensor, version at trace time) of every torch tensor whose VALUES went into constants
-        self.derived = {}        # id(tensor made INSIDE the callables from real tensors) -> (tensor, [the tensors it came from]):
-        #                          B.to(state.device), W @ W.T, ... are constants of the functor too; the version watch must sit
+        # (tensor, version at trace time) of every torch tensor whose VALUES went into constants
+        self.captured = []
+        # id(tensor made INSIDE the callables from real tensors) -> (tensor, [the tensors it came from]):
+        self.derived = {}
+        #                          B.to(state.device), W @ W.T, ... are constants of the functor too; the version watch
+        #                          must sit
         #                          on what they were made from (the copy itself is never written again)
-        # dense layers kept AS LAYERS (F.linear on a real weight tensor, >= DENSE_MIN multiply-adds): node ("lin", layer, o) is
-        # output o of layers[layer] = dict(IN, OUT, inputs=[node ids], wbase, bbase | None) -- weights and bias are parameter-
-        # vector reads.  Code generation prints chains of them as mlp_first / mlp_mid / mlp_last calls (csrc/mlp_wide.hpp): fma
+        # dense layers kept AS LAYERS (F.linear on a real weight tensor, >= DENSE_MIN multiply-adds): node ("lin",
+        # layer, o) is
+        # output o of layers[layer] = dict(IN, OUT, inputs=[node ids], wbase, bbase | None) -- weights and bias are
+        # parameter-
+        # vector reads.  Code generation prints chains of them as mlp_first / mlp_mid / mlp_last calls
+        # (csrc/mlp_wide.hpp): fma
         # chains per lane in the ordinary kernels, matrix-core tiles of sixteen samples in the wide kernel
         self.layers = []
         self.dense_layers = os.environ.get("MPPI_TRACE_DENSE", "1") != "0"
-        self.param_tensors = []  # (tensor, base): TRAINABLE tensors -- element i is the leaf ("p", base + i), read from the
+        # (tensor, base): TRAINABLE tensors -- element i is the leaf ("p", base + i), read from the
+        self.param_tensors = []
         self._param_base = {}    # model's parameter vector at run time (re-gathered when the tensor's version moves)
         self.n_params = 0
         self.max_nodes = max_nodes
@@ -119,7 +135,8 @@ class Graph:
         return self._mk((kind,) if i is None else (kind, int(i)))
 
     def param_leaves(self, t, max_params=32768):
-        """node ids (shape of t) of the run-time parameter leaves of a trainable tensor (or of a promoted one: `dynamic`)"""
+        """node ids (shape of t) of the run-time parameter leaves of a trainable tensor (or of a promoted one:
+        `dynamic`)"""
         base = self._param_base.get(id(t))
         if base is None:
             if self.n_params + t.numel() > max_params:
@@ -211,7 +228,8 @@ class Graph:
                 if e == 0:
                     return self.const(1.0)
                 r = a
-                for _ in range(e - 1):                               # torch.pow with a small integer exponent: repeated products
+                # torch.pow with a small integer exponent: repeated products
+                for _ in range(e - 1):
                     r = self.bin("mul", r, a)
                 return r
             if cb == 0.5:
@@ -271,13 +289,16 @@ class SymT:
                 raise TraceUnsupported("boolean constant tensors")
             if isinstance(v, torch.nn.Parameter) or v.requires_grad or id(v) in self.g.dynamic:
                 # a TRAINABLE tensor: its values are expected to change (online learning of the dynamics, as in the
-                # reference's tests/pendulum_approximate.py:47-67,140-170) -- baking them into the functor would go stale
+                # reference's tests/pendulum_approximate.py:47-67,140-170) -- baking them into the functor would go
+                # stale
                 # with the first optimizer step.  Its elements become reads of the model's parameter vector p[]: the
                 # functor stays valid, the vector is re-gathered when the tensor's version counter moves.  (Same for a
                 # tensor the controller has seen change at its place: Graph.dynamic, PathParam.)
                 return SymT(self.g, self.g.param_leaves(v))
-            for r in self.g.roots_of(v):                 # captured BY VALUE: the controller watches the version counters of
-                if not any(r is c for c, _ in self.g.captured):     # the tensor -- or of what it was made from inside the callable
+            # captured BY VALUE: the controller watches the version counters of
+            for r in self.g.roots_of(v):
+                # the tensor -- or of what it was made from inside the callable
+                if not any(r is c for c, _ in self.g.captured):
                     self.g.captured.append((r, r._version))
             v = v.detach().cpu().double().numpy()
         if isinstance(v, np.ndarray):
@@ -337,12 +358,14 @@ class SymT:
         if not self.boolean or (o is not None and not (isinstance(o, SymT) and o.boolean)):
             raise TraceUnsupported("logical operator on tensors that are not traced comparisons")
         if o is None:
-            return SymT(self.g, np.vectorize(lambda i: self.g.logic("not", int(i)), otypes=[np.int64])(self.a), boolean=True)
+            return SymT(self.g, np.vectorize(lambda i: self.g.logic("not", int(i)), otypes=[np.int64])(self.a),
+                    boolean=True)
         try:
             a, b = np.broadcast_arrays(self.a, o.a)
         except ValueError as e:
             raise TraceUnsupported(f"broadcast: {e}")
-        return SymT(self.g, np.vectorize(lambda i, j: self.g.logic(op, int(i), int(j)), otypes=[np.int64])(a, b), boolean=True)
+        return SymT(self.g, np.vectorize(lambda i, j: self.g.logic(op, int(i), int(j)), otypes=[np.int64])(a, b),
+                boolean=True)
     def __and__(self, o): return self._logic("and", o)
     def __or__(self, o): return self._logic("or", o)
     def __xor__(self, o): return self._logic("xor", o)
@@ -363,15 +386,19 @@ class SymT:
 
     def __getitem__(self, idx):
         if isinstance(idx, SymT) and idx.boolean:
-            # x[mask]: a data-dependent selection.  Only the read-modify-write idiom `x[mask] op= scalar` / `x[mask] = ...` can be
-            # traced (as a select under the mask): the result is a placeholder that takes scalar arithmetic and goes back into
+            # x[mask]: a data-dependent selection.  Only the read-modify-write idiom `x[mask] op= scalar` / `x[mask] =
+            # ...` can be
+            # traced (as a select under the mask): the result is a placeholder that takes scalar arithmetic and goes
+            # back into
             # `x[mask] = ...` with the SAME mask
             return _Masked(self.clone(), idx)
         first = idx[0] if isinstance(idx, tuple) else idx
         if isinstance(first, SymT) and first.a.ndim == 0 and not first.boolean:
-            first = SymS(self.g, int(first.a))                     # (the timestep after a trip through a torch function)
+            # (the timestep after a trip through a torch function)
+            first = SymS(self.g, int(first.a))
         if isinstance(first, SymS):
-            # table[t] (or table[t, ...]): a constant reference / schedule looked up by the timestep -> one small constant
+            # table[t] (or table[t, ...]): a constant reference / schedule looked up by the timestep -> one small
+            # constant
             # array per selected element in the functor, read at index clamp(t, 0, len - 1)
             rest = idx[1:] if isinstance(idx, tuple) else ()
             cols = np.moveaxis(self.a, 0, -1)                      # (..., N)
@@ -412,13 +439,15 @@ class SymT:
         if isinstance(v, _Masked):
             raise TraceUnsupported("a masked selection used outside x[mask] = ...")
         v = self._lift(v)
-        idx = tuple(i.detach().cpu().numpy() if isinstance(i, torch.Tensor) else i for i in idx) if isinstance(idx, tuple) else idx
+        idx = tuple(i.detach().cpu().numpy() if isinstance(i, torch.Tensor) else i for i in idx) if isinstance(idx,
+                tuple) else idx
         try:
             self.a[idx] = v.a          # (the traced inputs are handed to the callable as copies: an in-place write
         except (IndexError, ValueError, TypeError) as e:    # into `state` stays local, like state.clone() first)
             raise TraceUnsupported(f"item assignment: {e}")
 
-    # -- in-place forms: write through self.a (a numpy view of the parent's ids where torch would have a view) --------------
+    # -- in-place forms: write through self.a (a numpy view of the parent's ids where torch would have a view)
+    # --------------
     def _inplace(self, r):
         try:
             self.a[...] = np.broadcast_to(self._lift(r).a, self.a.shape)
@@ -544,7 +573,8 @@ class SymT:
         e = end_dim % len(sh)
         s = start_dim % len(sh)
         return self.view(*(sh[:s] + [-1] + sh[e + 1:]))
-    def unsqueeze(self, d): return SymT(self.g, np.expand_dims(self.a, d if d >= 0 else d + self.a.ndim + 1), self.boolean)
+    def unsqueeze(self, d): return SymT(self.g, np.expand_dims(self.a, d if d >= 0 else d + self.a.ndim + 1),
+            self.boolean)
     def squeeze(self, d=None):
         if d is None:
             return SymT(self.g, np.squeeze(self.a), self.boolean)
@@ -635,18 +665,21 @@ class SymT:
         a = np.moveaxis(self.a, dim, 0).copy()
         for r in range(1, a.shape[0]):
             fo, fp = a[r].reshape(-1), a[r - 1].reshape(-1)
-            a[r] = np.array([self.g.bin("add", int(p_), int(o_)) for p_, o_ in zip(fp, fo)], dtype=np.int64).reshape(a[r].shape)
+            a[r] = np.array([self.g.bin("add", int(p_), int(o_)) for p_, o_ in zip(fp, fo)],
+                    dtype=np.int64).reshape(a[r].shape)
         return SymT(self.g, np.moveaxis(a, 0, dim))
     def cumprod(self, dim, dtype=None):
         a = np.moveaxis(self.a, dim, 0).copy()
         for r in range(1, a.shape[0]):
             fo, fp = a[r].reshape(-1), a[r - 1].reshape(-1)
-            a[r] = np.array([self.g.bin("mul", int(p_), int(o_)) for p_, o_ in zip(fp, fo)], dtype=np.int64).reshape(a[r].shape)
+            a[r] = np.array([self.g.bin("mul", int(p_), int(o_)) for p_, o_ in zip(fp, fo)],
+                    dtype=np.int64).reshape(a[r].shape)
         return SymT(self.g, np.moveaxis(a, 0, dim))
     def outer(self, o):
         o = self._lift(o)
         return self.unsqueeze(-1) * o.unsqueeze(-2)
-    def diagonal(self, offset=0, dim1=0, dim2=1): return SymT(self.g, np.diagonal(self.a, offset, dim1, dim2), self.boolean)
+    def diagonal(self, offset=0, dim1=0, dim2=1): return SymT(self.g, np.diagonal(self.a, offset, dim1, dim2),
+            self.boolean)
     def trace(self): return self.diagonal().sum(-1)
     def diag(self, diagonal=0):
         if self.a.ndim == 2:
@@ -684,7 +717,8 @@ class SymT:
     def minimum(self, o): return self._ew2("min", o)
     fmax, fmin = maximum, minimum
     def mv(self, o): return self.matmul(o)
-    def inner(self, o): return (self * o).sum(-1) if self.a.ndim == 1 else self.matmul(self._lift(o).mT if self._lift(o).a.ndim > 1 else o)
+    def inner(self, o): return (self * o).sum(-1) if self.a.ndim == 1 else self.matmul(self._lift(o).mT
+            if self._lift(o).a.ndim > 1 else o)
     def any(self, dim=None, keepdim=False):
         if not self.boolean:
             raise TraceUnsupported("any() of a tensor that is not a traced comparison")
@@ -706,7 +740,8 @@ class SymT:
         if out is not None or kw:
             raise TraceUnsupported("clamp(out=...)")
         r = self
-        if min is not None and max is not None and not isinstance(min, (SymT, torch.Tensor)) and not isinstance(max, (SymT, torch.Tensor)):
+        if min is not None and max is not None and not isinstance(min, (SymT, torch.Tensor)) and not isinstance(max,
+                (SymT, torch.Tensor)):
             lo, hi = self._lift(min), self._lift(max)
             out = np.empty(self.a.shape, dtype=np.int64)
             fa, fo = self.a.reshape(-1), out.reshape(-1)
@@ -813,7 +848,8 @@ class SymT:
                     for k in range(a2.shape[-1]):
                         ia, ib = int(a2[bi + (i, k)]), int(b2[bi + (k, j)])
                         if g.cval(ia) == 0.0 or g.cval(ib) == 0.0:
-                            # a structural zero of a CONSTANT matrix: torch adds 0 * x = 0 for finite x; dropping the term is
+                            # a structural zero of a CONSTANT matrix: torch adds 0 * x = 0 for finite x; dropping the
+                            # term is
                             # exact for finite states (the sparse B / selection matrices of test code)
                             continue
                         p = g.bin("mul", ia, ib)
@@ -830,13 +866,15 @@ class SymT:
 
 
 class _Masked:
-    """`x[mask]` of a traced boolean mask: the full-shape values with the mask beside them.  Scalar arithmetic only; it can
+    """`x[mask]` of a traced boolean mask: the full-shape values with the mask beside them.  Scalar arithmetic only; it
+    can
     go back into `x[mask] = ...` (see SymT.__setitem__); any other use is refused."""
     def __init__(self, full, mask):
         self.full, self.mask = full, mask
 
     def _b(self, op, o, rev=False):
-        if isinstance(o, (SymT, SymS, _Masked)) or (isinstance(o, (torch.Tensor, np.ndarray)) and o.size != 1 if isinstance(o, np.ndarray) else
+        if isinstance(o, (SymT, SymS, _Masked)) or (isinstance(o, (torch.Tensor, np.ndarray)) and o.size != 1
+                if isinstance(o, np.ndarray) else
                                                       isinstance(o, torch.Tensor) and o.numel() != 1):
             raise TraceUnsupported("arithmetic between a masked selection and a tensor")
         return _Masked(self.full._ew2(op, o, reverse=rev), self.mask)
@@ -854,7 +892,8 @@ class _Masked:
 
 
 class _ValuesOnly:
-    """result of Tensor.max(dim) / min(dim): the values can be traced, the indices cannot (they would be data-dependent)"""
+    """result of Tensor.max(dim) / min(dim): the values can be traced, the indices cannot (they would be
+    data-dependent)"""
     def __init__(self, values): self.values = values
     @property
     def indices(self): raise TraceUnsupported("argmax / argmin indices")
@@ -902,7 +941,8 @@ class SymS:
     __int__ = __index__
     def __float__(self): raise TraceUnsupported("the timestep converted to a Python float")
     def __lt__(self, o): raise TraceUnsupported("comparison on the timestep")
-    # == / != / hashing must fail as loudly as < does: left at the object defaults, `if t == T - 1:` would evaluate to a plain
+    # == / != / hashing must fail as loudly as < does: left at the object defaults, `if t == T - 1:` would evaluate to a
+    # plain
     # False while tracing and the branch would be dropped without a word (`t in (...)`, dict lookups by t: the same)
     __le__ = __gt__ = __ge__ = __eq__ = __ne__ = __lt__
     def __hash__(self): raise TraceUnsupported("the timestep used as a dictionary key / set member")
@@ -913,8 +953,10 @@ class SymS:
         return _call(_graph_of(args, kwargs or {}), getattr(func, "__name__", str(func)), args, kwargs or {})
 
 
-_DUNDERS = {"__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__", "__pow__",
-            "__rpow__", "__mod__", "__neg__", "__pos__", "__abs__", "__lt__", "__le__", "__gt__", "__ge__", "__matmul__",
+_DUNDERS = {"__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__",
+        "__pow__",
+            "__rpow__", "__mod__", "__neg__", "__pos__", "__abs__", "__lt__", "__le__", "__gt__", "__ge__",
+                    "__matmul__",
             "__rmatmul__", "__getitem__"}
 _NP_UFUNCS = {"sin": "sin", "cos": "cos", "tan": "tan", "tanh": "tanh", "exp": "exp", "log": "log", "sqrt": "sqrt",
               "absolute": "abs", "fabs": "abs", "negative": "neg", "square": "square", "add": "add", "subtract": "sub",
@@ -1024,16 +1066,19 @@ def _call(g, name, args, kwargs):
             raise TraceUnsupported("where(condition) without values")
         return _where(g, args[0], args[1], args[2])
     if name in ("zeros_like", "ones_like", "full_like", "empty_like"):
-        v = {"zeros_like": 0.0, "ones_like": 1.0, "empty_like": 0.0}.get(name, rest[0] if rest else kwargs.get("fill_value"))
+        v = {"zeros_like": 0.0, "ones_like": 1.0, "empty_like": 0.0}.get(name, rest[0] if rest
+                else kwargs.get("fill_value"))
         return SymT(g, np.full(a0.a.shape, g.const(v), dtype=np.int64))
     if name == "linear":                               # F.linear(input, weight, bias): nn.Linear inside a module
         b_ = rest[1] if len(rest) > 1 else kwargs.get("bias")
         W_ = rest[0]
-        if (g.dense_layers and isinstance(W_, torch.Tensor) and W_.dim() == 2 and W_.is_floating_point() and W_.numel() >= DENSE_MIN
+        if (g.dense_layers and isinstance(W_, torch.Tensor) and W_.dim() == 2 and W_.is_floating_point()
+                and W_.numel() >= DENSE_MIN
                 and isinstance(a0, SymT) and a0.a.ndim >= 1 and a0.a.shape[-1] == W_.shape[1] and not a0.boolean
                 and (b_ is None or (isinstance(b_, torch.Tensor) and b_.dim() == 1 and b_.numel() == W_.shape[0]))
                 and id(W_) not in g.dynamic and (b_ is None or id(b_) not in g.dynamic)):
-            # a dense layer stays a layer: its weights become parameter-vector reads (trainable or not: a frozen network's
+            # a dense layer stays a layer: its weights become parameter-vector reads (trainable or not: a frozen
+            # network's
             # weights are followed by version counter and storage like any parameter), its outputs `lin` nodes
             rows = a0.a.reshape(-1, a0.a.shape[-1])
             out = np.empty((rows.shape[0], int(W_.shape[0])), dtype=np.int64)
@@ -1055,7 +1100,8 @@ def _call(g, name, args, kwargs):
         p_ = kwargs.get("ord", kwargs.get("p", rest[0] if rest else 2))
         dim = kwargs.get("dim", rest[1] if len(rest) > 1 else None)
         return a0.norm(2 if p_ is None else p_, dim, kwargs.get("keepdim", rest[2] if len(rest) > 2 else False))
-    if name in ("tensor", "as_tensor", "asarray"):     # `if not torch.is_tensor(x): x = torch.tensor(x)` on a traced input
+    # `if not torch.is_tensor(x): x = torch.tensor(x)` on a traced input
+    if name in ("tensor", "as_tensor", "asarray"):
         return a0
     if name == "cdist":                                # torch.cdist(x1 (..,P,M), x2 (..,R,M), p=2) -> (..,P,R)
         x2 = _as_sym(g, rest[0])
@@ -1110,7 +1156,8 @@ def _call(g, name, args, kwargs):
             y = y * w
         return y + b if b is not None else y
     if name in ("hardtanh", "relu6", "elu", "selu", "celu", "gelu", "tanhshrink", "softsign", "mish", "hardswish",
-                "hardsigmoid", "logsigmoid", "log_sigmoid", "threshold", "softshrink", "hardshrink", "silu", "relu", "relu_", "elu_",
+                "hardsigmoid", "logsigmoid", "log_sigmoid", "threshold", "softshrink", "hardshrink", "silu", "relu",
+                        "relu_", "elu_",
                 "hardtanh_", "threshold_"):
         name = {"log_sigmoid": "logsigmoid"}.get(name, name.rstrip("_"))
         if name == "relu":
@@ -1145,7 +1192,8 @@ def _call(g, name, args, kwargs):
         if name == "logsigmoid":
             return a0.minimum(0.0) - (-a0.abs()).exp().log1p()         # stable on both sides
         if name == "threshold":
-            th, val = kwargs.get("threshold", rest[0] if rest else None), kwargs.get("value", rest[1] if len(rest) > 1 else None)
+            th, val = kwargs.get("threshold", rest[0] if rest else None), kwargs.get("value", rest[1]
+                    if len(rest) > 1 else None)
             return _where(g, a0 > float(th), a0, _as_sym(g, float(val)))
         lam = float(kwargs.get("lambd", rest[0] if rest else 0.5))
         if name == "softshrink":
@@ -1164,7 +1212,8 @@ def _call(g, name, args, kwargs):
     if name in ("leaky_relu",):
         slope = kwargs.get("negative_slope", rest[0] if rest else 0.01)
         return _where(g, a0 > 0.0, a0, a0 * slope)
-    if name == "batch_norm":                           # F.batch_norm(input, running_mean, running_var, weight, bias, training, momentum, eps)
+    # F.batch_norm(input, running_mean, running_var, weight, bias, training, momentum, eps)
+    if name == "batch_norm":
         if kwargs.get("training", rest[4] if len(rest) > 4 else False):
             raise TraceUnsupported("batch_norm in training mode (statistics over the batch)")
         rm, rv = rest[0], rest[1]
@@ -1181,8 +1230,10 @@ def _call(g, name, args, kwargs):
         raise TraceUnsupported(f"torch.nn.functional.{name}")
     if name in ("__getitem__",):
         return a0[rest[0]]
-    meth = {"absolute": "abs", "negative": "neg", "true_divide": "div", "divide": "div", "multiply": "mul", "subtract": "sub",
-            "clip": "clamp", "arctan2": "atan2", "linalg_cross": "cross", "linalg_matmul": "matmul", "bitwise_and": "logical_and",
+    meth = {"absolute": "abs", "negative": "neg", "true_divide": "div", "divide": "div", "multiply": "mul",
+            "subtract": "sub",
+            "clip": "clamp", "arctan2": "atan2", "linalg_cross": "cross", "linalg_matmul": "matmul",
+                    "bitwise_and": "logical_and",
             "bitwise_or": "logical_or", "bitwise_not": "logical_not", "bitwise_xor": "logical_xor"}.get(name, name)
     if a0 is not None and hasattr(SymT, meth) and (not meth.startswith("_") or meth in _DUNDERS):
         f = getattr(a0, meth)
@@ -1197,7 +1248,8 @@ def _call(g, name, args, kwargs):
 # ---------------------------------------------------------------------------------------------------------------
 def _flatten_result(r, want, what):
     if isinstance(r, torch.Tensor):
-        raise TraceUnsupported(f"{what} returned a constant tensor (it does not depend on its inputs, or left the traced ops)")
+        raise TraceUnsupported(f"{what} returned a constant tensor (it does not depend on its inputs, or left the "
+                f"traced ops)")
     if not isinstance(r, SymT):
         raise TraceUnsupported(f"{what} returned {type(r).__name__}")
     a = r.a.reshape(-1)
@@ -1206,17 +1258,24 @@ def _flatten_result(r, want, what):
     return [int(v) for v in a]
 
 
-_FACTORIES = {"zeros", "ones", "empty", "full", "tensor", "as_tensor", "eye", "from_numpy", "linspace", "diag", "diag_embed",
+_FACTORIES = {"zeros", "ones", "empty", "full", "tensor", "as_tensor", "eye", "from_numpy", "linspace", "diag",
+        "diag_embed",
               "zeros_like", "ones_like", "full_like", "empty_like", "scalar_tensor", "asarray"}
-DENSE_MIN = 64        # multiply-adds from which F.linear on a real weight tensor is kept as a layer (below: scalar terms)
-_META = {"size", "dim", "numel", "nelement", "stride", "is_floating_point", "is_contiguous", "data_ptr", "element_size", "get_device",
-         "is_complex", "storage_offset", "__len__", "ndimension", "type", "is_pinned", "__format__", "__repr__", "__str__"}
-_RANDOM = {"randn", "rand", "randn_like", "rand_like", "normal", "randint", "bernoulli", "multinomial", "randperm", "poisson"}
+# multiply-adds from which F.linear on a real weight tensor is kept as a layer (below: scalar terms)
+DENSE_MIN = 64
+_META = {"size", "dim", "numel", "nelement", "stride", "is_floating_point", "is_contiguous", "data_ptr",
+        "element_size", "get_device",
+         "is_complex", "storage_offset", "__len__", "ndimension", "type", "is_pinned", "__format__", "__repr__",
+                 "__str__"}
+_RANDOM = {"randn", "rand", "randn_like", "rand_like", "normal", "randint", "bernoulli", "multinomial", "randperm",
+        "poisson"}
 
 
 class _TraceMode(torch.overrides.TorchFunctionMode):
-    """While the callables run on symbolic inputs: floating tensors they CREATE (torch.zeros(B, nx) to be filled column by
-    column, torch.tensor([...]) constants) become symbolic constants too, so that item assignment of traced values into them
+    """While the callables run on symbolic inputs: floating tensors they CREATE (torch.zeros(B, nx) to be filled column
+    by
+    column, torch.tensor([...]) constants) become symbolic constants too, so that item assignment of traced values into
+    them
     works; random draws are refused (not a function of state, action and timestep); everything else passes through."""
     def __init__(self, g):
         super().__init__()
@@ -1229,26 +1288,31 @@ class _TraceMode(torch.overrides.TorchFunctionMode):
         dyn = self.g.dynamic
 
         def has_sym(v):
-            return isinstance(v, (SymT, SymS, _Masked)) or (isinstance(v, (tuple, list)) and any(has_sym(e) for e in v)) \
+            return isinstance(v, (SymT, SymS, _Masked)) or (isinstance(v, (tuple, list))
+                    and any(has_sym(e) for e in v)) \
                 or (dyn and isinstance(v, torch.Tensor) and id(v) in dyn)
 
-        def sym_dyn(v):          # a promoted tensor met by a torch function on its own (`self.goal.to(device)`, `goal[None]`)
+        # a promoted tensor met by a torch function on its own (`self.goal.to(device)`, `goal[None]`)
+        def sym_dyn(v):
             if isinstance(v, torch.Tensor) and id(v) in dyn:
                 return SymT(self.g, self.g.param_leaves(v))
             if isinstance(v, (tuple, list)) and any(isinstance(e, torch.Tensor) and id(e) in dyn for e in v):
                 return type(v)(sym_dyn(e) for e in v)
             return v
         if name in _RANDOM:
-            raise TraceUnsupported(f"torch.{name} inside the callable (random draws are not a function of state, action and timestep)")
+            raise TraceUnsupported(f"torch.{name} inside the callable (random draws are not a function of state, "
+                    f"action and timestep)")
         if any(has_sym(v) for v in args) or any(has_sym(v) for v in kwargs.values()):
             if any(isinstance(v, _Masked) for v in args):
                 raise TraceUnsupported("a masked selection x[mask] passed to a torch function")
             if name == "__setitem__" and isinstance(args[0], torch.Tensor):
-                raise TraceUnsupported("item assignment of a traced value into a tensor created outside the traced callables")
+                raise TraceUnsupported("item assignment of a traced value into a tensor created outside the traced "
+                        "callables")
             args = tuple(SymT(a.g, np.array(a.i)) if isinstance(a, SymS) else a for a in args)
             if dyn:
                 if name == "__get__" and isinstance(args[0], torch.Tensor):
-                    # a property of a promoted tensor: views become symbolic, metadata (shape, device, dtype, ...) stays real
+                    # a property of a promoted tensor: views become symbolic, metadata (shape, device, dtype, ...) stays
+                    # real
                     prop = getattr(getattr(func, "__self__", None), "__name__", "")
                     if prop not in ("T", "mT", "H", "mH", "data", "real"):
                         return func(*args, **kwargs)
@@ -1265,14 +1329,16 @@ class _TraceMode(torch.overrides.TorchFunctionMode):
             for o in (out if isinstance(out, (tuple, list)) else (out,)):
                 if isinstance(o, torch.Tensor):
                     self.g.note_derived(o, srcs)
-        if name in _FACTORIES and not srcs and isinstance(out, torch.Tensor) and out.is_floating_point() and out.numel() <= 65536 \
+        if name in _FACTORIES and not srcs and isinstance(out,
+                torch.Tensor) and out.is_floating_point() and out.numel() <= 65536 \
                 and not out.requires_grad:
             vals = out.detach().cpu().double().numpy()
             return SymT(self.g, np.vectorize(self.g.const, otypes=[np.int64])(vals))
         return out
 
 
-def trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, device=None, dtype=None,
+def trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, device=None,
+        dtype=None,
                     dynamic=()):
     """-> (Graph, step outputs [nx node ids], cost output id, terminal output id or None)"""
     g = Graph(device=device, dtype=dtype, dynamic=dynamic)
@@ -1290,7 +1356,8 @@ def trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost=None, st
         if terminal_state_cost is not None:
             # (1, K=1, T=2, nx): the functor's terminal() sees the LAST state only -- any use of an earlier state or of
             # the actions shows up as a 'y' / 'w' leaf in the result
-            st = np.array([[g.leaf("y", i) for i in range(nx)], [g.leaf("x", i) for i in range(nx)]], dtype=np.int64).reshape(1, 1, 2, nx)
+            st = np.array([[g.leaf("y", i) for i in range(nx)], [g.leaf("x", i) for i in range(nx)]],
+                    dtype=np.int64).reshape(1, 1, 2, nx)
             ac = np.array([g.leaf("w", i) for i in range(2 * nu)], dtype=np.int64).reshape(1, 1, 2, nu)
             tr = terminal_state_cost(SymT(g, st), SymT(g, ac))
             term_out = _flatten_result(tr, 1, "terminal_state_cost")[0]
@@ -1321,16 +1388,21 @@ def _reaches(g, roots, kinds):
 # ---------------------------------------------------------------------------------------------------------------
 # code generation
 # ---------------------------------------------------------------------------------------------------------------
-_FMT1 = {"neg": "(-{0})", "sin": "m_sin({0})", "cos": "m_cos({0})", "tan": "(m_sin({0}) / m_cos({0}))", "tanh": "m_tanh({0})",
+_FMT1 = {"neg": "(-{0})", "sin": "m_sin({0})", "cos": "m_cos({0})", "tan": "(m_sin({0}) / m_cos({0}))",
+        "tanh": "m_tanh({0})",
          "exp": "m_exp({0})", "log": "m_log({0})", "sqrt": "m_sqrt({0})", "abs": "m_abs({0})", "floor": "m_floor({0})",
          "sigmoid": "(T(1) / (T(1) + m_exp(-{0})))", "sign": "(T({0} > T(0)) - T({0} < T(0)))",
-         "erf": "m_erf({0})", "atan": "m_atan({0})", "asin": "m_asin({0})", "acos": "m_acos({0})", "sinh": "m_sinh({0})",
-         "cosh": "m_cosh({0})", "expm1": "m_expm1({0})", "log1p": "m_log1p({0})", "ceil": "m_ceil({0})", "round": "m_rint({0})",
+         "erf": "m_erf({0})", "atan": "m_atan({0})", "asin": "m_asin({0})", "acos": "m_acos({0})",
+                 "sinh": "m_sinh({0})",
+         "cosh": "m_cosh({0})", "expm1": "m_expm1({0})", "log1p": "m_log1p({0})", "ceil": "m_ceil({0})",
+                 "round": "m_rint({0})",
          "trunc": "m_trunc({0})", "not": "(!{0})"}
-_FMT2 = {"add": "({0} + {1})", "sub": "({0} - {1})", "mul": "({0} * {1})", "div": "({0} / {1})", "min": "m_min({0}, {1})",
+_FMT2 = {"add": "({0} + {1})", "sub": "({0} - {1})", "mul": "({0} * {1})", "div": "({0} / {1})",
+        "min": "m_min({0}, {1})",
          "max": "m_max({0}, {1})", "pow": "m_pow({0}, {1})", "atan2": "m_atan2({0}, {1})",
          "floormod": "({0} - m_floor({0} / {1}) * {1})", "fmod": "m_fmod({0}, {1})",
-         "lt": "({0} < {1})", "le": "({0} <= {1})", "gt": "({0} > {1})", "ge": "({0} >= {1})", "eq": "({0} == {1})", "ne": "({0} != {1})",
+         "lt": "({0} < {1})", "le": "({0} <= {1})", "gt": "({0} > {1})", "ge": "({0} >= {1})", "eq": "({0} == {1})",
+                 "ne": "({0} != {1})",
          "and": "({0} && {1})", "or": "({0} || {1})", "xor": "({0} != {1})"}
 
 
@@ -1355,10 +1427,13 @@ def _deps(g, n):
 
 
 def _dense_chains(g, roots):
-    """Which dense layers below `roots` feed each other through one elementwise activation and nothing else: -> (tail layer ->
+    """Which dense layers below `roots` feed each other through one elementwise activation and nothing else: -> (tail
+    layer ->
     [(layer, activation format or None) ...] from the chain's head to the tail, set of nodes internal to a chain).
-    Layer Lp is fused into L when L's inputs are act(lin(Lp, 0)), act(lin(Lp, 1)), ... in order, with ONE activation (a unary
-    function, or max / min / mul / add with a constant) and neither the outputs of Lp nor the activations are used anywhere else."""
+    Layer Lp is fused into L when L's inputs are act(lin(Lp, 0)), act(lin(Lp, 1)), ... in order, with ONE activation (a
+    unary
+    function, or max / min / mul / add with a constant) and neither the outputs of Lp nor the activations are used
+    anywhere else."""
     seen, stack, cons = set(), list(roots), {}
     for r in roots:
         cons[r] = cons.get(r, 0) + 1
@@ -1369,7 +1444,8 @@ def _dense_chains(g, roots):
             continue
         seen.add(i)
         n = g.nodes[i]
-        if n[0] == "lin":                       # a layer consumes each of its inputs ONCE, however many of its outputs are used
+        # a layer consumes each of its inputs ONCE, however many of its outputs are used
+        if n[0] == "lin":
             if n[1] in layer_seen:
                 continue
             layer_seen.add(n[1])
@@ -1383,17 +1459,20 @@ def _dense_chains(g, roots):
         spec, Lp = None, None
         ok = True
         for pos, a in enumerate(ins):
-            # walk from the input down to a layer output through operations of ONE operand (unary functions, max / min / mul /
+            # walk from the input down to a layer output through operations of ONE operand (unary functions, max / min /
+            # mul /
             # add / sub / div with a constant): the activation, innermost operation last in `path`
             path, cur, chain_nodes = [], a, []
             while g.nodes[cur][0] != "lin":
                 n = g.nodes[cur]
-                # (the distributed form pads a layer's outputs to whole blocks of 16 with zeros, which meet zero weights in the next
+                # (the distributed form pads a layer's outputs to whole blocks of 16 with zeros, which meet zero weights
+                # in the next
                 # layer: the activation must be FINITE at 0 -- log(0) or c / 0 would put inf * 0 = NaN into every sum)
                 if n[0] in _FMT1 and len(n) == 2 and n[0] not in ("log", "not"):
                     path.append((n[0],))
                     nxt = n[1]
-                elif n[0] in ("max", "min", "mul", "add", "sub", "div") and len(n) == 3 and (g.cval(n[1]) is not None) != (g.cval(n[2]) is not None) \
+                elif n[0] in ("max", "min", "mul", "add", "sub",
+                        "div") and len(n) == 3 and (g.cval(n[1]) is not None) != (g.cval(n[2]) is not None) \
                         and not (n[0] == "div" and g.cval(n[1]) is not None):
                     left_const = g.cval(n[1]) is not None
                     path.append((n[0], g.cval(n[1] if left_const else n[2]), left_const))
@@ -1418,7 +1497,8 @@ def _dense_chains(g, roots):
                 break
             spec, Lp = this, sl[1]
         if ok and Lp is not None and g.layers[Lp]["OUT"] % 16 != 0 and not _finite_at_zero(spec):
-            ok = False                                           # the padded lanes of the wide form would carry NaN / inf into L
+            # the padded lanes of the wide form would carry NaN / inf into L
+            ok = False
         if ok and Lp is not None and g.layers[Lp]["OUT"] == len(ins) and Lp != L:
             prev[L] = (Lp, spec)
     fused_into = {lp: L for L, (lp, _) in prev.items()}
@@ -1435,7 +1515,8 @@ def _dense_chains(g, roots):
             else:
                 chain.append((cur, None))
                 break
-        chain.reverse()            # head first; entry i = (layer, activation applied to the PREVIOUS layer's output before this one)
+        # head first; entry i = (layer, activation applied to the PREVIOUS layer's output before this one)
+        chain.reverse()
         chains[L] = chain
         for (Lc, _) in chain[:-1]:
             for o in range(g.layers[Lc]["OUT"]):
@@ -1447,14 +1528,19 @@ def _dense_chains(g, roots):
 
 
 def _finite_at_zero(spec):
-    """Is the activation path (operations of one operand, in the order they are applied) finite at 0?  The wide matrix-core form
-    pads a layer's outputs to whole blocks of 16 with zeros; `sqrt(h - 1)`, `log1p(h - 1)`, `asin(h + 2)` give NaN / inf on the
+    """Is the activation path (operations of one operand, in the order they are applied) finite at 0?  The wide
+    matrix-core form
+    pads a layer's outputs to whole blocks of 16 with zeros; `sqrt(h - 1)`, `log1p(h - 1)`, `asin(h + 2)` give NaN / inf
+    on the
     padded lanes, and inf * 0 = NaN in the next layer's products would poison every output of the sample.
     Evaluated on the host in fp64 with numpy's semantics (no exceptions: inf / nan are values)."""
     import numpy as np
-    f1 = {"neg": np.negative, "sin": np.sin, "cos": np.cos, "tan": np.tan, "tanh": np.tanh, "exp": np.exp, "log": np.log, "sqrt": np.sqrt,
-          "abs": np.abs, "floor": np.floor, "sigmoid": lambda v: 1.0 / (1.0 + np.exp(-v)), "sign": np.sign, "atan": np.arctan,
-          "asin": np.arcsin, "acos": np.arccos, "sinh": np.sinh, "cosh": np.cosh, "expm1": np.expm1, "log1p": np.log1p, "ceil": np.ceil,
+    f1 = {"neg": np.negative, "sin": np.sin, "cos": np.cos, "tan": np.tan, "tanh": np.tanh, "exp": np.exp,
+            "log": np.log, "sqrt": np.sqrt,
+          "abs": np.abs, "floor": np.floor, "sigmoid": lambda v: 1.0 / (1.0 + np.exp(-v)), "sign": np.sign,
+                  "atan": np.arctan,
+          "asin": np.arcsin, "acos": np.arccos, "sinh": np.sinh, "cosh": np.cosh, "expm1": np.expm1, "log1p": np.log1p,
+                  "ceil": np.ceil,
           "round": np.rint, "trunc": np.trunc, "erf": lambda v: np.float64(math.erf(float(v))) if np.isfinite(v) else v}
     f2 = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "min": np.minimum, "max": np.maximum}
     v = np.float64(0.0)
@@ -1473,7 +1559,8 @@ def _finite_at_zero(spec):
 
 
 def _act_code(spec, var):
-    """the activation between two fused layers (operations of one operand, applied in order) on the register array `var`, in place"""
+    """the activation between two fused layers (operations of one operand, applied in order) on the register array
+    `var`, in place"""
     if not spec:
         return ""
     e = f"{var}[i_]"
@@ -1487,7 +1574,8 @@ def _act_code(spec, var):
 
 def emit(g, roots, assign=None, ret=False, used=None):
     """C++ statements computing `roots` (node ids): temporaries in topological order, then either `x[i] = ...;`
-    assignments (`assign` = list of targets) or `return ...;`.  used: dict collecting the (layer, kind) pairs of the dense
+    assignments (`assign` = list of targets) or `return ...;`.  used: dict collecting the (layer, kind) pairs of the
+    dense
     layers the body calls (kind 0: replicated input, 1: distributed input; members of the functor: `layer_members`)."""
     used = {} if used is None else used
     chains, internal = _dense_chains(g, roots) if g.layers else ({}, set())
@@ -1497,7 +1585,8 @@ def emit(g, roots, assign=None, ret=False, used=None):
         if n[0] == "lin":
             if n[1] not in chains:
                 raise TraceUnsupported("internal: a fused layer's output used outside its chain")
-            return tuple(g.layers[chains[n[1]][0][0]]["inputs"])       # a chain's tail depends on the inputs of its head
+            # a chain's tail depends on the inputs of its head
+            return tuple(g.layers[chains[n[1]][0][0]]["inputs"])
         return _deps(g, n)
     order, seen = [], set()
     for r in roots:
@@ -1569,7 +1658,8 @@ def emit(g, roots, assign=None, ret=False, used=None):
             if k in _FMT1:
                 e = _FMT1[k].format(*ops)
             elif k == "floormod" and (g.cval(n[2]) or 0.0) > 0.0:
-                # a positive constant modulus (angle wrapping): the exact remainder -- k = floor(a / b) from the rounded quotient
+                # a positive constant modulus (angle wrapping): the exact remainder -- k = floor(a / b) from the rounded
+                # quotient
                 # is off by one at exact multiples of b, where torch's remainder (fmod + sign fix-up) is not
                 e = f"m_floormod({ops[0]}, {ops[1]})"
             elif k in _FMT2:
@@ -1586,7 +1676,8 @@ def emit(g, roots, assign=None, ret=False, used=None):
                 lines.append(f"const T v{i} = {e};")
             name[i] = f"v{i}"
     if assign is not None:
-        # x[] entries that are read by later assignments are protected by the temporaries above only when every output is a
+        # x[] entries that are read by later assignments are protected by the temporaries above only when every output
+        # is a
         # temporary or a leaf other than x[j], j != i: copy leaves first
         outs, copied = [], set()
         for tgt, r in zip(assign, roots):
@@ -1606,12 +1697,18 @@ def emit(g, roots, assign=None, ret=False, used=None):
 
 
 def match_mlp_residual(g, step_roots, cost_root, term_root, nx, nu):
-    """Is the traced model the shape the engine's hand-written matrix-core kernel rolls out (csrc/rollout_mlp_split.hip, BASELINE
-    configs[3]: x' = x + s (W2 tanh(W1 [x; u] + b1) + b2), cost = sum x^2, /root/reference/tests/pendulum_approximate.py:47-67 with
-    one hidden layer)?  Structural: exactly one chain of two dense layers with a bare tanh between them, the first reading
-    [x_0 .. x_nx-1, u_0 .. u_nu-1] in order, every state component's update `x_i + s * layer2_i` with ONE constant s (or none), the
-    cost a diagonal quadratic form sum_i qx_i x_i^2 + sum_n qu_n u_n^2 with constant weights (the plain sum x^2 included), no terminal cost.  Returns where W1, b1, W2, b2 sit in the functor's
-    parameter vector and s -- or None.  (Whether the kernel exists for (nx, nu, hidden) is the caller's question: jit.compile_traced.)"""
+    """Is the traced model the shape the engine's hand-written matrix-core kernel rolls out (csrc/rollout_mlp_split.hip,
+    BASELINE
+    configs[3]: x' = x + s (W2 tanh(W1 [x; u] + b1) + b2), cost = sum x^2,
+    /root/reference/tests/pendulum_approximate.py:47-67 with
+    one hidden layer)?  Structural: exactly one chain of two dense layers with a bare tanh between them, the first
+    reading
+    [x_0 .. x_nx-1, u_0 .. u_nu-1] in order, every state component's update `x_i + s * layer2_i` with ONE constant s (or
+    none), the
+    cost a diagonal quadratic form sum_i qx_i x_i^2 + sum_n qu_n u_n^2 with constant weights (the plain sum x^2
+    included), no terminal cost.  Returns where W1, b1, W2, b2 sit in the functor's
+    parameter vector and s -- or None.  (Whether the kernel exists for (nx, nu, hidden) is the caller's question:
+    jit.compile_traced.)"""
     if term_root is not None or len(g.layers) != 2:
         return None
     chains, _ = _dense_chains(g, list(step_roots) + [cost_root])
@@ -1649,7 +1746,8 @@ def match_mlp_residual(g, step_roots, cost_root, term_root, nx, nu):
         if scale is not None and c != scale:
             return None
         scale = c
-    # cost: a sum of constant multiples of squares of state components and of controls (any association; factors in front of
+    # cost: a sum of constant multiples of squares of state components and of controls (any association; factors in
+    # front of
     # sub-sums distribute): sum_i qx_i x_i^2 + sum_n qu_n u_n^2, nothing else
     qx, qu = [0.0] * nx, [0.0] * nu
 
@@ -1680,31 +1778,41 @@ def match_mlp_residual(g, step_roots, cost_root, term_root, nx, nu):
     if not walk(cost_root, 1.0):
         return None
     plain = qx == [1.0] * nx and qu == [0.0] * nu
-    return dict(H=int(l1["OUT"]), w1=int(l1["wbase"]), b1=None if l1["bbase"] is None else int(l1["bbase"]), w2=int(l2["wbase"]),
-                b2=None if l2["bbase"] is None else int(l2["bbase"]), scale=float(scale), **({} if plain else dict(qx=qx, qu=qu)))
+    return dict(H=int(l1["OUT"]), w1=int(l1["wbase"]), b1=None if l1["bbase"] is None else int(l1["bbase"]),
+            w2=int(l2["wbase"]),
+                b2=None if l2["bbase"] is None else int(l2["bbase"]), scale=float(scale), **({} if plain
+                        else dict(qx=qx, qu=qu)))
 
 
-def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, device=None, dtype=None, dynamic=()):
+def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, device=None, dtype=None,
+        dynamic=()):
     """-> dict(step=..., cost=..., terminal=... or None, n_ops=...): the C++ bodies for jit.compile_model.
     device / dtype: what the symbolic inputs report (the controller's; default cpu / float64).
     dynamic: places (watch.Path) whose tensors become run-time parameters instead of constants."""
-    g, so, co, to = trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost, step_dependent, device, dtype, dynamic)
+    g, so, co, to = trace_callables(dynamics, running_cost, nx, nu, terminal_state_cost, step_dependent, device, dtype,
+            dynamic)
     used = {}
     step = emit(g, so, assign=[f"x[{i}]" for i in range(nx)], used=used)
     cost = emit(g, [co], ret=True, used=used)
     term = emit(g, [to], ret=True, used=used) if to is not None else None
     members, ctor = layer_members(g, used)
-    return dict(step=step, cost=cost, terminal=term, n_ops=len(g.nodes), captured=g.captured, param_tensors=g.param_tensors,
+    return dict(step=step, cost=cost, terminal=term, n_ops=len(g.nodes), captured=g.captured,
+            param_tensors=g.param_tensors,
                 n_params=g.n_params, dynamic=list(dynamic), members=members, ctor=ctor,
-                numbers=frozenset(n[1] for n in g.nodes if n[0] == "c"),     # every numeric constant of the graph (mppi.MPPI._settle_moved)
+                # every numeric constant of the graph (mppi.MPPI._settle_moved)
+                numbers=frozenset(n[1] for n in g.nodes if n[0] == "c"),
                 mlp_residual=None if step_dependent else match_mlp_residual(g, so, co, to, nx, nu),
-                dense=[dict(IN=g.layers[L]["IN"], OUT=g.layers[L]["OUT"], kind=k) for (L, k) in sorted(used)])   # layers kept as layers
+                # layers kept as layers
+                dense=[dict(IN=g.layers[L]["IN"], OUT=g.layers[L]["OUT"], kind=k) for (L, k) in sorted(used)])
 
 
 def layer_members(g, used):
-    """the functor's dense layers as members (csrc/mlp_wide.hpp MlpLayer) and the constructor statements that bind them to
-    their weights in the parameter vector.  In the wide form a layer's A operands and bias live in registers for the whole
-    launch (PRE) as long as all layers together stay below ~160 registers per lane; beyond that they are read where used."""
+    """the functor's dense layers as members (csrc/mlp_wide.hpp MlpLayer) and the constructor statements that bind them
+    to
+    their weights in the parameter vector.  In the wide form a layer's A operands and bias live in registers for the
+    whole
+    launch (PRE) as long as all layers together stay below ~160 registers per lane; beyond that they are read where
+    used."""
     regs = 0
     for (L, kind) in used:
         lay = g.layers[L]
@@ -1743,12 +1851,14 @@ def same_param_sources(a, b):
 
 
 def gather_params(param_tensors, n_params):
-    """the model's parameter vector: the trainable tensors' current values, flattened at their bases (on their own device)"""
+    """the model's parameter vector: the trainable tensors' current values, flattened at their bases (on their own
+    device)"""
     if not param_tensors:
         return None
     with torch.no_grad():
         ts = [param_tensor(src).detach().reshape(-1).double() for src, _ in param_tensors]
-        dev = next((t.device for t in ts if t.device.type != "cpu"), ts[0].device)     # (a goal kept on the host beside device weights)
+        # (a goal kept on the host beside device weights)
+        dev = next((t.device for t in ts if t.device.type != "cpu"), ts[0].device)
         return torch.cat([t.to(dev) for t in ts])
 
 
@@ -1794,20 +1904,26 @@ template <int IN, int OUT, int KIND, bool WX_, bool PRE, typename U, typename P>
   P w, b;
   void load(P w_, P b_) { w = w_; b = b_; }
   void apply(const U* in, U* out) const {
-    for (int o = 0; o < OUT; ++o) { U acc = b ? b[o] : U(0); for (int i = 0; i < IN; ++i) acc += w[o * IN + i] * in[i]; out[o] = acc; }
+    for (int o = 0; o < OUT; ++o) { U acc = b ? b[o] : U(0); for (int i = 0; i < IN; ++i) acc += w[o * IN + i] * in[i];
+    out[o] = acc; }
   }
 };
-template <class L, int IN, int OUT> static inline void mlp_first(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in, d); }
-template <class L, int IN, int OUT> static inline void mlp_mid(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in, d); }
-template <class L, int IN, int OUT> static inline void mlp_last(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in, d); }
-template <class L, int IN, int OUT> static inline void mlp_single(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in, d); }
+template <class L, int IN, int OUT> static inline void mlp_first(const L& l, const T (&in)[IN], T (&d)[OUT]) {
+l.apply(in, d); }
+template <class L, int IN, int OUT> static inline void mlp_mid(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in,
+d); }
+template <class L, int IN, int OUT> static inline void mlp_last(const L& l, const T (&in)[IN], T (&d)[OUT]) {
+l.apply(in, d); }
+template <class L, int IN, int OUT> static inline void mlp_single(const L& l, const T (&in)[IN], T (&d)[OUT]) {
+l.apply(in, d); }
 static const int NX = %(nx)d, NU = %(nu)d;
 static const double* p;
 %(members)s
 static inline void step_(T (&x)[NX], const T (&u)[NU], int t) { %(step)s }
 static inline T cost_(const T (&x)[NX], const T (&u)[NU], int t) { %(cost)s }
 static inline T term_(const T (&x)[NX]) { %(terminal)s }
-extern "C" void run(int B, const double* X, const double* U, int t, double* Xn, double* Cc, double* Tc, const double* P) {
+extern "C" void run(int B, const double* X, const double* U, int t, double* Xn, double* Cc, double* Tc, const double* P)
+{
   p = P;
   %(ctor)s
   for (int b = 0; b < B; ++b) {
@@ -1824,11 +1940,13 @@ extern "C" void run(int B, const double* X, const double* U, int t, double* Xn, 
 
 
 def evaluate_on_host(code, X, U, nx, nu, t=0):
-    """The generated bodies, compiled for the host, on a batch: (next states (B,nx), running costs (B,), terminal costs (B,))
+    """The generated bodies, compiled for the host, on a batch: (next states (B,nx), running costs (B,), terminal costs
+    (B,))
     in fp64 -- what the device functor computes, for tests and for looking at a translation by hand."""
     src = _HOST % dict(nx=nx, nu=nu, step=code["step"], cost=code["cost"], terminal=code["terminal"] or "return T(0);",
                        members=code.get("members", ""), ctor=code.get("ctor", ""))
-    X, U = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, nx), np.ascontiguousarray(U, dtype=np.float64).reshape(-1, nu)
+    X, U = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, nx), np.ascontiguousarray(U,
+            dtype=np.float64).reshape(-1, nu)
     B = X.shape[0]
     with tempfile.TemporaryDirectory() as d:
         cpp, so = os.path.join(d, "v.cpp"), os.path.join(d, "v.so")
@@ -1845,7 +1963,8 @@ def evaluate_on_host(code, X, U, nx, nu, t=0):
     return Xn, Cc, Tc
 
 
-def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, B=24, rtol=1e-9, horizon=None):
+def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=None, step_dependent=False, B=24,
+        rtol=1e-9, horizon=None):
     """Compile the generated bodies for the host and compare with the callables on random batches (fp64).
     Raises TraceUnsupported on any disagreement (the caller keeps the generic path)."""
     src = _HOST % dict(nx=nx, nu=nu, step=code["step"], cost=code["cost"], terminal=code["terminal"] or "return T(0);",
@@ -1864,11 +1983,13 @@ def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=Non
         if not torch.cuda.is_available():
             forms = [f for f in forms if f[0] == "cpu"]
         form = None                                    # (device, dtype) the callables accept: found on the first batch
-        # three batches around the origin and one far out (fp64 callables only): rewrites that are only equal where nothing
+        # three batches around the origin and one far out (fp64 callables only): rewrites that are only equal where
+        # nothing
         # overflows -- log(1 + exp(x)) for softplus -- show up there, matching inf / nan patterns count as agreement
         batches = [(1.0, 0), (3.0, 5), (0.1, 11), (40.0, 2)]
         if step_dependent and horizon is not None:
-            # a step-dependent callable is checked at EVERY timestep of the horizon (the last one first: terminal-style terms
+            # a step-dependent callable is checked at EVERY timestep of the horizon (the last one first: terminal-style
+            # terms
             # `c + (t == T - 1) * ...` live there); the host check costs a fraction of a millisecond per batch
             H = int(horizon)
             batches += [(1.0, t) for t in [H - 1] + [t for t in range(H - 1) if t not in (0, 2, 5, 11)][:1023]]
@@ -1876,7 +1997,8 @@ def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=Non
             if scale > 10.0 and form is not None and form[1] != torch.float64:
                 continue
             if horizon is not None:
-                t = min(t, int(horizon) - 1)           # (a schedule indexed by the timestep is only as long as the horizon)
+                # (a schedule indexed by the timestep is only as long as the horizon)
+                t = min(t, int(horizon) - 1)
             X = torch.randn(B, nx, generator=gen, dtype=torch.float64) * scale
             U = torch.randn(B, nu, generator=gen, dtype=torch.float64) * scale
             Xn, Cc, Tc = np.zeros((B, nx)), np.zeros(B), np.zeros(B)
@@ -1899,7 +2021,8 @@ def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=Non
                 ref_c = running_cost(X.to(dev, dt), U.to(dev, dt), *extra).cpu()
             tol = rtol if dt == torch.float64 else max(rtol, 2e-5)
             if ref_x.numel() != B * nx or ref_c.numel() != B:
-                raise TraceUnsupported(f"the callables return {tuple(ref_x.shape)} / {tuple(ref_c.shape)} for a batch of {B}: not one "
+                raise TraceUnsupported(f"the callables return {tuple(ref_x.shape)} / {tuple(ref_c.shape)} for a batch "
+                        f"of {B}: not one "
                                        f"next state ({nx} values) and one cost per sample")
             pairs = [("dynamics", Xn, ref_x.detach().double().reshape(B, -1).numpy()),
                      ("running_cost", Cc, ref_c.detach().double().reshape(-1).numpy())]
@@ -1909,19 +2032,24 @@ def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=Non
                 pairs.append(("terminal_state_cost", Tc, ref_t.detach().double().reshape(-1).numpy()))
             for what, got, ref in pairs:
                 if got.shape != ref.shape:
-                    raise TraceUnsupported(f"{what}: traced result has shape {got.shape}, the callable returns {ref.shape}")
+                    raise TraceUnsupported(f"{what}: traced result has shape {got.shape}, the callable returns "
+                            f"{ref.shape}")
                 fin = np.isfinite(ref)
-                if not np.array_equal(fin, np.isfinite(got)) or not np.array_equal(np.sign(ref[~fin & ~np.isnan(ref)]), np.sign(got[~fin & ~np.isnan(ref)])) \
+                if not np.array_equal(fin, np.isfinite(got)) or not np.array_equal(np.sign(ref[~fin & ~np.isnan(ref)]),
+                        np.sign(got[~fin & ~np.isnan(ref)])) \
                         or not np.array_equal(np.isnan(ref), np.isnan(got)):
-                    raise TraceUnsupported(f"{what}: the traced functor and the callable disagree on which results are finite")
+                    raise TraceUnsupported(f"{what}: the traced functor and the callable disagree on which results "
+                            f"are finite")
                 if not fin.any():
                     continue
                 s = max(1.0, float(np.abs(ref[fin]).max()))
                 err = float(np.abs(got[fin] - ref[fin]).max())
                 if not (err <= tol * s):
-                    raise TraceUnsupported(f"{what}: traced functor differs from the callable by {err:.3g} (scale {s:.3g})")
+                    raise TraceUnsupported(f"{what}: traced functor differs from the callable by {err:.3g} (scale "
+                            f"{s:.3g})")
     return True
 
 
 def source_key(code, nx, nu):
-    return hashlib.sha256(repr((sorted((k, v) for k, v in code.items() if k in ("step", "cost", "terminal")), nx, nu)).encode()).hexdigest()[:12]
+    return hashlib.sha256(repr((sorted((k, v) for k, v in code.items() if k in ("step", "cost", "terminal")), nx,
+            nu)).encode()).hexdigest()[:12]

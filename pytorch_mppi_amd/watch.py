@@ -1,9 +1,12 @@
 """What a traced callable can read besides its arguments -- and whether it still says what it said when it was traced.
 
 The reference evaluates the user's `dynamics` / `running_cost` / `terminal_state_cost` on every command
-(/root/reference/src/pytorch_mppi/mppi.py:314, :318, :325), so whatever Python-level state they read is live: an attribute
-rebound between two commands (`cost.goal = new_goal`; tests/smooth_mppi.py:54-58 reads `self.goal` on every call), a Python
-float gain, a module swapped for another one, a global.  The tracer (trace.py) runs the callables ONCE and bakes what they
+(/root/reference/src/pytorch_mppi/mppi.py:314, :318, :325), so whatever Python-level state they read is live: an
+attribute
+rebound between two commands (`cost.goal = new_goal`; tests/smooth_mppi.py:54-58 reads `self.goal` on every call), a
+Python
+float gain, a module swapped for another one, a global.  The tracer (trace.py) runs the callables ONCE and bakes what
+they
 read into the device functor.  `StateWatch` closes that gap from the outside: it walks everything reachable from the
 callables -- closure cells, defaults, the globals their code names, `__self__`, instance dictionaries, `nn.Module`
 parameters / buffers / sub-modules, container items -- and snapshots every place a value can be read from:
@@ -13,7 +16,8 @@ parameters / buffers / sub-modules, container items -- and snapshots every place
     small numpy arrays .................. by identity and value
     everything else ..................... by identity (and walked further)
 
-`changed()` re-reads those places (a flat loop, ~0.1 us per place; typical callables have 5 - 60) and returns the ones that
+`changed()` re-reads those places (a flat loop, ~0.1 us per place; typical callables have 5 - 60) and returns the ones
+that
 moved.  The controller then re-traces (symbolically: milliseconds): the same functor source means the change was
 irrelevant (a call counter, a simulator's own state) and the place is dropped from the list; a different one means the
 fused kernels are out of date -- the controller returns to the callables at once and compiles the new functor beside the
@@ -32,13 +36,16 @@ import torch
 _MISSING = object()
 _PRIMS = (int, float, bool, str, bytes, complex, type(None), torch.dtype, torch.device, torch.Size)
 # modules whose instances are not user state (walking them finds nothing a callable's result depends on, only noise)
-_OPAQUE_MODULE_PREFIXES = ("pytorch_mppi_amd", "threading", "logging", "ctypes", "torch.cuda", "torch._C", "torch.distributed",
-                           "torch.optim", "torch.utils", "multiprocessing", "concurrent", "socket", "io", "_io", "matplotlib")
+_OPAQUE_MODULE_PREFIXES = ("pytorch_mppi_amd", "threading", "logging", "ctypes", "torch.cuda", "torch._C",
+        "torch.distributed",
+                           "torch.optim", "torch.utils", "multiprocessing", "concurrent", "socket", "io", "_io",
+                                   "matplotlib")
 _MODULE_STATE = ("_parameters", "_buffers", "_modules", "training")
 
 
 class Path:
-    """A place a value is read from: `holder[key]` (dictionaries: instance `__dict__`, globals, `Module._parameters`, ...;
+    """A place a value is read from: `holder[key]` (dictionaries: instance `__dict__`, globals, `Module._parameters`,
+    ...;
     lists), `holder.cell_contents` (closure cells) or `getattr(holder, key)`."""
     __slots__ = ("kind", "holder", "key", "_owner")
 
@@ -78,7 +85,8 @@ class StateWatch:
         self.places = []            # (Path, snapshot kind, reference object / value)
         self.truncated = False      # the walk stopped at max_places: rely on the spot-check for the rest
         self.dropped = 0
-        self.dropped_paths = []     # the places forgotten by drop(): a watch rebuilt over the same roots forgets them again
+        # the places forgotten by drop(): a watch rebuilt over the same roots forgets them again
+        self.dropped_paths = []
         self.benign = {}            # (id(holder), key) -> benign moves in a row (mppi.MPPI._settle_moved)
         self._seen = set()
         self._keep = []             # objects whose id() is in _seen must stay alive for the ids to stay unique
@@ -102,7 +110,8 @@ class StateWatch:
             return (path, "v", v)
         if isinstance(v, torch.Tensor):
             trainable = isinstance(v, torch.nn.Parameter) or v.requires_grad
-            # a trainable tensor's VALUES are run-time parameters of the functor (jit.CustomModel.refresh_params follows its
+            # a trainable tensor's VALUES are run-time parameters of the functor (jit.CustomModel.refresh_params follows
+            # its
             # version counter and storage): only its identity is watched here
             return (path, "T" if trainable else "t", (v, v._version, v.data_ptr()))
         if isinstance(v, np.ndarray):
@@ -200,7 +209,8 @@ class StateWatch:
     def _compile(self):
         """split the places by what has to be compared and how they are read (tight loops in `changed`: most places are
         dictionary slots compared by identity, ~70 ns each)"""
-        self._ident_d, self._ident_o, self._vals_d, self._vals_o, self._tens, self._arrs, self._lens = [], [], [], [], [], [], []
+        self._ident_d, self._ident_o, self._vals_d, self._vals_o = [], [], [], []
+        self._tens, self._arrs, self._lens = [], [], []
         for i, (path, kind, ref) in enumerate(self.places):
             if isinstance(path.holder, _Len):
                 self._lens.append((i, path.holder.c, ref))
@@ -263,7 +273,8 @@ class StateWatch:
         self._compile()
 
     def forget(self, paths):
-        """drop the places at these paths (tensors promoted to run-time parameters: jit.CustomModel.refresh_params follows
+        """drop the places at these paths (tensors promoted to run-time parameters: jit.CustomModel.refresh_params
+        follows
         what sits there from now on -- identity, version counter, storage -- and re-gathers instead of re-tracing)"""
         idx = [i for i, (p, _, _) in enumerate(self.places)
                if any(p.kind == q.kind and p.holder is q.holder and p.key == q.key for q in paths)]
@@ -285,7 +296,8 @@ class StateWatch:
         for i in idx:
             path, kind, ref = self.places[i]
             v = path.get()
-            if kind in ("t", "o", "v") and isinstance(v, torch.Tensor) and v.is_floating_point() and 0 < v.numel() <= max_numel \
+            if kind in ("t", "o", "v") and isinstance(v,
+                    torch.Tensor) and v.is_floating_point() and 0 < v.numel() <= max_numel \
                     and not (isinstance(v, torch.nn.Parameter) or v.requires_grad) and path.kind in ("d", "c", "l"):
                 out.append(path)
         return out

@@ -32,9 +32,10 @@ def timeit(name, ctrl, state, n=None):
     t0 = time.perf_counter()
     for _ in range(n):
         ctrl.command(state)
+    issue = (time.perf_counter() - t0) / n          # the host's share: how long the Python thread needs to get through a command
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print(f"{name:34s} {dt * 1e3:8.4f} ms/command   {K / dt:10.3e} rollouts/s", flush=True)
+    print(f"{name:34s} {dt * 1e3:8.4f} ms/command   {K / dt:10.3e} rollouts/s   (host issue {issue * 1e6:6.1f} us/command)", flush=True)
 
 
 kw = dict(num_samples=K, horizon=T, device=dev, lambda_=50.0)
