@@ -37,7 +37,8 @@ ran and why (`config.process_model`, `config.process_model_choice`, `host_issue_
 exchange is staged (device copies / gloo): a test rig for the code path, labelled as such.
 `cpu_baseline` times the oracle (CPU restatement of the reference path, kind "port") on the same
 workload at the full K on the host cores (at most 3 timed calls); the live reference itself, timed
-in the build container beside the port, is on record in profiles/r02_cpu_reference_vs_port.txt.
+in the build container beside the port, is on record in profiles/r06_cpu_reference_vs_port.txt and its
+ratio to the port travels in the line (`cpu_baseline.live_reference_over_port`, a lookup).
 """
 import argparse
 import json
@@ -165,6 +166,15 @@ def cpu_baseline(wl, budget_s=15.0):
            "sample": f"oracle command() incl. randn, K={K} of {Kfull}, T={T}, nx={nx}, nu={nu}, fp32, "
                      f"median of {n} calls ({t * 1e3:.1f} ms each)",
            "state_evals_per_s": K * T / t}
+    try:
+        # how the port stands to the LIVE reference on the same workload (timed side by side in the build container, where
+        # /root/reference exists; a lookup -- this box has no reference to time): VERDICT r05 next #7
+        ref = json.load(open(os.path.join(ROOT, "profiles", "cpu_reference_vs_port.json")))
+        out["live_reference_over_port"] = ref[wl]["live_reference_over_port"]
+        out["live_reference_over_port_source"] = ref["source"] + " (reference time / port time, build container; a lookup)"
+        out["estimated_live_reference_value"] = out["value"] / ref[wl]["live_reference_over_port"]
+    except Exception:
+        out["live_reference_over_port"] = None
     try:
         with torch.device("cuda"):
             tg, ng = _time_oracle(wl, Kfull, 5.0, 30, torch.cuda.synchronize)
@@ -303,6 +313,71 @@ def _onchip_valu_lookup(workload, k1_us):
             "source": "profiles/pmc_onchip_valu.json (rocprofv3 --pmc passes: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES, SQ_WAIT_*; "
                       "FETCH_SIZE doubled per the gfx950 note) -- a lookup, not measured in this run; `issue_floor_us` = the share x this "
                       "run's measured launch time"}
+
+
+def mlp_shapes(pm, device, lib, N):
+    """Dense-MLP dynamics beyond C4's one shape (shape source /root/reference/tests/pendulum_approximate.py:47-67):
+    K = 65536, T = 64, x' = x + 0.1 (W2 tanh(W1 [x;u] + b1) + b2), per (nx, nu, hidden) and per kernel form -- the split-operand
+    matrix-core kernel (the default where it is instantiated), the exact-fp32 form (MPPI_MLP_EXACT=1: fp32 MFMA for (16,4), per lane
+    otherwise) and the per-lane form (MPPI_MLP_VALU=1) -- the command's time, K1's launch time (device-clock stamps + the C4
+    dispatch offset), the algorithmic fp32 TFLOP/s of the two dense layers over K1's time, and which kernel ran."""
+    K, T = 65536, 64
+    out = {}
+    for nx, nu, H in ((16, 4, 256), (12, 6, 128), (8, 2, 64), (16, 8, 256), (32, 8, 256)):
+        rec = {}
+        flops = 2.0 * ((nx + nu) * H + H * nx) * K * T
+        native = bool(N.model_supported(N.MODEL_MLP, nx, nu, N.F32, H))
+        for form, env in (("split", {}), ("exact", {"MPPI_MLP_EXACT": "1"}), ("per_lane", {"MPPI_MLP_VALU": "1"})):
+            if not native and form != "split":
+                continue
+            for k_, v_ in env.items():
+                os.environ[k_] = v_
+            try:
+                torch.manual_seed(0)
+                model = pm.models.MLPResidual.random(nx, nu, H, seed=2)
+                c = pm.MPPI(model.dynamics, model.running_cost, nx, torch.eye(nu), num_samples=K, horizon=T, device=device, lambda_=1.0,
+                            U_init=torch.randn(T, nu) * 0.02, rng="philox", seed=1234, auto_jit=False)
+                x = torch.randn(nx).to(device)
+                c.command(x)
+                c.lambda_ = float(c.cost_total.float().std())
+                n = 8 if (form == "split" and native) else 3
+                for _ in range(2):
+                    c.command(x)
+                n0 = int(lib.mppi_stat_mlp_split_launches())
+                lib.mppi_profile_enable(STAMPS_ONLY)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    c.command(x)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / n
+                dv, _ = N.profile_read_launches()
+                lib.mppi_profile_enable(0)
+                dvs = _stats(dv)
+                if not native:
+                    kern = "callback path: no native kernel (nx > 16 needs a second output tile and layer-1 k-step: not built)"
+                elif int(lib.mppi_stat_mlp_split_launches()) - n0 >= n:
+                    kern = "rollout_mlp_split_kernel (bf16x3 / fp16x2 operands on v_mfma_f32_16x16x32)"
+                elif form == "exact" and (nx, nu) == (16, 4):
+                    kern = "rollout_mlp_mfma_kernel (v_mfma_f32_16x16x4_f32)"
+                else:
+                    kern = "rollout_cost_kernel<MlpModel> (one lane per sample, fma chains)"
+                r = {"ms_per_step": dt * 1e3, "kernel": kern}
+                if dvs and native:
+                    k1 = dvs["avg"] + DISPATCH_OFFSET_US_BY_WORKLOAD["c4"]
+                    r.update(k1_avg_us=k1, k1_algorithmic_tflops=flops / (k1 * 1e-6) / 1e12)
+                rec[form] = r
+                del c
+            except Exception as e:                   # an extra: never a reason to lose the bench line
+                rec[form] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            finally:
+                for k_ in env:
+                    os.environ.pop(k_, None)
+        out[f"nx{nx}_nu{nu}_H{H}"] = rec
+    out["note"] = ("K = 65536, T = 64, fp32, rng = philox (generator launch -> rows -> K1 -> K3 -> K4); k1_algorithmic_tflops = "
+                   "2 ((nx + nu) H + H nx) K T / k1_avg_us.  The split kernel lays every shape into C4's 16-state x 32-slot tile: its "
+                   "instruction stream -- and matrix-pipe share -- is C4's whatever (nx, nu <= 16, 8) is")
+    return out
 
 
 def latency_synced(ctrl, x0, warmup=3, iters=20):
@@ -1041,6 +1116,8 @@ def main():
             others[wl] = rec
             del cw
         out["other_workloads"] = others
+        if args.workload == "c3":
+            out["mlp_shapes"] = mlp_shapes(pm, device, lib, N)
         # small / typical problem sizes at the headline's T, nx, nu (launch-bound, and not in the line until now):
         # which form the command takes and what it costs, pipelined and by the reference's synchronised protocol
         if args.workload == "c3":

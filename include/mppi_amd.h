@@ -360,6 +360,9 @@ int64_t mppi_stat_single_launch_commands(void);
  * when given).  Problems outside that scope with p->z == NULL run K1 + K3 with the rows generated twice, as before.
  * MPPI_ONCHIP=0 in the environment disables the form (A/B runs).  Count of commands that took it: */
 int64_t mppi_stat_onchip_commands(void);
+/* ABI 22: launches of the split-operand matrix-core K1 of MPPI_MODEL_MLP (csrc/rollout_mlp_split.hip) in this process -- which
+ * kernel a dense-MLP command ran is otherwise invisible to the caller (the per-lane form gives the same results to parity) */
+int64_t mppi_stat_mlp_split_launches(void);
 /* ABI 19: the form the CALLING THREAD's last mppi_command took (thread-local; the two counters above are process-wide and
  * cannot answer "did my command run on chip" once two controllers command from two threads). */
 #define MPPI_FORM_NONE 0           /* no command yet on this thread, or the last one failed before its first launch */

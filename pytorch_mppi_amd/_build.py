@@ -22,7 +22,7 @@ SOURCES = ["capi.hip", "dist.hip", "group.hip", "update.hip", "rollout_pendulum.
 # translation units: (source, object name, extra flags).  The two heaviest sources are compiled as several units each
 # (groups of model dimensions selected with a define) so that the parallel build is not one long compile
 _GROUPS = {"rollout_integrator.hip": ("MPPI_INTEGRATOR_GROUP", 4), "rollout_linear_goal.hip": ("MPPI_LINEAR_GROUP", 3),
-           "rollout_mlp.hip": ("MPPI_MLP_GROUP", 3)}
+           "rollout_mlp.hip": ("MPPI_MLP_GROUP", 6), "rollout_mlp_split.hip": ("MPPI_SPLIT_GROUP", 2)}
 
 
 def _units():
@@ -40,7 +40,8 @@ def _units():
                     "rollout_mlp_g1.o": 75,
             "rollout_mlp_g2.o": 75, "rollout_pendulum.o": 70, "rollout_linear_goal_g1.o": 68,
                     "rollout_integrator_g3.o": 45,
-            "rollout_mlp_split.o": 27}
+            "rollout_mlp_g3.o": 75, "rollout_mlp_g4.o": 75, "rollout_mlp_g5.o": 75, "rollout_mlp_split_g0.o": 30,
+            "rollout_mlp_split_g1.o": 35}
     return sorted(units, key=lambda u: -cost.get(u[1], 5))
 # -ffp-contract=fast: mul+add pairs fuse into v_fma / v_pk_fma.  torch eager rounds twice where
 # the kernels round once, a <= 1 ulp difference per operation that the parity tests bound
@@ -62,16 +63,13 @@ EXTRA = {"update.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
          "rollout_integrator.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
          "rollout_linear_goal.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
          # the torch.randn stream, bit for bit: rocrand's Box-Muller with the contraction rule the library itself is
-         # built
-         # with (a later -ffp-contract wins; with =fast one value in ~10^5 differs from torch's in its last bit)
+         # built with (a later -ffp-contract wins; with =fast one value in ~10^5 differs from torch's in its last bit)
          "noise_torch.hip": ["-ffp-contract=on"]}
 K1_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]     # for translation units built around csrc/rollout.hpp (jit.py)
 # heavy user models (jit.py) only: the SLP vectorizer pairs the products of a traced network into v_pk_mul_f32 before fp
 # contraction sees them (570 mul + add pairs instead of fmas in a 3700-operation step); packed fp32 arithmetic is no
-# faster
-# than two scalar instructions on gfx950.  Light models keep the flags of the built-in units (a snippet model that
-# restates a
-# built-in one compiles to the same kernel, bit for bit: tests/test_gpu_jit_models.py)
+# faster than two scalar instructions on gfx950.  Light models keep the flags of the built-in units (a snippet model
+# that restates a built-in one compiles to the same kernel, bit for bit: tests/test_gpu_jit_models.py)
 K1_HEAVY_FLAGS = ["-fno-slp-vectorize"]
 
 
@@ -99,10 +97,8 @@ def _deps_hash():
 # ---- evidence guard: which sources a measured kernel was built from
 # -----------------------------------
 # bench.py quotes counter passes committed under profiles/ (pmc_*.json).  Each such entry records the hash below of the
-# kernel's
-# translation unit AS IT WAS WHEN THE COUNTERS WERE COLLECTED; bench.py prints `lookup_stale` and
-# tests/test_lookup_evidence.py
-# fails when a committed entry no longer matches the tree.
+# kernel's translation unit AS IT WAS WHEN THE COUNTERS WERE COLLECTED; bench.py prints `lookup_stale` and
+# tests/test_lookup_evidence.py fails when a committed entry no longer matches the tree.
 KERNEL_UNITS = {"rollout_onchip_kernel": "rollout_integrator.hip", "rollout_cost_kernel": "rollout_integrator.hip",
                 "rollout_kmppi_kernel": "rollout_integrator.hip", "rollout_mlp_split_kernel": "rollout_mlp_split.hip",
                 "rollout_mlp_mfma_kernel": "rollout_mlp_mfma.hip", "weights_partial_rows_kernel": "noise_torch.hip",
@@ -186,6 +182,60 @@ def build(force=False, verbose=True):
     if verbose:
         print(f"[pytorch_mppi_amd] built {LIB}", file=sys.stderr)
     return LIB
+
+
+# ---- host AddressSanitizer variant (CPU only -- the pool refuses GPU ASan)
+# ----------
+# The C-ABI's own host code (argument validation, workspace carving, the RCCL binding, the device group's threads and
+# hand-over protocol: capi.hip, dist.hip, group.hip) compiled with -fsanitize=address on the HOST side only
+# (-Xarch_host: the device code is the product's) and linked with the product build's other objects into
+# libmppi_amd_asan.so.  tests/test_abi_asan.py drives the
+# refusal paths of every entry point through it from a sanitized C client.
+ASAN_UNITS = ["capi.hip", "dist.hip", "group.hip"]
+ASAN_LIB = os.path.join(HERE, "libmppi_amd_asan.so")
+
+
+def asan_runtime_dir():
+    """directory of clang's shared ASan runtime (libclang_rt.asan-x86_64.so), or None"""
+    import glob
+    for base in ("/opt/rocm/lib/llvm/lib/clang", "/opt/rocm/llvm/lib/clang"):
+        for p in sorted(glob.glob(os.path.join(base, "*", "lib", "linux", "libclang_rt.asan-x86_64.so"))):
+            return os.path.dirname(p)
+    return None
+
+
+def build_asan(verbose=False):
+    """libmppi_amd_asan.so (see above); needs the product build's objects (build() runs first).  Returns the path."""
+    build(verbose=verbose)
+    hipcc = _hipcc()
+    d = os.path.join(CSRC, "build_asan")
+    os.makedirs(d, exist_ok=True)
+    key = hashlib.sha256((_deps_hash() + "asan-1").encode()).hexdigest()
+    stamp = ASAN_LIB + ".stamp"
+    if os.path.exists(ASAN_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == key:
+        return ASAN_LIB
+    san = ["-O1", "-g", "-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fno-omit-frame-pointer"]
+
+    def one(src):
+        obj = os.path.join(d, src.replace(".hip", ".o"))
+        cmd = [hipcc, *[f for f in FLAGS if f != "-O3"], *san, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc (ASan host build) failed on {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=len(ASAN_UNITS)) as ex:
+        objs = list(ex.map(one, ASAN_UNITS))
+    skip = {u.replace(".hip", ".o") for u in ASAN_UNITS}
+    others = [os.path.join(OBJ_DIR, u[1]) for u in _units() if u[1] not in skip]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-shared-libasan", "-o", ASAN_LIB,
+            *objs, *others, "-ldl"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link (ASan host build) failed:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(key)
+    return ASAN_LIB
 
 
 if __name__ == "__main__":

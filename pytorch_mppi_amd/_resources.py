@@ -4,8 +4,7 @@
 --offloading` writes them next to its input), reads the AMDGPU metadata note of each gfx950 code object (`llvm-readelf
 --notes`) and returns {demangled kernel name: {vgpr, agpr, sgpr, scratch, vgpr_spill, sgpr_spill, lds}}.  Used by
 tests/test_kernel_resources.py (a kernel that starts spilling is a performance regression no parity test sees: VERDICT
-r03
-weak #2, the KMPPI-fused K1 went from 20 B to 528 B of scratch and from 70.7 to 94 us unnoticed) and by
+r03 weak #2, the KMPPI-fused K1 went from 20 B to 528 B of scratch and from 70.7 to 94 us unnoticed) and by
 tools/kernel_resources.py.  Needs no GPU."""
 import os
 import re

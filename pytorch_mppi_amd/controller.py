@@ -47,8 +47,7 @@ class MPPI(Draws, Forms, JitGlue):
 
     def __new__(cls, *args, devices=None, **kw):
         # devices=[d0, d1, ...] (two or more): ONE Python process commanding on several GPUs -- the object is a device
-        # group
-        # (pytorch_mppi_amd/group.py: one shard controller per device, a subclass of `cls`); SURVEY.md 8b / 8e
+        # group (pytorch_mppi_amd/group.py: one shard controller per device, a subclass of `cls`); SURVEY.md 8b / 8e
         if devices is not None and len(devices) > 1:
             from .group import DeviceGroup, group_class
             if not issubclass(cls, DeviceGroup):
@@ -175,10 +174,8 @@ class MPPI(Draws, Forms, JitGlue):
         if rng not in ("torch", "torch-native", "philox", "philox7"):
             raise ValueError("rng must be 'torch', 'torch-native', 'philox' or 'philox7'")
         # rng="philox7": the engine's generator with Philox4x32-7 (Random123's philox4x32_R<7>: the fewest rounds that
-        # pass BigCrush)
-        # instead of -10 -- another stream, everything else as rng="philox"; 30 % fewer of the multiplies the on-chip
-        # command's
-        # time is made of (MppiProblem.philox_rounds; oracle/philox.py `rounds`)
+        # pass BigCrush) instead of -10 -- another stream, everything else as rng="philox"; 30 % fewer of the multiplies
+        # the on-chip command's time is made of (MppiProblem.philox_rounds; oracle/philox.py `rounds`)
         self.philox_rounds = 7 if rng == "philox7" else 10
         self.rng = rng = "philox" if rng == "philox7" else rng
         self.philox_store = True   # rng="philox": K1 stores the generated rows, K3 re-reads them
@@ -198,36 +195,31 @@ class MPPI(Draws, Forms, JitGlue):
         self.philox_fill = None
         # rng="philox": the on-chip command (csrc/rollout_onchip.hpp) -- no (K,T,nu) array at all: one launch generates,
         # rolls out, keeps the bounded noise in accumulation registers / LDS and leaves one partial record per
-        # workgroup,
-        # a second one combines them.  None: whenever the problem is in its scope (fp32, diagonal Sigma, plain MPPI,
-        # M = 1, no sampler rows) and too large for the single-launch form; True / False: force / forbid.
+        # workgroup, a second one combines them.  None: whenever the problem is in its scope (fp32, diagonal Sigma,
+        # plain MPPI, M = 1, no sampler rows) and too large for the single-launch form; True / False: force / forbid.
         # (a full Sigma is coloured in the lane: L z + mu per timestep out of LDS)
         self.philox_onchip = None
         self._onchip_refused = False
         # rng="torch": read (K,T,nu) in place when possible
         self.ktn_direct = os.environ.get("MPPI_KTN_DIRECT", "1") != "0"
         # the on-chip command: let what fits neither registers nor LDS wait in memory (one array per controller,
-        # allocated on first
-        # use) instead of generating it twice
+        # allocated on first use) instead of generating it twice
         self.onchip_spill = os.environ.get("MPPI_ONCHIP_SPILL", "1") != "0"
         self._spill = None
         # rng="torch": compute torch.randn's values straight into the engine's rows (see _torch_stream_fill); off: call
         # torch.randn and read / convert its (K,T,nu) array
         self.torch_rows = os.environ.get("MPPI_TORCH_ROWS", "1") != "0"
         # ... and the NEXT command's draw inside this command's K3 launch (ABI 21; adopted at the next command when the
-        # generator
-        # is where that assumed: _torch_stream_fill).  Costs a second row buffer
+        # generator is where that assumed: _torch_stream_fill).  Costs a second row buffer
         self.draw_ahead = os.environ.get("MPPI_DRAW_AHEAD", "1") != "0"
         # (draws of fewer normals than this keep their own tiny launch: carving them into K3's few workgroups costs more
         # than it saves
         # -- profiles/r05_small_k_sweep.txt)
         self.draw_ahead_min = int(os.environ.get("MPPI_DRAW_AHEAD_MIN", str(1 << 19)))
         # the same for the ENGINE's generator (rng="philox" with rows in memory, MPPI_NEXT_DRAW_PHILOX): built,
-        # bit-exact, and OFF --
-        # that generator launch is already bound by its 201 MB of stores (34 us at C3), not by the VALU, and a launch
-        # that reads K3's
-        # rows while it writes the next ones moves the same 403 MB slower (mixed traffic: 5.3 TB/s against 5.9 one after
-        # the other;
+        # bit-exact, and OFF -- that generator launch is already bound by its 201 MB of stores (34 us at C3), not by the
+        # VALU, and a launch that reads K3's rows while it writes the next ones moves the same 403 MB slower (mixed
+        # traffic: 5.3 TB/s against 5.9 one after the other;
         # C3 rows-in-memory command 0.1186 ms with, 0.1096 without; profiles/r05_draw_ahead_forms.txt)
         self.draw_ahead_philox = os.environ.get("MPPI_DRAW_AHEAD_PHILOX", "0") == "1"
         # (shape key, generator, seed, offset, rows): generated, waiting for the next command
@@ -256,20 +248,17 @@ class MPPI(Draws, Forms, JitGlue):
         self.jit_note = None
         self._jit_pending = None
         # auto_jit: True / "sync" = trace and compile now (construction blocks for the hipcc run unless the object is
-        # cached);
-        # "async" = trace now, compile in a background thread -- commands run the callbacks until the fused kernels are
-        # there; False / "0" = off.  None: the environment's MPPI_AUTO_JIT (default "async")
+        # cached); "async" = trace now, compile in a background thread -- commands run the callbacks until the fused
+        # kernels are there; False / "0" = off.  None: the environment's MPPI_AUTO_JIT (default "async")
         mode = _auto_jit_mode(auto_jit if auto_jit is not None else os.environ.get("MPPI_AUTO_JIT", "async"))
         # traced callables are re-checked against the live ones: a flat watch of the places they can read from on every
         # command (watch.StateWatch), and functor-against-callables on a small random batch on the device at adoption
-        # and
-        # every MPPI_JIT_CHECK_EVERY commands (default 256; 0 = never) -- _check_traced / _spot_check below
+        # and every MPPI_JIT_CHECK_EVERY commands (default 256; 0 = never) -- _check_traced / _spot_check below
         self._jit_mode = mode
         self._jit_check_every = int(os.environ.get("MPPI_JIT_CHECK_EVERY", "256"))
         self._jit_cmds = 0             # fused commands since the current traced model was adopted
         # share of the issuing time the spot-checks may take: the interval is stretched beyond `_jit_check_every` where
-        # a check
-        # (~1 ms) would cost more than this (0: never stretched)
+        # a check (~1 ms) would cost more than this (0: never stretched)
         self._jit_check_share = float(os.environ.get("MPPI_JIT_CHECK_SHARE", "0.01"))
         self._jit_next_check = 0       # ... and the command at which the next on-device spot-check is due
         self._jit_last_check = None    # (command number, time) of the previous one
@@ -467,12 +456,11 @@ class MPPI(Draws, Forms, JitGlue):
 
     def _prepare(self, state, shift):
         """The host part of a command up to (not including) the fused path's launch: the problem block with this
-        command's
-        draw, buffers and state bound.  `p._deferred`: the fused launch is still to be issued -- by `_launch_prepared`
-        on
+        command's draw, buffers and state bound.  `p._deferred`: the fused launch is still to be issued -- by
+        `_launch_prepared` on
         this thread, or by the device group's worker thread of this shard's device (group.py, csrc/group.hip).  The
-        generic
-        (callback) path cannot be handed over: it has run K1's stand-in, K3 and K4 when this returns (`_deferred`
+        generic (callback) path cannot be handed over: it has run K1's stand-in, K3 and K4 when this returns
+        (`_deferred`
         False)."""
         lib = N.lib()
         self.state = self._to_state(state)
@@ -699,9 +687,8 @@ class GraphedCommand:
     def __init__(self, ctrl, state, shift, warmup):
         self.ctrl = ctrl
         # rng="torch": torch.randn registers its generator with the graph and replays advance it; the engine's own
-        # launch of
-        # the same values (MPPI._torch_stream_fill) takes the generator's offset as an argument, which a graph would
-        # freeze
+        # launch of the same values (MPPI._torch_stream_fill) takes the generator's offset as an argument, which a graph
+        # would freeze
         ctrl._in_capture = True
         try:
             self._capture(ctrl, state, shift, warmup)

@@ -619,6 +619,7 @@ extern "C" int64_t mppi_stat_single_launch_commands(void) { return g_single_laun
 static std::atomic<long long> g_onchip_commands{0};
 static std::atomic<long long> g_kmppi_onchip_updates{0};
 extern "C" int64_t mppi_stat_onchip_commands(void) { return g_onchip_commands.load(); }
+extern "C" int64_t mppi_stat_mlp_split_launches(void) { return (int64_t)mlp_split_launches(); }
 // which form the calling THREAD's last mppi_command took (the counters above are process-wide: with two controllers
 // commanding from two threads, "did MY command run on chip" cannot be read off a shared count -- ADVICE r03)
 static thread_local int t_last_form = MPPI_FORM_NONE;

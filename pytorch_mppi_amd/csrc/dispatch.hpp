@@ -22,4 +22,5 @@ int rollout_mlp_mfma(const KArgs<float>& a, hipStream_t st);
 // bf16 matrix cores with three-piece operand splitting, fp32-level accuracy (rollout_mlp_split.hip)
 bool mlp_split_supported(int nx, int nu, int hidden);
 int rollout_mlp_split(const KArgs<float>& a, hipStream_t st);
+long long mlp_split_launches();      // successful launches of it in this process (mppi_stat_mlp_split_launches)
 }  // namespace mppi

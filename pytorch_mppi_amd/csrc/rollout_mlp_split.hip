@@ -1,6 +1,9 @@
 // K1 for the 2-layer MLP residual model on the 16-bit matrix cores with fp32-level accuracy:
 // every fp32 operand is split into 16-bit pieces and the significant piece products are accumulated
-// in fp32 -- BASELINE.json configs[3..4]: nx=16, nu=4, hidden=256.
+// in fp32 -- BASELINE.json configs[3..4]: nx=16, nu=4, hidden=256; since round 6 any nx <= 16, nu <= 8 that is instantiated
+// (template parameters NX, NU: the model is laid into the same 16-state x (16 + 8 + bias)-input tile, rows and k-slots beyond its
+// dimensions zero -- the instruction stream, and with it the matrix-pipe share, is C4's; reference shape source:
+// tests/pendulum_approximate.py:47-67).
 //
 //   x' = x + s * (W2 tanh(W1 [x;u] + b1) + b2),   cost = sum x^2
 //
@@ -27,8 +30,8 @@
 // tools/micro/mfma_bf16_layout.hip): A[i][k] and B[k][j] hold k = 8g + e (e = 0..7) at i = j = s,
 // D[i][j] holds i = 4g + r (r = 0..3) at j = s.
 //   layer 1   H^T (16 hidden x 16 samples) = A1[m] (16 x 32) . B1 (32 x 16)    per hidden tile m
-//       k-slot (g, e):  e < 4 -> state x[4g+e]   e = 4 -> control u[g]   e = 5, g = 0 -> constant 1
-//       (the bias b1 rides in that column of A1)   e = 6, 7 -> 0
+//       k-slot (g, e):  e < 4 -> state x[4g+e]   e = 4 -> control u[g]   (nu > 4: e = 5 -> control u[g+4])
+//       e = 5 (nu <= 4) | 6 (nu > 4), g = 0 -> constant 1 (the bias b1 rides in that column of A1)   the rest -> 0
 //       => B1 is built from what lane (g,s) already holds: the layer-2 output rows 4g+r and its own
 //          control dimension g.
 //   layer 2   O^T (16 states x 16 samples) = sum_j A2[j] (16 x 32) . B2[j] (32 x 16),  j = 0..H/32-1
@@ -39,6 +42,7 @@
 // sample tiles per wave.  tanh = 1 - 2r, r = 1 / (2^x + 1): the affine parts are folded into the
 // weights exactly as in the fp32 kernel, only v_exp + v_add + v_rcp run per hidden unit.
 #include <hip/hip_ext.h>
+#include <atomic>
 #include <type_traits>
 #include "actions.hpp"
 #include "dispatch.hpp"
@@ -54,7 +58,6 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr float B3_EXP2_SCALE = 2.8853900817779268f;   // 2 * log2(e)
-constexpr int B3_NX = 16, B3_NU = 4, B3_NI = 20;
 constexpr int B3_NT = 2;                                // sample tiles (of 16) per wave
 #ifndef MPPI_SPLIT_VPU
 #define MPPI_SPLIT_VPU 2
@@ -176,10 +179,16 @@ __device__ __forceinline__ float pick4(const float (&z)[4], int g) {
   return (g & 2) ? hi : lo;
 }
 
-template <int HT /* hidden / 16 */, int NOISE, bool DIAG>
+template <int HT /* hidden / 16 */, int NOISE, bool DIAG, int NX = 16, int NU = 4>
 __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const KArgs<float> a_in) {
   static_assert(HT % 2 == 0, "layer 2 consumes hidden tiles in pairs");
-  constexpr int NU = B3_NU, NX = B3_NX, NT = B3_NT, H = HT * 16, HP = HT / 2;
+  static_assert(NX >= 1 && NX <= 16 && NU >= 1 && NU <= 8, "one 16-state output tile, one 32-slot layer-1 k-step");
+  // lane group g owns state rows 4g..4g+3 and the control dimensions g (and g + 4 where nu > 4); what lies beyond the model's
+  // nx / nu is zero in the weights and in the inputs.  (NX, NU) = (16, 4): every guard below folds away.
+  constexpr int NC = NU > 4 ? 2 : 1, BIAS_E = 4 + NC, NI = NX + NU;
+  constexpr int NT = B3_NT, H = HT * 16, HP = HT / 2;
+  // rows that are not one row-of-4 per timestep (nu != 4) are read component-wise only: external rows, diagonal / coloured form
+  static_assert(NU == 4 || (NOISE != MPPI_NOISE_PHILOX && (DIAG || NOISE == MPPI_NOISE_ACTIONS)), "nu != 4: ROW1 forms only");
   const KArgs<float> a = env_view(a_in);
   stamp_entry(a.tstamp);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -191,30 +200,38 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int g = lane >> 4, s = lane & 15;
 
-  // ---- parameters: blob = W1 (H,20) | b1 (H) | W2 (16,H) | b2 (16) | res_scale | qx (16) | qu (4) ----
+  // ---- parameters: blob = W1 (H,nx+nu) | b1 (H) | W2 (nx,H) | b2 (nx) | res_scale | qx (nx) | qu (nu) ----
   const float* __restrict__ W1 = a.mp;
-  const float* __restrict__ b1 = W1 + H * B3_NI;
+  const float* __restrict__ b1 = W1 + H * NI;
   const float* __restrict__ W2 = b1 + H;
   const float* __restrict__ b2 = W2 + NX * H;
   const float rs = b2[NX];
-  // cost = sum_i qx_i x_i^2 + sum_n qu_n u_n^2: this lane's four state rows 4g + r and its control dimension g
+  // cost = sum_i qx_i x_i^2 + sum_n qu_n u_n^2: this lane's four state rows 4g + r and its control dimension(s) g (, g + 4)
   float qx4[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) qx4[r] = b2[NX + 1 + 4 * g + r];
-  const float qu_g = b2[NX + 1 + NX + g];
+  for (int r = 0; r < 4; ++r) qx4[r] = 4 * g + r < NX ? b2[NX + 1 + 4 * g + r] : 0.f;
+  bool own[NC];
+  float qu_c[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    own[c] = g + 4 * c < NU;
+    qu_c[c] = own[c] ? b2[NX + 1 + NX + g + 4 * c] : 0.f;
+  }
 
   // A fragments, three bf16 planes each, resident for the whole launch
   Planes A1[HT];
   PlanesH A2[HP];
 #pragma unroll
   for (int m = 0; m < HT; ++m) {
-    const float* __restrict__ row = W1 + (16 * m + s) * B3_NI;     // hidden unit 16m + s
+    const float* __restrict__ row = W1 + (16 * m + s) * NI;        // hidden unit 16m + s
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = B3_EXP2_SCALE * row[4 * g + e];
-    v[4] = B3_EXP2_SCALE * row[NX + g];
-    v[5] = g == 0 ? B3_EXP2_SCALE * b1[16 * m + s] : 0.f;          // bias column (B1 holds 1 there)
-    v[6] = 0.f; v[7] = 0.f;
+    for (int e = 0; e < 4; ++e) v[e] = 4 * g + e < NX ? B3_EXP2_SCALE * row[4 * g + e] : 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[4 + c] = own[c] ? B3_EXP2_SCALE * row[NX + g + 4 * c] : 0.f;
+    v[BIAS_E] = g == 0 ? B3_EXP2_SCALE * b1[16 * m + s] : 0.f;     // bias column (B1 holds 1 there)
+#pragma unroll
+    for (int e = BIAS_E + 1; e < 8; ++e) v[e] = 0.f;
     A1[m] = split_pack8(v);
   }
   float rowsum = 0.f;                                              // of row s of W2, this lane's quarter
@@ -223,7 +240,7 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float w = W2[s * H + 16 * (2 * j + (e >> 2)) + 4 * g + (e & 3)];   // state row s, hidden h(j,g,e)
+      const float w = s < NX ? W2[s * H + 16 * (2 * j + (e >> 2)) + 4 * g + (e & 3)] : 0.f;   // state row s, hidden h(j,g,e)
       rowsum += w;
       v[e] = -2.0f * w;
     }
@@ -243,7 +260,7 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
   rowsum += __shfl_xor(rowsum, 32, WAVE);
   float b2r[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) b2r[r] = b2[4 * g + r] + __shfl(rowsum, 4 * g + r, WAVE);   // D rows are 4g+r
+  for (int r = 0; r < 4; ++r) b2r[r] = (4 * g + r < NX ? b2[4 * g + r] : 0.f) + __shfl(rowsum, 4 * g + r, WAVE);   // D rows are 4g+r
 
   ActionConsts<float, NU> ac;
   ac.load(a, DIAG ? nullptr : fac);
@@ -271,7 +288,14 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
     G[j] = a.lambda_ * gg;
   }
   __syncthreads();
-  const float sd_g = a.coloured ? 1.f : a.L[g * NU + g], lo_g = a.umin[g], hi_g = a.umax[g];
+  float sd_c[NC], lo_c[NC], hi_c[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int n = own[c] ? g + 4 * c : 0;
+    sd_c[c] = a.coloured ? 1.f : a.L[n * NU + n];
+    lo_c[c] = a.umin[n];
+    hi_c[c] = a.umax[n];
+  }
   float Lrow[NU];
   if constexpr (!DIAG) {
 #pragma unroll
@@ -284,7 +308,7 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
     const int kbase = chunk * B3_SAMPLES + wv * (NT * 16);
     int kk[NT], orow[NT];
     bool act[NT];
-    float x[NT][4], cpart[NT], ppart[NT], vprev[NT];
+    float x[NT][4], cpart[NT], ppart[NT], vprev[NT][NC];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int kraw = kbase + 16 * i + s;
@@ -293,23 +317,32 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
       orow[i] = overwrite_row(a, a.k_offset + kk[i]);
       const float* __restrict__ s0 = a.state_per_sample ? a.state + (long long)kk[i] * NX : a.state;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x[i][r] = s0[4 * g + r];
+      for (int r = 0; r < 4; ++r) x[i][r] = 4 * g + r < NX ? s0[4 * g + r] : 0.f;
       cpart[i] = 0.f;
       ppart[i] = 0.f;
-      vprev[i] = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) vprev[i][c] = 0.f;
     }
 
     // nu = 4: one row-of-4 per (timestep, sample).  Lane (g,s) needs only component g of it unless the
     // row must be coloured by a full Sigma (or is generated here): a 4-byte load of that component --
     // picking it out of a loaded float4 with a lane-dependent select makes hipcc index the row
-    // dynamically, i.e. through scratch memory
+    // dynamically, i.e. through scratch memory.  Other nu: the lane's component(s) n = g (, g + 4) of timestep t are element
+    // t nu + n of the sample's flat (T nu) sequence = component (t nu + n) & 3 of row (t nu + n) >> 2.
     constexpr bool ROW1 = NOISE != MPPI_NOISE_PHILOX && (DIAG || NOISE == MPPI_NOISE_ACTIONS);
     float zc[NT][4], zn[NT][4];
     auto fetch = [&](int t, float (&dst)[NT][4]) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
-        if constexpr (ROW1) dst[i][0] = a.z[((long long)t * a.zp + kk[i]) * 4 + g];
-        else noise4<float, NOISE == MPPI_NOISE_ACTIONS ? MPPI_NOISE_TNK4 : NOISE>(a, t, kk[i], dst[i]);
+        if constexpr (ROW1) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int j = t * NU + (own[c] ? g + 4 * c : 0);
+            dst[i][c] = a.z[((long long)(j >> 2) * a.zp + kk[i]) * 4 + (j & 3)];
+          }
+        } else {
+          noise4<float, NOISE == MPPI_NOISE_ACTIONS ? MPPI_NOISE_TNK4 : NOISE>(a, t, kk[i], dst[i]);
+        }
       }
     };
     fetch(0, zn);
@@ -318,7 +351,7 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
 #pragma unroll
-        for (int c = 0; c < (ROW1 ? 1 : 4); ++c) zc[i][c] = zn[i][c];
+        for (int c = 0; c < (ROW1 ? NC : 4); ++c) zc[i][c] = zn[i][c];
       }
       if constexpr (NOISE == MPPI_NOISE_PHILOX) {
         if (a.z != nullptr && g == 0) {
@@ -329,38 +362,50 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
       }
       fetch(t + 1 < a.Tn ? t + 1 : t, zn);   // prefetch the next step's rows (compute >> latency here)
 
-      // ---- actions (identical to the fp32 matrix-core kernel): lane (g,s) owns control dimension g ----
-      const float Ut = Ue[t * NU + g], Umt = Um[t * NU + g], Gt = G[t * NU + g];
+      // ---- actions (identical to the fp32 matrix-core kernel): lane (g,s) owns control dimension g (and g + 4 where nu > 4) ----
+      float Ut[NC], Umt[NC], Gt[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int jn = t * NU + (own[c] ? g + 4 * c : 0);
+        Ut[c] = Ue[jn]; Umt[c] = Um[jn]; Gt[c] = own[c] ? G[jn] : 0.f;
+      }
       Planes B1[NT];
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
-        float v;
-        if constexpr (NOISE == MPPI_NOISE_ACTIONS) {
-          v = zc[i][0];                                   // ROW1: component g was loaded
-        } else if constexpr (DIAG) {
-          const float zg = ROW1 ? zc[i][0] : pick4(zc[i], g);
-          v = fmaf(zg, sd_g, Umt);
-        } else {
-          float acc = Umt;
+        float uu[NC];
 #pragma unroll
-          for (int m = 0; m < NU; ++m) acc = fmaf(zc[i][m], Lrow[m], acc);
-          v = acc;
+        for (int c = 0; c < NC; ++c) {
+          float v;
+          if constexpr (NOISE == MPPI_NOISE_ACTIONS) {
+            v = zc[i][c];                                   // ROW1: the lane's component was loaded
+          } else if constexpr (DIAG) {
+            const float zg = ROW1 ? zc[i][c] : pick4(zc[i], g);
+            v = fmaf(zg, sd_c[c], Umt[c]);
+          } else {
+            float acc = Umt[c];
+#pragma unroll
+            for (int m = 0; m < NU; ++m) acc = fmaf(zc[i][m], Lrow[m], acc);
+            v = acc;
+          }
+          if (orow[i] == -1) v = 0.f;
+          else if (orow[i] >= 0) v = a.sampler[((long long)orow[i] * a.Tn + t) * NU + (own[c] ? g + 4 * c : 0)];
+          v = clampT(v, lo_c[c], hi_c[c]);
+          if (NU != 4 && NU != 8) v = own[c] ? v : 0.f;                           // a lane group without a control of its own
+          const float e = (v - Ut[c]) * ac.e_scale;                               // e_scale = 1 | 1/dt (SMPPI, mppi.py:544)
+          ppart[i] = fmaf(Gt[c], ac.abs_cost ? fabsf(e) : e, ppart[i]);
+          if (a.smooth_w != 0.f) {
+            // SMPPI smoothness cost w |v[t] - v[t-1]|^2 (mppi.py:559-562), this lane's control dimension(s); the
+            // dimensions of a sample meet in the reduction over g at the end of the chunk
+            const float d = v - vprev[i][c];
+            if (t > 0) cpart[i] = fmaf(a.smooth_w * d, d, cpart[i]);
+            vprev[i][c] = v;
+          }
+          uu[c] = a.u_scale * v;
+          cpart[i] = fmaf(qu_c[c] * uu[c], uu[c], cpart[i]);                      // control effort (qu = 0: + 0)
         }
-        if (orow[i] == -1) v = 0.f;
-        else if (orow[i] >= 0) v = a.sampler[((long long)orow[i] * a.Tn + t) * NU + g];
-        v = clampT(v, lo_g, hi_g);
-        const float e = (v - Ut) * ac.e_scale;                                  // e_scale = 1 | 1/dt (SMPPI, mppi.py:544)
-        ppart[i] = fmaf(Gt, ac.abs_cost ? fabsf(e) : e, ppart[i]);
-        if (a.smooth_w != 0.f) {
-          // SMPPI smoothness cost w |v[t] - v[t-1]|^2 (mppi.py:559-562), this lane's control dimension; the four
-          // dimensions of a sample meet in the reduction over g at the end of the chunk
-          const float d = v - vprev[i];
-          if (t > 0) cpart[i] = fmaf(a.smooth_w * d, d, cpart[i]);
-          vprev[i] = v;
-        }
-        const float uu = a.u_scale * v;
-        cpart[i] = fmaf(qu_g * uu, uu, cpart[i]);                               // control effort (qu = 0: + 0)
-        const float in[8] = {x[i][0], x[i][1], x[i][2], x[i][3], uu, g == 0 ? 1.0f : 0.0f, 0.f, 0.f};
+        float in[8] = {x[i][0], x[i][1], x[i][2], x[i][3], uu[0], 0.f, 0.f, 0.f};
+        if constexpr (NC == 2) in[5] = uu[1];
+        in[BIAS_E] = g == 0 ? 1.0f : 0.0f;
         B1[i] = split_pack8(in);
       }
 
@@ -512,12 +557,15 @@ __global__ void __launch_bounds__(B3_THREADS, 1) rollout_mlp_split_kernel(const 
   }
 }
 
-template <int HT>
+template <int HT, int NX, int NU>
 static int launch_b3(const KArgs<float>& a_in, hipStream_t st) {
   KArgs<float> a = a_in;
   const bool diag = a.diag != 0 || a.coloured != 0;
-  const size_t smem = (size_t)(3 * a.J + 2 * B3_NU * B3_NU) * sizeof(float);
+  const size_t smem = (size_t)(3 * a.J + 2 * NU * NU) * sizeof(float);
   if (smem > 60 * 1024) return MPPI_E_UNSUPPORTED;
+  // nu != 4: the rows are read component-wise -- external rows (TNK4 / raw actions) in the diagonal (or coloured) form only;
+  // anything else (rows generated inside K1, a full Sigma coloured in the lane) runs the per-lane kernel (rollout_mlp.hip)
+  if (NU != 4 && (a.noise_src == MPPI_NOISE_PHILOX || !(diag || a.noise_src == MPPI_NOISE_ACTIONS))) return MPPI_E_UNSUPPORTED;
   const int nchunks = (a.K + B3_SAMPLES - 1) / B3_SAMPLES;
   static const int n_cu = [] {
     int dev = 0, n = 256;
@@ -535,29 +583,71 @@ static int launch_b3(const KArgs<float>& a_in, hipStream_t st) {
     if (ev1 != nullptr) hipExtLaunchKernelGGL(KERNEL, grid, block, smem, st, ev0, ev1, 0, a);        \
     else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, a);                                       \
   } while (0)
+  if constexpr (NU == 4) {
 #define MPPI_LAUNCH(NOISE_)                                                                          \
   do {                                                                                               \
-    if (diag) MPPI_LAUNCH1((rollout_mlp_split_kernel<HT, NOISE_, true>));                           \
-    else MPPI_LAUNCH1((rollout_mlp_split_kernel<HT, NOISE_, false>));                               \
+    if (diag) MPPI_LAUNCH1((rollout_mlp_split_kernel<HT, NOISE_, true, NX, NU>));                   \
+    else MPPI_LAUNCH1((rollout_mlp_split_kernel<HT, NOISE_, false, NX, NU>));                       \
   } while (0)
-  if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCH(MPPI_NOISE_PHILOX);
-  else if (a.noise_src == MPPI_NOISE_ACTIONS) MPPI_LAUNCH(MPPI_NOISE_ACTIONS);
-  else MPPI_LAUNCH(MPPI_NOISE_TNK4);
+    if (a.noise_src == MPPI_NOISE_PHILOX) MPPI_LAUNCH(MPPI_NOISE_PHILOX);
+    else if (a.noise_src == MPPI_NOISE_ACTIONS) MPPI_LAUNCH(MPPI_NOISE_ACTIONS);
+    else MPPI_LAUNCH(MPPI_NOISE_TNK4);
 #undef MPPI_LAUNCH
+  } else {
+    if (a.noise_src == MPPI_NOISE_ACTIONS) MPPI_LAUNCH1((rollout_mlp_split_kernel<HT, MPPI_NOISE_ACTIONS, true, NX, NU>));
+    else MPPI_LAUNCH1((rollout_mlp_split_kernel<HT, MPPI_NOISE_TNK4, true, NX, NU>));
+  }
 #undef MPPI_LAUNCH1
   return (int)hipGetLastError();
 }
 
-bool mlp_split_supported(int nx, int nu, int hidden) {
-  return nx == B3_NX && nu == B3_NU && (hidden == 64 || hidden == 128 || hidden == 256);
+// The (nx, nu) pairs with a split-operand instantiation, two translation units (MPPI_SPLIT_GROUP, set by _build.py): 0 = C4's
+// (16, 4) with every noise form, 1 = the further shapes (external rows only, see launch_b3)
+#ifndef MPPI_SPLIT_GROUP
+#define MPPI_SPLIT_GROUP 0
+#endif
+#define MPPI_SPLIT_DIMS_0(X) X(16, 4)
+#define MPPI_SPLIT_DIMS_1(X) X(8, 2) X(12, 6) X(16, 8)
+
+template <int NX, int NU>
+static int launch_b3_h(const KArgs<float>& a, hipStream_t st) {
+  if (a.hidden == 64) return launch_b3<4, NX, NU>(a, st);
+  if (a.hidden == 128) return launch_b3<8, NX, NU>(a, st);
+  return launch_b3<16, NX, NU>(a, st);
 }
+
+#if MPPI_SPLIT_GROUP == 0
+int rollout_mlp_split_g1(const KArgs<float>& a, hipStream_t st);
+
+bool mlp_split_supported(int nx, int nu, int hidden) {
+  if (!(hidden == 64 || hidden == 128 || hidden == 256)) return false;
+#define X(NX, NU) if (nx == NX && nu == NU) return true;
+  MPPI_SPLIT_DIMS_0(X) MPPI_SPLIT_DIMS_1(X)
+#undef X
+  return false;
+}
+
+static std::atomic<long long> g_split_launches{0};
+long long mlp_split_launches() { return g_split_launches.load(); }
 
 int rollout_mlp_split(const KArgs<float>& a, hipStream_t st) {
   if (a.mp == nullptr) return MPPI_E_BADARG;
   if (!mlp_split_supported(a.nx, a.nu, a.hidden) || a.states != nullptr) return MPPI_E_UNSUPPORTED;
-  if (a.hidden == 64) return launch_b3<4>(a, st);
-  if (a.hidden == 128) return launch_b3<8>(a, st);
-  return launch_b3<16>(a, st);
+  int r = MPPI_E_UNSUPPORTED;
+#define X(NX, NU) if (a.nx == NX && a.nu == NU) r = launch_b3_h<NX, NU>(a, st); else
+  MPPI_SPLIT_DIMS_0(X)
+#undef X
+  r = rollout_mlp_split_g1(a, st);
+  if (r == 0) ++g_split_launches;
+  return r;
 }
+#else
+int rollout_mlp_split_g1(const KArgs<float>& a, hipStream_t st) {
+#define X(NX, NU) if (a.nx == NX && a.nu == NU) return launch_b3_h<NX, NU>(a, st);
+  MPPI_SPLIT_DIMS_1(X)
+#undef X
+  return MPPI_E_UNSUPPORTED;
+}
+#endif
 
 }  // namespace mppi

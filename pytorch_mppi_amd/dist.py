@@ -104,8 +104,8 @@ class ShardPlan:
             raise ValueError("need at least one sample per rank")
         # a process-local plan (a device group's shard: `rank` is the shard's index, not a process rank) never touches
         # torch.distributed -- in a process whose default group is RCCL-backed (a device group per torchrun rank) a
-        # broadcast
-        # of U or an ncclCommInitRank with shard indices for ranks would hang or mix the ranks' sequences
+        # broadcast of U or an ncclCommInitRank with shard indices for ranks would hang or mix the ranks' sequences
+        # 
         self.local = isinstance(group, str) and group == LOCAL
         if self.local:
             group = None

@@ -3,13 +3,10 @@
 (K,T,nu) draw per command) and how they reach the kernels.
 
 `Draws` is the part of `MPPI` that binds a draw to the problem block: injected noise (parity tests), rng="torch" --
-torch.randn's
-own values, computed by the engine's launch straight into its sample-minor rows (`_torch_stream_fill`), the next
-command's draw
-inside this command's K3 launch (draw-ahead) --, rng="torch-native", and the engine's Philox generator in its three
-forms (on
-chip: no array at all; generator launch + rows in memory; inside K1).  Row buffers are owned here (one per size, reused
-by every
+torch.randn's own values, computed by the engine's launch straight into its sample-minor rows (`_torch_stream_fill`),
+the next command's draw inside this command's K3 launch (draw-ahead) --, rng="torch-native", and the engine's Philox
+generator in its three forms (on chip: no array at all; generator launch + rows in memory; inside K1).  Row buffers are
+owned here (one per size, reused by every
 command)."""
 import ctypes as C
 import logging
@@ -105,9 +102,8 @@ class Draws:
                 self.last_draw = "philox-onchip"
                 if self.onchip_spill:
                     # the rows that fit neither registers nor LDS wait for their sample's weight in this array (stored
-                    # once,
-                    # fetched once) instead of being generated a second time: 75.8 -> 71.3 us at C3 (include/mppi_amd.h,
-                    # ABI 20)
+                    # once, fetched once) instead of being generated a second time: 75.8 -> 71.3 us at C3
+                    # (include/mppi_amd.h, ABI 20)
                     key = (K, Tn, nu)
                     sp = self._spill if self._spill is not None and self._spill[0] == key else None
                     if sp is None:
@@ -138,8 +134,8 @@ class Draws:
                         int(p.call)) and (fill or pf[2]):
                     # the rows of THIS command exist already: generated inside the previous command's K3 launch (ABI 21,
                     # csrc/noise_torch.hip -- the VALU that HBM-bound launch leaves idle; for small commands, the CUs)
-                    # or while the
-                    # previous command's collective ran.  Rows are a pure function of (seed, command, sample, row).
+                    # or while the previous command's collective ran.  Rows are a pure function of (seed, command,
+                    # sample, row).
                     zn = pf[1]
                     self._pf_hits += 1
                     if pf[2]:
@@ -192,10 +188,8 @@ class Draws:
         if (self.dtype != torch.float32 or (Tn * nu) % 4 or self.d.type != "cuda" or self._in_capture
                 or _TORCH_ROWS.get("off") or torch.cuda.is_current_stream_capturing()):
             # (a capture: torch.randn registers its generator with the graph and replays advance it; the offset this
-            # launch
-            # takes as an argument would be frozen -- capture_command() says so itself, a user's own torch.cuda.graph()
-            # is
-            # caught by the query)
+            # launch takes as an argument would be frozen -- capture_command() says so itself, a user's own
+            # torch.cuda.graph() is caught by the query)
             return False
         gen = self._shard_gen if self._shard_gen is not None else torch.cuda.default_generators[self._dev_index]
         numel = K * Tn * nu
@@ -245,8 +239,7 @@ class Draws:
             # command n-1's K3 launch generated exactly this draw beside its row stream (ABI 21, csrc/noise_torch.hip):
             # the
             # generator is where that launch assumed it would be -- same seed, same offset: the same values, by
-            # construction.
-            # The two row buffers change roles
+            # construction. The two row buffers change roles
             n_el = self._zelems(Tn)
             self._zbuf_alt[n_el], self._zbuf[n_el] = zn, nd[4]
             zn = nd[4]
@@ -267,17 +260,13 @@ class Draws:
         self._next_cmds += 1
         if self.draw_ahead and numel >= self.draw_ahead_min and (self._next_misses < 2 or self._next_cmds % 64 == 0):
             # (a caller that draws from the generator between every two commands -- the reference's benchmark protocol
-            # calls
-            # reset() -- makes every draw-ahead useless and K3 pays for it: after two misses in a row it is tried only
-            # every 64th
-            # command)
+            # calls reset() -- makes every draw-ahead useless and K3 pays for it: after two misses in a row it is tried
+            # only every 64th command)
             # ... and this command's K3 launch generates the NEXT draw -- the values torch.randn will produce from
-            # (seed,
-            # off + inc) if nobody else draws from this generator in between -- into the other row buffer, on the VALU
-            # the
-            # HBM-bound row stream leaves idle.  Whether the engine did (only the streaming diagonal K3 carries it) is
-            # read
-            # back behind the command (_settle_next); whether the assumption held is checked above, at the next command
+            # (seed, off + inc) if nobody else draws from this generator in between -- into the other row buffer, on the
+            # VALU the HBM-bound row stream leaves idle.  Whether the engine did (only the streaming diagonal K3 carries
+            # it) is read back behind the command (_settle_next); whether the assumption held is checked above, at the
+            # next command
             n_el = self._zelems(Tn)
             alt = self._zbuf_alt.get(n_el)
             if alt is None or alt.dtype != self.dtype or alt.device != zn.device:

@@ -1,10 +1,8 @@
 """Which form a command takes and the problem block it hands to the engine (include/mppi_amd.h `MppiProblem`).
 
 `Forms` is the part of `MPPI` that resolves parameters into device vectors (`_vec`), builds and caches the static part
-of the
-problem block (`_static_key`, `_problem`), owns the workspace, moves the state to the device, decides between the fused
-path and
-the callback path (`_needs_generic`), runs the callback path's rollout around the engine's prepare kernel
+of the problem block (`_static_key`, `_problem`), owns the workspace, moves the state to the device, decides between the
+fused path and the callback path (`_needs_generic`), runs the callback path's rollout around the engine's prepare kernel
 (/root/reference/src/pytorch_mppi/mppi.py:297-373 is the contract the user's callables see) and materialises the lazily
 derived
 public arrays."""
@@ -196,8 +194,8 @@ class Forms:
 
     def _fused_multi_ok(self):
         """M > 1 rollouts per action sequence inside K1 (csrc/rollout.hpp rollout_stream_multi): MPPI, SMPPI and KMPPI
-        (its
-        two-launch form: interpolated raw actions in memory), at most 4 copies of the state per lane; anything else runs
+        (its two-launch form: interpolated raw actions in memory), at most 4 copies of the state per lane; anything else
+        runs
         the reference's callback loop."""
         return (1 < self.M <= 4 and self.specific_action_sampler is None and not getattr(self._model, "heavy", False))
 
@@ -236,19 +234,16 @@ class Forms:
 
     def _callback_rollout(self, v):
         """The callback path's K1: the user's callables over the bounded actions `v` (K,T,nu) that `mppi_prepare` wrote,
-        one batched
-        call per timestep -> (rollout cost (K,), visited states | None, applied actions | None).
+        one batched call per timestep -> (rollout cost (K,), visited states | None, applied actions | None).
 
         What the callables see is the reference's contract (mppi.py:297-373), restated around one loop: with M = 1 they
-        get (K, .)
-        rows, and the visited states / applied actions are kept -- as (1,K,T,.) -- only when a terminal cost wants them;
-        with M > 1
-        rollouts per action sequence they get M stacked copies of the batch, (M*K, .) rows, every copy is kept, and the
-        cost is
-        the mean over the copies plus `rollout_var_cost` x the discounted unbiased variance across them.  A sampler's
+        get (K, .) rows, and the visited states / applied actions are kept -- as (1,K,T,.) -- only when a terminal cost
+        wants them; with M > 1 rollouts per action sequence they get M stacked copies of the batch, (M*K, .) rows, every
+        copy is kept, and the cost is the mean over the copies plus `rollout_var_cost` x the discounted unbiased
+        variance across them.  A sampler's
         `specific_dynamics` post-processes the state after every step (3-D tensors; in the single-copy case it is handed
-        the
-        post-dynamics state for both its `next_state` and `state` arguments, in the stacked case the INITIAL states for
+        the post-dynamics state for both its `next_state` and `state` arguments, in the stacked case the INITIAL states
+        for
         `state`)."""
         K, T, nu = v.shape
         M = int(self.M)

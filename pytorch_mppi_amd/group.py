@@ -2,14 +2,10 @@
 
 The reference's caller is ONE process stepping ONE environment (/root/reference/src/pytorch_mppi/mppi.py:876-898,
 tests/pendulum.py:68-79): with `shard=(rank, world)` it has to re-launch its whole loop under torch.distributed.run and
-step a
-replica of the environment on every rank.  `devices=[...]` keeps `.command(state)` the single drop-in call: the object
-the
-constructor returns holds one shard controller per listed device (the same code a rank of the per-process model runs --
-contiguous
-split of the K samples by global index, K1 / K3 / K4 against the shard's own minimum, one (2 + T nu)-element record per
-shard), and
-a command is
+step a replica of the environment on every rank.  `devices=[...]` keeps `.command(state)` the single drop-in call: the
+object the constructor returns holds one shard controller per listed device (the same code a rank of the per-process
+model runs -- contiguous split of the K samples by global index, K1 / K3 / K4 against the shard's own minimum, one (2 +
+T nu)-element record per shard), and a command is
 
     this thread:  the state to device 0; per shard the problem block of this command (`MPPI._prepare`: draw, buffers,
     parameters)
@@ -18,39 +14,30 @@ a command is
     worker g:     one thread per device inside the library, that device current in it: the state from device 0 (peer
     copy),
                   K1, K3, K4 (record only), the exchange -- ncclAllGather on the device's own communicator
-                  (ncclCommInitAll), or
-                  copies behind events when a device is listed twice / there is no RCCL ("staged") -- and K5, the
-                  rank-order
+                  (ncclCommInitAll), or copies behind events when a device is listed twice / there is no RCCL ("staged")
+                  -- and K5, the rank-order
                   combine -> bit-identical U on every device
     this thread:  return device 0's action
 
 so the host's share of a command is N block hand-overs plus ONE device's launches, not N x (Python + launches): commands
-no longer
-have to be longer than N x 40 us to be GPU-bound (profiles/r06_group_host_issue.txt).  What has no one-call form (the
-callback
-path, KMPPI's two-launch form) is issued shard by shard from this thread as before, the exchange through
-mppi_exchange_combine_all / device copies.  MPPI_GROUP_THREADS=0 forces that serial form (A/B).
+no longer have to be longer than N x 40 us to be GPU-bound (profiles/r06_group_host_issue.txt).  What has no one-call
+form (the callback path, KMPPI's two-launch form) is issued shard by shard from this thread as before, the exchange
+through mppi_exchange_combine_all / device copies.  MPPI_GROUP_THREADS=0 forces that serial form (A/B).
 
 The returned object is an instance of the class that was asked for (a subclass made on the fly), but holds no controller
-state of
-its own: attribute reads go to shard 0 -- except the per-sample results (`cost_total`, `omega`, `noise`, ...), which are
-the
-shards' parts concatenated on device 0 in global sample order --, attribute writes go to every shard (tensors moved to
-the shard's
-device), methods other than `command` run on every shard and the replicated sequences (`U`, `theta`, `action_sequence`)
-are then
+state of its own: attribute reads go to shard 0 -- except the per-sample results (`cost_total`, `omega`, `noise`, ...),
+which are the shards' parts concatenated on device 0 in global sample order --, attribute writes go to every shard
+(tensors moved to the shard's device), methods other than `command` run on every shard and the replicated sequences
+(`U`, `theta`, `action_sequence`) are then
 re-copied from shard 0 (a `reset()` draws on device 0 only, like rank 0's draw is broadcast in the per-process model).
 
 User callables (the reference's plugin API) are called by every shard with tensors on THAT shard's device.
 `torch.nn.Module`s --
 the callable itself or the object a bound method belongs to: /root/reference/tests/pendulum_approximate.py's network --
-are
-deep-copied onto each further device at construction and re-synchronised (`load_state_dict`) whenever the original's
-parameters
-were written (retraining between commands, mppi.py:890-893); `models.NativeModel`s keep a parameter blob per device
-themselves.
-Anything else -- a closure over a tensor on cuda:0 -- must be device-agnostic (`tensor.to(state.device)`): the error a
-device
+are deep-copied onto each further device at construction and re-synchronised (`load_state_dict`) whenever the original's
+parameters were written (retraining between commands, mppi.py:890-893); `models.NativeModel`s keep a parameter blob per
+device themselves. Anything else -- a closure over a tensor on cuda:0 -- must be device-agnostic
+(`tensor.to(state.device)`): the error a device
 mismatch raises inside such a callable is re-raised with that advice."""
 import contextlib
 import ctypes as C
@@ -305,9 +292,8 @@ class DeviceGroup:
         object.__getattribute__(self, "_replicas").sync()
         eng = object.__getattribute__(self, "_engine")
         # the state: ONCE to device 0 (a host state travels in a launch packet, MPPI._to_state); the other devices get
-        # it by a
-        # peer copy in front of their K1, issued by their worker thread -- unless the shards take different rows of it
-        # (per-sample initial states of the global problem, mppi.py:302-305) or there are no workers
+        # it by a peer copy in front of their K1, issued by their worker thread -- unless the shards take different rows
+        # of it (per-sample initial states of the global problem, mppi.py:302-305) or there are no workers
         states, bc = [state] * len(shards), None
         if eng is not None:
             with _on(s0.d):
@@ -326,8 +312,7 @@ class DeviceGroup:
                     if getattr(s._model, "watch", None) is not None:
                         s._check_traced(state if s is s0 else None)
                     # (MPPI._to_state moves the state to the shard's device and, for per-sample initial states of the
-                    # global
-                    # problem -- (K, nx), mppi.py:302-305 --, takes this shard's rows)
+                    # global problem -- (K, nx), mppi.py:302-305 --, takes this shard's rows)
                     ps.append(s._prepare(states[g], shift))
         except RuntimeError as e:
             if "Expected all tensors to be on the same device" in str(e):

@@ -1,17 +1,15 @@
 """Traced callables against the live ones: what keeps a controller honest once plain torch callables have been turned
-into a
-fused device functor (pytorch_mppi_amd/trace.py -> jit.py).
+into a fused device functor (pytorch_mppi_amd/trace.py -> jit.py).
 
 The reference calls the user's `dynamics` / `running_cost` on every command
 (/root/reference/src/pytorch_mppi/mppi.py:314, :318): a
 functor traced from them has to notice when they would now compute something else.  `JitGlue` is the part of `MPPI` that
-traces
-(`_try_trace`), adopts a background compile (`_adopt_background_model`), watches every place the callables can read from
-(`_check_traced` -> watch.StateWatch), re-traces and compares when something moved (`_traced_state_moved`,
+traces (`_try_trace`), adopts a background compile (`_adopt_background_model`), watches every place the callables can
+read from (`_check_traced` -> watch.StateWatch), re-traces and compares when something moved (`_traced_state_moved`,
 `_settle_moved`) and
 spot-checks the functor against the callables on the device (`_spot_check`).  Outside SURVEY.md section 8's hot path: an
-additive
-convenience (`auto_jit=`) around the drop-in boundary; a controller built on a `models.NativeModel` never enters this
+additive convenience (`auto_jit=`) around the drop-in boundary; a controller built on a `models.NativeModel` never
+enters this
 file."""
 import logging
 import os
@@ -158,9 +156,8 @@ class JitGlue:
         if self._jit_check_every > 0 and n >= self._jit_next_check and state is not None \
                 and not torch.cuda.is_current_stream_capturing():
             # every `_jit_check_every` commands -- stretched, for problems so small that a check (a millisecond: the
-            # user's
-            # callables on a batch, a tiny fused rollout, one device sync) would cost more than `_jit_check_share` (1 %)
-            # of the
+            # user's callables on a batch, a tiny fused rollout, one device sync) would cost more than
+            # `_jit_check_share` (1 %) of the
             # time between two of them, to that many commands: a 20 us command is checked every ~6000 commands = 0.12 s
             import time
             t0 = time.perf_counter()
@@ -182,8 +179,8 @@ class JitGlue:
     def _traced_state_moved(self, moved, why):
         """Something the traced callables can read is not what it was.  Re-trace (symbolic: milliseconds) and compare:
         the same functor source and parameter sources -> irrelevant (forget the places); the same source, parameters
-        read
-        from other tensors (a sub-module replaced by one of the same architecture) -> re-bind, no compile; anything else
+        read from other tensors (a sub-module replaced by one of the same architecture) -> re-bind, no compile; anything
+        else
         -> the fused kernels are out of date: back to the callables NOW (the reference's behaviour), new functor
         compiled
         beside the loop with the tensors that moved as run-time parameters."""
@@ -209,11 +206,9 @@ class JitGlue:
             return
         if why is not None and trace.same_functor(code, m._code) and trace.same_param_sources(code, m._code):
             # a spot-check mismatch that a fresh trace does not explain (a discontinuous cost on a boundary sample,
-            # state
-            # behind a C extension, a tracer bug): the parameters were re-gathered by the spot-check.  Said aloud, and
-            # after
-            # three in a row the controller stops trusting the functor: back to the callables, the reference's behaviour
-            # (this is the case the spot-check exists for)
+            # state behind a C extension, a tracer bug): the parameters were re-gathered by the spot-check.  Said aloud,
+            # and after three in a row the controller stops trusting the functor: back to the callables, the reference's
+            # behaviour (this is the case the spot-check exists for)
             self._jit_benign += 1
             self._jit_unexplained = getattr(self, "_jit_unexplained", 0) + 1
             import logging
@@ -285,20 +280,14 @@ class JitGlue:
 
     def _settle_moved(self, m, moved, code, adoption=False):
         """A fresh trace prints the same functor although these watched places moved.  Which of them may be forgotten?
-        Only
-        those the trace did NOT read (`cost.goal = torch.tensor([2., 1.])` -- same values, a new object,
-        what a
-        planner does every cycle -- was judged benign and `GoalCost.goal` dropped from the watch for good; the next,
-        real
-        change of the goal then went unseen).  A place keeps being watched, with its present value as the new reference,
-        when
-        that value is a tensor / array among the roots of the trace's constants or its parameter tensors, or a number /
-        string
-        equal to one of the graph's numeric constants; integers, booleans and strings (what Python-level control flow
-        reads
+        Only those the trace did NOT read (`cost.goal = torch.tensor([2., 1.])` -- same values, a new
+        object, what a planner does every cycle -- was judged benign and `GoalCost.goal` dropped from the watch for
+        good; the next, real change of the goal then went unseen).  A place keeps being watched, with its present value
+        as the new reference, when that value is a tensor / array among the roots of the trace's constants or its
+        parameter tensors, or a number / string equal to one of the graph's numeric constants; integers, booleans and
+        strings (what Python-level control flow reads
         without leaving a constant behind) are forgotten only after three benign moves in a row, or at adoption (what
-        moved
-        while the callables were being traced and verified is their own bookkeeping).  A place re-bound to a NEW
+        moved while the callables were being traced and verified is their own bookkeeping).  A place re-bound to a NEW
         container or
         object gets the watch rebuilt over the roots, so that what hangs below the new object is watched too."""
         import numpy as np
@@ -320,14 +309,14 @@ class JitGlue:
                 was_read = any(v is r for r in read)
                 (keep if was_read else drop).append(i)
                 continue
-            if isinstance(v, (bool, str)) or (isinstance(v, int) and not isinstance(path.holder, watch_mod._Len)):
+            if isinstance(v, (bool, str, float)) or (isinstance(v, int) and not isinstance(path.holder, watch_mod._Len)):
+                # numbers and strings: what Python-level control flow reads leaves no constant behind (`if self.gain > 0.5:`),
+                # so "not in the graph" does not mean "not read" -- floats too: kept, with the present value as
+                # the new reference, until three benign moves in a row (or adoption)
                 n = w.benign.get(key, 0) + 1
                 w.benign[key] = n
-                in_graph = isinstance(v, (int, bool)) and float(v) in numbers
+                in_graph = isinstance(v, (int, bool, float)) and float(v) in numbers
                 (drop if (adoption or n >= 3) and not in_graph else keep).append(i)
-                continue
-            if isinstance(v, float):
-                (keep if v in numbers else drop).append(i)
                 continue
             if v is watch_mod._MISSING or v is None or isinstance(path.holder, watch_mod._Len) or isinstance(v,
                     watch_mod._PRIMS):
@@ -352,11 +341,10 @@ class JitGlue:
 
     def _spot_check(self, state, samples=64, steps=4):
         """The fused functor against the user's callables on a small random batch ON THE DEVICE (`samples` states around
-        the
-        current one, `steps` timesteps of random bounded actions): total costs and visited states of a tiny fused
-        rollout
-        against the reference's own loop (mppi.py:297-332) over the same actions.  What the watch cannot see ends here:
-        writes through `.data`, state behind C extensions, a tracer bug the host check did not meet.  One device
+        the current one, `steps` timesteps of random bounded actions): total costs and visited states of a tiny fused
+        rollout against the reference's own loop (mppi.py:297-332) over the same actions.  What the watch cannot see
+        ends here: writes through `.data`, state behind C extensions, a tracer bug the host check did not meet.  One
+        device
         sync."""
         from .controller import MPPI
         m = self._model

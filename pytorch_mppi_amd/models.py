@@ -159,13 +159,16 @@ class LinearGoal(NativeModel):
         return ((goal - states[..., -1, :]) ** 2).sum(dim=-1)
 
 
+# (nx, nu) with an instantiation of the split-operand matrix-core kernel (csrc/rollout_mlp_split.hip MPPI_SPLIT_DIMS_*)
+MLP_MATRIX_CORE_SHAPES = ((16, 4), (8, 2), (12, 6), (16, 8))
+
+
 def mlp_kernel_width(nx, nu, hidden):
-    """The hidden width the engine's matrix-core MLP kernels are built for (csrc/rollout_mlp_split.hip: (nx, nu) = (16,
-    4), hidden 64 /
-    128 / 256) that holds `hidden` units, or `hidden` itself where no such kernel exists (the per-lane kernel takes any
-    width).  Padding
-    units have zero weights in and out and zero bias: tanh(0) = 0 contributes exactly nothing."""
-    if (int(nx), int(nu)) == (16, 4):
+    """The hidden width the engine's matrix-core MLP kernels are built for (csrc/rollout_mlp_split.hip: the (nx, nu) of
+    MLP_MATRIX_CORE_SHAPES, hidden 64 / 128 / 256) that holds `hidden` units, or `hidden` itself where no such kernel exists (the
+    per-lane kernel takes any width).  Padding units have zero weights in and out and zero bias: tanh(0) = 0 contributes exactly
+    nothing."""
+    if (int(nx), int(nu)) in MLP_MATRIX_CORE_SHAPES:
         for w in (64, 128, 256):
             if hidden <= w:
                 return w
@@ -199,8 +202,7 @@ class MLPResidual(NativeModel):
         self.W1, self.b1, self.W2, self.b2 = (torch.as_tensor(t) for t in (W1, b1, W2, b2))
         self.nx, self.nu = int(nx), int(nu)
         # `hidden` is what the kernels see: odd widths are zero-padded to the next width the matrix-core kernels are
-        # built for
-        # (hidden 100 on the per-lane kernel costs 13 x the matrix-core time)
+        # built for (hidden 100 on the per-lane kernel costs 13 x the matrix-core time)
         self.hidden_units = int(self.W1.shape[0])
         self.hidden = mlp_kernel_width(nx, nu, self.hidden_units)
         self.res_scale = float(res_scale)
@@ -214,10 +216,9 @@ class MLPResidual(NativeModel):
 
     def flags(self):
         """The default matrix-core kernel runs layer 2 on two-piece fp16 operands (csrc/rollout_mlp_split.hip): its
-        weights
-        (-2 W2) must stay inside fp16's range.  Weights beyond it -- checked here every time the parameter version
-        changes,
-        i.e. also after `invalidate()` behind an in-place update -- select the exact fp32 MFMA kernel, which has no such
+        weights (-2 W2) must stay inside fp16's range.  Weights beyond it -- checked here every time the parameter
+        version changes, i.e. also after `invalidate()` behind an in-place update -- select the exact fp32 MFMA kernel,
+        which has no such
         limit."""
         if getattr(self, "_flags_version", None) != self._param_version:
             self._flags = N.MODEL_FLAG_EXACT_FP32 if float(torch.as_tensor(self.W2).abs().max()) >= 3.0e4 else 0

@@ -10,8 +10,7 @@ Symbolic tensors are NOT torch.Tensor subclasses: `SymT` implements the tensor m
 (indexing, views, arithmetic, reductions, elementwise maths), `__torch_function__` for the torch.* / torch.nn.functional
 entry points (torch.cat, torch.clamp, F.linear through an nn.Module, ...) and `__array_ufunc__` for numpy ufuncs applied
 to tensors (the reference's own pendulum uses np.sin / np.clip on tensors: tests/pendulum.py:45-46).  Shapes are
-concrete
-(numpy arrays of node ids with a batch axis of size 1), so every view / broadcast / concatenation is numpy's.
+concrete (numpy arrays of node ids with a batch axis of size 1), so every view / broadcast / concatenation is numpy's.
 
 Scope: elementwise maths, + - * / ** %, clamp / where / min / max, small constant matrices (captured tensors, nn.Linear
 weights), cat / stack / slicing / views, sum / mean / prod over non-batch axes.  Anything else -- data-dependent control
@@ -41,9 +40,8 @@ class StaleTrace(Exception):
 class PathParam:
     """A NON-trainable tensor the callables read from a fixed place (watch.Path: an attribute, a closure cell, a global)
     whose values the functor reads from its parameter vector instead of carrying them as constants: the controller
-    promotes
-    a tensor to this once it has SEEN it change (`cost.goal = new_goal`; mppi.MPPI._traced_state_moved), so that the
-    next
+    promotes a tensor to this once it has SEEN it change (`cost.goal = new_goal`; mppi.MPPI._traced_state_moved), so
+    that the next
     change is one small copy, not a compile.  `tensor()` is whatever sits at the place now."""
     def __init__(self, path, t):
         self.path, self.shape = path, tuple(t.shape)
@@ -88,9 +86,8 @@ class Graph:
             if isinstance(v, torch.Tensor) and v.is_floating_point() and v.numel() > 0:
                 self.dynamic[id(v)] = (v, path)
         # what the symbolic inputs report as .device / .dtype: the controller's own, so that `net.to(state.device,
-        # state.dtype)`
-        # or `if state.is_cuda:` inside the callables behave as they will at run time (and a module is not dragged to
-        # the host)
+        # state.dtype)` or `if state.is_cuda:` inside the callables behave as they will at run time (and a module is not
+        # dragged to the host)
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.dtype = dtype if dtype is not None else torch.float64
         self.nodes = []          # tuples: ("c", float) | ("x", i) | ("u", n) | ("t",) | ("y", i) | (op, ids...)
@@ -100,15 +97,12 @@ class Graph:
         # id(tensor made INSIDE the callables from real tensors) -> (tensor, [the tensors it came from]):
         self.derived = {}
         #                          B.to(state.device), W @ W.T, ... are constants of the functor too; the version watch
-        #                          must sit
-        #                          on what they were made from (the copy itself is never written again)
+        #                          must sit on what they were made from (the copy itself is never written again)
         # dense layers kept AS LAYERS (F.linear on a real weight tensor, >= DENSE_MIN multiply-adds): node ("lin",
-        # layer, o) is
-        # output o of layers[layer] = dict(IN, OUT, inputs=[node ids], wbase, bbase | None) -- weights and bias are
-        # parameter-
-        # vector reads.  Code generation prints chains of them as mlp_first / mlp_mid / mlp_last calls
-        # (csrc/mlp_wide.hpp): fma
-        # chains per lane in the ordinary kernels, matrix-core tiles of sixteen samples in the wide kernel
+        # layer, o) is output o of layers[layer] = dict(IN, OUT, inputs=[node ids], wbase, bbase | None) -- weights and
+        # bias are parameter- vector reads.  Code generation prints chains of them as mlp_first / mlp_mid / mlp_last
+        # calls (csrc/mlp_wide.hpp): fma chains per lane in the ordinary kernels, matrix-core tiles of sixteen samples
+        # in the wide kernel
         self.layers = []
         self.dense_layers = os.environ.get("MPPI_TRACE_DENSE", "1") != "0"
         # (tensor, base): TRAINABLE tensors -- element i is the leaf ("p", base + i), read from the
@@ -290,10 +284,9 @@ class SymT:
             if isinstance(v, torch.nn.Parameter) or v.requires_grad or id(v) in self.g.dynamic:
                 # a TRAINABLE tensor: its values are expected to change (online learning of the dynamics, as in the
                 # reference's tests/pendulum_approximate.py:47-67,140-170) -- baking them into the functor would go
-                # stale
-                # with the first optimizer step.  Its elements become reads of the model's parameter vector p[]: the
-                # functor stays valid, the vector is re-gathered when the tensor's version counter moves.  (Same for a
-                # tensor the controller has seen change at its place: Graph.dynamic, PathParam.)
+                # stale with the first optimizer step.  Its elements become reads of the model's parameter vector p[]:
+                # the functor stays valid, the vector is re-gathered when the tensor's version counter moves.  (Same for
+                # a tensor the controller has seen change at its place: Graph.dynamic, PathParam.)
                 return SymT(self.g, self.g.param_leaves(v))
             # captured BY VALUE: the controller watches the version counters of
             for r in self.g.roots_of(v):
@@ -398,8 +391,7 @@ class SymT:
             first = SymS(self.g, int(first.a))
         if isinstance(first, SymS):
             # table[t] (or table[t, ...]): a constant reference / schedule looked up by the timestep -> one small
-            # constant
-            # array per selected element in the functor, read at index clamp(t, 0, len - 1)
+            # constant array per selected element in the functor, read at index clamp(t, 0, len - 1)
             rest = idx[1:] if isinstance(idx, tuple) else ()
             cols = np.moveaxis(self.a, 0, -1)                      # (..., N)
             if any(self.g.cval(int(v)) is None for v in cols.reshape(-1)):
@@ -849,8 +841,7 @@ class SymT:
                         ia, ib = int(a2[bi + (i, k)]), int(b2[bi + (k, j)])
                         if g.cval(ia) == 0.0 or g.cval(ib) == 0.0:
                             # a structural zero of a CONSTANT matrix: torch adds 0 * x = 0 for finite x; dropping the
-                            # term is
-                            # exact for finite states (the sparse B / selection matrices of test code)
+                            # term is exact for finite states (the sparse B / selection matrices of test code)
                             continue
                         p = g.bin("mul", ia, ib)
                         acc = p if acc is None else g.bin("add", acc, p)
@@ -942,8 +933,8 @@ class SymS:
     def __float__(self): raise TraceUnsupported("the timestep converted to a Python float")
     def __lt__(self, o): raise TraceUnsupported("comparison on the timestep")
     # == / != / hashing must fail as loudly as < does: left at the object defaults, `if t == T - 1:` would evaluate to a
-    # plain
-    # False while tracing and the branch would be dropped without a word (`t in (...)`, dict lookups by t: the same)
+    # plain False while tracing and the branch would be dropped without a word (`t in (...)`, dict lookups by t: the
+    # same)
     __le__ = __gt__ = __ge__ = __eq__ = __ne__ = __lt__
     def __hash__(self): raise TraceUnsupported("the timestep used as a dictionary key / set member")
     __array_priority__ = 1000
@@ -1078,8 +1069,7 @@ def _call(g, name, args, kwargs):
                 and (b_ is None or (isinstance(b_, torch.Tensor) and b_.dim() == 1 and b_.numel() == W_.shape[0]))
                 and id(W_) not in g.dynamic and (b_ is None or id(b_) not in g.dynamic)):
             # a dense layer stays a layer: its weights become parameter-vector reads (trainable or not: a frozen
-            # network's
-            # weights are followed by version counter and storage like any parameter), its outputs `lin` nodes
+            # network's weights are followed by version counter and storage like any parameter), its outputs `lin` nodes
             rows = a0.a.reshape(-1, a0.a.shape[-1])
             out = np.empty((rows.shape[0], int(W_.shape[0])), dtype=np.int64)
             for r in range(rows.shape[0]):
@@ -1273,9 +1263,8 @@ _RANDOM = {"randn", "rand", "randn_like", "rand_like", "normal", "randint", "ber
 
 class _TraceMode(torch.overrides.TorchFunctionMode):
     """While the callables run on symbolic inputs: floating tensors they CREATE (torch.zeros(B, nx) to be filled column
-    by
-    column, torch.tensor([...]) constants) become symbolic constants too, so that item assignment of traced values into
-    them
+    by column, torch.tensor([...]) constants) become symbolic constants too, so that item assignment of traced values
+    into them
     works; random draws are refused (not a function of state, action and timestep); everything else passes through."""
     def __init__(self, g):
         super().__init__()
@@ -1428,11 +1417,10 @@ def _deps(g, n):
 
 def _dense_chains(g, roots):
     """Which dense layers below `roots` feed each other through one elementwise activation and nothing else: -> (tail
-    layer ->
-    [(layer, activation format or None) ...] from the chain's head to the tail, set of nodes internal to a chain).
-    Layer Lp is fused into L when L's inputs are act(lin(Lp, 0)), act(lin(Lp, 1)), ... in order, with ONE activation (a
-    unary
-    function, or max / min / mul / add with a constant) and neither the outputs of Lp nor the activations are used
+    layer -> [(layer, activation format or None) ...] from the chain's head to the tail, set of nodes internal to a
+    chain). Layer Lp is fused into L when L's inputs are act(lin(Lp, 0)), act(lin(Lp, 1)), ... in order, with ONE
+    activation (a unary function, or max / min / mul / add with a constant) and neither the outputs of Lp nor the
+    activations are used
     anywhere else."""
     seen, stack, cons = set(), list(roots), {}
     for r in roots:
@@ -1460,14 +1448,13 @@ def _dense_chains(g, roots):
         ok = True
         for pos, a in enumerate(ins):
             # walk from the input down to a layer output through operations of ONE operand (unary functions, max / min /
-            # mul /
-            # add / sub / div with a constant): the activation, innermost operation last in `path`
+            # mul / add / sub / div with a constant): the activation, innermost operation last in `path`
             path, cur, chain_nodes = [], a, []
             while g.nodes[cur][0] != "lin":
                 n = g.nodes[cur]
                 # (the distributed form pads a layer's outputs to whole blocks of 16 with zeros, which meet zero weights
-                # in the next
-                # layer: the activation must be FINITE at 0 -- log(0) or c / 0 would put inf * 0 = NaN into every sum)
+                # in the next layer: the activation must be FINITE at 0 -- log(0) or c / 0 would put inf * 0 = NaN into
+                # every sum)
                 if n[0] in _FMT1 and len(n) == 2 and n[0] not in ("log", "not"):
                     path.append((n[0],))
                     nxt = n[1]
@@ -1529,9 +1516,8 @@ def _dense_chains(g, roots):
 
 def _finite_at_zero(spec):
     """Is the activation path (operations of one operand, in the order they are applied) finite at 0?  The wide
-    matrix-core form
-    pads a layer's outputs to whole blocks of 16 with zeros; `sqrt(h - 1)`, `log1p(h - 1)`, `asin(h + 2)` give NaN / inf
-    on the
+    matrix-core form pads a layer's outputs to whole blocks of 16 with zeros; `sqrt(h - 1)`, `log1p(h - 1)`, `asin(h +
+    2)` give NaN / inf on the
     padded lanes, and inf * 0 = NaN in the next layer's products would poison every output of the sample.
     Evaluated on the host in fp64 with numpy's semantics (no exceptions: inf / nan are values)."""
     import numpy as np
@@ -1659,8 +1645,7 @@ def emit(g, roots, assign=None, ret=False, used=None):
                 e = _FMT1[k].format(*ops)
             elif k == "floormod" and (g.cval(n[2]) or 0.0) > 0.0:
                 # a positive constant modulus (angle wrapping): the exact remainder -- k = floor(a / b) from the rounded
-                # quotient
-                # is off by one at exact multiples of b, where torch's remainder (fmod + sign fix-up) is not
+                # quotient is off by one at exact multiples of b, where torch's remainder (fmod + sign fix-up) is not
                 e = f"m_floormod({ops[0]}, {ops[1]})"
             elif k in _FMT2:
                 e = _FMT2[k].format(*ops)
@@ -1677,8 +1662,7 @@ def emit(g, roots, assign=None, ret=False, used=None):
             name[i] = f"v{i}"
     if assign is not None:
         # x[] entries that are read by later assignments are protected by the temporaries above only when every output
-        # is a
-        # temporary or a leaf other than x[j], j != i: copy leaves first
+        # is a temporary or a leaf other than x[j], j != i: copy leaves first
         outs, copied = [], set()
         for tgt, r in zip(assign, roots):
             if g.nodes[r][0] == "x" and name[r] != tgt:
@@ -1698,15 +1682,12 @@ def emit(g, roots, assign=None, ret=False, used=None):
 
 def match_mlp_residual(g, step_roots, cost_root, term_root, nx, nu):
     """Is the traced model the shape the engine's hand-written matrix-core kernel rolls out (csrc/rollout_mlp_split.hip,
-    BASELINE
-    configs[3]: x' = x + s (W2 tanh(W1 [x; u] + b1) + b2), cost = sum x^2,
+    BASELINE configs[3]: x' = x + s (W2 tanh(W1 [x; u] + b1) + b2), cost = sum x^2,
     /root/reference/tests/pendulum_approximate.py:47-67 with
     one hidden layer)?  Structural: exactly one chain of two dense layers with a bare tanh between them, the first
-    reading
-    [x_0 .. x_nx-1, u_0 .. u_nu-1] in order, every state component's update `x_i + s * layer2_i` with ONE constant s (or
-    none), the
-    cost a diagonal quadratic form sum_i qx_i x_i^2 + sum_n qu_n u_n^2 with constant weights (the plain sum x^2
-    included), no terminal cost.  Returns where W1, b1, W2, b2 sit in the functor's
+    reading [x_0 .. x_nx-1, u_0 .. u_nu-1] in order, every state component's update `x_i + s * layer2_i` with ONE
+    constant s (or none), the cost a diagonal quadratic form sum_i qx_i x_i^2 + sum_n qu_n u_n^2 with constant weights
+    (the plain sum x^2 included), no terminal cost.  Returns where W1, b1, W2, b2 sit in the functor's
     parameter vector and s -- or None.  (Whether the kernel exists for (nx, nu, hidden) is the caller's question:
     jit.compile_traced.)"""
     if term_root is not None or len(g.layers) != 2:
@@ -1747,8 +1728,7 @@ def match_mlp_residual(g, step_roots, cost_root, term_root, nx, nu):
             return None
         scale = c
     # cost: a sum of constant multiples of squares of state components and of controls (any association; factors in
-    # front of
-    # sub-sums distribute): sum_i qx_i x_i^2 + sum_n qu_n u_n^2, nothing else
+    # front of sub-sums distribute): sum_i qx_i x_i^2 + sum_n qu_n u_n^2, nothing else
     qx, qu = [0.0] * nx, [0.0] * nu
 
     def walk(i, f):
@@ -1808,10 +1788,9 @@ def generate(dynamics, running_cost, nx, nu, terminal_state_cost=None, step_depe
 
 def layer_members(g, used):
     """the functor's dense layers as members (csrc/mlp_wide.hpp MlpLayer) and the constructor statements that bind them
-    to
-    their weights in the parameter vector.  In the wide form a layer's A operands and bias live in registers for the
-    whole
-    launch (PRE) as long as all layers together stay below ~160 registers per lane; beyond that they are read where
+    to their weights in the parameter vector.  In the wide form a layer's A operands and bias live in registers for the
+    whole launch (PRE) as long as all layers together stay below ~160 registers per lane; beyond that they are read
+    where
     used."""
     regs = 0
     for (L, kind) in used:
@@ -1904,26 +1883,20 @@ template <int IN, int OUT, int KIND, bool WX_, bool PRE, typename U, typename P>
   P w, b;
   void load(P w_, P b_) { w = w_; b = b_; }
   void apply(const U* in, U* out) const {
-    for (int o = 0; o < OUT; ++o) { U acc = b ? b[o] : U(0); for (int i = 0; i < IN; ++i) acc += w[o * IN + i] * in[i];
-    out[o] = acc; }
+    for (int o = 0; o < OUT; ++o) { U acc = b ? b[o] : U(0); for (int i = 0; i < IN; ++i) acc += w[o * IN + i] * in[i]; out[o] = acc; }
   }
 };
-template <class L, int IN, int OUT> static inline void mlp_first(const L& l, const T (&in)[IN], T (&d)[OUT]) {
-l.apply(in, d); }
-template <class L, int IN, int OUT> static inline void mlp_mid(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in,
-d); }
-template <class L, int IN, int OUT> static inline void mlp_last(const L& l, const T (&in)[IN], T (&d)[OUT]) {
-l.apply(in, d); }
-template <class L, int IN, int OUT> static inline void mlp_single(const L& l, const T (&in)[IN], T (&d)[OUT]) {
-l.apply(in, d); }
+template <class L, int IN, int OUT> static inline void mlp_first(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in, d); }
+template <class L, int IN, int OUT> static inline void mlp_mid(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in, d); }
+template <class L, int IN, int OUT> static inline void mlp_last(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in, d); }
+template <class L, int IN, int OUT> static inline void mlp_single(const L& l, const T (&in)[IN], T (&d)[OUT]) { l.apply(in, d); }
 static const int NX = %(nx)d, NU = %(nu)d;
 static const double* p;
 %(members)s
 static inline void step_(T (&x)[NX], const T (&u)[NU], int t) { %(step)s }
 static inline T cost_(const T (&x)[NX], const T (&u)[NU], int t) { %(cost)s }
 static inline T term_(const T (&x)[NX]) { %(terminal)s }
-extern "C" void run(int B, const double* X, const double* U, int t, double* Xn, double* Cc, double* Tc, const double* P)
-{
+extern "C" void run(int B, const double* X, const double* U, int t, double* Xn, double* Cc, double* Tc, const double* P) {
   p = P;
   %(ctor)s
   for (int b = 0; b < B; ++b) {
@@ -1984,8 +1957,8 @@ def verify_on_host(code, dynamics, running_cost, nx, nu, terminal_state_cost=Non
             forms = [f for f in forms if f[0] == "cpu"]
         form = None                                    # (device, dtype) the callables accept: found on the first batch
         # three batches around the origin and one far out (fp64 callables only): rewrites that are only equal where
-        # nothing
-        # overflows -- log(1 + exp(x)) for softplus -- show up there, matching inf / nan patterns count as agreement
+        # nothing overflows -- log(1 + exp(x)) for softplus -- show up there, matching inf / nan patterns count as
+        # agreement
         batches = [(1.0, 0), (3.0, 5), (0.1, 11), (40.0, 2)]
         if step_dependent and horizon is not None:
             # a step-dependent callable is checked at EVERY timestep of the horizon (the last one first: terminal-style

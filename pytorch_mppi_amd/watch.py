@@ -2,14 +2,12 @@
 
 The reference evaluates the user's `dynamics` / `running_cost` / `terminal_state_cost` on every command
 (/root/reference/src/pytorch_mppi/mppi.py:314, :318, :325), so whatever Python-level state they read is live: an
-attribute
-rebound between two commands (`cost.goal = new_goal`; tests/smooth_mppi.py:54-58 reads `self.goal` on every call), a
-Python
-float gain, a module swapped for another one, a global.  The tracer (trace.py) runs the callables ONCE and bakes what
-they
-read into the device functor.  `StateWatch` closes that gap from the outside: it walks everything reachable from the
-callables -- closure cells, defaults, the globals their code names, `__self__`, instance dictionaries, `nn.Module`
-parameters / buffers / sub-modules, container items -- and snapshots every place a value can be read from:
+attribute rebound between two commands (`cost.goal = new_goal`; tests/smooth_mppi.py:54-58 reads `self.goal` on every
+call), a Python float gain, a module swapped for another one, a global.  The tracer (trace.py) runs the callables ONCE
+and bakes what they read into the device functor.  `StateWatch` closes that gap from the outside: it walks everything
+reachable from the callables -- closure cells, defaults, the globals their code names, `__self__`, instance
+dictionaries, `nn.Module` parameters / buffers / sub-modules, container items -- and snapshots every place a value can
+be read from:
 
     numbers / strings / None ............ by value
     tensors ............................. by identity, in-place version counter and storage pointer
@@ -17,8 +15,7 @@ parameters / buffers / sub-modules, container items -- and snapshots every place
     everything else ..................... by identity (and walked further)
 
 `changed()` re-reads those places (a flat loop, ~0.1 us per place; typical callables have 5 - 60) and returns the ones
-that
-moved.  The controller then re-traces (symbolically: milliseconds): the same functor source means the change was
+that moved.  The controller then re-traces (symbolically: milliseconds): the same functor source means the change was
 irrelevant (a call counter, a simulator's own state) and the place is dropped from the list; a different one means the
 fused kernels are out of date -- the controller returns to the callables at once and compiles the new functor beside the
 loop, with the tensors that changed promoted to RUN-TIME PARAMETERS (`Path`), so that the next `cost.goal = ...` is one
@@ -111,8 +108,7 @@ class StateWatch:
         if isinstance(v, torch.Tensor):
             trainable = isinstance(v, torch.nn.Parameter) or v.requires_grad
             # a trainable tensor's VALUES are run-time parameters of the functor (jit.CustomModel.refresh_params follows
-            # its
-            # version counter and storage): only its identity is watched here
+            # its version counter and storage): only its identity is watched here
             return (path, "T" if trainable else "t", (v, v._version, v.data_ptr()))
         if isinstance(v, np.ndarray):
             return (path, "n", (v, v.copy() if v.size <= 4096 else None))

@@ -230,6 +230,35 @@ def test_c4_mlp_65536x64_philox_generator_mfma(regime):
     _run_case(C4, "philox", regime, "philox-fill")
 
 
+# the further (nx, nu) of the split-operand matrix-core kernel (round 6: csrc/rollout_mlp_split.hip is a template on them; the model
+# is laid into C4's 16-state x 32-slot tile, the instruction stream is C4's) -- VERDICT r05 next #5: each with a C4-style test
+MLP_SHAPES = [dict(kind="mlp", K=65536, T=64, nx=12, nu=6, H=128), dict(kind="mlp", K=65536, T=64, nx=8, nu=2, H=64),
+              dict(kind="mlp", K=65536, T=64, nx=16, nu=8, H=256), dict(kind="mlp", K=30000, T=40, nx=12, nu=6, H=100)]
+
+
+@pytest.mark.parametrize("regime", ["healthy", "peaked"])
+@pytest.mark.parametrize("cfg", MLP_SHAPES, ids=[f"nx{c['nx']}-nu{c['nu']}-H{c['H']}-K{c['K']}" for c in MLP_SHAPES])
+def test_mlp_shapes_on_the_split_operand_kernel_65536x64(cfg, regime):
+    """command() against the fp64 / fp32 oracle on the consumed draw, like C4 -- and the kernel that ran is the split-operand one
+    (hidden 100: zero-padded to 128 by the host, models.mlp_kernel_width)"""
+    from pytorch_mppi_amd import _native as N
+    n0 = int(N.lib().mppi_stat_mlp_split_launches())
+    _run_case(cfg, "philox", regime, "philox-fill")
+    assert int(N.lib().mppi_stat_mlp_split_launches()) > n0, "the matrix-core kernel must take this shape"
+
+
+def test_mlp_shapes_fall_back_to_the_per_lane_kernel_where_the_split_kernel_does_not_read_the_rows(monkeypatch):
+    """nu != 4: rows generated inside K1 (short horizon), fp64, the exact-kernel knob -- the per-lane form, same results to parity"""
+    from pytorch_mppi_amd import _native as N
+    cfg = dict(kind="mlp", K=4096, T=8, nx=12, nu=6, H=64)          # 12 rows per sample: generated inside K1
+    n0 = int(N.lib().mppi_stat_mlp_split_launches())
+    _run_case(cfg, "philox", "healthy", "philox-k1")
+    assert int(N.lib().mppi_stat_mlp_split_launches()) == n0
+    monkeypatch.setenv("MPPI_MLP_EXACT", "1")
+    _run_case(dict(cfg, K=8192, T=32), "philox", "healthy", "philox-fill")
+    assert int(N.lib().mppi_stat_mlp_split_launches()) == n0
+
+
 def test_c5_eight_shards_of_the_mlp_equal_oracle_on_the_global_draw():
     """BASELINE config C5: the MLP dynamics (nx=16, H=256, nu=4), K = 524288 sharded over 8 ranks of 65536 -- emulated
     back to back on one device exactly like the two-shard case below (per shard: generator launch with the shard's global
@@ -439,15 +468,16 @@ def test_c3_shape_smppi_65536x64_lifted_controls(regime, form):
     assert (50 <= n_eff <= 5000) if regime == "healthy" else n_eff <= 30, n_eff
 
 
-@pytest.mark.parametrize("H", [256, 64])
-def test_smppi_with_mlp_dynamics_runs_on_the_matrix_cores(H, monkeypatch):
+@pytest.mark.parametrize("nx,nu,H", [(16, 4, 256), (16, 4, 64), (12, 6, 128)])
+def test_smppi_with_mlp_dynamics_runs_on_the_matrix_cores(nx, nu, H, monkeypatch):
     """SMPPI over the C4 MLP model (K 16384 x T 32): the split-operand MFMA kernel carries the base sequence, the 1/dt
     rescaling and the smoothness cost (it used to send lifted controls to the per-lane VALU kernel, 13x slower).  Against
     `oracle.smppi_command` in fp64 / fp32 on the consumed draw, and against the VALU kernel's clock."""
     import time
     import pytorch_mppi_amd as pm
     from oracle import mppi_oracle as orc
-    cfg = dict(C4, K=16384, T=32, H=H)
+    cfg = dict(C4, K=16384, T=32, H=H, nx=nx, nu=nu)
+    tag = f"smppi mlp H{H} 16384x32" if (nx, nu) == (16, 4) else f"smppi mlp ({nx},{nu}) H{H} 16384x32"
     model, mk, sigma, kw, x0, U0 = _setup(cfg)
     K, T, nu = cfg["K"], cfg["T"], cfg["nu"]
     dt_, w_ = 0.1, 0.7
@@ -474,7 +504,7 @@ def test_smppi_with_mlp_dynamics_runs_on_the_matrix_cores(H, monkeypatch):
         outs.append(orc.smppi_command(p, Ud0.to(dt), A0.to(dt), x0.to(dt), z.to(dt), -amax.to(dt), amax.to(dt), w_, dt_, True))
     r64, r32 = outs
     got = dict(action=act, U=ctrl.U, action_sequence=ctrl.action_sequence, cost_total=ctrl.cost_total, omega=ctrl.omega)
-    _check(f"smppi mlp H{H} 16384x32", got, r64, r32, keys=tuple(got))
+    _check(tag, got, r64, r32, keys=tuple(got))
     if monkeypatch is None:
         return                     # tools/margin_distributions.py: the parity part only, on many seeds
 
@@ -497,7 +527,7 @@ def test_smppi_with_mlp_dynamics_runs_on_the_matrix_cores(H, monkeypatch):
     t_mfma = clock(ctrl, 5, 4)
     monkeypatch.setenv("MPPI_MLP_VALU", "1")
     t_valu = clock(make(lam), 2, 2)
-    margins.record(f"smppi mlp H{H} 16384x32", "ms_per_command", t_mfma * 1e3, None, None, "per-lane VALU kernel: %.3f ms" % (t_valu * 1e3))
+    margins.record(tag, "ms_per_command", t_mfma * 1e3, None, None, "per-lane VALU kernel: %.3f ms" % (t_valu * 1e3))
     assert t_mfma * 2.5 < t_valu, (t_mfma, t_valu)
 
 

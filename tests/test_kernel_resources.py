@@ -45,7 +45,10 @@ BUDGETS = [
     (("rollout_kmppi_kernel<mppi::IntegratorModel<float, 16, 12>, 0>",), 20, 0),
     (("rollout_kmppi_kernel<mppi::LinearGoalModel<float, 12, 4>, 1>",), 20, 0),
     # the MLP on the matrix cores (C4 / C5): split-operand kernel, hidden 256
-    (("rollout_mlp_split_kernel<16, 0, true>",), 0, 0),
+    (("rollout_mlp_split_kernel<16, 0, true, 16, 4>",), 0, 0),      # C4
+    (("rollout_mlp_split_kernel<16, 0, true, 12, 6>",), 0, 0),      # the further (nx, nu) of the split-operand kernel: no scratch either
+    (("rollout_mlp_split_kernel<16, 0, true, 8, 2>",), 0, 0),
+    (("rollout_mlp_split_kernel<16, 0, true, 16, 8>",), 0, 0),
 ]
 
 

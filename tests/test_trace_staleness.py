@@ -299,16 +299,11 @@ def test_flags_are_forgotten_only_after_three_benign_moves(monkeypatch):
     cost = ModeCost()
     c = _controller(lambda x, u: x + 0.1 * u, cost)
     m0 = c._model
-    cost.ticks = 0.125                                  # a float that is no constant of the graph: forgotten at once
-    c._check_traced()
-    cost.ticks = 0.25
-    c._check_traced()
-    assert c._jit_benign == 1 and c._model is m0
     cost.mode = 1                                       # same branch: same functor -- but still watched
     c._check_traced()
     cost.mode = 2
     c._check_traced()
-    assert c._model is m0 and c._jit_benign == 3
+    assert c._model is m0 and c._jit_benign == 2
     cost.mode = 3                                       # the other branch
     c._check_traced()
     assert c._model is None and c._jit_retraces == 1
@@ -358,3 +353,36 @@ def test_unexplained_spot_check_mismatches_end_on_the_callables(monkeypatch, cap
         c._traced_state_moved([], "the fused functor and the callables disagree on a random batch")
     assert c._model is None and "three spot-checks in a row" in c.jit_note
     assert sum("prints the same functor" in r.getMessage() for r in caplog.records) == 3
+
+
+def test_floats_read_only_by_control_flow_are_watched_through_benign_moves(monkeypatch):
+    """a float read only in Python control flow (`if self.gain > 0.5:`) leaves no constant in the graph; it used to be
+    forgotten on its first benign move, and the move that flips the branch then went unseen until the periodic spot-check"""
+    _stub_compile(monkeypatch)
+
+    class GainCost:
+        def __init__(self):
+            self.gain = 0.1
+            self.ticks = 0.0
+
+        def __call__(self, x, u):
+            if self.gain > 0.5:
+                return (x * x).sum(-1) * 5.0
+            return (x * x).sum(-1)
+    cost = GainCost()
+    c = _controller(lambda x, u: x + 0.1 * u, cost)
+    m0 = c._model
+    cost.gain = 0.2                                     # same branch: a benign move -- still watched
+    c._check_traced()
+    assert c._model is m0 and c._jit_benign == 1
+    cost.gain = 0.9                                     # the other branch, on the SECOND move: must be seen
+    c._check_traced()
+    assert c._model is None and c._jit_retraces == 1
+    # ... while a float nothing reads is forgotten after three benign moves, like an integer
+    cost2 = GainCost()
+    c2 = _controller(lambda x, u: x + 0.1 * u, cost2)
+    m2 = c2._model
+    for i, v in enumerate((0.125, 0.25, 0.5, 0.75, 1.5)):
+        cost2.ticks = v
+        c2._check_traced()
+    assert c2._model is m2 and c2._jit_benign == 3      # the fourth and fifth move were no longer looked at

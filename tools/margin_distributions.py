@@ -38,8 +38,8 @@ def scenarios():
         ("onchip pendulum K20000 T48", lambda s: O.test_onchip_command_matches_streaming_command_and_fp64_oracle(pend), ("-",)),
         ("c4 mlp healthy", lambda s: F.test_c4_mlp_65536x64_philox_generator_mfma("healthy"), both),
         ("c4 mlp peaked", lambda s: F.test_c4_mlp_65536x64_philox_generator_mfma("peaked"), both),
-        ("smppi mlp H256", lambda s: F.test_smppi_with_mlp_dynamics_runs_on_the_matrix_cores(256, None), both),
-        ("smppi mlp H64", lambda s: F.test_smppi_with_mlp_dynamics_runs_on_the_matrix_cores(64, None), both),
+        ("smppi mlp H256", lambda s: F.test_smppi_with_mlp_dynamics_runs_on_the_matrix_cores(16, 4, 256, None), both),
+        ("smppi mlp H64", lambda s: F.test_smppi_with_mlp_dynamics_runs_on_the_matrix_cores(16, 4, 64, None), both),
         ("c5 mlp 8 shards", lambda s: F.test_c5_eight_shards_of_the_mlp_equal_oracle_on_the_global_draw(), both),
         # the callback path's random configurations are a seed sweep by construction (its worst r05 entry was its seed 17)
         ("generic random config", lambda s: R._generic_vs_oracle(5000 + s, R._case(5000 + s)), ("-",)),
