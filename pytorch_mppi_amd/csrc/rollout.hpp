@@ -1015,6 +1015,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
 #include "rollout_kmppi.hpp"   // KMPPI: interpolation inside K1 (needs rollout_step)
 #include "mlp_wide.hpp"        // traced models with dense layers: matrix-core execution, sixteen samples per wave (needs rollout_stream_heavy)
 #include "rollout_onchip.hpp"  // rng="philox" without a (K,T,nu) array: generate, roll out, keep eps' on chip, partial records
+#include "rollout_copies.hpp" // M > 1 rollouts per action sequence: one wave per copy (needs Stream, make_action)
 namespace mppi {
 
 // LDS-DMA ring depth (rows of 1 KiB per wave) for this launch, 0 = register ring.  One workgroup
@@ -1131,6 +1132,9 @@ static int launch_rollout(const KArgs<T>& a_in, hipStream_t st) {
     // interpolated raw actions); MPPI, SMPPI (base sequence + smoothness cost) and KMPPI's two-launch form
     if (a.M > 4 || (a.noise_src != MPPI_NOISE_TNK4 && a.noise_src != MPPI_NOISE_ACTIONS)) return MPPI_E_UNSUPPORTED;
     if constexpr (!model_heavy<Model>::value) {
+      // one wave per rollout copy where that form applies (rollout_copies.hpp): the same results, four times the waves
+      const int rc = launch_rollout_copies<Model, T>(a_in, st);
+      if (rc != -1) return rc;
       if (diag) MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_TNK4, true, 0, false, 4>));
       else MPPI_LAUNCH1((rollout_cost_kernel<Model, T, MPPI_NOISE_TNK4, false, 0, false, 4>));
     }

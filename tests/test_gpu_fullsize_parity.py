@@ -59,6 +59,9 @@ def _setup(cfg):
     return model, mk, sigma, kw, x0, U0
 
 
+ORACLE_DEVICE = "cpu"   # where _run_case runs the oracle: the host cores (the suite) | "cuda": the same torch-op restatement with its
+#                         tensors on the GPU (ATen kernels), what tools/margin_distributions.py uses to afford 32 seeds of C4 (25 s per
+#                         seed on the host cores)
 TORCH_ROWS = True   # rng="torch": the engine computes torch.randn's values into its rows | False = torch.randn's own (K,T,nu) array
 ONCHIP = None      # rng="philox": None = the controller's own choice | False = the streaming command (rows in memory)
 
@@ -147,7 +150,10 @@ def _run_case(cfg, rng, regime, expect_draw):
     act = ctrl.command(x0.cuda())
     assert ctrl.last_draw == expect_draw, ctrl.last_draw
     z = _consumed_normals(ctrl)
-    r64, r32 = _oracle_pair(cfg, mk, sigma, kw, lam, U0, x0, z)
+    odev = ORACLE_DEVICE if cfg["kind"] == "mlp" else "cpu"              # (the other models' oracle runs take a second on the host)
+    if odev != "cpu":
+        cfg = dict(cfg, _weights=(model.W1, model.b1, model.W2, model.b2))
+    r64, r32 = _oracle_pair(cfg, mk, sigma, kw, lam, U0, x0, z, device=odev)
     n_eff = _n_eff(r64["omega"])
     if regime == "healthy":
         assert 50 <= n_eff <= 5000, n_eff
@@ -457,10 +463,19 @@ def test_c3_shape_smppi_65536x64_lifted_controls(regime, form):
     assert ctrl.last_draw == ("philox-onchip" if form == "on-chip" else "philox-fill"), ctrl.last_draw
     z = _consumed_normals(ctrl)
     outs = []
+    dev = ORACLE_DEVICE
     for dt in (torch.float64, torch.float32):
-        f, q = mk(dt)
-        p = orc.Problem(dynamics=f, running_cost=q, nx=cfg["nx"], noise_sigma=sigma.to(dt), K=K, T=T, lambda_=lam)
-        outs.append(orc.smppi_command(p, Ud0.to(dt), A0.to(dt), x0.to(dt), z.to(dt), -amax.to(dt), amax.to(dt), w_, dt_, True))
+        if dev == "cpu":
+            f, q = mk(dt)
+        else:
+            from oracle import dynamics as dyn
+            f, q = dyn.make_mlp(*[w.to(device=dev, dtype=dt) for w in (model.W1, model.b1, model.W2, model.b2)])
+        to = lambda t_: t_.to(device=dev, dtype=dt)
+        import contextlib
+        with (torch.device(dev) if dev != "cpu" else contextlib.nullcontext()):
+            p = orc.Problem(dynamics=f, running_cost=q, nx=cfg["nx"], noise_sigma=to(sigma), K=K, T=T, lambda_=lam)
+            r = orc.smppi_command(p, to(Ud0), to(A0), to(x0), to(z), -to(amax), to(amax), w_, dt_, True)
+        outs.append({k_: (v_.cpu() if torch.is_tensor(v_) else v_) for k_, v_ in r.items()})
     r64, r32 = outs
     got = dict(action=act, U=ctrl.U, action_sequence=ctrl.action_sequence, cost_total=ctrl.cost_total, omega=ctrl.omega)
     _check(f"smppi 65536x64 {regime} {form}", got, r64, r32, keys=tuple(got))

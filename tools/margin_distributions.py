@@ -47,6 +47,7 @@ def scenarios():
 
 
 def main():
+    F.ORACLE_DEVICE = os.environ.get("MARGIN_ORACLE_DEVICE", "cuda")     # (the full-size oracle runs: 25 s per seed of C4 on the host cores)
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     prefix = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "r06_margin_distributions")
     only = sys.argv[3] if len(sys.argv) > 3 else ""
@@ -72,6 +73,9 @@ def main():
                     failures.append((name, kern, s, f"{type(e).__name__}: {str(e)[:300]}"))
                 torch.cuda.synchronize()
             timing[(name, kern)] = time.time() - t0
+            # (a long run that is cut off must not take everything with it: the tagged ledger so far, after every scenario)
+            json.dump({"n_seeds": n_seeds, "done": [list(k) for k in timing], "ledger": [e for e in margins._LEDGER if e.get("tag")],
+                       "failures": failures}, open(prefix + ".partial.json", "w"))
             print(f"[{time.strftime('%H:%M:%S')}] {name} / {kern}: {n_seeds} seeds in {timing[(name, kern)]:.0f} s", flush=True)
     os.environ.pop("MPPI_MLP_EXACT", None)
     os.environ.pop("MPPI_MARGIN_SEED", None)
@@ -102,7 +106,7 @@ def main():
                          max_ratio_among_above=float(np.nanmax(ratios[above])) if above.any() else None,
                          worst_seed=int(list(per_seed)[int(np.nanargmax(np.where(above, ratios, -1.0)))]) if above.any() else None))
     lines = [f"# tools/margin_distributions.py: {n_seeds} seeds per scenario; err = max |engine fp32 - oracle fp64| / scale, floor = the oracle's own fp32 "
-             "run against its fp64 run on the same draw",
+             "run against its fp64 run on the same draw (the full-size oracle runs with its tensors on the GPU: ATen kernels, MARGIN_ORACLE_DEVICE)",
              "# ratio = err / OWN floor (no sibling rule); SURVEY 7.3 passes err <= max(1e-5, 2 x floor); budget of tests/test_zz_margin_budget.py: 1.5",
              "# only (scenario, quantity, kernel) rows with at least one seed above 1e-5 are listed; `>1e-5` = seeds above / seeds run; "
              "max* = max ratio among the seeds above 1e-5 (what the budget test looks at)",

@@ -22,10 +22,21 @@ only = sys.argv[2] if len(sys.argv) > 2 else ""
 N_CMDS = int(os.environ.get("VARIANTS_N", "50"))
 
 
+HEALTHY = os.environ.get("VARIANTS_HEALTHY_LAMBDA", "1") != "0"
+
+
 def timeit(name, ctrl, state, n=None):
     n = n or N_CMDS
     if (only[1:] != name) if only.startswith("=") else (only not in name):      # "=MPPI": that entry alone
         return
+    if HEALTHY and "peaked" not in name:
+        # every entry at ITS OWN healthy lambda = std of its costs (bench.py's recipe): with one fixed lambda the softmax of the
+        # unbounded entries collapses (N_eff = 1: K3 skips 98 % of its 64-sample groups) while the bounded ones stay dense, and
+        # the table compares K3's sparse path with its dense one instead of the options (profiles/r06_diag_torch_bounds.txt:
+        # what round 5 read as "bounds + null action lose a fast form")
+        ctrl.command(state)
+        ct = ctrl.cost_total
+        ctrl.lambda_ = float(ct.float().std(dim=-1).mean()) if ct.dim() > 1 else float(ct.float().std())
     for _ in range(5):
         ctrl.command(state)
     torch.cuda.synchronize()
