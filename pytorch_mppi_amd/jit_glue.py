@@ -309,10 +309,12 @@ class JitGlue:
                 was_read = any(v is r for r in read)
                 (keep if was_read else drop).append(i)
                 continue
-            if isinstance(v, (bool, str, float)) or (isinstance(v, int) and not isinstance(path.holder, watch_mod._Len)):
-                # numbers and strings: what Python-level control flow reads leaves no constant behind (`if self.gain > 0.5:`),
-                # so "not in the graph" does not mean "not read" -- floats too: kept, with the present value as
-                # the new reference, until three benign moves in a row (or adoption)
+            if isinstance(v, (bool, str, float)) or (isinstance(v, int) and not isinstance(path.holder,
+                    watch_mod._Len)):
+                # numbers and strings: what Python-level control flow reads leaves no constant behind (`if self.gain >
+                # 0.5:`),
+                # so "not in the graph" does not mean "not read" -- floats too: kept, with the present
+                # value as the new reference, until three benign moves in a row (or adoption)
                 n = w.benign.get(key, 0) + 1
                 w.benign[key] = n
                 in_graph = isinstance(v, (int, bool, float)) and float(v) in numbers

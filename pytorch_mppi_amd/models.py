@@ -165,8 +165,9 @@ MLP_MATRIX_CORE_SHAPES = ((16, 4), (8, 2), (12, 6), (16, 8))
 
 def mlp_kernel_width(nx, nu, hidden):
     """The hidden width the engine's matrix-core MLP kernels are built for (csrc/rollout_mlp_split.hip: the (nx, nu) of
-    MLP_MATRIX_CORE_SHAPES, hidden 64 / 128 / 256) that holds `hidden` units, or `hidden` itself where no such kernel exists (the
-    per-lane kernel takes any width).  Padding units have zero weights in and out and zero bias: tanh(0) = 0 contributes exactly
+    MLP_MATRIX_CORE_SHAPES, hidden 64 / 128 / 256) that holds `hidden` units, or `hidden` itself where no such kernel
+    exists (the per-lane kernel takes any width).  Padding units have zero weights in and out and zero bias: tanh(0) = 0
+    contributes exactly
     nothing."""
     if (int(nx), int(nu)) in MLP_MATRIX_CORE_SHAPES:
         for w in (64, 128, 256):

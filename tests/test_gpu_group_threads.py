@@ -233,3 +233,44 @@ def test_two_real_devices_hold_identical_U_and_match_the_unsharded_controller(cl
         assert a.device == torch.device("cuda", 0)
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
         assert float((grp.cost_total - one.cost_total).abs().max()) <= 1e-5 * float(one.cost_total.abs().max())
+
+
+@pytest.mark.parametrize("K,T,upc", [(2 * 49152, 32, 1), (6000, 8, 2)])
+def test_the_rearmed_steady_state_command_commands_the_bits_of_the_ordinary_one(monkeypatch, K, T, upc):
+    """a plain MPPI group on the engine's generator re-arms the previous command's blocks (group.DeviceGroup._command_rearmed) --
+    against the same group with MPPI_GROUP_REARM=0, over a loop with everything a caller may do in between: another state, a host
+    state, attribute writes, a method call, a read of the lazily derived arrays, shift off, injected noise"""
+    nx, nu = 16, 12
+    monkeypatch.setenv("MPPI_GROUP_THREADS", "1")
+    a = _mk(pm.MPPI, K, T, nx, nu, "philox", [0, 0, 0], u_per_command=upc)
+    monkeypatch.setenv("MPPI_GROUP_REARM", "0")
+    b = _mk(pm.MPPI, K, T, nx, nu, "philox", [0, 0, 0], u_per_command=upc)
+    monkeypatch.delenv("MPPI_GROUP_REARM")
+    x = torch.linspace(-1, 1, nx, device="cuda")
+    kept = []
+    fast = 0
+    for i in range(14):
+        if i == 4:
+            for g in (a, b):
+                g.lambda_ = 11.0                                     # an attribute write: the next command is an ordinary one
+        if i == 7:
+            for g in (a, b):
+                g.change_horizon(T)                                  # a method call, likewise
+        if i == 9:
+            z = torch.randn(K, T, nu, generator=torch.Generator().manual_seed(i))
+            a.inject_noise(z), b.inject_noise(z)
+        st = x * (1.0 + 0.1 * i) if i % 3 else [0.05 * i] * nx        # a device tensor / a host list
+        shift = i != 5
+        ua, ub = a.command(st, shift_nominal_trajectory=shift), b.command(st, shift_nominal_trajectory=shift)
+        fast += object.__getattribute__(a, "_fast") is not None and not object.__getattribute__(a, "_dirty")
+        assert torch.equal(ua, ub), i
+        assert ua.shape == ((nu,) if upc == 1 else (upc, nu))
+        assert all(torch.equal(a.shards[0].U, s.U) for s in a.shards[1:])
+        assert torch.equal(a.U, b.U) and torch.equal(a.cost_total, b.cost_total) and torch.equal(a.omega, b.omega), i
+        kept.append((ua, ub.clone()))
+        if i in (2, 11):
+            assert torch.equal(a.noise, b.noise) and torch.equal(a.perturbed_action, b.perturbed_action)
+    assert fast >= 8, "most commands of the loop must have gone the re-armed way"
+    assert object.__getattribute__(b, "_fast") is None
+    for ua, ub in kept:
+        assert torch.equal(ua, ub), "an action returned earlier must never change (mppi.py:270-275)"

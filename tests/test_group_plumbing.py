@@ -63,6 +63,8 @@ def _group(G=3, K=12):
     object.__setattr__(g, "_replicas", group._Replicas())
     object.__setattr__(g, "_state_bufs", None)
     object.__setattr__(g, "_rec_bufs", {})
+    object.__setattr__(g, "_fast", None)
+    object.__setattr__(g, "_dirty", True)
     return g
 
 
