@@ -6,6 +6,7 @@ import json
 import os
 
 _LEDGER = []
+ASSERT = True    # False: `check` records without asserting (seed sweeps that judge the DISTRIBUTION: median_ratio_over_seeds)
 TAG = None       # tools/margin_distributions.py: (seed, kernel) of the run an entry belongs to
 
 
@@ -30,10 +31,15 @@ def over_budget(ledger=None, budget=BUDGET):
     """SURVEY 7.3 lets an entry above rtol pass at up to 2 x the reference's own fp32 error; the suite keeps
     its entries below `budget` x that floor, so that a change drifting towards 2 x is noticed while there is still room.
     The floor of an `action` entry is the larger of its own and that of the sequence it is the first row of (`U`, same test and
-    step): the returned action IS U[0] (mppi.py:271-275), its error is bounded by U's, and the accidental value of the reference's
-    fp32 error on those nu numbers alone is a sample of one (r04's worst entry, 1.74 x on `smppi mlp H256 :: action`, reads 0.97 x
-    with the exact-fp32 kernel and 1.75 x with the split-operand one while every other quantity of the two runs agrees to 5 %:
-    profiles/r05_smppi_mlp_margins_by_kernel.txt).  Returns [(ratio, entry, floor used)] of the entries over budget."""
+    step): the returned action IS U[0] (mppi.py:271-275), its error is bounded by U's, and the reference's fp32 error on those nu
+    numbers alone is a sample of one.  Round 6 put seed distributions behind that (profiles/r06_margin_distributions.txt, 32 draws
+    per scenario, tools/margin_distributions.py): err / OWN floor of an `action` entry has median ~1.0-1.3 like every other
+    quantity but p95 3-15 and maxima up to 30 -- with the EXACT-fp32 kernel as much as with the split-operand one -- while `U` of
+    the same runs stays at p95 ~1.7-2.2: the own floor of nu numbers is not a yardstick, U's is.  The same table is why this is a
+    budget on the suite's FIXED seeds and no more: for the ill-conditioned scenarios (peaked softmax, SMPPI's 1/dt, the pendulum)
+    the ratio is a random variable of median ~1 whose p95 is ~2-3 for ANY fp32 implementation, the reference's own included; what
+    is asserted about it across seeds is its median (`median_ratio_over_seeds`, tests/test_gpu_fullsize_parity.py).
+    Returns [(ratio, entry, floor used)] of the entries over budget."""
     ledger = _LEDGER if ledger is None else ledger
     by_key = {(e["test"], e["quantity"]): e for e in ledger}
     bad = []
@@ -62,9 +68,19 @@ def check(test, quantity, got, ref64, ref32=None, rtol=1e-5, scale_floor=0.0, no
     err = float(np.abs(g - r).max())
     floor = float(np.abs(np.asarray(ref32, dtype=np.float64) - r).max()) if ref32 is not None else 0.0
     record(test, quantity, err / scale, floor / scale if ref32 is not None else None, rtol, note, scale)
-    assert err <= max(rtol * scale, floor_factor * floor), (test, quantity, "err/scale", err / scale, "ref32 floor/scale", floor / scale, "rtol", rtol,
+    assert not ASSERT or err <= max(rtol * scale, floor_factor * floor), (test, quantity, "err/scale", err / scale, "ref32 floor/scale", floor / scale, "rtol", rtol,
                                                             "floor factor", floor_factor)
     return err / scale, floor / scale
+
+
+def median_ratio_over_seeds(entries):
+    """{quantity: (median of err / own floor, worst err / scale, seeds)} of ledger entries that differ only in the seed"""
+    import numpy as np
+    by = {}
+    for e in entries:
+        if e.get("floor_over_scale"):
+            by.setdefault(e["quantity"], []).append((e["err_over_scale"] / e["floor_over_scale"], e["err_over_scale"]))
+    return {q: (float(np.median([r for r, _ in v])), float(max(x for _, x in v)), len(v)) for q, v in by.items()}
 
 
 def dump(path=None):

@@ -242,15 +242,62 @@ MLP_SHAPES = [dict(kind="mlp", K=65536, T=64, nx=12, nu=6, H=128), dict(kind="ml
               dict(kind="mlp", K=65536, T=64, nx=16, nu=8, H=256), dict(kind="mlp", K=30000, T=40, nx=12, nu=6, H=100)]
 
 
+def _run_case_over_seeds(cfg, rng, regime, expect_draw, seeds=5, median_budget=2.0, worst=5e-4):
+    """`_run_case` on `seeds` draws (MPPI_MARGIN_SEED), judged as a DISTRIBUTION (round 6, profiles/r06_margin_distributions.txt):
+    `cost_total` -- what the kernel itself computes -- must meet SURVEY 7.3's rule on every seed; for the quantities derived from
+    it through the softmax (omega, U, action: errors of the costs amplified by 1/lambda, the same for any fp32 implementation) the
+    per-seed ratio err / floor is a random variable of median ~1 with p95 ~2-3 even for the exact-fp32 kernel, so what is asserted
+    is its MEDIAN over the seeds (<= `median_budget` x the reference's own fp32 error -- SURVEY 7.3's factor 2 by default --, or the
+    whole sweep below 1e-5) and a sanity
+    bound on the worst seed.  The oracle runs with its tensors on the GPU (ATen kernels): five seeds of a C4-sized case on the host
+    cores would take two minutes."""
+    import os
+    global ORACLE_DEVICE
+    keep_dev, keep_seed, keep_tag, n0 = ORACLE_DEVICE, os.environ.get("MPPI_MARGIN_SEED"), margins.TAG, len(margins._LEDGER)
+    ORACLE_DEVICE, margins.ASSERT = "cuda", False
+    try:
+        for sd in range(seeds):
+            os.environ["MPPI_MARGIN_SEED"] = str(sd)
+            margins.TAG = ["seed sweep", regime, sd]
+            _run_case(cfg, rng, regime, expect_draw)
+    finally:
+        ORACLE_DEVICE, margins.ASSERT, margins.TAG = keep_dev, True, keep_tag
+        if keep_seed is None:
+            os.environ.pop("MPPI_MARGIN_SEED", None)
+        else:
+            os.environ["MPPI_MARGIN_SEED"] = keep_seed
+    mine = margins._LEDGER[n0:]
+    for e in mine:
+        if e["quantity"] == "cost_total":
+            assert e["err_over_scale"] <= max(1e-5, 2 * e["floor_over_scale"]), e
+    stats = margins.median_ratio_over_seeds(mine)
+    for q, (med, worst_err, n) in stats.items():
+        assert n == seeds and worst_err <= worst, (q, med, worst_err, n)
+        assert med <= median_budget or worst_err <= 1e-5, (q, "median err / own fp32 floor over the seeds", med, "worst err/scale", worst_err)
+    return stats
+
+
 @pytest.mark.parametrize("regime", ["healthy", "peaked"])
 @pytest.mark.parametrize("cfg", MLP_SHAPES, ids=[f"nx{c['nx']}-nu{c['nu']}-H{c['H']}-K{c['K']}" for c in MLP_SHAPES])
 def test_mlp_shapes_on_the_split_operand_kernel_65536x64(cfg, regime):
-    """command() against the fp64 / fp32 oracle on the consumed draw, like C4 -- and the kernel that ran is the split-operand one
-    (hidden 100: zero-padded to 128 by the host, models.mlp_kernel_width)"""
+    """command() against the fp64 / fp32 oracle on the consumed draw, like C4, on five draws -- and the kernel that ran is the
+    split-operand one (hidden 100: zero-padded to 128 by the host, models.mlp_kernel_width)"""
     from pytorch_mppi_amd import _native as N
     n0 = int(N.lib().mppi_stat_mlp_split_launches())
-    _run_case(cfg, "philox", regime, "philox-fill")
+    _run_case_over_seeds(cfg, "philox", regime, "philox-fill")
     assert int(N.lib().mppi_stat_mlp_split_launches()) > n0, "the matrix-core kernel must take this shape"
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["split-operand kernel", "exact-fp32 kernel"])
+def test_c4_margins_are_distributed_like_the_references_own_fp32_error(exact, monkeypatch):
+    """VERDICT r05 next #2, as a test: eight draws of C4 at a peaked lambda -- the worst-conditioned full-size scenario of the ledger --
+    under the product's matrix-core kernel and under the exact-fp32 one: the median of err / own fp32 floor is <= 1.5 for every public
+    output (it is ~1.0: the engine's fp32 error is distributed like the reference's own), for BOTH kernels (no systematic
+    split-operand excess: no dropped piece product to add back)"""
+    if exact:
+        monkeypatch.setenv("MPPI_MLP_EXACT", "1")
+    stats = _run_case_over_seeds(C4, "philox", "peaked", "philox-fill", seeds=8, median_budget=1.5)
+    assert set(stats) >= {"cost_total", "omega", "U", "action"}
 
 
 def test_mlp_shapes_fall_back_to_the_per_lane_kernel_where_the_split_kernel_does_not_read_the_rows(monkeypatch):
