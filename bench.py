@@ -424,28 +424,37 @@ def _self_spawn(n, argv):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
-def host_issue_probe(pm, wl, devs, commands=400):
-    """What the host needs to get ONE sharded command out (VERDICT r05 next #1a): a device group over `devs` on the workload's model
-    and horizon but K = 256 per shard -- the GPU's share of such a command is a few microseconds, what is left is the host: the
-    N problem blocks, the hand-over to the engine's worker threads, one device's launches.  Microseconds per command."""
-    _, kind, nx, nu, _, T = WORKLOADS[wl]
+def host_issue_probe(pm, wl, devs, rng="philox", bursts=6, burst=20):
+    """What the host needs to get ONE sharded command of THIS workload out (VERDICT r05 next #1a): the device group at the workload's
+    own size (K per shard, T, model: the form the command takes -- on chip, streaming, ... -- decides what the host has to do),
+    timed in short bursts that start from an idle queue, so that the host never waits for the GPU while it issues and the time per
+    command is the host's own whatever the GPUs take.  Returns microseconds per command: total, the calling thread's own share
+    (problem blocks + hand-over), and the wait for the engine's worker threads (one device's launches when the devices are
+    distinct; on a rig whose shards share ONE device the workers' launches serialise on that device's queue and the wait grows
+    with N -- `devices_distinct` says which it was)."""
+    _, kind, nx, nu, Kper, T = WORKLOADS[wl]
     dev0 = torch.device("cuda", devs[0])
-    ctrl, x0, _ = make_controller(pm, wl, dev0, "philox", None, 256 * len(devs), devices=devs)
-    for _ in range(50):
-        ctrl.command(x0)
-    # short bursts, each from an idle queue: the host must never wait for the GPU while it issues (with the shards of a rig on ONE
-    # device the kernels' fixed costs add up to more than the host's share, and a long loop would measure the queue filling up)
-    burst, issue = 60, float("inf")
-    for _ in range(max(3, commands // burst)):
-        for d in sorted(set(devs)):
+    ctrl, x0, _ = make_controller(pm, wl, dev0, rng, None, Kper * len(devs), devices=devs)
+    uniq = sorted(set(devs))
+
+    def sync():
+        for d in uniq:
             torch.cuda.synchronize(d)
+    for _ in range(30):
+        ctrl.command(x0)
+    best = (float("inf"), 0.0)
+    for _ in range(bursts):
+        sync()
+        w0 = ctrl.wait_seconds
         t0 = time.perf_counter()
         for _ in range(burst):
             ctrl.command(x0)
-        issue = min(issue, (time.perf_counter() - t0) / burst)
-    for d in sorted(set(devs)):
-        torch.cuda.synchronize(d)
-    return issue * 1e6, ctrl.issue
+        dt = (time.perf_counter() - t0) / burst
+        if dt < best[0]:
+            best = (dt, (ctrl.wait_seconds - w0) / burst)
+    sync()
+    return {"host_issue_us": best[0] * 1e6, "caller_us": (best[0] - best[1]) * 1e6, "wait_for_workers_us": best[1] * 1e6,
+            "devices_distinct": len(uniq) == len(devs), "issued_by": ctrl.issue, "draw": ctrl.shards[0].last_draw}
 
 
 def validate_devices(args):
@@ -483,7 +492,8 @@ def choose_process_model(args):
     n = args.gpus
     have = torch.cuda.device_count()
     devs = list(range(n)) if have >= n else [i % max(1, have) for i in range(n)]
-    ev = {"rule": "devices iff host_issue_us < 0.8 * single_gpu_us_per_step (and, on N real devices, the group validates); else spawn"}
+    ev = {"rule": "devices iff host_issue_us (measured: this workload's own group, bursts from an idle queue) < 0.8 * single_gpu_us_per_step "
+                  "(and, on N real devices, the group validates); else spawn"}
     dev0 = torch.device("cuda", devs[0])
     torch.cuda.set_device(dev0)
     desc, kind, nx, nu, Kper, T = WORKLOADS[args.workload]
@@ -507,12 +517,20 @@ def choose_process_model(args):
                 return "spawn", ev
         else:
             ev["validation"] = f"skipped: {n} shards share {have} GPU(s) (a rig for the code path)"
-        us, how = host_issue_probe(pm, args.workload, devs)
-        ev["host_issue_us"], ev["host_issue_us_per_device"], ev["issued_by"] = us, us / n, how
+        pr = host_issue_probe(pm, args.workload, devs, args.rng)
+        ev.update(pr)
+        ev["host_issue_us_per_device"] = pr["caller_us"] / n
+        # what N DISTINCT devices would need per command: the caller's N blocks + ONE device's launches (each worker issues its own
+        # device's in parallel) -- on a rig of one device the measured wait is N devices' launches one behind the other
+        ev["host_issue_us_if_devices_were_distinct"] = pr["caller_us"] + pr["wait_for_workers_us"] / (1 if pr["devices_distinct"] else n)
     except Exception as e:                           # (subprocess timeout, a failing group: the per-process model needs neither)
         ev["error"] = f"{type(e).__name__}: {e}"[:300]
         return "spawn", ev
-    return ("devices" if ev["host_issue_us"] < 0.8 * ev["single_gpu_us_per_step"] else "spawn"), ev
+    fits = ev["host_issue_us"] < 0.8 * ev["single_gpu_us_per_step"]
+    if not fits and not ev["devices_distinct"] and ev["host_issue_us_if_devices_were_distinct"] < 0.8 * ev["single_gpu_us_per_step"]:
+        ev["note"] = ("on this rig (shards share a device) the group is bound by that one device anyway; with distinct devices the host "
+                      "share would fit: `spawn` is chosen because the MEASURED figure decides")
+    return ("devices" if fits else "spawn"), ev
 
 
 def main_devices(args, choice=None):
@@ -563,8 +581,8 @@ def main_devices(args, choice=None):
     torch.cuda.synchronize()
     d1 = time.perf_counter() - t1
     if choice is None:
-        us, how = host_issue_probe(pm, args.workload, devs)
-        choice = {"host_issue_us": us, "host_issue_us_per_device": us / n, "issued_by": how, "rule": "--process-model devices (forced)"}
+        choice = host_issue_probe(pm, args.workload, devs, args.rng)
+        choice.update(host_issue_us_per_device=choice["caller_us"] / n, rule="--process-model devices (forced)")
     out = {
         "metric": "rollouts/sec (K x T state evals) per .command() call",
         "value": Kglobal * args.steps / dt, "unit": "rollouts/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -584,7 +602,7 @@ def main_devices(args, choice=None):
                          "weak_scaling_speedup": n * d1 / dt, "weak_scaling_efficiency": d1 / dt,
                          "note": "against the same workload unsharded at K_per_gpu on device 0, timed in this run with the same loop.  Each "
                                  "device's launches are issued by a worker thread of the engine (csrc/group.hip): the calling thread's share "
-                                 "is the N problem blocks (`host_issue_us_per_device` x N, measured on a K = 256 problem)"},
+                                 "is the N problem blocks (`host_issue_us_per_device` x N; config.process_model_choice has the split)"},
     }
     print(json.dumps(out), flush=True)
 

@@ -42,6 +42,7 @@ mismatch raises inside such a callable is re-raised with that advice."""
 import contextlib
 import ctypes as C
 import os
+import time
 
 import torch
 
@@ -80,7 +81,7 @@ def _dev_index(d):
 
 _OWN = frozenset(("_shards", "_devs", "_comms", "_staged", "_base", "exchange", "_engine", "_replicas", "_state_bufs",
         "_rec_bufs",
-                  "_threads", "issue", "_fast", "_dirty"))
+                  "_threads", "issue", "_fast", "_dirty", "wait_seconds"))
 
 
 def _module_of(fn):
@@ -173,6 +174,10 @@ class DeviceGroup:
         object.__setattr__(self, "_rec_bufs", {})
         object.__setattr__(self, "_fast", None)
         object.__setattr__(self, "_dirty", True)
+        # seconds the calling thread has spent in mppi_group_wait (the workers issuing their launches): the rest of a command's
+        # issue time is the caller's own share -- what bench.py's host probe tells apart (on a rig whose shards share ONE device the
+        # workers' launches serialise on that device's queue, which N real devices do not)
+        object.__setattr__(self, "wait_seconds", 0.0)
         object.__setattr__(self, "_staged", len(set(devs)) < len(devs))
         object.__setattr__(self, "exchange", None)
         object.__setattr__(self, "issue", None)
@@ -435,7 +440,9 @@ class DeviceGroup:
                 N.check(rc, "mppi_group_submit")
             outs.append((U_out, cost, omega, wnz, record))
         forms = (C.c_int32 * G)()
+        t_w = time.perf_counter()
         rc = lib.mppi_group_wait(eng, forms, None)
+        object.__setattr__(self, "wait_seconds", object.__getattribute__(self, "wait_seconds") + time.perf_counter() - t_w)
         if rc != 0:
             object.__setattr__(self, "_fast", None)
             N.check(rc, "mppi_group_wait")
@@ -513,7 +520,9 @@ class DeviceGroup:
                     lib.mppi_group_abort(eng)
                     N.check(rc, "mppi_group_submit")
             forms, nds = (C.c_int32 * G)(), (C.c_int32 * G)()
+            t_w = time.perf_counter()
             rc = lib.mppi_group_wait(eng, forms, nds)
+            object.__setattr__(self, "wait_seconds", object.__getattribute__(self, "wait_seconds") + time.perf_counter() - t_w)
             if rc == 0:
                 for g, (s, p) in enumerate(zip(shards, ps)):
                     s._launched(p, int(forms[g]), int(nds[g]))

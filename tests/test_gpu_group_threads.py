@@ -235,7 +235,7 @@ def test_two_real_devices_hold_identical_U_and_match_the_unsharded_controller(cl
         assert float((grp.cost_total - one.cost_total).abs().max()) <= 1e-5 * float(one.cost_total.abs().max())
 
 
-@pytest.mark.parametrize("K,T,upc", [(2 * 49152, 32, 1), (6000, 8, 2)])
+@pytest.mark.parametrize("K,T,upc", [(3 * 49152, 32, 1), (6000, 4, 2)])       # on chip | rows generated inside K1
 def test_the_rearmed_steady_state_command_commands_the_bits_of_the_ordinary_one(monkeypatch, K, T, upc):
     """a plain MPPI group on the engine's generator re-arms the previous command's blocks (group.DeviceGroup._command_rearmed) --
     against the same group with MPPI_GROUP_REARM=0, over a loop with everything a caller may do in between: another state, a host

@@ -308,7 +308,7 @@ def test_bench_gpus_2_in_one_process_on_a_device_group():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MPPI_BENCH_BACKEND")}
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2"],
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--process-model", "devices"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -316,6 +316,7 @@ def test_bench_gpus_2_in_one_process_on_a_device_group():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["K_global"] == 2 * d["config"]["K_per_gpu"] and d["value"] > 0
     assert d["config"]["devices_hold_identical_U"] is True and "ONE process" in d["config"]["process_model"]
+    assert d["host_issue_us_per_device"] > 0 and "worker thread" in d["config"]["process_model"]
     if torch.cuda.device_count() < 2:
         assert d["config"]["devices"] == [0, 0] and "not a measurement" in d["config"]["process_model"]
     assert d["weak_scaling"]["single_gpu_ms_per_step"] > 0

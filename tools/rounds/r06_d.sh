@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 REPO=$PWD
-P=r06_d
+P=${1:-r06_d}
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${P}_pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/${P}_pytest.log
 grep -n "^FAILED\|passed\|failed" gpurun_out/${P}_pytest.log | tail -12 | cut -c1-300
 timeout 900 python tools/group_host_issue.py gpurun_out/${P}_group_host_issue.txt 2>&1 | tail -14
