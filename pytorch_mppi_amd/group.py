@@ -81,7 +81,7 @@ def _dev_index(d):
 
 _OWN = frozenset(("_shards", "_devs", "_comms", "_staged", "_base", "exchange", "_engine", "_replicas", "_state_bufs",
         "_rec_bufs",
-                  "_threads", "issue", "_fast", "_dirty", "wait_seconds"))
+                  "_threads", "issue", "_fast", "_dirty", "wait_seconds", "_rearm"))
 
 
 def _module_of(fn):
@@ -174,6 +174,7 @@ class DeviceGroup:
         object.__setattr__(self, "_rec_bufs", {})
         object.__setattr__(self, "_fast", None)
         object.__setattr__(self, "_dirty", True)
+        object.__setattr__(self, "_rearm", os.environ.get("MPPI_GROUP_REARM", "1") != "0")      # (A/B, tests: "0" = rebuild every block)
         # seconds the calling thread has spent in mppi_group_wait (the workers issuing their launches): the rest of a command's
         # issue time is the caller's own share -- what bench.py's host probe tells apart (on a rig whose shards share ONE device the
         # workers' launches serialise on that device's queue, which N real devices do not)
@@ -373,7 +374,7 @@ class DeviceGroup:
     def _arm(self, ps, fresh, states, bc, forms):
         object.__setattr__(self, "_fast", None)
         shards = object.__getattribute__(self, "_shards")
-        if forms is None or fresh is None or bc is None or os.environ.get("MPPI_GROUP_REARM", "1") == "0":
+        if forms is None or fresh is None or bc is None or not object.__getattribute__(self, "_rearm"):
             return
         s0 = shards[0]
         if not all(type(s)._prepare is _plain_prepare and type(s)._end is _plain_end and self._light(s)

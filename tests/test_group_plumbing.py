@@ -65,6 +65,8 @@ def _group(G=3, K=12):
     object.__setattr__(g, "_rec_bufs", {})
     object.__setattr__(g, "_fast", None)
     object.__setattr__(g, "_dirty", True)
+    object.__setattr__(g, "_rearm", True)
+    object.__setattr__(g, "wait_seconds", 0.0)
     return g
 
 

@@ -45,6 +45,34 @@ run_pmc stream_write "WRITE_SIZE" --rng philox-stream
 run_pmc torch_fetch "FETCH_SIZE" --rng torch
 run_pmc torch_write "WRITE_SIZE" --rng torch
 run_pmc c4_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --workload c4
+# the matrix-pipe share of the split-operand kernel on the further shapes (within 15 % of C4's)
+for shp in "12 6 128" "16 8 256" "8 2 64"; do
+  tag=$(echo $shp | tr ' ' '_')
+  (cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $REPO/gpurun_out/pmc_mlp_$tag -o mlp -- python $REPO/tools/mlp_shape_run.py $shp > $REPO/gpurun_out/${P}_pmc_mlp_$tag.log 2>&1)
+  DB=$(find gpurun_out/pmc_mlp_$tag -name "*.db" | head -1); [ -n "$DB" ] && python tools/pmc_summary.py $DB gpurun_out/${P}_pmc_mlp_$tag.txt > /dev/null; rm -rf gpurun_out/pmc_mlp_$tag
+done
+python - <<PY
+import re
+def tab(path, kernel):
+    out = {}
+    try:
+        for line in open(path):
+            m = re.match(r"\\s*(\\S+)\\s+(\\d+)\\s+([\\d.]+)\\s+([\\d.]+)\\s+([\\d.]+)\\s+(.*)", line)
+            if m and kernel in m.group(6):
+                out[m.group(1)] = float(m.group(3))
+    except Exception:
+        pass
+    return out
+lines = ["# matrix-pipe busy share of rollout_mlp_split_kernel = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024), K = 65536, T = 64 (rocprofv3 --pmc, means over the launches)"]
+for name, f in (("c4 (16,4,256)", "gpurun_out/${P}_pmc_c4_mfma.txt"), ("(12,6,128)", "gpurun_out/${P}_pmc_mlp_12_6_128.txt"), ("(16,8,256)", "gpurun_out/${P}_pmc_mlp_16_8_256.txt"), ("(8,2,64)", "gpurun_out/${P}_pmc_mlp_8_2_64.txt")):
+    t = tab(f, "rollout_mlp_split_kernel")
+    if t.get("GRBM_GUI_ACTIVE"):
+        lines.append(f"  {name:<16} busy {t['SQ_VALU_MFMA_BUSY_CYCLES'] / (t['GRBM_GUI_ACTIVE'] / 8 * 1024):.4f}   (MFMA busy cycles {t['SQ_VALU_MFMA_BUSY_CYCLES']:.0f}, GRBM_GUI_ACTIVE {t['GRBM_GUI_ACTIVE']:.0f})")
+    else:
+        lines.append(f"  {name:<16} no counters")
+open("gpurun_out/${P}_mlp_shapes_mfma_busy.txt", "w").write("\\n".join(lines) + "\\n")
+print("\\n".join(lines))
+PY
 trace() {
   name=$1; pat=$2; shift; shift
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_$name -o $name -- python "$@" > $REPO/gpurun_out/${P}_run_$name.log 2>&1)
