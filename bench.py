@@ -302,11 +302,14 @@ def _onchip_valu_lookup(workload, k1_us):
     except Exception:
         return None
     w = c["waves"]
+    wps = c.get("waves_per_simd", 1)                  # the two-wave kernel (round 6): a SIMD's VALU is busy when EITHER wave's is
     frac = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
     return {"stale": _lookup_stale(c, "rollout_onchip_kernel", "pmc_onchip_valu.json"),
-            "valu_active_share_of_wave_cycles": frac, "valu_insts_per_wave": c["SQ_INSTS_VALU"] / w,
+            "kernel": c.get("kernel", "rollout_onchip_kernel"), "waves_per_simd": wps,
+            "valu_active_share_of_wave_cycles": frac, "valu_busy_share_of_simd_cycles": frac * wps,
+            "valu_insts_per_wave": c["SQ_INSTS_VALU"] / w,
             "valu_active_cycles_per_wave": 4.0 * c["SQ_ACTIVE_INST_VALU"] / w, "wave_cycles": 4.0 * c["SQ_WAVE_CYCLES"] / w,
-            "issue_floor_us": frac * k1_us if k1_us else None,
+            "issue_floor_us": frac * wps * k1_us if k1_us else None,
             "cycles_per_valu_inst": 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"],
             "waiting_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stall_share": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
             "traffic_bytes": (2 * c["FETCH_SIZE_KiB"] + c["WRITE_SIZE_KiB"]) * 1024,
@@ -755,7 +758,7 @@ def main():
         # rocprofv3 trace of this very process)
         onchip_now = ctrl.last_draw == "philox-onchip"
         json.dump({"warmup": args.warmup, "steps": args.steps, "regions": {
-            "headline": {"pattern": "rollout_onchip_kernel" if onchip_now else K1_KERNEL_PATTERN[kind], "spans_us": k1_dev_us,
+            "headline": {"pattern": "rollout_onchip" if onchip_now else K1_KERNEL_PATTERN[kind], "spans_us": k1_dev_us,
                          "launches_before": (1 if kind != "pendulum" else 0) + args.warmup + n_clock_warmup}}}, open(dump, "w"))
     if world > 1:
         tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -832,7 +835,11 @@ def main():
         ext_bytes = 4 * ctrl.K_local * T * nu + 4 * ctrl.K_local
         spill_bytes = 4 * ctrl._spill[1].numel() if getattr(ctrl, "_spill", None) and ctrl._spill[1] is not None else 0
         oc_traffic = _pmc_lookup(f"{args.workload}/philox-onchip", "rollout_onchip_kernel") if world == 1 else (None, None)
-        onchip = {"kernel": "rollout_onchip_kernel (csrc/rollout_onchip.hpp) + finalize_blocks_kernel",
+        # which on-chip K1 ran: two waves per 64-sample group (csrc/rollout_onchip_pair.hpp, round 6) or one wave per SIMD
+        pair = int(lib.mppi_stat_onchip_pair_launches()) > 0
+        oc_kernel = "rollout_onchip_pair_kernel" if pair else "rollout_onchip_kernel"
+        onchip = {"kernel": f"{oc_kernel} (csrc/{'rollout_onchip_pair.hpp: two waves per 64-sample group' if pair else 'rollout_onchip.hpp'}) + finalize_blocks_kernel",
+                  "k1_kernel": oc_kernel,
                   "no_hbm_mode": spill_bytes == 0,
                   "spill_array_bytes": spill_bytes,
                   "avg_launch_us": oc_us, "avg_launch_us_device_span": oc_dev["avg"] if oc_dev else None,
@@ -974,7 +981,7 @@ def main():
         # normals and writes K costs; K3 reads them again with the costs and writes the (T,nu) update): the kernel itself keeps the
         # normals on chip and is VALU-bound, so this is an HBM-EQUIVALENT rate (how fast the replaced streaming work would have to
         # move its bytes to keep up), not traffic; `frac_k1_bytes` prices the same launch against K1's bytes alone.
-        head = {"bound": "hbm", "kernel": "rollout_onchip_kernel", "unit": "GB/s",
+        head = {"bound": "hbm", "kernel": onchip["k1_kernel"], "unit": "GB/s",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS if ach else None,
                 "bytes": b_cmd, "bytes_kind": "algorithmic bytes of the work one launch does: B_cmd = B1 + B3 (SURVEY.md 8d) = "
                                               "2 * (4*K*T*nu + 4*K) + 8*T*nu -- HBM-equivalent, the kernel itself streams no (K,T,nu) array",

@@ -360,6 +360,13 @@ int64_t mppi_stat_single_launch_commands(void);
  * when given).  Problems outside that scope with p->z == NULL run K1 + K3 with the rows generated twice, as before.
  * MPPI_ONCHIP=0 in the environment disables the form (A/B runs).  Count of commands that took it: */
 int64_t mppi_stat_onchip_commands(void);
+/* Round 6 (still ABI 22: additive): on-chip commands whose K1 ran with TWO waves per 64-sample group (csrc/rollout_onchip_pair.hpp:
+ * the waves of a pair own alternating chunks of the horizon, each generates, keeps and later sums its own rows, the rollout's state
+ * goes from one to the other through LDS -- a second wave per SIMD hides the first one's waits; bit for bit the results of the
+ * one-wave kernel).  Taken by the plain command (no |noise| cost, u_scale 1, no SMPPI terms, diagonal Sigma) when the caller's
+ * `onchip_spill` array has mppi_onchip_spill_elems() elements (the larger of the two forms' needs); MPPI_ONCHIP_PAIR=0 / 1 in the
+ * environment forces the one-wave / allows the two-wave kernel (read at every launch). */
+int64_t mppi_stat_onchip_pair_launches(void);
 /* ABI 22: launches of the split-operand matrix-core K1 of MPPI_MODEL_MLP (csrc/rollout_mlp_split.hip) in this process -- which
  * kernel a dense-MLP command ran is otherwise invisible to the caller (the per-lane form gives the same results to parity) */
 int64_t mppi_stat_mlp_split_launches(void);

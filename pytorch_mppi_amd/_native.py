@@ -89,6 +89,7 @@ SYMBOLS = {
     "mppi_command": (C.c_int, [_PP, C.c_int, _vp]),
     "mppi_stat_single_launch_commands": (C.c_int64, []),
     "mppi_stat_onchip_commands": (C.c_int64, []),
+    "mppi_stat_onchip_pair_launches": (C.c_int64, []),
     "mppi_stat_mlp_split_launches": (C.c_int64, []),
     "mppi_last_command_form": (C.c_int, []),
     "mppi_last_next_draw": (C.c_int, []),

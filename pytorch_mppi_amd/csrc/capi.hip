@@ -620,6 +620,9 @@ static std::atomic<long long> g_onchip_commands{0};
 static std::atomic<long long> g_kmppi_onchip_updates{0};
 extern "C" int64_t mppi_stat_onchip_commands(void) { return g_onchip_commands.load(); }
 extern "C" int64_t mppi_stat_mlp_split_launches(void) { return (int64_t)mlp_split_launches(); }
+static std::atomic<long long> g_onchip_pair_launches{0};
+namespace mppi { void onchip_pair_launched() { ++g_onchip_pair_launches; } }
+extern "C" int64_t mppi_stat_onchip_pair_launches(void) { return g_onchip_pair_launches.load(); }
 // which form the calling THREAD's last mppi_command took (the counters above are process-wide: with two controllers
 // commanding from two threads, "did MY command run on chip" cannot be read off a shared count -- ADVICE r03)
 static thread_local int t_last_form = MPPI_FORM_NONE;
@@ -660,7 +663,16 @@ extern "C" int64_t mppi_onchip_spill_elems(const MppiProblem* p) {
   const mppi::OnChipGeometry g = mppi::onchip_geometry(p->nu, p->T, p->sigma_diagonal != 0);
   if (!g.ok || g.nsm <= 0) return 0;
   const int64_t nkc = (p->K + mppi::BLOCK - 1) / mppi::BLOCK;
-  return (int64_t)g.nsm * g.P4 * nkc * mppi::BLOCK * 4;
+  int64_t n = (int64_t)g.nsm * g.P4 * nkc * mppi::BLOCK * 4;
+  // the two-waves-per-sample form (rollout_onchip_pair.hpp) keeps fewer rows in registers: its array is the larger one
+  // (the models it is instantiated for: rollout_onchip_pair.hpp onchip_pair_model_ok)
+  const bool pair_model = p->model_id == MPPI_MODEL_INTEGRATOR && p->nx == 16 && p->nu == 12;
+  const mppi::OnChipPairGeometry gp = mppi::onchip_pair_geometry(p->nu, p->nx, p->T);
+  if (pair_model && gp.ok && gp.nch >= 4 && p->sigma_diagonal != 0) {
+    const int64_t np = (int64_t)gp.nsm * gp.P4 * nkc * 2 * mppi::BLOCK * 4;
+    if (np > n) n = np;
+  }
+  return n;
 }
 
 extern "C" int mppi_command(const MppiProblem* p, int apply, void* stream) {

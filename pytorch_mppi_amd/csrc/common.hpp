@@ -72,6 +72,9 @@ __device__ __forceinline__ void stamp_exit(unsigned long long* ts) {      // cal
     atomicMax(&ts[2 * ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & (STAMP_SLOTS - 1)) + 1], (unsigned long long)wall_clock64());
 }
 
+#ifndef MPPI_ONCHIP_PBROWS
+#define MPPI_ONCHIP_PBROWS 12   // rows generated together by the on-chip command (csrc/rollout_onchip.hpp OnChip<NU>::PB)
+#endif
 #ifndef MPPI_ONCHIP_NTA
 #define MPPI_ONCHIP_NTA 5   // weighting tiles the on-chip command keeps in registers (csrc/rollout_onchip.hpp OnChip<NU>::NTA)
 #endif
@@ -115,6 +118,72 @@ static inline OnChipGeometry onchip_geometry(int nu, int Tn, bool diag) {
   g.nsm = g.ntiles * g.SW - g.AG_SS - nsl;
   if (g.nsm < 0) g.nsm = 0;
   g.smem = L.bytes();
+  return g;
+}
+
+// The same command with TWO waves per sample group (csrc/rollout_onchip_pair.hpp): the super-steps go to the two waves of a pair in
+// alternating chunks of CH; each wave keeps ITS rows -- the first KR local super-steps in registers, the next `nsl` (whole tiles) in LDS,
+// the remaining `nsm` in the spill array ([local row][workgroup thread of 512][4]).  `nls` counts the local super-steps of the wave
+// that owns the even chunks (the other one has as many or one chunk fewer), `ntl` its weighting tiles.
+#ifndef MPPI_ONCHIP_PAIR_DEFAULT
+#define MPPI_ONCHIP_PAIR_DEFAULT 1   // MPPI_ONCHIP_PAIR unset: 0 = the one-wave kernel, 1 = the pair kernel wherever it applies
+#endif
+#ifndef MPPI_PAIR_KT
+#define MPPI_PAIR_KT 1      // weighting tiles per wave kept in registers (each wave has 256 registers, not 512: two tiles spill)
+#endif
+#ifndef MPPI_PAIR_ND
+#define MPPI_PAIR_ND -1     // weighting tiles per wave generated a second time beside the fetch of those that waited in memory; -1: chosen below
+#endif
+struct OnChipPairGeometry {
+  int P4, TT, SW, CH, KR, nss, nch, nit, nls, ntl, nsl, nsm, shn;
+  size_t smem;
+  bool ok;
+};
+static inline OnChipPairGeometry onchip_pair_geometry(int nu, int nx, int Tn) {
+  OnChipPairGeometry g{};
+  const int G = (nu % 4 == 0) ? 4 : ((nu % 2 == 0) ? 2 : 1);
+  g.P4 = nu / G;
+  g.TT = 4 / G;
+  g.SW = (16 / g.P4) > 0 ? (16 / g.P4) : 1;
+  g.CH = (MPPI_ONCHIP_PBROWS / g.P4) > 0 ? (MPPI_ONCHIP_PBROWS / g.P4) : 1;
+  g.KR = MPPI_PAIR_KT * g.SW;
+  g.nss = (Tn + g.TT - 1) / g.TT;
+  g.nch = (g.nss + g.CH - 1) / g.CH;
+  g.nit = (g.nch + 1) / 2;
+  g.nls = g.nit * g.CH;
+  g.ntl = (g.nls + g.SW - 1) / g.SW;
+  const int hand = (nx + 2) * BLOCK, ex = 8 * g.ntl * 64;
+  g.shn = hand > ex ? hand : ex;                                      // floats: the state hand-over, later the waves' column sums
+  const long long fixed = ((long long)3 * g.nss * g.P4 * 4 + 16 + g.shn) * 4;
+  g.ok = g.P4 <= 16 && fixed <= 160 * 1024;
+  if (!g.ok) return g;
+  const long long room = (160 * 1024 - fixed) / ((long long)g.P4 * 2 * BLOCK * 16);
+  int nsl = (g.nch / 2) * g.CH - g.KR;                                // only what BOTH waves of a pair really write may wait in LDS
+  if (nsl < 0) nsl = 0;
+  if (nsl > room) nsl = (int)room;
+  nsl -= nsl % g.SW;
+  g.nsl = nsl;
+  // The wave's last `nd` tiles are generated a second time instead of waiting in memory.  The weighting phase is bound either by the
+  // fetch of the memory tiles (chip-wide ~0.27 us per row-of-4 of every wave: profiles/r06_h_onchip_pair_check.txt) or by its VALU work
+  // (two waves per SIMD: ~0.6 us per tile's column sums, ~0.22 us per regenerated row); the two proceed side by side, so nd is what
+  // makes the larger of them smallest (C3, T = 64: 2 -- the partial last tile and one whole one; T = 48: 1).
+  int nd = MPPI_PAIR_ND;
+  const int after = g.ntl - MPPI_PAIR_KT - nsl / g.SW;                // tiles beyond registers and LDS
+  if (nd < 0) {
+    double best = 1e30;
+    for (int c = 0; c <= 3 && c <= (after > 0 ? after : 0); ++c) {
+      int dss = 0;                                                    // real local super-steps in the last c tiles
+      for (int ls = (g.ntl - c) * g.SW; ls < g.nls; ++ls) dss += ((2 * (ls / g.CH)) * g.CH + ls % g.CH) < g.nss ? 1 : 0;
+      const double mem = 0.267 * (after - c) * g.SW * g.P4;
+      const double valu = 2.0 * (0.6 * (g.ntl - c) + 0.223 * dss * g.P4);
+      const double t = mem > valu ? mem : valu;
+      if (t < best - 1e-9) { best = t; nd = c; }
+    }
+    if (nd < 0) nd = 0;
+  }
+  g.nsm = g.ntl * g.SW - g.KR - nsl - nd * g.SW;
+  if (g.nsm < 0) g.nsm = 0;
+  g.smem = (size_t)fixed + (size_t)nsl * g.P4 * 2 * BLOCK * 16;
   return g;
 }
 

@@ -23,4 +23,7 @@ int rollout_mlp_mfma(const KArgs<float>& a, hipStream_t st);
 bool mlp_split_supported(int nx, int nu, int hidden);
 int rollout_mlp_split(const KArgs<float>& a, hipStream_t st);
 long long mlp_split_launches();      // successful launches of it in this process (mppi_stat_mlp_split_launches)
+// the on-chip command's two-waves-per-sample kernel (rollout_onchip_pair.hpp): counted by the library (capi.hip,
+// mppi_stat_onchip_pair_launches); a weak reference, so that stand-alone tools including rollout.hpp link without it
+void onchip_pair_launched() __attribute__((weak));
 }  // namespace mppi

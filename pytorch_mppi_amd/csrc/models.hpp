@@ -45,9 +45,12 @@ struct IntegratorModel {
     for (int n = 0; n < NU && n < NX; ++n) x[n] = x[n] + u[n];         // :67-70
   }
   __device__ __forceinline__ T cost(const T (&x)[NX], const T (&)[NU], int) const {
+    // (explicit fused multiply-adds: under -ffp-contract=fast the compiler decides per CONTEXT whether `c += x * x` becomes one fma
+    //  or a packed multiply and an add -- the one-wave and the two-wave on-chip kernels came out differently, one or two ulps of
+    //  cost_total apart, round 6.  Spelled out, every kernel that rolls this model out forms the same bits)
     T c = x[0] * x[0];
 #pragma unroll
-    for (int i = 1; i < NX; ++i) c += x[i] * x[i];                     // :74-76
+    for (int i = 1; i < NX; ++i) c = m_fma(x[i], x[i], c);             // :74-76
     return c;
   }
   __device__ __forceinline__ T terminal(const T (&)[NX]) const { return T(0); }

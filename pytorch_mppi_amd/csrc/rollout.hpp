@@ -1015,6 +1015,7 @@ __global__ void __launch_bounds__(K1_BLOCK) rollout_cost_kernel(const KArgs<T> a
 #include "rollout_kmppi.hpp"   // KMPPI: interpolation inside K1 (needs rollout_step)
 #include "mlp_wide.hpp"        // traced models with dense layers: matrix-core execution, sixteen samples per wave (needs rollout_stream_heavy)
 #include "rollout_onchip.hpp"  // rng="philox" without a (K,T,nu) array: generate, roll out, keep eps' on chip, partial records
+#include "rollout_onchip_pair.hpp"  // the same command with two waves per sample group (a second wave per SIMD hides the first one's waits)
 #include "rollout_copies.hpp" // M > 1 rollouts per action sequence: one wave per copy (needs Stream, make_action)
 namespace mppi {
 

@@ -37,9 +37,7 @@ namespace mppi {
 template <int NU>
 struct OnChip {
   static constexpr int P4 = Stream<NU>::P4, TT = Stream<NU>::TT;
-#ifndef MPPI_ONCHIP_PBROWS
-#define MPPI_ONCHIP_PBROWS 12
-#endif
+  // (MPPI_ONCHIP_PBROWS: common.hpp)
   static constexpr int PB = (MPPI_ONCHIP_PBROWS / P4) > 0 ? (MPPI_ONCHIP_PBROWS / P4) : 1;   // super-steps generated together (~12 rows: the Philox chains interleave)
   static constexpr int SW = (16 / P4) > 0 ? (16 / P4) : 1;       // super-steps per weighting tile
   static constexpr int TRW = SW * P4;                            // rows per tile (15 for nu = 12, else <= 16)
@@ -179,8 +177,13 @@ __device__ __forceinline__ void onchip_steps(const KArgs<float>& a, const Action
 
 // SEVEN: Philox4x32-7 instead of -10 (rng="philox7") -- a template parameter here: as a run-time (wave-uniform) branch inside the twelve
 // interleaved generator chains it cost the kernel 10 spilled VGPRs (44 B of scratch)
+#if defined(MPPI_ONCHIP_EXP) && (MPPI_ONCHIP_EXP & 16)   // experiment: two workgroups per CU (with bits 1 | 4: what a second wave per SIMD buys G + R)
+#define MPPI_ONCHIP_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define MPPI_ONCHIP_OCC
+#endif
 template <class Model, bool DIAG, bool SEVEN = false>
-__global__ void __launch_bounds__(K1_BLOCK) rollout_onchip_kernel(const KArgs<float> a, const int nsl, const int nsm) {
+__global__ void __launch_bounds__(K1_BLOCK) MPPI_ONCHIP_OCC rollout_onchip_kernel(const KArgs<float> a, const int nsl, const int nsm) {
   using T = float;
   constexpr int NX = Model::NX, NU = Model::NU;
   using OC = OnChip<NU>;
@@ -488,6 +491,10 @@ struct onchip_seven_ok : std::true_type {};
 template <>
 struct onchip_seven_ok<LinearGoalModel<float, 12, 4>> : std::false_type {};
 
+template <class Model>
+static int launch_rollout_onchip_pair(const KArgs<float>& a, hipStream_t st);     // rollout_onchip_pair.hpp
+static inline int onchip_pair_mode();
+
 // returns MPPI_OK_ONCHIP when the launch was issued, a positive HIP error, or -1: not this path
 template <class Model, typename T>
 static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
@@ -507,6 +514,10 @@ static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
     using OC = OnChip<NU>;
     KArgs<T> a = a_in;
     onchip_carve(a);
+    if (onchip_pair_mode() != 0) {
+      const int rp = launch_rollout_onchip_pair<Model>(a, st);          // two waves per sample group where that form applies
+      if (rp != -1) return rp;
+    }
     const bool diag = a.diag != 0;
     const OnChipGeometry g = onchip_geometry(NU, a.Tn, diag);
     static_assert(OC::OK, "onchip_model_ok");
@@ -522,7 +533,11 @@ static int launch_rollout_onchip(const KArgs<T>& a_in, hipStream_t st) {
       if (nsm > spill_max) nsm = spill_max;
       nsm -= nsm % OC::SW;
     }
+#if defined(MPPI_ONCHIP_EXP) && (MPPI_ONCHIP_EXP & 16)
+    const size_t smem = OnChipLds{g.nss * g.P4 * 4, g.ntiles, 0, g.P4, 0}.bytes();   // tables + exchange only: two workgroups fit a CU
+#else
     const size_t smem = g.smem;
+#endif
     const dim3 grid(a.nkc), block(K1_BLOCK);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     profile_next_events(&ev0, &ev1, &a.tstamp);

@@ -96,6 +96,52 @@ def test_onchip_spill_size_is_the_geometry_restated(nu, T):
         assert _spill_rows(nu, T) == 90           # C3: 25 super-steps in registers, 10 in LDS, 6 tiles = 30 super-steps x 3 rows wait
 
 
+def _pair_spill_rows(nu, nx, T, kt=1, pbrows=12):
+    """the same for the two-waves-per-sample form (csrc/common.hpp onchip_pair_geometry), restated: rows-of-4 per THREAD of the
+    512-thread workgroup; 0 when the form does not apply"""
+    g = 4 if nu % 4 == 0 else (2 if nu % 2 == 0 else 1)
+    p4, tt = nu // g, 4 // g
+    sw = max(16 // p4, 1)
+    ch = max(pbrows // p4, 1)
+    kr = kt * sw
+    nss = -(-T // tt)
+    nch = -(-nss // ch)
+    nit = (nch + 1) // 2
+    nls = nit * ch
+    ntl = -(-nls // sw)
+    shn = max((nx + 2) * 256, 8 * ntl * 64)
+    fixed = (3 * nss * p4 * 4 + 16 + shn) * 4
+    if p4 > 16 or fixed > 160 * 1024 or nch < 4:
+        return 0
+    room = (160 * 1024 - fixed) // (p4 * 512 * 16)
+    nsl = max(0, min((nch // 2) * ch - kr, room))
+    nsl -= nsl % sw
+    after = ntl - kt - nsl // sw
+    best, nd = 1e30, 0
+    for c in range(0, min(3, max(after, 0)) + 1):
+        dss = sum(1 for ls in range((ntl - c) * sw, nls) if (2 * (ls // ch)) * ch + ls % ch < nss)
+        t = max(0.267 * (after - c) * sw * p4, 2.0 * (0.6 * (ntl - c) + 0.223 * dss * p4))
+        if t < best - 1e-9:
+            best, nd = t, c
+    return max(0, ntl * sw - kr - nsl - nd * sw) * p4
+
+
+@pytest.mark.parametrize("T", [64, 48, 33, 100, 15, 200])
+def test_onchip_spill_size_covers_the_two_wave_form(T):
+    """round 6: the array is the larger of the two forms' needs for the model the pair kernel is instantiated for (integrator
+    16 x 12); at C3 (T = 64) the two coincide: 90 rows x 256 = 45 rows x 512 per workgroup"""
+    p = N.MppiProblem()
+    p.K, p.T, p.nx, p.nu, p.dtype, p.sigma_diagonal, p.model_id = 65536, T, 16, 12, N.F32, 1, N.MODEL_INTEGRATOR
+    one = _spill_rows(12, T) * 65536 * 4
+    two = _pair_spill_rows(12, 16, T) * 2 * 65536 * 4
+    # (a horizon whose rows all fit registers + LDS of the one-wave kernel has no array, and without one the pair kernel is not used)
+    assert int(N.lib().mppi_onchip_spill_elems(C.byref(p))) == (max(one, two) if one else 0), (T, one, two)
+    if T == 64:
+        assert one == two == 90 * 65536 * 4
+    p.model_id = N.MODEL_LINEAR_GOAL
+    assert int(N.lib().mppi_onchip_spill_elems(C.byref(p))) == one
+
+
 def test_model_support_table():
     assert N.model_supported(N.MODEL_PENDULUM, 2, 1, N.F32)
     assert N.model_supported(N.MODEL_PENDULUM, 2, 1, N.F64)

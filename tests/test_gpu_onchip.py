@@ -152,6 +152,76 @@ def test_rows_waiting_in_memory_change_no_bit(case):
         assert a._spill[1].numel() == want and int(a._last.onchip_spill) == a._spill[1].data_ptr()
 
 
+PAIR_CASES = [
+    # K, T, lambda, extra ctor kwargs -- all on the model the two-wave kernel is instantiated for (integrator 16 x 12)
+    (65536, 64, None, {}),                                                                                   # C3, healthy softmax
+    (65536, 64, 0.05, {}),                                                                                   # peaked: dead waves skip their tiles
+    (50000, 64, None, dict(sample_null_action=True, u_min=torch.tensor([-0.4] * 12), u_max=torch.tensor([0.6] * 12))),   # ragged K, bounds, null row
+    (65536, 48, None, dict(sample_null_action=True)),                                                        # 12 chunks: one regenerated tile
+    (49152, 33, None, dict(u_min=torch.tensor([-0.5] * 12), u_max=torch.tensor([0.5] * 12))),                # odd chunk count: the odd wave owns one fewer
+    (49152, 100, None, {}),                                                                                  # 25 chunks, three regenerated tiles
+    (3000, 70, None, dict(u_per_command=2)),                                                                 # small K (forced on chip), partial last chunk
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES, ids=[f"K{c[0]}-T{c[1]}-lam{c[2]}-{'-'.join(c[3]) or 'plain'}" for c in PAIR_CASES])
+def test_two_waves_per_sample_group_change_no_bit(case, monkeypatch):
+    """Round 6 (csrc/rollout_onchip_pair.hpp): the on-chip K1 with two waves per 64-sample group -- alternating chunks of the horizon,
+    each wave generating, keeping and summing its own rows, the rollout's state handed from one to the other through LDS.  Same
+    Philox counters, same arithmetic per row, every sum in the one-wave kernel's order: every output bit for bit, over chunk counts
+    even and odd, rows regenerated in the weighting phase (0..3 tiles), bounds, the null-action row, ragged K, a peaked softmax,
+    shift on / off, several commands in a row -- and the counter says which kernel ran."""
+    from pytorch_mppi_amd import _native as N
+    K, T, lam, kw = case
+    lib = N.lib()
+    x0 = torch.randn(16, generator=torch.Generator().manual_seed(3)).cuda() * 0.3
+    if lam is None:
+        probe, _, _, _ = _make("integrator", 16, 12, K, T, True, lam=1.0, **kw)
+        probe.command(x0)
+        c = probe.cost_total
+        lam = max(float((c - c.min()).median()), 1e-3)                   # a healthy softmax for this problem's cost spread
+    a, _, _, _ = _make("integrator", 16, 12, K, T, True, lam=lam, **kw)
+    b, _, _, _ = _make("integrator", 16, 12, K, T, True, lam=lam, **kw)
+    for step, shift in enumerate((True, False, True)):
+        monkeypatch.setenv("MPPI_ONCHIP_PAIR", "1")
+        n0 = int(lib.mppi_stat_onchip_pair_launches())
+        ua = a.command(x0, shift_nominal_trajectory=shift)
+        torch.cuda.synchronize()
+        assert int(lib.mppi_stat_onchip_pair_launches()) == n0 + 1 and a.last_draw == "philox-onchip", "the two-wave kernel took it"
+        monkeypatch.setenv("MPPI_ONCHIP_PAIR", "0")
+        ub = b.command(x0, shift_nominal_trajectory=shift)
+        torch.cuda.synchronize()
+        assert int(lib.mppi_stat_onchip_pair_launches()) == n0 + 1 and int(lib.mppi_last_command_form()) == N.FORM_ONCHIP
+        for name, xa, xb in (("action", ua, ub), ("U", a.U, b.U), ("cost_total", a.cost_total, b.cost_total), ("omega", a.omega, b.omega)):
+            assert torch.equal(xa, xb), (name, step, float((xa - xb).abs().max()))
+        if step == 0:
+            n_eff = float(1.0 / (a.omega.double() ** 2).sum())
+            assert (n_eff > 8) == (case[2] is None), n_eff                 # the healthy cases are healthy, the peaked one is peaked
+
+
+def test_what_the_two_wave_kernel_does_not_take_stays_on_the_one_wave_kernel(monkeypatch):
+    """SMPPI terms, |noise| cost, u_scale != 1, a full Sigma, another model, no spill array: the one-wave kernel (still on chip)."""
+    import pytorch_mppi_amd as pm
+    from pytorch_mppi_amd import _native as N
+    lib = N.lib()
+    monkeypatch.setenv("MPPI_ONCHIP_PAIR", "1")
+    x0 = torch.zeros(16).cuda()
+    for kw in (dict(noise_abs_cost=True), dict(u_scale=1.5)):
+        c, _, _, _ = _make("integrator", 16, 12, 49152, 64, True, lam=30.0, **kw)
+        n0, m0 = int(lib.mppi_stat_onchip_pair_launches()), _onchip_count()
+        c.command(x0)
+        assert int(lib.mppi_stat_onchip_pair_launches()) == n0 and _onchip_count() == m0 + 1, kw
+    c, _, _, _ = _make("integrator", 16, 12, 49152, 64, True, lam=30.0)
+    c.onchip_spill = False
+    n0, m0 = int(lib.mppi_stat_onchip_pair_launches()), _onchip_count()
+    c.command(x0)
+    assert int(lib.mppi_stat_onchip_pair_launches()) == n0 and _onchip_count() == m0 + 1
+    c, _, _, _ = _make("integrator", 12, 6, 49152, 64, True, lam=30.0)
+    n0, m0 = int(lib.mppi_stat_onchip_pair_launches()), _onchip_count()
+    c.command(torch.zeros(12).cuda())
+    assert int(lib.mppi_stat_onchip_pair_launches()) == n0 and _onchip_count() == m0 + 1
+
+
 def test_spill_array_size_at_c3():
     """87 of a sample's 192 rows-of-4 wait in memory at C3: 25 super-steps in registers, 10 in LDS, the other 29 -- as 6 whole
     weighting tiles = 30 super-steps of 3 rows each, the horizon's last, partial tile included -- in the array: 90 rows x 65536

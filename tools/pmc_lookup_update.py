@@ -18,7 +18,8 @@ def table(path, kernel):
     out = {}
     for line in open(path):
         m = re.match(r"\s*(\S+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(.*)", line)
-        if m and kernel in m.group(6):
+        # (the on-chip K1 is rollout_onchip_kernel or, round 6, rollout_onchip_pair_kernel: whichever the pass ran)
+        if m and (kernel in m.group(6) or (kernel == "rollout_onchip_kernel" and "rollout_onchip_pair_kernel" in m.group(6))):
             out[m.group(1)] = float(m.group(3))
     return out
 
@@ -51,8 +52,12 @@ def main(prefix):
         if name in c:
             e[name] = c[name]
     e["FETCH_SIZE_KiB"], e["WRITE_SIZE_KiB"] = c["FETCH_SIZE"], c["WRITE_SIZE"]
+    # which on-chip K1 the passes ran: the two-wave kernel (round 6) has 2048 waves at C3, two per SIMD
+    pair = "rollout_onchip_pair_kernel" in open(f"{prefix}_pmc_c3_valu.txt").read()
+    e["kernel"] = "rollout_onchip_pair_kernel" if pair else "rollout_onchip_kernel"
+    e["waves"], e["waves_per_simd"] = (2048, 2) if pair else (1024, 1)
     e["sources_sha256"], e["collected"] = H[k], tag
-    d["_comment"] = (f"SQ counters of the on-chip K1 (rollout_onchip_kernel<Integrator<16,12>>, K = 65536 = 1024 waves, one per SIMD) from separate rocprofv3 --pmc "
+    d["_comment"] = (f"SQ counters of the on-chip K1 (the kernel the default bench ran: rollout_onchip_pair_kernel<Integrator<16,12>> since round 6 -- K = 65536 = 2048 waves, two per SIMD -- rollout_onchip_kernel before) from separate rocprofv3 --pmc "
                      f"passes of `bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline` on MI355X: profiles/{tag}_pmc_c3_valu.txt, _wait.txt, _fetch.txt, "
                      f"_write.txt (instruction classes `by_class`: profiles/r04_spill_pmc_c3_classes.txt, an earlier build of the kernel).  SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count "
                      f"quad-cycles summed over the waves (MI355X_MICROARCH.md); means over the dispatches of the pass.  sources_sha256: the kernel's "

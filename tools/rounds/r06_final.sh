@@ -24,7 +24,7 @@ run_prof() {
   python tools/timeline_gaps.py $DB $TLK gpurun_out/${P}_timeline_gaps_$name.txt > /dev/null 2>&1
   rm -rf gpurun_out/prof_$name
 }
-TLK=rollout_onchip_kernel run_prof c3 --steps 20 --warmup 5 --no-extras --hbm-cold
+TLK=rollout_onchip run_prof c3 --steps 20 --warmup 5 --no-extras --hbm-cold
 TLK=rollout_cost_kernel run_prof torch --rng torch --steps 300 --warmup 30 --no-extras
 timeout 600 python bench.py --rng torch --no-extras --no-cpu-baseline --steps 300 --warmup 30 2>/dev/null | tail -1 > gpurun_out/${P}_bench_torch.json
 timeout 600 python bench.py --workload c4 --no-extras 2>/dev/null | tail -1 > gpurun_out/${P}_bench_c4.json
