@@ -667,10 +667,12 @@ extern "C" int64_t mppi_onchip_spill_elems(const MppiProblem* p) {
   // the two-waves-per-sample form (rollout_onchip_pair.hpp) keeps fewer rows in registers: its array is the larger one
   // (the models it is instantiated for: rollout_onchip_pair.hpp onchip_pair_model_ok)
   const bool pair_model = p->model_id == MPPI_MODEL_INTEGRATOR && p->nx == 16 && p->nu == 12;
-  const mppi::OnChipPairGeometry gp = mppi::onchip_pair_geometry(p->nu, p->nx, p->T);
-  if (pair_model && gp.ok && gp.nch >= 4 && p->sigma_diagonal != 0) {
-    const int64_t np = (int64_t)gp.nsm * gp.P4 * nkc * 2 * mppi::BLOCK * 4;
-    if (np > n) n = np;
+  for (int plain = 0; plain < 2; ++plain) {     // (the SMPPI terms' hand-over is larger: LDS may hold a tile fewer)
+    const mppi::OnChipPairGeometry gp = mppi::onchip_pair_geometry(p->nu, p->nx, p->T, plain != 0);
+    if (pair_model && gp.ok && gp.nch >= 4 && p->sigma_diagonal != 0) {
+      const int64_t np = (int64_t)gp.nsm * gp.P4 * nkc * 2 * mppi::BLOCK * 4;
+      if (np > n) n = np;
+    }
   }
   return n;
 }

@@ -139,20 +139,22 @@ struct OnChipPairGeometry {
   size_t smem;
   bool ok;
 };
-static inline OnChipPairGeometry onchip_pair_geometry(int nu, int nx, int Tn) {
+// plain: the command without |noise| cost, u_scale, SMPPI terms; otherwise the previous timestep's action rides in the hand-over too
+static inline OnChipPairGeometry onchip_pair_geometry(int nu, int nx, int Tn, bool plain = true) {
   OnChipPairGeometry g{};
   const int G = (nu % 4 == 0) ? 4 : ((nu % 2 == 0) ? 2 : 1);
   g.P4 = nu / G;
   g.TT = 4 / G;
   g.SW = (16 / g.P4) > 0 ? (16 / g.P4) : 1;
   g.CH = (MPPI_ONCHIP_PBROWS / g.P4) > 0 ? (MPPI_ONCHIP_PBROWS / g.P4) : 1;
+  if (!plain && g.CH >= 2) --g.CH;                                    // (OnChipPair<NU, false>::CH)
   g.KR = MPPI_PAIR_KT * g.SW;
   g.nss = (Tn + g.TT - 1) / g.TT;
   g.nch = (g.nss + g.CH - 1) / g.CH;
   g.nit = (g.nch + 1) / 2;
   g.nls = g.nit * g.CH;
   g.ntl = (g.nls + g.SW - 1) / g.SW;
-  const int hand = (nx + 2) * BLOCK, ex = 8 * g.ntl * 64;
+  const int hand = (nx + 2 + (plain ? 0 : nu)) * BLOCK, ex = 8 * g.ntl * 64;
   g.shn = hand > ex ? hand : ex;                                      // floats: the state hand-over, later the waves' column sums
   const long long fixed = ((long long)3 * g.nss * g.P4 * 4 + 16 + g.shn) * 4;
   g.ok = g.P4 <= 16 && fixed <= 160 * 1024;

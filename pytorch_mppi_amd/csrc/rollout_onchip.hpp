@@ -165,6 +165,9 @@ __device__ __forceinline__ void onchip_steps(const KArgs<float>& a, const Action
         for (int n = 0; n < NU; ++n) {
           en[n] = ac.abs_cost ? fabsf(en[n]) : en[n];
           u[n] *= a.u_scale;                                             // :313
+          // (the scaled action is a value of its own: left to -ffp-contract=fast, `x + u * u_scale` in the model's step became one
+          //  fma in one on-chip kernel and a multiply and an add in the other -- an ulp of the action apart, round 6)
+          asm volatile("" : "+v"(u[n]));
         }
       }
 #pragma unroll

@@ -23,18 +23,21 @@
 //
 // Results: bit for bit those of rollout_onchip_kernel (same Philox counters, same arithmetic per row, same order of every sum; the
 // column sums' lane tree does not depend on where a column sits in its tile) -- tests/test_gpu_onchip.py compares the two forms.
-// Scope: what the launcher below accepts -- the plain command (no |noise| cost, u_scale = 1, no SMPPI terms: those would ride in the
-// hand-over too), diagonal Sigma, a spill array; everything else stays on the one-wave kernel.
+// Scope: what the launcher below accepts -- MPPI and SMPPI (|noise| cost, u_scale, base sequence, 1/dt rescaling and the smoothness cost,
+// whose operand -- the previous timestep's action -- rides in the hand-over too), diagonal Sigma, a spill array, the models of
+// onchip_pair_model_ok; everything else stays on the one-wave kernel.
 #pragma once
 // (included from rollout.hpp behind rollout_onchip.hpp)
 
 namespace mppi {
 
-template <int NU>
+template <int NU, bool PLAIN = true>
 struct OnChipPair {
   using OC = OnChip<NU>;
   static constexpr int P4 = OC::P4, TT = OC::TT, SW = OC::SW, TRW = OC::TRW, TC = OC::TC;
-  static constexpr int CH = OC::PB;                              // super-steps per chunk: generated together, owned by one wave
+  // super-steps per chunk: generated together, owned by one wave.  With the SMPPI terms compiled in, one fewer: their operands
+  // cost the generator's live set the registers of a super-step's z and v (the four-super-step form spilled 14-40 VGPRs)
+  static constexpr int CH = (PLAIN || OC::PB < 2) ? OC::PB : OC::PB - 1;
   static constexpr int KT = MPPI_PAIR_KT, KR = KT * SW;          // weighting tiles / local super-steps a wave keeps in registers
   static constexpr int NCA = (KR + CH - 1) / CH;                 // local chunks that touch the registers (static indices)
   static constexpr bool OK = OC::OK;
@@ -54,11 +57,13 @@ struct OnChipRowG {
   }
 };
 
-template <class Model, bool SEVEN = false>
+// PLAIN: no |noise| cost, u_scale == 1, no SMPPI terms (the common case, compiled without them); PLAIN = false: those terms as the
+// one-wave kernel applies them, and the previous timestep's action (the smoothness cost's operand) in the hand-over
+template <class Model, bool SEVEN = false, bool PLAIN = true>
 __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const KArgs<float> a, const int nsl, const int nsm) {
   using T = float;
   constexpr int NX = Model::NX, NU = Model::NU;
-  using OP = OnChipPair<NU>;
+  using OP = OnChipPair<NU, PLAIN>;
   constexpr int P4 = OP::P4, TT = OP::TT, CH = OP::CH, SW = OP::SW, TRW = OP::TRW, TC = OP::TC, KT = OP::KT, KR = OP::KR, NCA = OP::NCA;
   constexpr int NT = 2 * K1_BLOCK;
   static_assert(K1_BLOCK == 256 && K1_BLOCK == BLOCK, "a pair kernel workgroup is eight waves over one 256-sample record");
@@ -73,7 +78,8 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
   T* red = G + Jp;                       // [8] | the pairs' progress counters [4] (+ 4 unused)
   int* flag = reinterpret_cast<int*>(red + 8) + ((threadIdx.x >> 6) & 3);   // this pair's: chunks rolled out so far
   T* sh = red + 16;                      // the hand-over [NX + 2][256], later the waves' column sums [8][ntl][64]
-  const int hand_n = (NX + 2) * K1_BLOCK, ex_n = 8 * ntl * 64;
+  constexpr int HAND = NX + 2 + (PLAIN ? 0 : NU);
+  const int hand_n = HAND * K1_BLOCK, ex_n = 8 * ntl * 64;
   float4* keepL = reinterpret_cast<float4*>(sh + (hand_n > ex_n ? hand_n : ex_n));
   for (int j = threadIdx.x; j < Jp; j += NT) {
     const bool in = j < a.J;
@@ -81,7 +87,7 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
     const T u = in ? u_base(a, j) : T(0);
     Ue[j] = u;
     Um[j] = in ? u + a.mu[n] : T(0);
-    G[j] = in ? a.lambda_ * (u * a.sinv[n * NU + n]) : T(0);
+    G[j] = in ? a.lambda_ * ((a.B != nullptr ? u_eff(a, j) : u) * a.sinv[n * NU + n]) : T(0);   // always the true U
   }
   const int lane = threadIdx.x & (WAVE - 1), wv8 = threadIdx.x / WAVE;
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);      // 0: even chunks, 1: odd chunks (wave-uniform)
@@ -99,6 +105,10 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
     for (int i = 0; i < NX; ++i) sh[i * K1_BLOCK + s256] = s0[i];                                 // mppi.py:302-305
     sh[NX * K1_BLOCK + s256] = T(0);
     sh[(NX + 1) * K1_BLOCK + s256] = T(0);
+    if constexpr (!PLAIN) {
+#pragma unroll
+      for (int n = 0; n < NU; ++n) sh[(NX + 2 + n) * K1_BLOCK + s256] = T(0);
+    }
   }
   if (threadIdx.x < 4) reinterpret_cast<int*>(red + 8)[threadIdx.x] = 0;
   ActionConsts<T, NU> ac;
@@ -144,7 +154,7 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
         const int ss = ss0 + b;
         OnChipRow<NU> row;
         row.load(tb, ss < nss ? ss : nss - 1, false);
-        onchip_actions<NU, true>(ac, row, orow, null_in_wave, zb[b], vb[b], false);
+        onchip_actions<NU, true>(ac, row, orow, null_in_wave, zb[b], vb[b], !PLAIN);
       }
     }
     // (Holding only v and forming eps' = v - U again where it is used -- 48 registers fewer in the generator's live set -- was tried:
@@ -174,6 +184,10 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
       for (int i = 0; i < NX; ++i) x[i] = sh[i * K1_BLOCK + s256];
       rollout = sh[NX * K1_BLOCK + s256];
       pert = sh[(NX + 1) * K1_BLOCK + s256];
+      if constexpr (!PLAIN) {
+#pragma unroll
+        for (int n = 0; n < NU; ++n) vprev[n] = sh[(NX + 2 + n) * K1_BLOCK + s256];
+      }
 #pragma unroll
       for (int b = 0; b < CH; ++b) {
         const int ss = ss0 + b;
@@ -182,12 +196,16 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
         OnChipRow<NU> row;
 #pragma unroll
         for (int q = 0; q < P4 * 4; ++q) row.g[q] = rg.g[q];
-        onchip_steps<Model>(a, ac, model, row, ss, zb[b], vb[b], x, vprev, rollout, pert, true);
+        onchip_steps<Model>(a, ac, model, row, ss, zb[b], vb[b], x, vprev, rollout, pert, PLAIN);
       }
 #pragma unroll
       for (int i = 0; i < NX; ++i) sh[i * K1_BLOCK + s256] = x[i];
       sh[NX * K1_BLOCK + s256] = rollout;
       sh[(NX + 1) * K1_BLOCK + s256] = pert;
+      if constexpr (!PLAIN) {
+#pragma unroll
+        for (int n = 0; n < NU; ++n) sh[(NX + 2 + n) * K1_BLOCK + s256] = vprev[n];
+      }
       __hip_atomic_store(flag, c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #if defined(MPPI_PAIR_EXP) && (MPPI_PAIR_EXP & 4)        // experiment (tools/micro/onchip_pair_check.hip): nothing kept
       continue;
@@ -341,7 +359,7 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
           }
           OnChipRow<NU> row;
           row.load(tb, ss, false);
-          onchip_actions<NU, true>(ac, row, orow, null_in_wave, zg, vg, false);
+          onchip_actions<NU, true>(ac, row, orow, null_in_wave, zg, vg, !PLAIN);
 #pragma unroll
           for (int q = 0; q < P4 * 4; ++q) acc[g * P4 * 4 + q] = wk * zg[q];
         } else {
@@ -404,12 +422,12 @@ static int launch_rollout_onchip_pair(const KArgs<float>& a, hipStream_t st) {
     return -1;
   } else {
   constexpr int NU = Model::NU, NX = Model::NX;
-  using OP = OnChipPair<NU>;
+  using OP = OnChipPair<NU, true>;
   if (a.spill == nullptr || a.diag == 0) return -1;
   const bool plain = !a.abs_cost && a.u_scale == 1.f && a.e_scale == 1.f && a.smooth_w == 0.f && a.B == nullptr;
-  if (!plain) return -1;
-  const OnChipPairGeometry g = onchip_pair_geometry(NU, NX, a.Tn);
-  if (!g.ok || g.P4 != OP::P4 || g.TT != OP::TT || g.SW != OP::SW || g.CH != OP::CH || g.KR != OP::KR) return -1;
+  const OnChipPairGeometry g = onchip_pair_geometry(NU, NX, a.Tn, plain);
+  if (!g.ok || g.P4 != OP::P4 || g.TT != OP::TT || g.SW != OP::SW || g.KR != OP::KR ||
+      g.CH != (plain ? OnChipPair<NU, true>::CH : OnChipPair<NU, false>::CH)) return -1;
   if (g.nch < 4) return -1;                                            // a horizon of fewer than four chunks: nothing to alternate
   if ((long long)g.nsm * g.P4 * a.nkc * 2 * K1_BLOCK * 4 > a.spill_cap) return -1;     // the caller's array is the one-wave form's size
   const dim3 grid(a.nkc), block(2 * K1_BLOCK);
@@ -424,9 +442,12 @@ static int launch_rollout_onchip_pair(const KArgs<float>& a, hipStream_t st) {
     else hipLaunchKernelGGL(KERNEL, grid, block, smem, st, b, g.nsl, g.nsm);                                      \
   } while (0)
   if (a.seven) {
-    if constexpr (onchip_seven_ok<Model>::value) MPPI_PAIR_LAUNCH((rollout_onchip_pair_kernel<Model, true>));
-    else return -1;
-  } else MPPI_PAIR_LAUNCH((rollout_onchip_pair_kernel<Model, false>));
+    if constexpr (onchip_seven_ok<Model>::value) {
+      if (plain) MPPI_PAIR_LAUNCH((rollout_onchip_pair_kernel<Model, true, true>));
+      else MPPI_PAIR_LAUNCH((rollout_onchip_pair_kernel<Model, true, false>));
+    } else return -1;
+  } else if (plain) MPPI_PAIR_LAUNCH((rollout_onchip_pair_kernel<Model, false, true>));
+  else MPPI_PAIR_LAUNCH((rollout_onchip_pair_kernel<Model, false, false>));
 #undef MPPI_PAIR_LAUNCH
   const int e = (int)hipGetLastError();
   if (e == 0 && onchip_pair_launched) onchip_pair_launched();

@@ -161,6 +161,8 @@ PAIR_CASES = [
     (49152, 33, None, dict(u_min=torch.tensor([-0.5] * 12), u_max=torch.tensor([0.5] * 12))),                # odd chunk count: the odd wave owns one fewer
     (49152, 100, None, {}),                                                                                  # 25 chunks, three regenerated tiles
     (3000, 70, None, dict(u_per_command=2)),                                                                 # small K (forced on chip), partial last chunk
+    (65536, 64, None, dict(noise_abs_cost=True, u_scale=1.5, sample_null_action=True)),                      # the terms of the other instantiation:
+    (49152, 50, None, dict(u_scale=0.5, u_min=torch.tensor([-0.5] * 12), u_max=torch.tensor([0.5] * 12))),   #   chunks of three super-steps
 ]
 
 
@@ -199,22 +201,46 @@ def test_two_waves_per_sample_group_change_no_bit(case, monkeypatch):
             assert (n_eff > 8) == (case[2] is None), n_eff                 # the healthy cases are healthy, the peaked one is peaked
 
 
-def test_what_the_two_wave_kernel_does_not_take_stays_on_the_one_wave_kernel(monkeypatch):
-    """SMPPI terms, |noise| cost, u_scale != 1, a full Sigma, another model, no spill array: the one-wave kernel (still on chip)."""
+def test_smppi_on_the_two_wave_kernel_changes_no_bit(monkeypatch):
+    """SMPPI (mppi.py:451-570) at C3's shape: base sequence, 1/dt rescaling of the bounded noise, the smoothness cost -- whose operand,
+    the previous timestep's action, rides in the hand-over between the waves of a pair."""
     import pytorch_mppi_amd as pm
     from pytorch_mppi_amd import _native as N
     lib = N.lib()
+    model = pm.models.Integrator(16, 12)
+    x0 = torch.randn(16, generator=torch.Generator().manual_seed(4)).cuda() * 0.3
+
+    def make():
+        c = pm.SMPPI(model.dynamics, model.running_cost, 16, torch.eye(12) * 0.5, num_samples=65536, horizon=64, device="cuda", lambda_=2000.0,
+                     rng="philox", seed=21 + margins.seed_offset(), w_action_seq_cost=3.0, delta_t=0.5,
+                     action_min=torch.tensor([-1.0] * 12), action_max=torch.tensor([1.0] * 12))
+        c.philox_onchip = True
+        return c
+    a, b = make(), make()
+    for step in range(3):
+        monkeypatch.setenv("MPPI_ONCHIP_PAIR", "1")
+        n0 = int(lib.mppi_stat_onchip_pair_launches())
+        ua = a.command(x0)
+        torch.cuda.synchronize()
+        assert int(lib.mppi_stat_onchip_pair_launches()) == n0 + 1 and a.last_draw == "philox-onchip"
+        monkeypatch.setenv("MPPI_ONCHIP_PAIR", "0")
+        ub = b.command(x0)
+        torch.cuda.synchronize()
+        assert int(lib.mppi_stat_onchip_pair_launches()) == n0 + 1 and b.last_draw == "philox-onchip"
+        for name, xa, xb in (("action", ua, ub), ("U", a.U, b.U), ("action_sequence", a.action_sequence, b.action_sequence),
+                             ("cost_total", a.cost_total, b.cost_total), ("omega", a.omega, b.omega)):
+            assert torch.equal(xa, xb), (name, step, float((xa - xb).abs().max()))
+
+
+def test_what_the_two_wave_kernel_does_not_take_stays_on_the_one_wave_kernel(monkeypatch):
+    """no spill array, another model: the one-wave kernel (still on chip)."""
+    from pytorch_mppi_amd import _native as N
+    lib = N.lib()
     monkeypatch.setenv("MPPI_ONCHIP_PAIR", "1")
-    x0 = torch.zeros(16).cuda()
-    for kw in (dict(noise_abs_cost=True), dict(u_scale=1.5)):
-        c, _, _, _ = _make("integrator", 16, 12, 49152, 64, True, lam=30.0, **kw)
-        n0, m0 = int(lib.mppi_stat_onchip_pair_launches()), _onchip_count()
-        c.command(x0)
-        assert int(lib.mppi_stat_onchip_pair_launches()) == n0 and _onchip_count() == m0 + 1, kw
     c, _, _, _ = _make("integrator", 16, 12, 49152, 64, True, lam=30.0)
     c.onchip_spill = False
     n0, m0 = int(lib.mppi_stat_onchip_pair_launches()), _onchip_count()
-    c.command(x0)
+    c.command(torch.zeros(16).cuda())
     assert int(lib.mppi_stat_onchip_pair_launches()) == n0 and _onchip_count() == m0 + 1
     c, _, _, _ = _make("integrator", 12, 6, 49152, 64, True, lam=30.0)
     n0, m0 = int(lib.mppi_stat_onchip_pair_launches()), _onchip_count()

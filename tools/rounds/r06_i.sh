@@ -14,3 +14,5 @@ r=d["roofline"]
 print("pair=$m", "ms", round(d["ms_per_step"],5), "value", "%.4g"%d["value"], "kernel", r.get("kernel"), "k1_us", r.get("avg_launch_us"), "frac", round(r.get("frac"),4), "synced", d.get("latency_ms_synced",{}).get("median_ms"))
 PY
 done
+for m in 1 0; do MPPI_ONCHIP_PAIR=$m timeout 300 python tools/variants_bench.py philox "SMPPI" 2>&1 | grep -v amdgpu | sed "s/^/pair=$m /"; done
+for m in 1 0; do MPPI_ONCHIP_PAIR=$m timeout 300 python tools/variants_bench.py philox "MPPI" 2>&1 | grep -v amdgpu | sed "s/^/pair=$m /"; done
