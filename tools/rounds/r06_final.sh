@@ -27,6 +27,12 @@ run_prof() {
 TLK=rollout_onchip run_prof c3 --steps 20 --warmup 5 --no-extras --hbm-cold
 TLK=rollout_cost_kernel run_prof torch --rng torch --steps 300 --warmup 30 --no-extras
 timeout 600 python bench.py --rng torch --no-extras --no-cpu-baseline --steps 300 --warmup 30 2>/dev/null | tail -1 > gpurun_out/${P}_bench_torch.json
+# the one-wave on-chip K1 beside the default (two waves per sample group, csrc/rollout_onchip_pair.hpp): same command, same box
+MPPI_ONCHIP_PAIR=0 timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${P}_bench_one_wave_onchip.json
+TLK=rollout_onchip MPPI_ONCHIP_PAIR=0 run_prof c3_one_wave --steps 20 --warmup 5 --no-extras
+if [ -x tools/micro/onchip_pair_check_prod ]; then
+  for a in "65536 20000 0 64 0.001" "65536 20000 1 48 0.001" "60000 40 1 64 0.05"; do timeout 120 tools/micro/onchip_pair_check_prod $a; done > gpurun_out/${P}_onchip_pair_check.txt 2>&1
+fi
 timeout 600 python bench.py --workload c4 --no-extras 2>/dev/null | tail -1 > gpurun_out/${P}_bench_c4.json
 timeout 600 python bench.py --workload c2 --no-extras 2>/dev/null | tail -1 > gpurun_out/${P}_bench_c2.json
 run_pmc() {
@@ -46,7 +52,7 @@ run_pmc torch_fetch "FETCH_SIZE" --rng torch
 run_pmc torch_write "WRITE_SIZE" --rng torch
 run_pmc c4_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --workload c4
 # the matrix-pipe share of the split-operand kernel on the further shapes (within 15 % of C4's)
-for shp in "12 6 128" "16 8 256" "8 2 64"; do
+for shp in "12 6 128" "16 8 256" "8 2 64" "12 6 256"; do
   tag=$(echo $shp | tr ' ' '_')
   (cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $REPO/gpurun_out/pmc_mlp_$tag -o mlp -- python $REPO/tools/mlp_shape_run.py $shp > $REPO/gpurun_out/${P}_pmc_mlp_$tag.log 2>&1)
   DB=$(find gpurun_out/pmc_mlp_$tag -name "*.db" | head -1); [ -n "$DB" ] && python tools/pmc_summary.py $DB gpurun_out/${P}_pmc_mlp_$tag.txt > /dev/null; rm -rf gpurun_out/pmc_mlp_$tag
@@ -64,7 +70,7 @@ def tab(path, kernel):
         pass
     return out
 lines = ["# matrix-pipe busy share of rollout_mlp_split_kernel = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024), K = 65536, T = 64 (rocprofv3 --pmc, means over the launches)"]
-for name, f in (("c4 (16,4,256)", "gpurun_out/${P}_pmc_c4_mfma.txt"), ("(12,6,128)", "gpurun_out/${P}_pmc_mlp_12_6_128.txt"), ("(16,8,256)", "gpurun_out/${P}_pmc_mlp_16_8_256.txt"), ("(8,2,64)", "gpurun_out/${P}_pmc_mlp_8_2_64.txt")):
+for name, f in (("c4 (16,4,256)", "gpurun_out/${P}_pmc_c4_mfma.txt"), ("(12,6,256)", "gpurun_out/${P}_pmc_mlp_12_6_256.txt"), ("(12,6,128)", "gpurun_out/${P}_pmc_mlp_12_6_128.txt"), ("(16,8,256)", "gpurun_out/${P}_pmc_mlp_16_8_256.txt"), ("(8,2,64)", "gpurun_out/${P}_pmc_mlp_8_2_64.txt")):
     t = tab(f, "rollout_mlp_split_kernel")
     if t.get("GRBM_GUI_ACTIVE"):
         lines.append(f"  {name:<16} busy {t['SQ_VALU_MFMA_BUSY_CYCLES'] / (t['GRBM_GUI_ACTIVE'] / 8 * 1024):.4f}   (MFMA busy cycles {t['SQ_VALU_MFMA_BUSY_CYCLES']:.0f}, GRBM_GUI_ACTIVE {t['GRBM_GUI_ACTIVE']:.0f})")
@@ -97,7 +103,7 @@ done
 python - <<PY
 import json
 P="gpurun_out/$P"
-for n in ("default","torch","c4","c2","gpus2_auto","gpus2_devices","gpus2_spawn"):
+for n in ("default","one_wave_onchip","torch","c4","c2","gpus2_auto","gpus2_devices","gpus2_spawn"):
     try:
         d=json.load(open(f"{P}_bench_{n}.json")); print(n, d["ms_per_step"], d["value"], d.get("lookup_stale"))
     except Exception as e:
