@@ -1,6 +1,7 @@
 // common.hpp -- kernel argument block, Philox4x32-10 + Box-Muller, wave64 reductions.
 // gfx950 only: wavefront = 64 lanes is hard-coded throughout.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/mppi_amd.h"
@@ -131,9 +132,6 @@ static inline OnChipGeometry onchip_geometry(int nu, int Tn, bool diag) {
 #ifndef MPPI_PAIR_KT
 #define MPPI_PAIR_KT 1      // weighting tiles per wave kept in registers (each wave has 256 registers, not 512: two tiles spill)
 #endif
-#ifndef MPPI_PAIR_ND
-#define MPPI_PAIR_ND -1     // weighting tiles per wave generated a second time beside the fetch of those that waited in memory; -1: chosen below
-#endif
 struct OnChipPairGeometry {
   int P4, TT, SW, CH, KR, nss, nch, nit, nls, ntl, nsl, nsm, shn;
   size_t smem;
@@ -165,26 +163,29 @@ static inline OnChipPairGeometry onchip_pair_geometry(int nu, int nx, int Tn, bo
   if (nsl > room) nsl = (int)room;
   nsl -= nsl % g.SW;
   g.nsl = nsl;
-  // The wave's last `nd` tiles are generated a second time instead of waiting in memory.  The weighting phase is bound either by the
-  // fetch of the memory tiles (chip-wide ~0.27 us per row-of-4 of every wave: profiles/r06_h_onchip_pair_check.txt) or by its VALU work
-  // (two waves per SIMD: ~0.6 us per tile's column sums, ~0.22 us per regenerated row); the two proceed side by side, so nd is what
-  // makes the larger of them smallest (C3, T = 64: 2 -- the partial last tile and one whole one; T = 48: 1).
-  int nd = MPPI_PAIR_ND;
-  const int after = g.ntl - MPPI_PAIR_KT - nsl / g.SW;                // tiles beyond registers and LDS
-  if (nd < 0) {
+  // The wave's last `dls` local super-steps are generated a second time instead of waiting in memory: the weighting phase is bound
+  // either by the fetch of the memory rows (out of the Infinity Cache, chip-wide) or by its VALU work (column sums + second generation,
+  // two waves per SIMD), and the two proceed side by side.  Measured at C3 (profiles/r06_k_onchip_pair_check.txt; 22 real super-steps
+  // beyond registers and LDS, 3 of padding): dls = 0 / 5 / 10 / 15 -> 67.1 / 62.0 / 60.4 / 62.9 us, splits inside a tile (6, 7: 62.3,
+  // 62.4) no better than their neighbours -- so whole tiles, as many as bring the regenerated share closest to a third of the real
+  // super-steps out there (C3: the last two tiles = 7 of 22).  MPPI_PAIR_DLS in the environment overrides it (measurements; any value).
+  const int after = g.ntl * g.SW - g.KR - nsl;                        // local super-steps beyond registers and LDS, padding included
+  static const int forced = [] { const char* e = getenv("MPPI_PAIR_DLS"); return (e && *e) ? atoi(e) : -1; }();
+  int dls = 0;
+  if (after > 0) {
+    auto real = [&](int ls) { return ls < g.nls && ((2 * (ls / g.CH)) * g.CH + ls % g.CH) < g.nss; };
+    int areal = 0;
+    for (int ls = g.KR + nsl; ls < g.ntl * g.SW; ++ls) areal += real(ls) ? 1 : 0;
     double best = 1e30;
-    for (int c = 0; c <= 3 && c <= (after > 0 ? after : 0); ++c) {
-      int dss = 0;                                                    // real local super-steps in the last c tiles
-      for (int ls = (g.ntl - c) * g.SW; ls < g.nls; ++ls) dss += ((2 * (ls / g.CH)) * g.CH + ls % g.CH) < g.nss ? 1 : 0;
-      const double mem = 0.267 * (after - c) * g.SW * g.P4;
-      const double valu = 2.0 * (0.6 * (g.ntl - c) + 0.223 * dss * g.P4);
-      const double t = mem > valu ? mem : valu;
-      if (t < best - 1e-9) { best = t; nd = c; }
+    for (int c = 0; c <= 3 && c * g.SW <= after; ++c) {
+      int dreal = 0;
+      for (int ls = (g.ntl - c) * g.SW; ls < g.ntl * g.SW; ++ls) dreal += real(ls) ? 1 : 0;
+      const double d = dreal - 0.32 * areal;
+      if ((d < 0 ? -d : d) < best - 1e-9) { best = d < 0 ? -d : d; dls = c * g.SW; }
     }
-    if (nd < 0) nd = 0;
+    if (forced >= 0) dls = forced < after ? forced : after;
   }
-  g.nsm = g.ntl * g.SW - g.KR - nsl - nd * g.SW;
-  if (g.nsm < 0) g.nsm = 0;
+  g.nsm = (after > 0 ? after : 0) - dls;
   g.smem = (size_t)fixed + (size_t)nsl * g.P4 * 2 * BLOCK * 16;
   return g;
 }

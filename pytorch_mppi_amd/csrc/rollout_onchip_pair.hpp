@@ -233,31 +233,36 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
       }
     }
   }
-  // local tiles: [0, tA) registers | [tA, tB) LDS | [tB, ntl) memory
+  // local tiles: [0, tA) registers | [tA, tB) LDS | [tB, tC) memory | tile tC: its first `mix` super-steps memory, the rest -- and
+  // every later tile -- generated a second time (nsm need not be whole tiles: the split that balances fetch and VALU is not)
   const int tA = ntl < KT ? ntl : KT;
   const int tB = tA + nsl / SW < ntl ? tA + nsl / SW : ntl;
   const int tC = tB + nsm / SW < ntl ? tB + nsm / SW : ntl;
+  const int mix = tC < ntl ? nsm % SW : 0;
+  const int tM = tC + (mix > 0 ? 1 : 0);                                 // tiles [tB, tM) read rows that waited in memory
   float4 pf[TRW];
 #if defined(MPPI_PAIR_EXP) && (MPPI_PAIR_EXP & 8)        // experiment: the tiles that waited in memory are not fetched (nor summed)
-  int mt = tC, work = 0;
+  int mt = tM;
 #else
-  int mt = tB, work = 0;
+  int mt = tB;
 #endif
+
   // rows of this wave that exist: its local super-steps map to increasing super-steps of the horizon, so they are a prefix
   int nreal = 0;
   for (int ls = 0; ls < nls; ++ls) nreal += ((2 * (ls / CH) + h) * CH + ls % CH) < nss ? P4 : 0;
+  const int nstored = nreal < M1 * P4 ? nreal : M1 * P4;                 // local rows [M0 P4, nstored) are in the array
   auto fetch = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < TRW; ++i) {
-      // (a row never stored is not fetched: the last real row is read again -- a hit -- and masked below.  No branch: the rows of
-      //  a tile are one batch of loads)
-      const int row = tile * TRW + i < nreal ? tile * TRW + i : nreal - 1;
+      // (a row never stored is not fetched: the last stored row is read again -- a hit -- and not used below.  No branch: the rows
+      //  of a tile are one batch of loads)
+      const int row = tile * TRW + i < nstored ? tile * TRW + i : nstored - 1;
       pf[i] = *spill_at(row - tB * TRW);
     }
   };
   // the first tile that waited in memory takes off now: it flies while the partner finishes the last chunk and the workgroup
   // agrees on its minimum (whether this wave's weights are all zero is not known yet: a dead wave fetches this one tile in vain)
-  if (mt < tC) fetch(mt);
+  if (mt < tM && nstored > tB * TRW) fetch(mt);
   // every chunk rolled out: the last hand-over holds the final state and the two cost sums
   while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nch) __builtin_amdgcn_s_sleep(1);
   {
@@ -289,19 +294,6 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
     for (int i = 0; i < 64; ++i) acc[i] = i < TC ? wk * e[(i < TC ? i : 0) / 4][i % 4] : T(0);
     ex[(wv8 * ntl + tile) * 64 + lane] = wave_reduce_transpose64<float>(acc);
   };
-  auto consume = [&]() __attribute__((always_inline)) {
-    T acc[64];
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      const int r = (i < TC ? i : 0) / 4, q = i % 4;
-      const float v = q == 0 ? pf[r].x : q == 1 ? pf[r].y : q == 2 ? pf[r].z : pf[r].w;
-      acc[i] = i < TC ? (mt * TRW + r < nreal ? wk * v : T(0)) : T(0);   // (rows past the horizon were never stored)
-    }
-    const int tile = mt++;
-    if (mt < tC) fetch(mt);
-    ex[(wv8 * ntl + tile) * 64 + lane] = wave_reduce_transpose64<float>(acc);
-    work = 0;
-  };
   auto from_registers = [&](int tile) __attribute__((always_inline)) {
     T e[TRW][4];
     static_for<0, KT>([&](auto tt) {
@@ -319,10 +311,7 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
   if (!live) {
     for (int tile = 0; tile < ntl; ++tile) ex[(wv8 * ntl + tile) * 64 + lane] = T(0);
   } else {
-    for (int tile = 0; tile < tA; ++tile) {
-      from_registers(tile);
-      if (++work >= 2 && mt < tC) consume();
-    }
+    for (int tile = 0; tile < tA; ++tile) from_registers(tile);
     for (int tile = tA; tile < tB; ++tile) {
       T e[TRW][4];
 #pragma unroll
@@ -331,17 +320,22 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
         e[i][0] = q4.x; e[i][1] = q4.y; e[i][2] = q4.z; e[i][3] = q4.w;
       }
       column_sums(tile, e);
-      if (++work >= 2 && mt < tC) consume();
     }
-    // D: the wave's last tiles are generated a second time while the memory tiles are on their way: the weighting phase of this
-    // kernel is bound by the fetch of the rows that waited in memory (6.5-7 TB/s of them), and its VALU is idle meanwhile -- a tile
-    // generated again costs about what a tile fetched at that rate costs, and the two proceed side by side
-    // (profiles/r06_h_onchip_pair_check.txt; the one-wave kernel found all-fetch best: there a second generation runs at one wave
-    // per SIMD).  The last tile of a wave is a partial one.
+    // The remaining tiles: rows that waited in memory and rows generated a second time.  The weighting phase of this kernel is
+    // bound either by the fetch of the memory rows (~8 TB/s of them out of the Infinity Cache, chip-wide) or by its VALU work (the
+    // column sums and the second generation, two waves per SIMD); the two proceed side by side, a memory tile's successor in
+    // flight while a regenerated tile is computed, and the launcher picks the split that makes the larger of them smallest
+    // (onchip_pair_geometry; profiles/r06_h_onchip_pair_check.txt, r06_k_*: all-fetch 67.5 us, whole tiles 62.4, balanced 6x).
+    // (The one-wave kernel found all-fetch best: there a second generation runs at one wave per SIMD.)
     int kd = blockIdx.x * K1_BLOCK + s256;
     asm volatile("" : "+v"(kd));
     const long long kgd = a.k_offset + (kd < a.K ? kd : a.K - 1);
-    for (int tile = tC; tile < ntl; ++tile) {
+    int dt = tM;                                                         // the next tile generated again in full
+    for (int step = 0; mt < tM || dt < ntl; ++step) {
+      // one body for every kind of tile: its first m super-steps out of `pf`, the rest generated again
+      const bool from_memory = mt < tM && ((step & 1) == 0 || dt >= ntl);
+      const int tile = from_memory ? mt : dt;
+      const int m = from_memory ? (mt < tC ? SW : mix) : 0;
       T acc[64];                                                         // (the products go straight into the reduction's operands)
 #pragma unroll
       for (int i = TC; i < 64; ++i) acc[i] = T(0);
@@ -349,7 +343,17 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
       for (int g = 0; g < SW; ++g) {
         const int ls = tile * SW + g;
         const int ss = (2 * (ls / CH) + h) * CH + ls % CH;
-        if (ss < nss) {
+        if (g < m) {
+#pragma unroll
+          for (int i = 0; i < P4; ++i) {
+            const float4 q4 = pf[g * P4 + i];
+            const bool real = ls * P4 + i < nstored;                     // (rows past the horizon were never stored)
+            acc[(g * P4 + i) * 4 + 0] = real ? wk * q4.x : T(0);
+            acc[(g * P4 + i) * 4 + 1] = real ? wk * q4.y : T(0);
+            acc[(g * P4 + i) * 4 + 2] = real ? wk * q4.z : T(0);
+            acc[(g * P4 + i) * 4 + 3] = real ? wk * q4.w : T(0);
+          }
+        } else if (ss < nss) {
           T zg[P4 * 4], vg[P4 * 4];
 #pragma unroll
           for (int i = 0; i < P4; ++i) {
@@ -367,10 +371,13 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
           for (int q = 0; q < P4 * 4; ++q) acc[g * P4 * 4 + q] = T(0);
         }
       }
+      if (from_memory) {
+        if (++mt < tM) fetch(mt);                                        // `pf` is consumed: the next memory tile takes off
+      } else {
+        ++dt;
+      }
       ex[(wv8 * ntl + tile) * 64 + lane] = wave_reduce_transpose64<float>(acc);
-      if (mt < tC) consume();
     }
-    while (mt < tC) consume();
   }
   __syncthreads();
   // one combine over the four waves that own a column, in wave order

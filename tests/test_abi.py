@@ -118,14 +118,21 @@ def _pair_spill_rows(nu, nx, T, plain=True, kt=1, pbrows=12):
     room = (160 * 1024 - fixed) // (p4 * 512 * 16)
     nsl = max(0, min((nch // 2) * ch - kr, room))
     nsl -= nsl % sw
-    after = ntl - kt - nsl // sw
-    best, nd = 1e30, 0
-    for c in range(0, min(3, max(after, 0)) + 1):
-        dss = sum(1 for ls in range((ntl - c) * sw, nls) if (2 * (ls // ch)) * ch + ls % ch < nss)
-        t = max(0.267 * (after - c) * sw * p4, 2.0 * (0.6 * (ntl - c) + 0.223 * dss * p4))
-        if t < best - 1e-9:
-            best, nd = t, c
-    return max(0, ntl * sw - kr - nsl - nd * sw) * p4
+    after = ntl * sw - kr - nsl                       # local super-steps beyond registers and LDS, padding included
+    if after <= 0:
+        return 0
+
+    def real(ls):
+        return ls < nls and (2 * (ls // ch)) * ch + ls % ch < nss
+    areal = sum(1 for ls in range(kr + nsl, ntl * sw) if real(ls))
+    best, dls = 1e30, 0
+    for c in range(0, 4):                              # whole tiles generated a second time: the share closest to a third
+        if c * sw > after:
+            break
+        d = abs(sum(1 for ls in range((ntl - c) * sw, ntl * sw) if real(ls)) - 0.32 * areal)
+        if d < best - 1e-9:
+            best, dls = d, c * sw
+    return (after - dls) * p4
 
 
 @pytest.mark.parametrize("T", [64, 48, 33, 100, 15, 200])
