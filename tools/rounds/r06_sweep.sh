@@ -8,6 +8,6 @@ MPPI_EXTRA_SEEDS=$N timeout 1500 python -m pytest tests/test_gpu_random_configs.
 echo "rc $?" >> gpurun_out/${P}_random.log
 tail -3 gpurun_out/${P}_random.log | cut -c1-300
 for i in 1 2 3 4 5; do
-  timeout 600 python -m pytest tests/test_gpu_group_threads.py tests/test_gpu_devices.py -m gpu -q -p no:cacheprovider 2>&1 | tail -1
+  timeout 600 python -m pytest tests/test_gpu_group_threads.py tests/test_gpu_devices.py -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed"
 done > gpurun_out/${P}_group_soak.log 2>&1
 cat gpurun_out/${P}_group_soak.log
