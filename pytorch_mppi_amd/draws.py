@@ -9,6 +9,7 @@ generator in its three forms (on chip: no array at all; generator launch + rows 
 owned here (one per size, reused by every
 command)."""
 import ctypes as C
+import os
 import logging
 
 import torch
@@ -328,8 +329,14 @@ class Draws:
         # generation over the chip.  Measured at T = 64, nu = 12 (tools/k_sweep.py, profiles/r03_k_sweep.txt against
         # r02_k_sweep.txt): K = 16384 0.083 vs 0.056 ms, K = 65536 0.087 vs 0.106, K >= 262144 8.0e8 vs 5.9e8 rollouts/s
         # ->
-        # from three quarters of a full chip (one wave per SIMD = 65536 samples) upwards
-        return K >= 49152
+        # from three quarters of a full chip (one wave per SIMD = 65536 samples) upwards.  Round 6: where the two-wave kernel runs
+        # (csrc/rollout_onchip_pair.hpp onchip_pair_model_ok: the integrator (16, 12) with a spill array) the launch costs ~60 us
+        # and the streaming form passes it at K ~ 27000 (tools/onchip_threshold_sweep.py, profiles/r06_onchip_threshold_sweep.txt:
+        # K = 28672 0.063 vs 0.064 ms, 32768 0.061 vs 0.068, 40960 0.062 vs 0.076)
+        # (horizons from 40 steps on: below, every row fits registers + LDS of the one-wave kernel, no array, no two-wave kernel)
+        two_wave = (self.onchip_spill and self._model.model_id == N.MODEL_INTEGRATOR and self.nx == 16 and nu == 12 and Tn >= 40
+                    and os.environ.get("MPPI_ONCHIP_PAIR", "1") != "0")
+        return K >= (28672 if two_wave else 49152)
 
     def _ktn_direct_ok(self, p, Tn, nu, z):
         return (self.ktn_direct and self.M == 1 and self.dtype == torch.float32 and self._diagonal_sigma
