@@ -325,7 +325,8 @@ __global__ void __launch_bounds__(2 * K1_BLOCK) rollout_onchip_pair_kernel(const
     // bound either by the fetch of the memory rows (~8 TB/s of them out of the Infinity Cache, chip-wide) or by its VALU work (the
     // column sums and the second generation, two waves per SIMD); the two proceed side by side, a memory tile's successor in
     // flight while a regenerated tile is computed, and the launcher picks the split that makes the larger of them smallest
-    // (onchip_pair_geometry; profiles/r06_h_onchip_pair_check.txt, r06_k_*: all-fetch 67.5 us, whole tiles 62.4, balanced 6x).
+    // (onchip_pair_geometry; profiles/r06_h_onchip_pair_check.txt, r06_k_onchip_pair_check.txt: everything fetched 67.1 us, the last two
+    // tiles generated again 60.4, splits inside a tile 62.3-62.4).
     // (The one-wave kernel found all-fetch best: there a second generation runs at one wave per SIMD.)
     int kd = blockIdx.x * K1_BLOCK + s256;
     asm volatile("" : "+v"(kd));
